@@ -1,0 +1,307 @@
+"""Benchmark of the learner hot path on MI355X (contract: see the round prompt / DESIGN.md §6).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one optimizer step's worth of the post-model hot path for the BASELINE config
+"Qwen2.5-7B GRPO bs=4096 seq=8192" on synthetic rollouts already resident in HBM:
+
+    K5  group advantages over the rank's sequences
+    K6  ONE pack launch writing every micro-batch of the step (PipelineBatchEncoding layout)
+    per micro-batch (8192 tokens, V = 152 064 fp32 logits resident in HBM):
+        fused K1 + token gradient + K1 backward  (d loss / d logits written to a second buffer)
+    K2+K3  ONE loss + 32-stat launch over all tokens of the step
+    one all-gather of the stats vector across ranks (N > 1)
+
+The transformer forward/backward itself is outside the path (stock PyTorch-ROCm).
+Scaling is STRONG: the global batch of 4096 sequences is fixed and sharded across ranks.
+Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (global batch, seq_length, vocab, attempts)
+    "7b_grpo_bs4096_seq8192": (4096, 8192, 152064, 8),
+    "0p5b_grpo_bs512_seq2048": (512, 2048, 151936, 8),
+    "tiny": (64, 512, 4096, 8),
+}
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=2)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--workload", default=os.environ.get("PRL_BENCH_WORKLOAD", "7b_grpo_bs4096_seq8192"), choices=list(WORKLOADS))
+    p.add_argument("--logits-mode", default=os.environ.get("PRL_BENCH_LOGITS_MODE", "fused"), choices=["fused", "two_pass"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-weight-sync", action="store_true")
+    return p.parse_args()
+
+
+class EventTimer:
+    """HIP events on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.pairs: dict[str, list] = {}
+
+    def time(self, name):
+        timer = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                self_inner.a = torch.cuda.Event(enable_timing=True)
+                self_inner.b = torch.cuda.Event(enable_timing=True)
+                self_inner.a.record()
+
+            def __exit__(self_inner, *exc):
+                self_inner.b.record()
+                timer.pairs.setdefault(name, []).append((self_inner.a, self_inner.b))
+
+        return _Ctx()
+
+    def summary(self) -> dict[str, dict]:
+        out = {}
+        for name, pairs in self.pairs.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = {"launches": len(ms), "avg_us": 1e3 * float(np.mean(ms)), "min_us": 1e3 * float(np.min(ms))}
+        return out
+
+
+def cpu_baseline(seq_length: int, vocab: int) -> dict:
+    """The CPU oracle (numpy restatement of the reference, pinned to it by golden vectors) timed on
+    this box's host cores on a bounded sample of the same workload.  A reported baseline only."""
+    from oracle import preprocess as opre
+    from oracle import rl_loss as orl
+    from pipelinerl_amd.synthetic import make_ragged, ragged_to_entries
+
+    n_seq, t_logits = 8, 192
+    rag, reasons = make_ragged(1, attempts=n_seq, seq_length=seq_length, vocab=vocab, seed=99, dense=True)
+    entries = ragged_to_entries(rag, reasons)
+    cfg = dict(policy_loss="ppo", epsilon_low=0.02, epsilon_high=0.02, kl_coef=0.0, final_kl_coef=0.0,
+               clamp_log_ratio_ref_new_value=5, divide_advantage_by_std=False, batch_size=4096, temperature=1.0)
+    t0 = time.perf_counter()
+    data = opre.preprocess_chunk(entries, 2, False)
+    batches = [opre.collate_packed([d], 2, 1) for d in data]
+    t_pre = (time.perf_counter() - t0) / n_seq  # s per sequence
+    # post-model loss path on a slice of one micro-batch (numpy fp32 over [t, V])
+    b = {k: (v[:, :t_logits] if isinstance(v, np.ndarray) and v.ndim == 2 else v) for k, v in batches[0].items()}
+    rng = np.random.default_rng(0)
+    logits = (rng.standard_normal((1, t_logits, vocab)) * 2).astype(np.float32)
+    t0 = time.perf_counter()
+    orl.rl_step(logits, b, cfg, 0, 10, True)
+    t_loss_tok = (time.perf_counter() - t0) / t_logits  # s per token
+    per_sample = t_pre + t_loss_tok * seq_length
+    return {
+        "value": 1.0 / per_sample,
+        "unit": "samples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"oracle (numpy port of the reference, single thread): preprocess+collate of {n_seq} x {seq_length}-token "
+                  f"sequences ({t_pre * 1e3:.1f} ms/seq) + logits->loss->dlogits on {t_logits} tokens x V={vocab} "
+                  f"({t_loss_tok * 1e6:.0f} us/token), extrapolated to {seq_length}-token samples",
+        "host": {"nproc": os.cpu_count()},
+    }
+
+
+def weight_sync_probe(rank: int, world: int, dev: torch.device) -> dict | None:
+    """Trainer -> actor weight broadcast (rank 0 -> all others) of a Qwen2.5-7B sized bf16 flat
+    bucket set over RCCL: plain broadcast vs scatter + all-gather.  Extra field, never `value`."""
+    import torch.distributed as dist
+
+    from pipelinerl_amd.weight_sync import WeightSyncGroup
+
+    total_bytes = int(os.environ.get("PRL_BENCH_WSYNC_BYTES", 15_231_233_024))  # 7.6B params bf16
+    bucket_bytes = 1 << 30
+    try:
+        grp = WeightSyncGroup.from_torch_distributed(rank, world, dev)
+        bucket = torch.empty(bucket_bytes, dtype=torch.uint8, device=dev)
+        n_buckets = (total_bytes + bucket_bytes - 1) // bucket_bytes
+        out = {"bytes": n_buckets * bucket_bytes, "n_receivers": world - 1, "bucket_bytes": bucket_bytes}
+        for mode in ("broadcast", "scatter_allgather"):
+            for it in range(2):  # first pass warms the RCCL channels
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_buckets):
+                    grp.broadcast_bucket(bucket, mode=mode)
+                torch.cuda.synchronize()
+                dist.barrier()
+                dt = time.perf_counter() - t0
+            t = torch.tensor([dt], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out[f"{mode}_ms"] = 1e3 * t.item()
+            out[f"{mode}_GBps"] = out["bytes"] / t.item() / 1e9
+        grp.close()
+        return out
+    except Exception as e:  # the probe must never take the benchmark line down
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def main():
+    args = parse_args()
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from pipelinerl_amd import _lib
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.hotpath import HotPathStep
+    from pipelinerl_amd.synthetic import make_ragged
+
+    _lib.load()
+    bs, seq_length, vocab, attempts = WORKLOADS[args.workload]
+    assert bs % (attempts * world) == 0, "global batch must split into whole groups per rank"
+    groups_per_rank = bs // attempts // world
+    cfg = RLConfig(policy_loss="ppo", epsilon_low=0.02, epsilon_high=0.02, kl_coef=0.0, final_kl_coef=0.0,
+                   clamp_log_ratio_ref_new_value=5, temperature=1.0, divide_advantage_by_std=False,
+                   group_normalization=False, batch_size=bs)
+
+    # synthetic rollouts of this rank's shard, resident in HBM before the timed region (§8d: dense)
+    rag_h, _ = make_ragged(groups_per_rank, attempts=attempts, seq_length=seq_length, vocab=vocab,
+                           seed=1234 + 2 + 1000 * rank, dense=True)
+    rag = rag_h.to(dev)
+    n_seq = rag.n_seqs
+    micro_batches = [[i] for i in range(n_seq)]  # dense: every sequence fills one seq_length budget
+    tokens_per_rank = int(rag_h.host_seq_off[-1])
+
+    # fp32 logits of one micro-batch (what the fp32 lm_head hands to the loss), generated once
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    logits = torch.empty((1, seq_length, vocab), dtype=torch.float32, device=dev)
+    logits.normal_(0.0, 2.0, generator=gen)
+    grad_logits = torch.empty_like(logits)
+    torch.cuda.synchronize()
+
+    timer = EventTimer()
+
+    def one_step(timed: bool):
+        step = HotPathStep(cfg, eos_token_id=2, current_step=0, max_step=10)
+        if timed:
+            with timer.time("preprocess_K5_K6"):
+                step.preprocess(rag, micro_batches)
+        else:
+            step.preprocess(rag, micro_batches)
+        for j in range(n_seq):
+            if args.logits_mode == "fused":
+                if timed:
+                    with timer.time("fused_logits_loss"):
+                        step.logits_backward(j, logits, grad_logits)
+                else:
+                    step.logits_backward(j, logits, grad_logits)
+            else:
+                step.logits_two_pass(j, logits, grad_logits)
+        if timed:
+            with timer.time("grpo_loss_step"):
+                loss, stats = step.finish()
+        else:
+            loss, stats = step.finish()
+        return loss, stats
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, stats = one_step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = 1e3 * elapsed / args.steps
+    stats_host = stats.cpu().tolist()
+    assert np.isfinite(stats_host[0]), "non-finite loss in the benchmark step"
+    assert int(stats_host[2]) == bs, f"step covered {int(stats_host[2])} sequences, expected {bs}"
+
+    kernels = timer.summary()
+    V4 = vocab * 4
+    algo = {
+        # algorithmic bytes per launch
+        "fused_logits_loss": seq_length * (2 * V4 + 56),          # logits read once + d logits written once
+        "grpo_loss_step": tokens_per_rank * 52,                   # 56 B/token minus the unwritten 4 B gradient
+        "preprocess_K5_K6": tokens_per_rank * (84 + 8),           # K6 16 B read + 68 B written; K5 scan 8 B read
+    }
+    for name, k in kernels.items():
+        if name in algo:
+            k["algorithmic_bytes"] = algo[name]
+            k["GBps"] = algo[name] / (k["avg_us"] * 1e-6) / 1e9
+            k["hbm_frac"] = k["GBps"] / HBM_PEAK_GBS
+    dom = "fused_logits_loss" if "fused_logits_loss" in kernels else max(kernels, key=lambda n: kernels[n]["avg_us"] * kernels[n]["launches"])
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_traffic.json"
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": kernels[dom]["hbm_frac"], "traffic": traffic,
+    }
+
+    wsync = None
+    if world > 1 and not args.no_weight_sync:
+        wsync = weight_sync_probe(rank, world, dev)
+
+    if rank == 0:
+        line = {
+            "metric": "learner samples/sec (post-model hot path: K5+K6 preprocess, fused logits->GRPO loss->dlogits, stats), 7B GRPO bs=4096",
+            "value": bs / (elapsed / args.steps),
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "global_batch": bs, "seq_len": seq_length, "vocab": vocab,
+                       "tokens_per_step": bs * seq_length, "parallelism": f"dp{world}", "logits_mode": args.logits_mode,
+                       "policy_loss": "ppo", "kl_coef": 0.0},
+            "roofline": roofline,
+            "kernels": kernels,
+            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(seq_length, vocab),
+            "weight_sync": wsync,
+            "loss": stats_host[0],
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

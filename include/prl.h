@@ -1,0 +1,370 @@
+/*
+ * prl.h — C ABI of libprl.so: the MI355X (gfx950) implementation of PipelineRL's
+ * rollout -> preprocess -> finetune hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, and returns an
+ * int status (PRL_OK == 0, negative errno-style codes otherwise).  After a non-zero
+ * return `prl_last_error()` gives a thread-local human readable message.
+ *
+ * Conventions
+ *   - "device" pointers are HIP device pointers owned by the caller (PyTorch-ROCm
+ *     tensors in the Python host).  The library never allocates device memory:
+ *     scratch space is passed in (`workspace`, sized by the *_workspace_bytes call).
+ *   - `stream` is a hipStream_t (as void*).  All work is enqueued on it; nothing
+ *     synchronises unless stated.
+ *   - batch tensors use the reference's dtypes/layout (PipelineBatchEncoding,
+ *     reference pipelinerl/finetune/types.py:46-75): int64 [rows, cols] and
+ *     float32 [rows, cols], row-major contiguous.  Packed batches are rows == 1.
+ *   - "token-aligned" per-token outputs (new_logprobs, entropy, their grads) live
+ *     on the UNSHIFTED axis: element [r, c] is the quantity for *predicting token
+ *     c of row r* (computed from logits[r, c-1]); column 0 is unused and written
+ *     as 0.  The reference's shifted tensor x[:, :-1] therefore equals ours[:, 1:].
+ *
+ * Reference interfaces replaced (file:line in ServiceNow/PipelineRL):
+ *   prl_logprob_entropy_fwd/bwd   pipelinerl/finetune/rl/__init__.py:207-233
+ *   prl_grpo_loss_fwd_bwd         pipelinerl/finetune/rl/__init__.py:238-439,
+ *                                 pipelinerl/finetune/rl/utils.py:26-92
+ *   prl_fused_logits_loss         the two above in one pass (no reference analogue)
+ *   prl_segment_sums              pipelinerl/finetune/rl/utils.py:106-208
+ *   prl_seq_scan / prl_group_advantages
+ *                                 pipelinerl/finetune/rl/__init__.py:453-570
+ *   prl_pack_collate              pipelinerl/finetune/data.py:215-283
+ *                                 (+ rl/__init__.py:573-594 field expansion)
+ *   prl_pad_collate               pipelinerl/finetune/data.py:163-212
+ *   prl_ring_*                    pipelinerl/shared_memory_array.py:9-196,
+ *                                 pipelinerl/streams.py:249-346
+ *   prl_wsync_*                   pipelinerl/finetune_loop.py:205-292,
+ *                                 pipelinerl/vllm1.py:62-134,
+ *                                 pipelinerl/torch_utils.py:70-94
+ */
+#ifndef PRL_H_
+#define PRL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRL_ABI_VERSION 1
+
+#define PRL_OK 0
+#define PRL_EINVAL (-22)   /* bad argument                                  */
+#define PRL_ENOMEM (-12)   /* workspace too small                           */
+#define PRL_EFAULT (-14)   /* HIP / RCCL runtime error (see prl_last_error) */
+#define PRL_EAGAIN (-11)   /* ring full / empty in non-blocking mode        */
+#define PRL_ETIMEDOUT (-110)
+#define PRL_ENOSYS (-38)   /* optional dependency (RCCL) not loadable       */
+#define PRL_EMSGSIZE (-90) /* ring record larger than a slot                */
+
+typedef void* prl_stream_t; /* hipStream_t */
+
+int prl_abi_version(void);
+const char* prl_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* K1 / K1e : logits -> (new_logprobs, entropy)                              */
+/* ------------------------------------------------------------------------- */
+
+#define PRL_DTYPE_F32 0
+#define PRL_DTYPE_BF16 1
+
+/*
+ * Forward.  logits: [rows*cols, vocab] (row stride `logits_row_stride` elements,
+ * dtype f32 or bf16), input_ids: int64 [rows, cols].
+ *   z            = logits / temperature                       (rl/__init__.py:207-208)
+ *   new_logprobs[r,c] = z[r,c-1, ids[r,c]] - logsumexp(z[r,c-1,:])      (:209-212)
+ *   entropy[r,c]      = -sum_v softmax(z)_v log_softmax(z)_v             (:215-233)
+ *   lse2[r,c]    = logsumexp in base-2 units of z*log2(e)   (saved for backward)
+ * All three outputs are float32 [rows, cols] token-aligned (col 0 := 0).
+ * An out-of-range id yields NaN (the host turns that into the reference's assert).
+ */
+int prl_logprob_entropy_fwd(int64_t rows, int64_t cols, int64_t vocab,
+                            const void* logits, int32_t logits_dtype,
+                            int64_t logits_row_stride, const int64_t* input_ids,
+                            float temperature, float* new_logprobs, float* entropy,
+                            float* lse2, prl_stream_t stream);
+
+/*
+ * Backward.  grad_logits[r,c-1,v] = scale * ( g*(1[v==id] - p_v)
+ *                                           - gH * p_v*(log p_v + H) ) / temperature
+ * with g = grad_new_logprobs[r,c], gH = grad_entropy[r,c] (nullable => 0),
+ * scale = *upstream (device scalar, nullable => 1).  Row (r, cols-1) gets zeros.
+ * grad_logits may alias logits (in-place); same dtype/stride as logits.
+ */
+int prl_logprob_entropy_bwd(int64_t rows, int64_t cols, int64_t vocab,
+                            const void* logits, int32_t logits_dtype,
+                            int64_t logits_row_stride, const int64_t* input_ids,
+                            float temperature, const float* lse2, const float* entropy,
+                            const float* grad_new_logprobs, const float* grad_entropy,
+                            const float* upstream, void* grad_logits,
+                            prl_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* K2 + K3 : GRPO/PPO/REINFORCE token loss + masked reduce + stats + grad    */
+/* ------------------------------------------------------------------------- */
+
+#define PRL_POLICY_PPO 0
+#define PRL_POLICY_REINFORCE 1
+
+typedef struct prl_loss_config {
+  int32_t policy_loss;         /* PRL_POLICY_*                      (RLConfig.policy_loss) */
+  int32_t use_advantages;      /* rl/__init__.py:274                                       */
+  int32_t relu_log_p_weights;  /* :275-276                                                 */
+  int32_t group_normalization; /* :245-250                                                 */
+  int32_t overlong_filtering;  /* :252-255                                                 */
+  int32_t use_entropy_loss;    /* entropy_bonus != 0 or final_entropy_bonus != 0 (:215)    */
+  int32_t flat_micro_batches;  /* 1: the [1, T] batch is several packed micro-batches laid
+                                  back to back (one launch per optimizer step); a position
+                                  with position_ids == 0 then starts a micro-batch or a
+                                  masked sequence and carries no prediction                */
+  int32_t reserved0;
+  float token_weight;          /* fp32(1)/fp32(batch_size)                       (:250)    */
+  float clip_lo;               /* fp32(1 - epsilon_low)                          (:300)    */
+  float clip_hi;               /* fp32(1 + epsilon_high)                         (:300,306)*/
+  float kl_coef;               /* linear_decay_coef(...) for this step           (:293)    */
+  float entropy_coef;          /* linear_decay_coef(...) for this step           (:292)    */
+  float clamp_log_ratio_ref_new; /* :280-286                                               */
+} prl_loss_config;
+
+/* stats vector (double[PRL_NUM_STATS], device).  Sums follow App. A of SURVEY.md:
+ * "mean" stats are sum over masked tokens of x / num_labels. */
+enum {
+  PRL_STAT_LOSS = 0,
+  PRL_STAT_NUM_OUTPUT_TOKENS = 1,
+  PRL_STAT_NUM_SEQUENCES = 2,
+  PRL_STAT_REWARD = 3,
+  PRL_STAT_MAX_REWARD = 4,
+  PRL_STAT_MIN_REWARD = 5,
+  PRL_STAT_ENTROPY = 6,
+  PRL_STAT_OLD_LOGPROBS = 7,
+  PRL_STAT_NEW_LOGPROBS = 8,
+  PRL_STAT_REF_LOGPROBS = 9,
+  PRL_STAT_ADVANTAGE = 10,
+  PRL_STAT_MAX_ADVANTAGE = 11,
+  PRL_STAT_MIN_ADVANTAGE = 12,
+  PRL_STAT_KL = 13,
+  PRL_STAT_KL_NEW_OLD = 14,
+  PRL_STAT_MEAN_ABS_LOG_RATIO_NEW_OLD = 15,
+  PRL_STAT_MAX_KL = 16,
+  PRL_STAT_MIN_KL = 17,
+  PRL_STAT_RATIO_NEW_OLD = 18,
+  PRL_STAT_RATIO_NEW_OLD_SUM = 19,
+  PRL_STAT_RATIO_NEW_OLD_SQUARED_SUM = 20,
+  PRL_STAT_RATIO_REF_NEW = 21,
+  PRL_STAT_RATIO_REF_OLD = 22,
+  PRL_STAT_CLAMP_REF_NEW_INDICATOR = 23,
+  PRL_STAT_CLAMP_NEW_OLD_INDICATOR = 24,
+  PRL_STAT_TOKEN_WEIGHT = 25,
+  PRL_STAT_MAX_TOKEN_WEIGHT = 26,
+  PRL_STAT_MIN_TOKEN_WEIGHT = 27,
+  PRL_STAT_NONFINITE_NEW_LOGPROBS = 28,   /* count; reference assert :213 */
+  PRL_STAT_NONFINITE_LOG_RATIO_REF_NEW = 29, /* :263 */
+  PRL_STAT_NONFINITE_KL = 30,             /* :291 */
+  PRL_STAT_BAD_GROUP_TOKENS = 31,         /* count of group_tokens <= 0 (:247) */
+  PRL_NUM_STATS = 32
+};
+
+int prl_grpo_loss_workspace_bytes(int64_t rows, int64_t cols, size_t* bytes);
+
+/*
+ * labels, position_ids: int64 [rows, cols] (position_ids nullable when rows > 1 or
+ * the batch is not packed: num_sequences := rows).  new_logprobs, entropy:
+ * token-aligned float32 [rows, cols].  The seven RL columns are the batch's
+ * float32 [rows, cols] tensors, unshifted.
+ * Outputs: grad_new_logprobs / grad_entropy (token-aligned d loss / d x, nullable),
+ * stats (double[PRL_NUM_STATS]).  loss = stats[PRL_STAT_LOSS], also written as a
+ * float to loss_out (device, nullable).
+ */
+int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, int64_t cols,
+                          const int64_t* labels, const int64_t* position_ids,
+                          const float* new_logprobs, const float* entropy,
+                          const float* old_logprobs, const float* ref_logprobs,
+                          const float* advantages, const float* rewards,
+                          const float* group_tokens, const float* num_labels,
+                          const float* overflow, float* grad_new_logprobs,
+                          float* grad_entropy, float* loss_out, double* stats,
+                          void* workspace, size_t workspace_bytes,
+                          prl_stream_t stream);
+
+/*
+ * Fused K1 + K2 gradient + K1 backward in ONE pass over the logits (no reference
+ * analogue: the reference materialises logits/temperature, log-softmax, and lets
+ * autograd re-read them).  Per logits row: online-softmax pass -> per-token loss
+ * gradient -> second pass writes d loss / d logits (grad_logits may alias logits).
+ * Also writes token-aligned new_logprobs / entropy / lse2 so that
+ * prl_grpo_loss_fwd_bwd can produce loss and stats from them.
+ */
+int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, int64_t cols,
+                          int64_t vocab, const void* logits, int32_t logits_dtype,
+                          int64_t logits_row_stride, float temperature,
+                          const int64_t* input_ids, const int64_t* labels,
+                          const float* old_logprobs, const float* ref_logprobs,
+                          const float* advantages, const float* rewards,
+                          const float* group_tokens, const float* overflow,
+                          float* new_logprobs, float* entropy, float* lse2,
+                          void* grad_logits, prl_stream_t stream);
+
+/*
+ * GSPO helper (rl/utils.py:106-208): per-segment masked sums of a and b plus token
+ * counts.  segment_ids int64 [1, cols]; mask = labels != -100; a, b token-aligned
+ * float32.  Outputs float64 [n_segments] x3, zeroed by the call.
+ */
+int prl_segment_sums(int64_t cols, int32_t n_segments, const int64_t* segment_ids,
+                     const int64_t* labels, const float* a, const float* b,
+                     double* a_sum, double* b_sum, double* count,
+                     prl_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* K5 : group-baseline advantages (populate_rl_data)                         */
+/* ------------------------------------------------------------------------- */
+
+#define PRL_FINISH_NONE 0    /* no usable finish_reason          (rl/__init__.py:543-552) */
+#define PRL_FINISH_LENGTH 1  /* "length"  -> overflow 1                                     */
+#define PRL_FINISH_STOP 2    /* "stop" / "content_filter" -> overflow 0                     */
+
+/*
+ * Per-sequence scan of the ragged token buffers: num_labels[s] = #labels != -100,
+ * overflow[s] per the finish_reason / finished / EOS-presence rule.
+ * tokens/labels: int32 ragged, seq_off int64 [n_seqs+1].
+ */
+int prl_seq_scan(int32_t n_seqs, const int32_t* tokens, const int32_t* labels,
+                 const int64_t* seq_off, const uint8_t* finish_code,
+                 const uint8_t* finished, int32_t eos_token_id, float* num_labels,
+                 float* overflow, prl_stream_t stream);
+
+/*
+ * Leave-one-out advantages per (group_id, step_index) key and mean rollout tokens
+ * per group, float64 arithmetic like the reference's pandas path.
+ *   key_off [n_keys+1], key_members [n_seqs]: CSR of sequences per key, members in
+ *       dataset order;  group_off/group_members likewise per group_id;
+ *   group_n_rollouts [n_groups]: number of distinct rollout_index per group.
+ * Outputs per sequence: advantage (f64 + f32 copy), group_tokens (f64 + f32 copy).
+ */
+int prl_group_advantages(int32_t n_seqs, int32_t n_keys, int32_t n_groups,
+                         const int32_t* key_off, const int32_t* key_members,
+                         const int32_t* group_off, const int32_t* group_members,
+                         const int32_t* group_n_rollouts, const double* reward,
+                         const int64_t* seq_off, int32_t divide_by_std,
+                         double* advantage64, double* group_tokens64,
+                         float* advantage32, float* group_tokens32,
+                         prl_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* K6 / K7 : pack / pad collate into PipelineBatchEncoding layout            */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Ragged sources (device): tokens/labels int32 [seq_off[n]], logprobs/ref_logprobs
+ * float32 over completion tokens only [lp_off[n]] (right-aligned inside each
+ * sequence, zero on the left, rl/__init__.py:587-588), per-sequence float32
+ * reward/advantage/group_tokens/num_labels/overflow.  `per_token_columns` is a bit
+ * mask (bit 0 reward, 1 advantage, 2 group_tokens, 3 num_labels, 4 overflow): a set
+ * bit means that column is instead a per-token ragged array aligned with `tokens`
+ * (the generic layout of the reference's example dicts).
+ *
+ * Packing plan (device, built on the host, O(#sequences)):
+ *   pk_src [m]    source sequence index, or -1 for a sentinel filler sequence
+ *                 (tokens = eos, labels = -100, group_tokens = num_labels = 1)
+ *   pk_dst [m+1]  destination offsets into the flat output (cumulative)
+ *   pk_seg [m]    segment id = index of the sequence inside its micro-batch
+ * Consecutive micro-batches are laid out back to back in the outputs; a sequence
+ * with pk_seg > 0 gets labels[first token] = -100 (data.py:264-265).
+ * Outputs (flat, length pk_dst[m]): input_ids, labels, attention_mask,
+ * position_ids, segment_ids (int64) and the seven float32 RL columns.
+ */
+int prl_pack_collate(int32_t m, int64_t total_tokens, const int32_t* pk_src,
+                     const int64_t* pk_dst, const int32_t* pk_seg,
+                     const int32_t* tokens, const int32_t* labels,
+                     const float* logprobs, const float* ref_logprobs,
+                     const int64_t* seq_off, const int64_t* lp_off,
+                     const float* reward, const float* advantage,
+                     const float* group_tokens, const float* num_labels,
+                     const float* overflow, int32_t per_token_columns,
+                     int32_t eos_token_id,
+                     int64_t* out_input_ids, int64_t* out_labels,
+                     int64_t* out_attention_mask, int64_t* out_position_ids,
+                     int64_t* out_segment_ids, float* out_rewards,
+                     float* out_advantages, float* out_ref_logprobs,
+                     float* out_old_logprobs, float* out_group_tokens,
+                     float* out_num_labels, float* out_overflow,
+                     prl_stream_t stream);
+
+/*
+ * Padded collate: outputs [n_rows, padded_len]; row i holds sequence row_src[i]
+ * right- or left-padded (pad_left != 0).  Pad values: labels -100, everything else
+ * 0 (data.py:195-205).  No position/segment ids in this mode.
+ */
+int prl_pad_collate(int32_t n_rows, int64_t padded_len, int32_t pad_left,
+                    const int32_t* row_src, const int32_t* tokens,
+                    const int32_t* labels, const float* logprobs,
+                    const float* ref_logprobs, const int64_t* seq_off,
+                    const int64_t* lp_off, const float* reward,
+                    const float* advantage, const float* group_tokens,
+                    const float* num_labels, const float* overflow,
+                    int32_t per_token_columns,
+                    int64_t* out_input_ids, int64_t* out_labels,
+                    int64_t* out_attention_mask, float* out_rewards,
+                    float* out_advantages, float* out_ref_logprobs,
+                    float* out_old_logprobs, float* out_group_tokens,
+                    float* out_num_labels, float* out_overflow,
+                    prl_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* Transport: shared-memory record ring (host side, no GPU)                  */
+/* ------------------------------------------------------------------------- */
+
+typedef struct prl_ring prl_ring;
+
+/* Create (unlinking any stale object of that name) or attach to a POSIX shm ring
+ * of `n_slots` slots of `slot_bytes` payload bytes.  Multi-producer /
+ * multi-consumer, FIFO by claim order. */
+int prl_ring_create(const char* name, uint32_t n_slots, uint64_t slot_bytes,
+                    prl_ring** out);
+int prl_ring_attach(const char* name, prl_ring** out);
+/* timeout_ms < 0: block forever; == 0: non-blocking (PRL_EAGAIN). */
+int prl_ring_put(prl_ring* r, const void* data, uint64_t nbytes, int64_t timeout_ms);
+/* Copies the next record into buf (cap bytes) and stores its size in *nbytes. */
+int prl_ring_get(prl_ring* r, void* buf, uint64_t cap, uint64_t* nbytes,
+                 int64_t timeout_ms);
+/* Zero-copy variants: reserve/commit a slot for writing, acquire/release for reading. */
+int prl_ring_reserve(prl_ring* r, void** slot_ptr, uint64_t* ticket, int64_t timeout_ms);
+int prl_ring_commit(prl_ring* r, uint64_t ticket, uint64_t nbytes);
+int prl_ring_acquire(prl_ring* r, const void** slot_ptr, uint64_t* nbytes,
+                     uint64_t* ticket, int64_t timeout_ms);
+int prl_ring_release(prl_ring* r, uint64_t ticket);
+int prl_ring_size(prl_ring* r, uint64_t* n_ready);
+int prl_ring_capacity(prl_ring* r, uint32_t* n_slots, uint64_t* slot_bytes);
+int prl_ring_max_record_bytes(prl_ring* r, uint64_t* nbytes);
+int prl_ring_close(prl_ring* r);           /* detach (creator also unlinks) */
+int prl_ring_unlink(const char* name);
+
+/* ------------------------------------------------------------------------- */
+/* Weight sync: trainer -> inference workers over RCCL / xGMI                */
+/* ------------------------------------------------------------------------- */
+
+typedef struct prl_wsync prl_wsync;
+
+#define PRL_WSYNC_UID_BYTES 128
+/* rank 0 creates the RCCL unique id; the host shares it (TCP store) with peers. */
+int prl_wsync_unique_id(uint8_t uid[PRL_WSYNC_UID_BYTES]);
+/* Collective: every rank of the update group calls this (rank 0 = trainer). */
+int prl_wsync_init(const uint8_t uid[PRL_WSYNC_UID_BYTES], int32_t rank,
+                   int32_t world_size, int32_t device, prl_wsync** out);
+/* Plain 1->N broadcast of a contiguous byte bucket from rank `src`. */
+int prl_wsync_bcast_bucket(prl_wsync* w, void* bucket, uint64_t nbytes, int32_t src,
+                           prl_stream_t stream);
+/*
+ * Scatter + all-gather broadcast from rank 0 to ranks 1..world-1: rank 0 sends a
+ * distinct 1/(world-1) slice to each receiver over its own xGMI link, receivers
+ * exchange slices among themselves.  Every rank passes the full bucket pointer.
+ */
+int prl_wsync_bcast_bucket_sag(prl_wsync* w, void* bucket, uint64_t nbytes,
+                               prl_stream_t stream);
+int prl_wsync_destroy(prl_wsync* w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRL_H_ */

@@ -1,0 +1,14 @@
+"""CPU oracle of the hot path — TEST INFRASTRUCTURE ONLY.
+
+Plain numpy / pure-python restatements of the reference algorithms (each function cites the
+reference file:line it follows).  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline`
+leg of `bench.py` may import this package, and only as the checker: the product
+(`pipelinerl_amd/`) never imports it and has no CPU fallback.
+
+Pinning: the reference ships no tests or golden vectors for this path, so
+the oracle is pinned against outputs of the reference's own functions run in the build
+container: `tests/golden/make_golden.py` imports `/root/reference/pipelinerl` and writes the
+fixtures under `tests/golden/`; `tests/test_oracle_golden.py` checks every oracle function
+against them.  The micro-batch schedule and the stream wire format could not be imported
+(missing third-party deps) and are restated from the source; see DESIGN.md "parity status".
+"""

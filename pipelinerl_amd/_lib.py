@@ -1,0 +1,190 @@
+"""ctypes binding of libprl.so (the C ABI declared in include/prl.h).
+
+The product path has NO fallback: if the shared object is missing, or a device entry point is
+called without a HIP device, this module raises.  Build with `python -m pipelinerl_amd.build`.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl.so"
+
+PRL_ABI_VERSION = 1
+PRL_OK = 0
+PRL_EINVAL = -22
+PRL_ENOMEM = -12
+PRL_EFAULT = -14
+PRL_EAGAIN = -11
+PRL_ETIMEDOUT = -110
+PRL_ENOSYS = -38
+PRL_EMSGSIZE = -90
+
+PRL_DTYPE_F32 = 0
+PRL_DTYPE_BF16 = 1
+PRL_POLICY_PPO = 0
+PRL_POLICY_REINFORCE = 1
+PRL_FINISH_NONE = 0
+PRL_FINISH_LENGTH = 1
+PRL_FINISH_STOP = 2
+PRL_NUM_STATS = 32
+PRL_WSYNC_UID_BYTES = 128
+
+# index of every public statistic in the device stats vector (enum in include/prl.h)
+STAT_INDEX = {
+    "loss": 0,
+    "num_output_tokens_sum": 1,
+    "num_sequences": 2,
+    "reward": 3,
+    "max_reward": 4,
+    "min_reward": 5,
+    "entropy": 6,
+    "old_logprobs": 7,
+    "new_logprobs": 8,
+    "ref_logprobs": 9,
+    "advantage": 10,
+    "max_advantage": 11,
+    "min_advantage": 12,
+    "kl": 13,
+    "kl_new_old": 14,
+    "mean_abs_log_ratio_new_old": 15,
+    "max_kl": 16,
+    "min_kl": 17,
+    "ratio_new_old": 18,
+    "ratio_new_old_sum": 19,
+    "ratio_new_old_squared_sum": 20,
+    "ratio_ref_new": 21,
+    "ratio_ref_old": 22,
+    "clamp_log_ratio_ref_new_indicator": 23,
+    "clamp_log_ratio_new_old_indicator": 24,
+    "token_weight": 25,
+    "max_token_weight": 26,
+    "min_token_weight": 27,
+    "nonfinite_new_logprobs": 28,
+    "nonfinite_log_ratio_ref_new": 29,
+    "nonfinite_kl": 30,
+    "bad_group_tokens": 31,
+}
+
+
+class PrlLossConfig(ctypes.Structure):
+    """Mirror of `struct prl_loss_config` (include/prl.h)."""
+
+    _fields_ = [
+        ("policy_loss", c_int32),
+        ("use_advantages", c_int32),
+        ("relu_log_p_weights", c_int32),
+        ("group_normalization", c_int32),
+        ("overlong_filtering", c_int32),
+        ("use_entropy_loss", c_int32),
+        ("flat_micro_batches", c_int32),
+        ("reserved0", c_int32),
+        ("token_weight", c_float),
+        ("clip_lo", c_float),
+        ("clip_hi", c_float),
+        ("kl_coef", c_float),
+        ("entropy_coef", c_float),
+        ("clamp_log_ratio_ref_new", c_float),
+    ]
+
+
+class PrlError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libprl error {code}: {message}")
+        self.code = code
+
+
+_P = c_void_p  # every device / host buffer pointer crosses the ABI as void*
+
+# name -> (restype, argtypes).  This table is also what tests/test_abi.py checks against
+# the declarations in include/prl.h.
+PROTOTYPES: dict[str, tuple] = {
+    "prl_abi_version": (c_int32, []),
+    "prl_last_error": (c_char_p, []),
+    "prl_logprob_entropy_fwd": (c_int32, [c_int64, c_int64, c_int64, _P, c_int32, c_int64, _P, c_float, _P, _P, _P, _P]),
+    "prl_logprob_entropy_bwd": (c_int32, [c_int64, c_int64, c_int64, _P, c_int32, c_int64, _P, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "prl_grpo_loss_workspace_bytes": (c_int32, [c_int64, c_int64, POINTER(c_size_t)]),
+    "prl_grpo_loss_fwd_bwd": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64] + [_P] * 11 + [_P, _P, _P, _P, _P, c_size_t, _P]),
+    "prl_fused_logits_loss": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64, c_int64, _P, c_int32, c_int64, c_float] + [_P] * 8 + [_P, _P, _P, _P, _P]),
+    "prl_segment_sums": (c_int32, [c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "prl_seq_scan": (c_int32, [c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),
+    "prl_group_advantages": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
+    "prl_pack_collate": (c_int32, [c_int32, c_int64] + [_P] * 14 + [c_int32, c_int32] + [_P] * 12 + [_P]),
+    "prl_pad_collate": (c_int32, [c_int32, c_int64, c_int32] + [_P] * 12 + [c_int32] + [_P] * 10 + [_P]),
+    "prl_ring_create": (c_int32, [c_char_p, c_uint32, c_uint64, POINTER(c_void_p)]),
+    "prl_ring_attach": (c_int32, [c_char_p, POINTER(c_void_p)]),
+    "prl_ring_put": (c_int32, [c_void_p, c_void_p, c_uint64, c_int64]),
+    "prl_ring_get": (c_int32, [c_void_p, c_void_p, c_uint64, POINTER(c_uint64), c_int64]),
+    "prl_ring_reserve": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_uint64), c_int64]),
+    "prl_ring_commit": (c_int32, [c_void_p, c_uint64, c_uint64]),
+    "prl_ring_acquire": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint64), c_int64]),
+    "prl_ring_release": (c_int32, [c_void_p, c_uint64]),
+    "prl_ring_size": (c_int32, [c_void_p, POINTER(c_uint64)]),
+    "prl_ring_capacity": (c_int32, [c_void_p, POINTER(c_uint32), POINTER(c_uint64)]),
+    "prl_ring_max_record_bytes": (c_int32, [c_void_p, POINTER(c_uint64)]),
+    "prl_ring_close": (c_int32, [c_void_p]),
+    "prl_ring_unlink": (c_int32, [c_char_p]),
+    "prl_wsync_unique_id": (c_int32, [POINTER(c_uint8)]),
+    "prl_wsync_init": (c_int32, [POINTER(c_uint8), c_int32, c_int32, c_int32, POINTER(c_void_p)]),
+    "prl_wsync_bcast_bucket": (c_int32, [c_void_p, c_void_p, c_uint64, c_int32, c_void_p]),
+    "prl_wsync_bcast_bucket_sag": (c_int32, [c_void_p, c_void_p, c_uint64, c_void_p]),
+    "prl_wsync_destroy": (c_int32, [c_void_p]),
+}
+
+_lib: ctypes.CDLL | None = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libprl.so once, set prototypes, verify the ABI version.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("PRL_LIB", LIB_PATH))
+    if not path.exists():
+        raise ImportError(
+            f"{path} not found: the HIP extension is not built. Run `python -m pipelinerl_amd.build` "
+            "(needs hipcc). There is no CPU fallback for the pipelinerl_amd hot path."
+        )
+    # torch first: its bundled HIP runtime / RCCL must be the ones the process uses.
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(str(path), mode=ctypes.RTLD_GLOBAL)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.prl_abi_version()
+    if got != PRL_ABI_VERSION:
+        raise ImportError(f"libprl.so ABI version {got} != expected {PRL_ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != PRL_OK:
+        msg = load().prl_last_error()
+        raise PrlError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def ptr(t) -> int | None:
+    """Device/host pointer of a torch tensor (None passes NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_ptr(device=None) -> int:
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device(*tensors) -> None:
+    """Fail loudly when a hot-path entry point is handed non-GPU tensors."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "pipelinerl_amd hot path needs tensors on a HIP device (got a CPU tensor); "
+                "there is no CPU fallback"
+            )

@@ -1,0 +1,517 @@
+// K1 / K1e: logits -> (new_logprobs, entropy) and its backward, plus the fused
+// one-pass variant that also applies the GRPO token gradient.
+//
+// Reference pipelinerl/finetune/rl/__init__.py:207-233 does: logits/temperature
+// (materialised copy), gather, logsumexp, then a 38-chunk entropy loop that re-reads
+// the logits; autograd later re-reads everything to build d logits.  Here each logits
+// row (V = 152 064 fp32 = 608 KB) is streamed ONCE by one workgroup with an online
+// softmax carrying three running values per lane:
+//     M = max_v y_v,  S = sum_v 2^(y_v - M),  W = sum_v (y_v - M) 2^(y_v - M),
+//     y = logits * (log2(e) / temperature)
+// so that  logsumexp = ln2 (M + log2 S),  entropy = ln2 (log2 S - W / S).
+// HBM-bound: V*4 bytes in per token forward; V*4 in + V*4 out backward.  16-byte loads,
+// UNROLL independent loads in flight per lane, wave64 shuffle combine, one LDS hop.
+//
+// Output convention: token-aligned (see include/prl.h): out[u] is computed from logits
+// row u-1; column 0 of every batch row is written as 0.
+
+#include "prl_common.h"
+#include "prl_token_math.h"
+
+namespace {
+
+using prl::kWave;
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kNegBig = -3.0e38f;  // finite "minus infinity" (keeps 0 * x well defined)
+
+// ---- dtype adapters: a 16-byte vector of NV logits --------------------------------
+struct F32 {
+  using scalar = float;
+  static constexpr int NV = 4;
+  struct alignas(16) vec {
+    float v[4];
+  };
+  __device__ static __forceinline__ void unpack(const vec& x, float (&o)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = x.v[i];
+  }
+  __device__ static __forceinline__ vec pack(const float (&o)[NV]) {
+    vec x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) x.v[i] = o[i];
+    return x;
+  }
+  __device__ static __forceinline__ float to_float(scalar s) { return s; }
+  __device__ static __forceinline__ scalar from_float(float f) { return f; }
+};
+
+struct BF16 {
+  using scalar = uint16_t;
+  static constexpr int NV = 8;
+  struct alignas(16) vec {
+    uint32_t w[4];
+  };
+  __device__ static __forceinline__ float to_float(scalar s) {
+    return __uint_as_float(((uint32_t)s) << 16);
+  }
+  __device__ static __forceinline__ scalar from_float(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (scalar)((u >> 16) | 0x40u);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                          // RNE
+    return (scalar)(u >> 16);
+  }
+  __device__ static __forceinline__ void unpack(const vec& x, float (&o)[NV]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(x.w[i] << 16);
+      o[2 * i + 1] = __uint_as_float(x.w[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ vec pack(const float (&o)[NV]) {
+    vec x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      x.w[i] = (uint32_t)from_float(o[2 * i]) | ((uint32_t)from_float(o[2 * i + 1]) << 16);
+    return x;
+  }
+};
+
+// ---- online softmax state ----------------------------------------------------------
+struct Osm {
+  float M, S, W;
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ void osm_init(Osm& s) {
+  s.M = kNegBig;
+  s.S = 0.0f;
+  s.W = 0.0f;
+}
+
+// fold N values (already scaled to base-2 units) into the state
+template <int N>
+__device__ __forceinline__ void osm_push(Osm& s, const float (&y)[N]) {
+  float mx = y[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) mx = fmaxf(mx, y[i]);
+  if (mx > s.M) {
+    const float dm = s.M - mx;
+    const float sc = fast_exp2(dm);
+    s.W = sc * __builtin_fmaf(dm, s.S, s.W);
+    s.S = sc * s.S;
+    s.M = mx;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float d = y[i] - s.M;
+    const float e = fast_exp2(d);
+    s.S += e;
+    s.W = __builtin_fmaf(d, e, s.W);
+  }
+}
+
+__device__ __forceinline__ Osm osm_merge(const Osm& a, const Osm& b) {
+  Osm r;
+  r.M = fmaxf(a.M, b.M);
+  const float da = a.M - r.M, db = b.M - r.M;
+  const float ea = fast_exp2(da), eb = fast_exp2(db);
+  r.S = ea * a.S + eb * b.S;
+  r.W = ea * __builtin_fmaf(da, a.S, a.W) + eb * __builtin_fmaf(db, b.S, b.W);
+  return r;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ Osm osm_block_reduce(Osm s, Osm* lds /* [BLOCK/64] */) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Osm t;
+    t.M = __shfl_xor(s.M, o, 64);
+    t.S = __shfl_xor(s.S, o, 64);
+    t.W = __shfl_xor(s.W, o, 64);
+    s = osm_merge(s, t);
+  }
+  constexpr int NW = BLOCK / kWave;
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  if (lane == 0) lds[wid] = s;
+  __syncthreads();
+  Osm r = lds[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) r = osm_merge(r, lds[w]);
+  return r;  // identical in every thread
+}
+
+// ---- pass 1: stream one row, return the block-wide state -----------------------------
+template <class T, int BLOCK, int UNROLL>
+__device__ __forceinline__ Osm row_softmax_stats(const typename T::scalar* row, int vocab, float k2,
+                                                 bool vec_ok, Osm* lds) {
+  using vec = typename T::vec;
+  constexpr int NV = T::NV;
+  Osm st;
+  osm_init(st);
+  const int tid = threadIdx.x;
+  int done = 0;  // elements covered by the vector path
+  if (vec_ok) {
+    const vec* rv = reinterpret_cast<const vec*>(row);
+    const int nvec = vocab / NV;
+    constexpr int TILE = BLOCK * UNROLL;
+    const int nfull = (nvec / TILE) * TILE;
+    for (int base = 0; base < nfull; base += TILE) {
+      vec v[UNROLL];
+#pragma unroll
+      for (int k = 0; k < UNROLL; ++k) v[k] = rv[base + k * BLOCK + tid];
+      float y[UNROLL * NV];
+#pragma unroll
+      for (int k = 0; k < UNROLL; ++k) {
+        float f[NV];
+        T::unpack(v[k], f);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) y[k * NV + i] = f[i] * k2;
+      }
+      osm_push<UNROLL * NV>(st, y);
+    }
+    for (int j = nfull + tid; j < nvec; j += BLOCK) {
+      float f[NV], y[NV];
+      T::unpack(rv[j], f);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) y[i] = f[i] * k2;
+      osm_push<NV>(st, y);
+    }
+    done = nvec * NV;
+  }
+  for (int j = done + tid; j < vocab; j += BLOCK) {
+    float y[1] = {T::to_float(row[j]) * k2};
+    osm_push<1>(st, y);
+  }
+  return osm_block_reduce<BLOCK>(st, lds);
+}
+
+// ---- pass 2: write d logits for one row --------------------------------------------
+//   dz_v = -g p_v - gH p_v (ln p_v + H);  d logit_v = (dz_v + g 1[v == id]) / temperature
+template <class T, int BLOCK, int UNROLL>
+__device__ __forceinline__ void row_write_grad(const typename T::scalar* row,
+                                               typename T::scalar* out, int vocab, float k2,
+                                               float inv_temp, float lse2, float H, float g,
+                                               float gH, int id, bool vec_ok) {
+  using vec = typename T::vec;
+  constexpr int NV = T::NV;
+  const int tid = threadIdx.x;
+  const float gi = g * inv_temp;
+  const float ngi = -g * inv_temp;
+  const float nhi = -gH * inv_temp;
+  const bool use_h = (gH != 0.0f);
+  auto one = [&](float x, int v) -> float {
+    const float d2 = __builtin_fmaf(x, k2, -lse2);  // log2 p
+    const float p = fast_exp2(d2);
+    float r = ngi * p;
+    if (use_h) r = __builtin_fmaf(nhi * p, __builtin_fmaf(d2, kLn2, H), r);
+    if (v == id) r += gi;
+    return r;
+  };
+  int done = 0;
+  if (vec_ok) {
+    const vec* rv = reinterpret_cast<const vec*>(row);
+    vec* ov = reinterpret_cast<vec*>(out);
+    const int nvec = vocab / NV;
+    constexpr int TILE = BLOCK * UNROLL;
+    const int nfull = (nvec / TILE) * TILE;
+    for (int base = 0; base < nfull; base += TILE) {
+      vec v[UNROLL];
+#pragma unroll
+      for (int k = 0; k < UNROLL; ++k) v[k] = rv[base + k * BLOCK + tid];
+#pragma unroll
+      for (int k = 0; k < UNROLL; ++k) {
+        const int j = base + k * BLOCK + tid;
+        float f[NV], o[NV];
+        T::unpack(v[k], f);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) o[i] = one(f[i], j * NV + i);
+        ov[j] = T::pack(o);
+      }
+    }
+    for (int j = nfull + tid; j < nvec; j += BLOCK) {
+      float f[NV], o[NV];
+      T::unpack(rv[j], f);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) o[i] = one(f[i], j * NV + i);
+      ov[j] = T::pack(o);
+    }
+    done = nvec * NV;
+  }
+  for (int j = done + tid; j < vocab; j += BLOCK)
+    out[j] = T::from_float(one(T::to_float(row[j]), j));
+}
+
+template <class T, int BLOCK>
+__device__ __forceinline__ void row_write_zero(typename T::scalar* out, int vocab, bool vec_ok) {
+  using vec = typename T::vec;
+  constexpr int NV = T::NV;
+  const int tid = threadIdx.x;
+  int done = 0;
+  if (vec_ok) {
+    vec* ov = reinterpret_cast<vec*>(out);
+    const int nvec = vocab / NV;
+    float z[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) z[i] = 0.0f;
+    const vec zv = T::pack(z);
+    for (int j = tid; j < nvec; j += BLOCK) ov[j] = zv;
+    done = nvec * NV;
+  }
+  for (int j = done + tid; j < vocab; j += BLOCK) out[j] = T::from_float(0.0f);
+}
+
+struct RowGeom {
+  int64_t n;     // rows * cols
+  int64_t cols;
+  int vocab;
+  int64_t stride;  // elements
+  int vec_ok;
+};
+
+// ---------------------------------------------------------------------------------------
+// forward: one workgroup per token-aligned output u (logits row u - 1)
+// ---------------------------------------------------------------------------------------
+template <class T, int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void logprob_entropy_fwd_kernel(
+    RowGeom geo, const typename T::scalar* __restrict__ logits, const int64_t* __restrict__ ids,
+    float k2, float* __restrict__ nlp, float* __restrict__ ent, float* __restrict__ lse2) {
+  __shared__ Osm lds[BLOCK / kWave];
+  const int64_t u = blockIdx.x;
+  const int64_t col = u % geo.cols;
+  if (col == 0) {
+    if (threadIdx.x == 0) {
+      nlp[u] = 0.0f;
+      ent[u] = 0.0f;
+      lse2[u] = 0.0f;
+    }
+    return;
+  }
+  const typename T::scalar* row = logits + (u - 1) * geo.stride;
+  const Osm st = row_softmax_stats<T, BLOCK, UNROLL>(row, geo.vocab, k2, geo.vec_ok, lds);
+  if (threadIdx.x == 0) {
+    const int64_t id = ids[u];
+    const float l2s = __log2f(st.S);
+    float y_sel = __builtin_nanf("");
+    if (id >= 0 && id < geo.vocab) y_sel = T::to_float(row[id]) * k2;
+    nlp[u] = (y_sel - st.M - l2s) * kLn2;
+    ent[u] = kLn2 * (l2s - st.W / st.S);
+    lse2[u] = st.M + l2s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward: one workgroup per logits row q (feeds token u = q + 1 unless q is a row's last)
+// ---------------------------------------------------------------------------------------
+template <class T, int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void logprob_entropy_bwd_kernel(
+    RowGeom geo, const typename T::scalar* logits, const int64_t* __restrict__ ids, float k2,
+    float inv_temp, const float* __restrict__ lse2, const float* __restrict__ ent,
+    const float* __restrict__ g_nlp, const float* __restrict__ g_ent,
+    const float* __restrict__ upstream, typename T::scalar* grad) {
+  const int64_t q = blockIdx.x;
+  const int64_t col = q % geo.cols;
+  typename T::scalar* out = grad + q * geo.stride;
+  float g = 0.0f, gH = 0.0f;
+  const int64_t u = q + 1;
+  if (col != geo.cols - 1) {
+    const float sc = upstream ? *upstream : 1.0f;
+    g = g_nlp[u] * sc;
+    gH = g_ent ? g_ent[u] * sc : 0.0f;
+  }
+  if (g == 0.0f && gH == 0.0f) {
+    row_write_zero<T, BLOCK>(out, geo.vocab, geo.vec_ok);
+    return;
+  }
+  const int64_t id64 = ids[u];
+  const int id = (id64 >= 0 && id64 < geo.vocab) ? (int)id64 : -1;
+  row_write_grad<T, BLOCK, UNROLL>(logits + q * geo.stride, out, geo.vocab, k2, inv_temp, lse2[u],
+                                   ent[u], g, gH, id, geo.vec_ok);
+}
+
+// ---------------------------------------------------------------------------------------
+// fused: forward stats -> token gradient -> d logits, one workgroup per logits row q
+// ---------------------------------------------------------------------------------------
+struct FusedArgs {
+  prl_loss_config cfg;
+  const int64_t* ids;
+  const int64_t* labels;
+  const float* old_lp;
+  const float* ref_lp;
+  const float* adv;
+  const float* reward;
+  const float* group_tokens;
+  const float* overflow;
+  float* nlp;
+  float* ent;
+  float* lse2;
+};
+
+template <class T, int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void fused_logits_loss_kernel(
+    RowGeom geo, FusedArgs a, const typename T::scalar* logits, float k2, float inv_temp,
+    typename T::scalar* grad) {
+  __shared__ Osm lds[BLOCK / kWave];
+  const int64_t q = blockIdx.x;
+  const int64_t col = q % geo.cols;
+  typename T::scalar* out = grad + q * geo.stride;
+  if (col == 0 && threadIdx.x == 0) {  // token-aligned column 0 has no prediction
+    a.nlp[q] = 0.0f;
+    a.ent[q] = 0.0f;
+    a.lse2[q] = 0.0f;
+  }
+  if (col == geo.cols - 1) {  // last logits row of a batch row predicts nothing
+    row_write_zero<T, BLOCK>(out, geo.vocab, geo.vec_ok);
+    return;
+  }
+  const int64_t u = q + 1;
+  const typename T::scalar* row = logits + q * geo.stride;
+  // read the selected logit BEFORE pass 1's barrier: with grad aliasing logits, pass 2 of a
+  // faster wave may already overwrite row[id] once the barrier has been passed.
+  const int64_t id64 = a.ids[u];
+  const int id = (id64 >= 0 && id64 < geo.vocab) ? (int)id64 : -1;
+  float y_sel = __builtin_nanf("");
+  if (id >= 0) y_sel = T::to_float(row[id]) * k2;
+  const Osm st = row_softmax_stats<T, BLOCK, UNROLL>(row, geo.vocab, k2, geo.vec_ok, lds);
+  const float l2s = __log2f(st.S);
+  const float nlp = (y_sel - st.M - l2s) * kLn2;
+  const float H = kLn2 * (l2s - st.W / st.S);
+  const float lse2 = st.M + l2s;
+  if (threadIdx.x == 0) {
+    a.nlp[u] = nlp;
+    a.ent[u] = H;
+    a.lse2[u] = lse2;
+  }
+  const bool m = a.labels[u] != -100;
+  float g = 0.0f, gH = 0.0f;
+  if (m) {
+    PrlTokenIn x{nlp,      H,           a.old_lp[u],       a.ref_lp[u], a.adv[u],
+                 a.reward[u], a.group_tokens[u], 1.0f /*num_labels unused*/, a.overflow[u]};
+    prl_token_grad(a.cfg, x, 1, &g, &gH);
+  }
+  if (g == 0.0f && gH == 0.0f) {
+    row_write_zero<T, BLOCK>(out, geo.vocab, geo.vec_ok);
+    return;
+  }
+  row_write_grad<T, BLOCK, UNROLL>(row, out, geo.vocab, k2, inv_temp, lse2, H, g, gH, id,
+                                   geo.vec_ok);
+}
+
+// ---- host-side dispatch ---------------------------------------------------------------
+constexpr int kBlock = 256;
+constexpr int kUnrollFwd = 8;
+constexpr int kUnrollBwd = 4;
+
+int check_geom(int64_t rows, int64_t cols, int64_t vocab, const void* logits, int32_t dtype,
+               int64_t stride, RowGeom* geo) {
+  PRL_CHECK_ARG(rows >= 1 && cols >= 1, "rows and cols must be >= 1");
+  PRL_CHECK_ARG(vocab >= 1 && vocab < (int64_t)1 << 31, "vocab out of range: %lld", (long long)vocab);
+  PRL_CHECK_ARG(dtype == PRL_DTYPE_F32 || dtype == PRL_DTYPE_BF16, "unsupported logits dtype %d", dtype);
+  PRL_CHECK_ARG(stride >= vocab, "logits_row_stride %lld < vocab %lld", (long long)stride, (long long)vocab);
+  PRL_CHECK_ARG(rows * cols < ((int64_t)1 << 31), "too many logits rows for one launch: %lld",
+                (long long)(rows * cols));
+  PRL_CHECK_ARG(logits != nullptr, "logits is null");
+  const int esz = dtype == PRL_DTYPE_F32 ? 4 : 2;
+  geo->n = rows * cols;
+  geo->cols = cols;
+  geo->vocab = (int)vocab;
+  geo->stride = stride;
+  geo->vec_ok = prl::aligned16(logits) && ((stride * esz) % 16 == 0);
+  return PRL_OK;
+}
+
+}  // namespace
+
+extern "C" int prl_logprob_entropy_fwd(int64_t rows, int64_t cols, int64_t vocab,
+                                       const void* logits, int32_t logits_dtype,
+                                       int64_t logits_row_stride, const int64_t* input_ids,
+                                       float temperature, float* new_logprobs, float* entropy,
+                                       float* lse2, prl_stream_t stream) {
+  RowGeom geo;
+  if (int rc = check_geom(rows, cols, vocab, logits, logits_dtype, logits_row_stride, &geo)) return rc;
+  PRL_CHECK_ARG(input_ids && new_logprobs && entropy && lse2, "null pointer");
+  PRL_CHECK_ARG(temperature > 0.0f, "temperature must be > 0");
+  const float k2 = kLog2e / temperature;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)geo.n), block(kBlock);
+  if (logits_dtype == PRL_DTYPE_F32) {
+    hipLaunchKernelGGL((logprob_entropy_fwd_kernel<F32, kBlock, kUnrollFwd>), grid, block, 0, s, geo,
+                       static_cast<const float*>(logits), input_ids, k2, new_logprobs, entropy, lse2);
+  } else {
+    hipLaunchKernelGGL((logprob_entropy_fwd_kernel<BF16, kBlock, kUnrollFwd>), grid, block, 0, s, geo,
+                       static_cast<const uint16_t*>(logits), input_ids, k2, new_logprobs, entropy,
+                       lse2);
+  }
+  PRL_LAUNCH_CHECK("logprob_entropy_fwd_kernel");
+  return PRL_OK;
+}
+
+extern "C" int prl_logprob_entropy_bwd(int64_t rows, int64_t cols, int64_t vocab,
+                                       const void* logits, int32_t logits_dtype,
+                                       int64_t logits_row_stride, const int64_t* input_ids,
+                                       float temperature, const float* lse2, const float* entropy,
+                                       const float* grad_new_logprobs, const float* grad_entropy,
+                                       const float* upstream, void* grad_logits,
+                                       prl_stream_t stream) {
+  RowGeom geo;
+  if (int rc = check_geom(rows, cols, vocab, logits, logits_dtype, logits_row_stride, &geo)) return rc;
+  PRL_CHECK_ARG(input_ids && lse2 && entropy && grad_new_logprobs && grad_logits, "null pointer");
+  PRL_CHECK_ARG(temperature > 0.0f, "temperature must be > 0");
+  geo.vec_ok = geo.vec_ok && prl::aligned16(grad_logits);
+  const float k2 = kLog2e / temperature;
+  const float inv_temp = 1.0f / temperature;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)geo.n), block(kBlock);
+  if (logits_dtype == PRL_DTYPE_F32) {
+    hipLaunchKernelGGL((logprob_entropy_bwd_kernel<F32, kBlock, kUnrollBwd>), grid, block, 0, s, geo,
+                       static_cast<const float*>(logits), input_ids, k2, inv_temp, lse2, entropy,
+                       grad_new_logprobs, grad_entropy, upstream, static_cast<float*>(grad_logits));
+  } else {
+    hipLaunchKernelGGL((logprob_entropy_bwd_kernel<BF16, kBlock, kUnrollBwd>), grid, block, 0, s, geo,
+                       static_cast<const uint16_t*>(logits), input_ids, k2, inv_temp, lse2, entropy,
+                       grad_new_logprobs, grad_entropy, upstream,
+                       static_cast<uint16_t*>(grad_logits));
+  }
+  PRL_LAUNCH_CHECK("logprob_entropy_bwd_kernel");
+  return PRL_OK;
+}
+
+extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, int64_t cols,
+                                     int64_t vocab, const void* logits, int32_t logits_dtype,
+                                     int64_t logits_row_stride, float temperature,
+                                     const int64_t* input_ids, const int64_t* labels,
+                                     const float* old_logprobs, const float* ref_logprobs,
+                                     const float* advantages, const float* rewards,
+                                     const float* group_tokens, const float* overflow,
+                                     float* new_logprobs, float* entropy, float* lse2,
+                                     void* grad_logits, prl_stream_t stream) {
+  RowGeom geo;
+  if (int rc = check_geom(rows, cols, vocab, logits, logits_dtype, logits_row_stride, &geo)) return rc;
+  PRL_CHECK_ARG(cfg != nullptr, "cfg is null");
+  PRL_CHECK_ARG(cfg->policy_loss == PRL_POLICY_PPO || cfg->policy_loss == PRL_POLICY_REINFORCE,
+                "unknown policy_loss %d", cfg->policy_loss);
+  PRL_CHECK_ARG(input_ids && labels && old_logprobs && ref_logprobs && advantages && rewards &&
+                    group_tokens && overflow && new_logprobs && entropy && lse2 && grad_logits,
+                "null pointer");
+  PRL_CHECK_ARG(temperature > 0.0f, "temperature must be > 0");
+  geo.vec_ok = geo.vec_ok && prl::aligned16(grad_logits);
+  FusedArgs a{*cfg,      input_ids, labels,       old_logprobs, ref_logprobs, advantages,
+              rewards,   group_tokens, overflow,  new_logprobs, entropy,      lse2};
+  const float k2 = kLog2e / temperature;
+  const float inv_temp = 1.0f / temperature;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)geo.n), block(kBlock);
+  if (logits_dtype == PRL_DTYPE_F32) {
+    hipLaunchKernelGGL((fused_logits_loss_kernel<F32, kBlock, kUnrollBwd>), grid, block, 0, s, geo, a,
+                       static_cast<const float*>(logits), k2, inv_temp,
+                       static_cast<float*>(grad_logits));
+  } else {
+    hipLaunchKernelGGL((fused_logits_loss_kernel<BF16, kBlock, kUnrollBwd>), grid, block, 0, s, geo, a,
+                       static_cast<const uint16_t*>(logits), k2, inv_temp,
+                       static_cast<uint16_t*>(grad_logits));
+  }
+  PRL_LAUNCH_CHECK("fused_logits_loss_kernel");
+  return PRL_OK;
+}

@@ -1,0 +1,497 @@
+// K2 + K3: GRPO / PPO / REINFORCE token loss, masked reduction, 32 statistics and
+// d loss / d new_logprobs in ONE streaming pass (reference
+// pipelinerl/finetune/rl/__init__.py:238-439 + rl/utils.py:26-92, which issue ~25
+// elementwise launches, a Python loop over segments and ~31 .item() host syncs).
+//
+// HBM-bound: 56 algorithmic bytes per token (labels i64 + position_ids i64 + nine
+// fp32 columns in, one fp32 gradient out).  Layout: every column is read with 16-byte
+// vector loads on the UNSHIFTED axis (4 tokens per lane per iteration, 13 independent
+// 16-byte loads in flight per lane); per-lane fp64 partial sums -> wave64 shuffle
+// reduction -> per-block partial record -> a second tiny kernel reduces the per-block
+// records in a fixed order (bitwise reproducible, no atomics, no host sync).
+//
+// Segment handling: the reference sums per packed segment and then across segments
+// (sum_sum).  The segments tile the shifted axis exactly once, so the result is the
+// plain masked sum; position_ids are still read to count sequence starts
+// (num_sequences scales the kl_coef / entropy_bonus_coef stats, rl/__init__.py:431-432).
+
+#include "prl_common.h"
+#include "prl_token_math.h"
+
+namespace {
+
+using prl::kWave;
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxBlocks = 2048;  // 256 CUs x 8 resident blocks
+
+// per-block partial record (doubles)
+enum {
+  P_LOSS = 0,       // sum of nan_to_num(loss_t * w)
+  P_REWARD,         // sum reward / num_labels
+  P_ENTROPY,
+  P_OLD,
+  P_NEW,
+  P_REF,
+  P_ADV,
+  P_KL,
+  P_KL_NO,
+  P_ABS_LR,
+  P_RATIO,
+  P_RATIO_SUM,
+  P_RATIO_SQ,
+  P_RATIO_REF_NEW,
+  P_RATIO_REF_OLD,
+  P_CLAMP_RN,
+  P_CLAMP_NO,
+  P_TW,
+  P_NUM_SUMS,  // = 18
+  P_N_MASKED = P_NUM_SUMS,
+  P_N_SEQ,
+  P_BAD_NLP,
+  P_BAD_LRRN,
+  P_BAD_KL,
+  P_BAD_GT,   // group_tokens <= 0 under group_normalization (reference assert :247)
+  P_NUM_ADD,  // = 24 additive entries
+  P_MAX_REWARD = P_NUM_ADD,
+  P_MAX_ADV,
+  P_MAX_KL,
+  P_MAX_TW,
+  P_MIN_REWARD,
+  P_MIN_ADV,
+  P_MIN_KL,
+  P_MIN_TW,
+  P_NUM = 32
+};
+static_assert(P_MIN_TW + 1 <= P_NUM, "partial record overflow");
+
+struct LossArgs {
+  prl_loss_config cfg;
+  int64_t n;     // rows * cols
+  int64_t cols;
+  int packed;    // rows == 1 (position_ids counted when non-null)
+  const int64_t* labels;
+  const int64_t* position_ids;
+  const float* nlp;
+  const float* ent;
+  const float* old_lp;
+  const float* ref_lp;
+  const float* adv;
+  const float* reward;
+  const float* group_tokens;
+  const float* num_labels;
+  const float* overflow;
+  float* g_nlp;
+  float* g_ent;
+  double* partials;  // [gridDim.x][P_NUM]
+};
+
+struct Acc {
+  double s[P_NUM_ADD];
+  float mx[4];
+  float mn[4];
+};
+
+__device__ __forceinline__ void acc_init(Acc& a) {
+#pragma unroll
+  for (int i = 0; i < P_NUM_ADD; ++i) a.s[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a.mx[i] = -INFINITY;
+    a.mn[i] = INFINITY;
+  }
+}
+
+// mask_sum element: (x / num_labels * mask).nan_to_num(0) for a masked token
+__device__ __forceinline__ double per_label(float x, float nl) {
+  return (double)prl_nan_to_num0(x / nl);
+}
+
+// One token on the unshifted axis. `valid_pos`: column >= 1 (a shifted position exists).
+__device__ __forceinline__ void token_step(const LossArgs& a, Acc& acc, bool valid_pos,
+                                           int64_t label, bool seq_start, float nlp,
+                                           float ent, float old_lp, float ref_lp, float adv,
+                                           float reward, float gt, float nl, float ovf,
+                                           float& g_nlp, float& g_ent) {
+  g_nlp = 0.0f;
+  g_ent = 0.0f;
+  if (seq_start) acc.s[P_N_SEQ] += 1.0;
+  if (!valid_pos) return;
+  if (a.cfg.group_normalization && !(gt > 0.0f)) acc.s[P_BAD_GT] += 1.0;
+  const bool m = (label != -100);
+  if (!m) {
+    int b0, b1, b2;
+    prl_token_flags(a.cfg, nlp, ref_lp, &b0, &b1, &b2);
+    acc.s[P_BAD_NLP] += b0;
+    acc.s[P_BAD_LRRN] += b1;
+    acc.s[P_BAD_KL] += b2;
+    return;
+  }
+  PrlTokenIn x{nlp, ent, old_lp, ref_lp, adv, reward, gt, nl, ovf};
+  PrlTokenOut o;
+  prl_token_eval(a.cfg, x, o);
+  g_nlp = o.g_nlp;
+  g_ent = o.g_ent;
+  acc.s[P_LOSS] += (double)o.contrib;
+  acc.s[P_REWARD] += per_label(reward, nl);
+  acc.s[P_ENTROPY] += per_label(ent, nl);
+  acc.s[P_OLD] += per_label(old_lp, nl);
+  acc.s[P_NEW] += per_label(nlp, nl);
+  acc.s[P_REF] += per_label(ref_lp, nl);
+  acc.s[P_ADV] += per_label(adv, nl);
+  acc.s[P_KL] += per_label(o.kl, nl);
+  acc.s[P_KL_NO] += per_label(o.kl_new_old, nl);
+  acc.s[P_ABS_LR] += per_label(o.abs_lrno, nl);
+  acc.s[P_RATIO] += per_label(o.ratio_stat, nl);
+  acc.s[P_RATIO_SUM] += (double)prl_nan_to_num0(o.ratio_stat);
+  acc.s[P_RATIO_SQ] += (double)prl_nan_to_num0(o.ratio_stat * o.ratio_stat);
+  acc.s[P_RATIO_REF_NEW] += per_label(o.exp_lrrn, nl);
+  acc.s[P_RATIO_REF_OLD] += per_label(o.exp_ref_old, nl);
+  acc.s[P_CLAMP_RN] += per_label(o.clamp_rn, nl);
+  acc.s[P_CLAMP_NO] += per_label(o.clamp_no, nl);
+  acc.s[P_TW] += per_label(o.w, nl);
+  acc.s[P_N_MASKED] += 1.0;
+  acc.s[P_BAD_NLP] += o.bad_nlp;
+  acc.s[P_BAD_LRRN] += o.bad_lrrn;
+  acc.s[P_BAD_KL] += o.bad_kl;
+  acc.mx[0] = fmaxf(acc.mx[0], reward);
+  acc.mn[0] = fminf(acc.mn[0], reward);
+  acc.mx[1] = fmaxf(acc.mx[1], adv);
+  acc.mn[1] = fminf(acc.mn[1], adv);
+  acc.mx[2] = fmaxf(acc.mx[2], o.kl);
+  acc.mn[2] = fminf(acc.mn[2], o.kl);
+  acc.mx[3] = fmaxf(acc.mx[3], o.w);
+  acc.mn[3] = fminf(acc.mn[3], o.w);
+}
+
+__device__ __forceinline__ void block_reduce_store(const Acc& acc, double* out) {
+  __shared__ double lds[kWavesPerBlock][P_NUM];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x / kWave;
+#pragma unroll
+  for (int i = 0; i < P_NUM_ADD; ++i) {
+    double v = prl::wave_sum(acc.s[i]);
+    if (lane == 0) lds[wid][i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float vx = prl::wave_max(acc.mx[i]);
+    float vn = prl::wave_min(acc.mn[i]);
+    if (lane == 0) {
+      lds[wid][P_MAX_REWARD + i] = (double)vx;
+      lds[wid][P_MIN_REWARD + i] = (double)vn;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < P_NUM) {
+    const int i = threadIdx.x;
+    double v = lds[0][i];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) {
+      const double o = lds[w][i];
+      if (i < P_NUM_ADD) {
+        v += o;
+      } else if (i < P_MIN_REWARD) {
+        v = fmax(v, o);
+      } else {
+        v = fmin(v, o);
+      }
+    }
+    out[i] = v;
+  }
+}
+
+// VEC = 4: all base pointers 16-byte aligned; the n % 4 tail is handled by block 0's
+// first lanes with scalar accesses.  VEC = 1: fully scalar fallback for odd views.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
+  Acc acc;
+  acc_init(acc);
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  const bool count_pos = a.packed && a.position_ids != nullptr;
+  const bool flat = count_pos && a.cfg.flat_micro_batches;
+
+  if constexpr (VEC == 4) {
+    const int64_t n4 = a.n >> 2;
+    for (int64_t i = tid; i < n4; i += nthreads) {
+      const int64_t u0 = i << 2;
+      const longlong2 lab01 = *reinterpret_cast<const longlong2*>(a.labels + u0);
+      const longlong2 lab23 = *reinterpret_cast<const longlong2*>(a.labels + u0 + 2);
+      longlong2 pos01 = make_longlong2(1, 1), pos23 = make_longlong2(1, 1);
+      if (count_pos) {
+        pos01 = *reinterpret_cast<const longlong2*>(a.position_ids + u0);
+        pos23 = *reinterpret_cast<const longlong2*>(a.position_ids + u0 + 2);
+      }
+      const float4 nlp = *reinterpret_cast<const float4*>(a.nlp + u0);
+      const float4 ent = *reinterpret_cast<const float4*>(a.ent + u0);
+      const float4 old = *reinterpret_cast<const float4*>(a.old_lp + u0);
+      const float4 ref = *reinterpret_cast<const float4*>(a.ref_lp + u0);
+      const float4 adv = *reinterpret_cast<const float4*>(a.adv + u0);
+      const float4 rew = *reinterpret_cast<const float4*>(a.reward + u0);
+      const float4 gt = *reinterpret_cast<const float4*>(a.group_tokens + u0);
+      const float4 nl = *reinterpret_cast<const float4*>(a.num_labels + u0);
+      const float4 ov = *reinterpret_cast<const float4*>(a.overflow + u0);
+
+      const int64_t lab[4] = {lab01.x, lab01.y, lab23.x, lab23.y};
+      const int64_t pos[4] = {pos01.x, pos01.y, pos23.x, pos23.y};
+      const float f_nlp[4] = {nlp.x, nlp.y, nlp.z, nlp.w};
+      const float f_ent[4] = {ent.x, ent.y, ent.z, ent.w};
+      const float f_old[4] = {old.x, old.y, old.z, old.w};
+      const float f_ref[4] = {ref.x, ref.y, ref.z, ref.w};
+      const float f_adv[4] = {adv.x, adv.y, adv.z, adv.w};
+      const float f_rew[4] = {rew.x, rew.y, rew.z, rew.w};
+      const float f_gt[4] = {gt.x, gt.y, gt.z, gt.w};
+      const float f_nl[4] = {nl.x, nl.y, nl.z, nl.w};
+      const float f_ov[4] = {ov.x, ov.y, ov.z, ov.w};
+      // column of the first element of the group (cols may be any value >= 1)
+      int64_t col = a.packed ? u0 : (u0 % a.cols);
+      float g[4], gh[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool valid_pos = (col != 0) && !(flat && pos[k] == 0);
+        const bool seq_start = count_pos && (pos[k] == 0 || (u0 + k) == 0);
+        token_step(a, acc, valid_pos, lab[k], seq_start, f_nlp[k], f_ent[k], f_old[k],
+                   f_ref[k], f_adv[k], f_rew[k], f_gt[k], f_nl[k], f_ov[k], g[k], gh[k]);
+        ++col;
+        if (!a.packed && col == a.cols) col = 0;
+      }
+      if (a.g_nlp) *reinterpret_cast<float4*>(a.g_nlp + u0) = make_float4(g[0], g[1], g[2], g[3]);
+      if (a.g_ent)
+        *reinterpret_cast<float4*>(a.g_ent + u0) = make_float4(gh[0], gh[1], gh[2], gh[3]);
+    }
+  }
+
+  // scalar path: whole range for VEC == 1, the n % 4 tail for VEC == 4
+  {
+    const int64_t begin = (VEC == 4) ? ((a.n >> 2) << 2) : 0;
+    for (int64_t u = begin + tid; u < a.n; u += nthreads) {
+      const int64_t col = a.packed ? u : (u % a.cols);
+      const bool seq_start = count_pos && (a.position_ids[u] == 0 || u == 0);
+      float g, gh;
+      token_step(a, acc, (col != 0) && !(flat && a.position_ids[u] == 0), a.labels[u], seq_start, a.nlp[u], a.ent[u], a.old_lp[u],
+                 a.ref_lp[u], a.adv[u], a.reward[u], a.group_tokens[u], a.num_labels[u],
+                 a.overflow[u], g, gh);
+      if (a.g_nlp) a.g_nlp[u] = g;
+      if (a.g_ent) a.g_ent[u] = gh;
+    }
+  }
+
+  block_reduce_store(acc, a.partials + (int64_t)blockIdx.x * P_NUM);
+}
+
+// Reduce the per-block records in a fixed order and emit the public stats vector.
+__global__ __launch_bounds__(kBlock) void grpo_loss_finalize_kernel(const double* partials,
+                                                                    int nblocks, int64_t rows,
+                                                                    int packed_counted,
+                                                                    double* stats,
+                                                                    float* loss_out) {
+  __shared__ double lds[8][P_NUM];
+  __shared__ double red[P_NUM];
+  const int i = threadIdx.x & (P_NUM - 1);  // entry
+  const int k = threadIdx.x / P_NUM;        // sub-lane 0..7
+  double v = (i < P_NUM_ADD) ? 0.0 : ((i < P_MIN_REWARD) ? -INFINITY : INFINITY);
+  for (int b = k; b < nblocks; b += 8) {
+    const double o = partials[(int64_t)b * P_NUM + i];
+    if (i < P_NUM_ADD) {
+      v += o;
+    } else if (i < P_MIN_REWARD) {
+      v = fmax(v, o);
+    } else {
+      v = fmin(v, o);
+    }
+  }
+  lds[k][i] = v;
+  __syncthreads();
+  if (threadIdx.x < P_NUM) {
+    double r = lds[0][i];
+    for (int j = 1; j < 8; ++j) {
+      const double o = lds[j][i];
+      if (i < P_NUM_ADD) {
+        r += o;
+      } else if (i < P_MIN_REWARD) {
+        r = fmax(r, o);
+      } else {
+        r = fmin(r, o);
+      }
+    }
+    red[i] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int j = 0; j < PRL_NUM_STATS; ++j) stats[j] = 0.0;
+    // final loss in fp32 like the reference's scalar (rl/__init__.py:365)
+    const double loss = -red[P_LOSS];
+    stats[PRL_STAT_LOSS] = loss;
+    stats[PRL_STAT_NUM_OUTPUT_TOKENS] = red[P_N_MASKED];
+    stats[PRL_STAT_NUM_SEQUENCES] = packed_counted ? red[P_N_SEQ] : (double)rows;
+    stats[PRL_STAT_REWARD] = red[P_REWARD];
+    stats[PRL_STAT_MAX_REWARD] = red[P_MAX_REWARD];
+    stats[PRL_STAT_MIN_REWARD] = red[P_MIN_REWARD];
+    stats[PRL_STAT_ENTROPY] = red[P_ENTROPY];
+    stats[PRL_STAT_OLD_LOGPROBS] = red[P_OLD];
+    stats[PRL_STAT_NEW_LOGPROBS] = red[P_NEW];
+    stats[PRL_STAT_REF_LOGPROBS] = red[P_REF];
+    stats[PRL_STAT_ADVANTAGE] = red[P_ADV];
+    stats[PRL_STAT_MAX_ADVANTAGE] = red[P_MAX_ADV];
+    stats[PRL_STAT_MIN_ADVANTAGE] = red[P_MIN_ADV];
+    stats[PRL_STAT_KL] = red[P_KL];
+    stats[PRL_STAT_KL_NEW_OLD] = red[P_KL_NO];
+    stats[PRL_STAT_MEAN_ABS_LOG_RATIO_NEW_OLD] = red[P_ABS_LR];
+    stats[PRL_STAT_MAX_KL] = red[P_MAX_KL];
+    stats[PRL_STAT_MIN_KL] = red[P_MIN_KL];
+    stats[PRL_STAT_RATIO_NEW_OLD] = red[P_RATIO];
+    stats[PRL_STAT_RATIO_NEW_OLD_SUM] = red[P_RATIO_SUM];
+    stats[PRL_STAT_RATIO_NEW_OLD_SQUARED_SUM] = red[P_RATIO_SQ];
+    stats[PRL_STAT_RATIO_REF_NEW] = red[P_RATIO_REF_NEW];
+    stats[PRL_STAT_RATIO_REF_OLD] = red[P_RATIO_REF_OLD];
+    stats[PRL_STAT_CLAMP_REF_NEW_INDICATOR] = red[P_CLAMP_RN];
+    stats[PRL_STAT_CLAMP_NEW_OLD_INDICATOR] = red[P_CLAMP_NO];
+    stats[PRL_STAT_TOKEN_WEIGHT] = red[P_TW];
+    stats[PRL_STAT_MAX_TOKEN_WEIGHT] = red[P_MAX_TW];
+    stats[PRL_STAT_MIN_TOKEN_WEIGHT] = red[P_MIN_TW];
+    stats[PRL_STAT_NONFINITE_NEW_LOGPROBS] = red[P_BAD_NLP];
+    stats[PRL_STAT_NONFINITE_LOG_RATIO_REF_NEW] = red[P_BAD_LRRN];
+    stats[PRL_STAT_NONFINITE_KL] = red[P_BAD_KL];
+    stats[PRL_STAT_BAD_GROUP_TOKENS] = red[P_BAD_GT];
+    if (loss_out) *loss_out = (float)loss;
+  }
+}
+
+int grid_for(int64_t n, int vec) {
+  const int64_t items = (n + vec - 1) / vec;
+  int64_t blocks = (items + kBlock - 1) / kBlock;
+  if (blocks < 1) blocks = 1;
+  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" int prl_grpo_loss_workspace_bytes(int64_t rows, int64_t cols, size_t* bytes) {
+  PRL_CHECK_ARG(bytes != nullptr, "bytes is null");
+  PRL_CHECK_ARG(rows >= 0 && cols >= 0, "negative shape");
+  (void)rows;
+  (void)cols;
+  *bytes = (size_t)kMaxBlocks * P_NUM * sizeof(double);
+  return PRL_OK;
+}
+
+extern "C" int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, int64_t cols,
+                                     const int64_t* labels, const int64_t* position_ids,
+                                     const float* new_logprobs, const float* entropy,
+                                     const float* old_logprobs, const float* ref_logprobs,
+                                     const float* advantages, const float* rewards,
+                                     const float* group_tokens, const float* num_labels,
+                                     const float* overflow, float* grad_new_logprobs,
+                                     float* grad_entropy, float* loss_out, double* stats,
+                                     void* workspace, size_t workspace_bytes,
+                                     prl_stream_t stream) {
+  PRL_CHECK_ARG(cfg != nullptr, "cfg is null");
+  PRL_CHECK_ARG(rows >= 1 && cols >= 1, "rows and cols must be >= 1 (got %lld x %lld)",
+                (long long)rows, (long long)cols);
+  PRL_CHECK_ARG(cfg->policy_loss == PRL_POLICY_PPO || cfg->policy_loss == PRL_POLICY_REINFORCE,
+                "unknown policy_loss %d", cfg->policy_loss);
+  PRL_CHECK_ARG(labels && new_logprobs && entropy && old_logprobs && ref_logprobs && advantages &&
+                    rewards && group_tokens && num_labels && overflow && stats,
+                "null input pointer");
+  PRL_CHECK_ARG(workspace != nullptr, "workspace is null");
+  PRL_CHECK_ARG(!cfg->flat_micro_batches || (rows == 1 && position_ids != nullptr),
+                "flat_micro_batches needs a packed [1, T] batch with position_ids");
+  size_t need = 0;
+  prl_grpo_loss_workspace_bytes(rows, cols, &need);
+  if (workspace_bytes < need)
+    return prl::set_error(PRL_ENOMEM, "workspace too small: %zu < %zu", workspace_bytes, need);
+
+  LossArgs a;
+  a.cfg = *cfg;
+  a.n = rows * cols;
+  a.cols = cols;
+  a.packed = (rows == 1);
+  a.labels = labels;
+  a.position_ids = position_ids;
+  a.nlp = new_logprobs;
+  a.ent = entropy;
+  a.old_lp = old_logprobs;
+  a.ref_lp = ref_logprobs;
+  a.adv = advantages;
+  a.reward = rewards;
+  a.group_tokens = group_tokens;
+  a.num_labels = num_labels;
+  a.overflow = overflow;
+  a.g_nlp = grad_new_logprobs;
+  a.g_ent = grad_entropy;
+  a.partials = static_cast<double*>(workspace);
+
+  const bool vec_ok = prl::aligned16(labels) && (!position_ids || prl::aligned16(position_ids)) &&
+                      prl::aligned16(new_logprobs) && prl::aligned16(entropy) &&
+                      prl::aligned16(old_logprobs) && prl::aligned16(ref_logprobs) &&
+                      prl::aligned16(advantages) && prl::aligned16(rewards) &&
+                      prl::aligned16(group_tokens) && prl::aligned16(num_labels) &&
+                      prl::aligned16(overflow) &&
+                      (!grad_new_logprobs || prl::aligned16(grad_new_logprobs)) &&
+                      (!grad_entropy || prl::aligned16(grad_entropy));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int nblocks;
+  if (vec_ok) {
+    nblocks = grid_for(a.n, 4);
+    hipLaunchKernelGGL(grpo_loss_partial_kernel<4>, dim3(nblocks), dim3(kBlock), 0, s, a);
+  } else {
+    nblocks = grid_for(a.n, 1);
+    hipLaunchKernelGGL(grpo_loss_partial_kernel<1>, dim3(nblocks), dim3(kBlock), 0, s, a);
+  }
+  PRL_LAUNCH_CHECK("grpo_loss_partial_kernel");
+  const int packed_counted = (a.packed && position_ids != nullptr) ? 1 : 0;
+  hipLaunchKernelGGL(grpo_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, a.partials, nblocks,
+                     rows, packed_counted, stats, loss_out);
+  PRL_LAUNCH_CHECK("grpo_loss_finalize_kernel");
+  return PRL_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// GSPO helper: per-segment masked sums (reference rl/utils.py:106-208, index_add_ x3).
+// One wave-level pre-reduction per run of equal segment ids would be faster, but GSPO is
+// not on any BASELINE config; a straightforward fp64 atomic scatter keeps it correct.
+// --------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(kBlock) void segment_sums_kernel(int64_t cols, int32_t n_segments,
+                                                              const int64_t* seg,
+                                                              const int64_t* labels,
+                                                              const float* a, const float* b,
+                                                              double* a_sum, double* b_sum,
+                                                              double* count) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t u = 1 + (int64_t)blockIdx.x * kBlock + threadIdx.x; u < cols; u += stride) {
+    if (labels[u] == -100) continue;
+    const int64_t s = seg[u];
+    if (s < 0 || s >= n_segments) continue;
+    atomicAdd(&count[s], 1.0);
+    atomicAdd(&a_sum[s], (double)a[u]);
+    atomicAdd(&b_sum[s], (double)b[u]);
+  }
+}
+
+}  // namespace
+
+extern "C" int prl_segment_sums(int64_t cols, int32_t n_segments, const int64_t* segment_ids,
+                                const int64_t* labels, const float* a, const float* b,
+                                double* a_sum, double* b_sum, double* count,
+                                prl_stream_t stream) {
+  PRL_CHECK_ARG(cols >= 0 && n_segments >= 0, "negative shape");
+  PRL_CHECK_ARG(segment_ids && labels && a && b && a_sum && b_sum && count, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_segments > 0) {
+    PRL_HIP_CHECK(hipMemsetAsync(a_sum, 0, sizeof(double) * n_segments, s));
+    PRL_HIP_CHECK(hipMemsetAsync(b_sum, 0, sizeof(double) * n_segments, s));
+    PRL_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(double) * n_segments, s));
+  }
+  if (cols > 1 && n_segments > 0) {
+    const int nblocks = grid_for(cols, 1);
+    hipLaunchKernelGGL(segment_sums_kernel, dim3(nblocks), dim3(kBlock), 0, s, cols, n_segments,
+                       segment_ids, labels, a, b, a_sum, b_sum, count);
+    PRL_LAUNCH_CHECK("segment_sums_kernel");
+  }
+  return PRL_OK;
+}

@@ -1,0 +1,333 @@
+"""Sample preparation and pad / pack collation (drop-in for reference
+pipelinerl/finetune/data.py:111-283) on top of the K6/K7 kernels.
+
+Two levels:
+
+* `pack_prepared` / `pad_prepared`: the MI355X path.  Inputs are `PreparedRollouts` (ragged SoA
+  buffers + per-sequence scalars, already in HBM); one launch writes a whole optimizer step's
+  micro-batches back to back and the returned `PipelineBatchEncoding`s are views.
+* `collate_packed` / `collate` / `preprocess_fn`: the reference's list-of-dicts signatures, for
+  callers that still hold python lists.  They flatten the lists to ragged arrays, upload, and
+  run the same kernels (per-token columns are honoured through `per_token_columns`).
+"""
+
+from __future__ import annotations
+
+import logging
+from typing import Any, Iterable, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..ragged import RaggedRollouts
+from .rl import RL_DATA_COLUMNS, PreparedRollouts, prepare_rl_fields
+from .types import PipelineBatchEncoding
+from .utils import create_sentinel_example
+
+logger = logging.getLogger(__name__)
+
+MASKED_TOKEN_ID = -100  # ignore_index of the LM loss
+
+# bit positions of `per_token_columns` (include/prl.h)
+_PER_TOKEN_BITS = {"rewards": 1, "advantages": 2, "group_tokens": 4, "num_labels": 8, "overflow": 16}
+
+
+# ---------------------------------------------------------------------------------------------
+# device level
+# ---------------------------------------------------------------------------------------------
+
+
+def _alloc_outputs(total: int, dev: torch.device, packed: bool) -> dict[str, torch.Tensor]:
+    names_i64 = ["input_ids", "labels", "attention_mask"] + (["position_ids", "segment_ids"] if packed else [])
+    out = {k: torch.empty(total, dtype=torch.int64, device=dev) for k in names_i64}
+    for k in ("rewards", "advantages", "ref_logprobs", "old_logprobs", "group_tokens", "num_labels", "overflow"):
+        out[k] = torch.empty(total, dtype=torch.float32, device=dev)
+    return out
+
+
+def pack_prepared(
+    prep: PreparedRollouts,
+    micro_batches: Sequence[Sequence[int]],
+    eos_token_id: int,
+    sentinel_pad: Sequence[int] | None = None,
+    per_token_columns: int = 0,
+    with_flat: bool = False,
+) -> list[PipelineBatchEncoding] | tuple[list[PipelineBatchEncoding], dict[str, torch.Tensor]]:
+    """Pack `micro_batches[j]` (lists of sequence indices into `prep`) into packed batches with a
+    single K6 launch.  `sentinel_pad[j]` > 0 appends that many filler tokens to micro-batch j
+    (sequence-parallel padding, reference data.py:222-230).  Returns one batch per micro-batch;
+    their tensors are views of shared flat buffers (also returned, as 1-D tensors over all the
+    step's tokens, when `with_flat`)."""
+    lib = _lib.load()
+    r = prep.rollouts
+    dev = r.device
+    lens = r.seq_lengths()
+    pk_src: list[int] = []
+    pk_seg: list[int] = []
+    pk_len: list[int] = []
+    mb_off = [0]
+    mb_nseq = []
+    for j, idxs in enumerate(micro_batches):
+        pad = int(sentinel_pad[j]) if sentinel_pad is not None else 0
+        for k, s in enumerate(idxs):
+            pk_src.append(int(s))
+            pk_seg.append(k)
+            pk_len.append(int(lens[s]))
+        n = len(idxs)
+        if pad:
+            pk_src.append(-1)
+            pk_seg.append(n)
+            pk_len.append(pad)
+            n += 1
+        mb_nseq.append(n)
+        mb_off.append(mb_off[-1] + n)
+    m = len(pk_src)
+    pk_dst = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(np.asarray(pk_len, dtype=np.int64), out=pk_dst[1:])
+    total = int(pk_dst[-1])
+    out = _alloc_outputs(total, dev, packed=True)
+    d_src = torch.from_numpy(np.asarray(pk_src, dtype=np.int32)).to(dev, non_blocking=True)
+    d_dst = torch.from_numpy(pk_dst).to(dev, non_blocking=True)
+    d_seg = torch.from_numpy(np.asarray(pk_seg, dtype=np.int32)).to(dev, non_blocking=True)
+    if m and total:
+        with torch.cuda.device(dev):
+            _lib.check(
+                lib.prl_pack_collate(
+                    m, total, _lib.ptr(d_src), _lib.ptr(d_dst), _lib.ptr(d_seg), _lib.ptr(r.tokens),
+                    _lib.ptr(r.labels), _lib.ptr(r.logprobs), _lib.ptr(r.ref_logprobs), _lib.ptr(r.seq_off),
+                    _lib.ptr(r.lp_off), _lib.ptr(prep.reward32), _lib.ptr(prep.advantage),
+                    _lib.ptr(prep.group_tokens), _lib.ptr(prep.num_labels), _lib.ptr(prep.overflow),
+                    int(per_token_columns), int(eos_token_id),
+                    _lib.ptr(out["input_ids"]), _lib.ptr(out["labels"]), _lib.ptr(out["attention_mask"]),
+                    _lib.ptr(out["position_ids"]), _lib.ptr(out["segment_ids"]), _lib.ptr(out["rewards"]),
+                    _lib.ptr(out["advantages"]), _lib.ptr(out["ref_logprobs"]), _lib.ptr(out["old_logprobs"]),
+                    _lib.ptr(out["group_tokens"]), _lib.ptr(out["num_labels"]), _lib.ptr(out["overflow"]),
+                    _lib.current_stream_ptr(dev),
+                )
+            )
+    mv = r.host_model_version
+    batches = []
+    for j, idxs in enumerate(micro_batches):
+        a, b = mb_off[j], mb_off[j + 1]
+        t0, t1 = int(pk_dst[a]), int(pk_dst[b])
+        fields = {k: v[t0:t1].unsqueeze(0) for k, v in out.items()}
+        bounds = (pk_dst[a : b + 1] - pk_dst[a]).astype(np.int32)
+        pad = int(sentinel_pad[j]) if sentinel_pad is not None else 0
+        batches.append(
+            PipelineBatchEncoding(
+                **fields,
+                model_version=int(min(mv[list(idxs)])) if len(idxs) else 0,
+                is_packed=True,
+                seq_boundaries=torch.from_numpy(bounds),
+                padding=pad,
+            )
+        )
+    return (batches, out) if with_flat else batches
+
+
+def pad_prepared(
+    prep: PreparedRollouts,
+    rows: Sequence[int],
+    padding_side: str = "right",
+    pad_to_multiple_of: int = 16,
+    per_token_columns: int = 0,
+) -> PipelineBatchEncoding:
+    """K7: one padded [B, Lp] batch out of sequences `rows` (reference data.py:163-212)."""
+    lib = _lib.load()
+    r = prep.rollouts
+    dev = r.device
+    lens = r.seq_lengths()
+    longest = int(max(lens[s] for s in rows))
+    if longest % pad_to_multiple_of:
+        longest += pad_to_multiple_of - (longest % pad_to_multiple_of)
+    B = len(rows)
+    out = _alloc_outputs(B * longest, dev, packed=False)
+    d_rows = torch.from_numpy(np.asarray(list(rows), dtype=np.int32)).to(dev, non_blocking=True)
+    with torch.cuda.device(dev):
+        _lib.check(
+            lib.prl_pad_collate(
+                B, longest, int(padding_side != "right"), _lib.ptr(d_rows), _lib.ptr(r.tokens), _lib.ptr(r.labels),
+                _lib.ptr(r.logprobs), _lib.ptr(r.ref_logprobs), _lib.ptr(r.seq_off), _lib.ptr(r.lp_off),
+                _lib.ptr(prep.reward32), _lib.ptr(prep.advantage), _lib.ptr(prep.group_tokens),
+                _lib.ptr(prep.num_labels), _lib.ptr(prep.overflow), int(per_token_columns),
+                _lib.ptr(out["input_ids"]), _lib.ptr(out["labels"]), _lib.ptr(out["attention_mask"]),
+                _lib.ptr(out["rewards"]), _lib.ptr(out["advantages"]), _lib.ptr(out["ref_logprobs"]),
+                _lib.ptr(out["old_logprobs"]), _lib.ptr(out["group_tokens"]), _lib.ptr(out["num_labels"]),
+                _lib.ptr(out["overflow"]), _lib.current_stream_ptr(dev),
+            )
+        )
+    fields = {k: v.view(B, longest) for k, v in out.items()}
+    mv = r.host_model_version
+    return PipelineBatchEncoding(**fields, model_version=int(min(mv[list(rows)])), is_packed=False)
+
+
+# ---------------------------------------------------------------------------------------------
+# list-of-dicts level (reference signatures)
+# ---------------------------------------------------------------------------------------------
+
+
+def _examples_to_prepared(examples: Sequence[dict[str, Any]], device: torch.device) -> tuple[PreparedRollouts, int]:
+    """Flatten example dicts (per-token python lists) into ragged device buffers.  All seven RL
+    columns are taken per token (`per_token_columns` = all bits) so arbitrary user-built lists
+    survive unchanged; old/ref logprobs are passed full-length (no implicit left padding)."""
+    n = len(examples)
+    lens = np.fromiter((len(e["input_ids"]) for e in examples), dtype=np.int64, count=n)
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    total = int(off[-1])
+
+    def flat(key: str, dtype, default=0) -> np.ndarray:
+        buf = np.empty(total, dtype=dtype)
+        for i, e in enumerate(examples):
+            v = e.get(key)
+            if v is None:
+                buf[off[i] : off[i + 1]] = default
+            else:
+                if len(v) != lens[i]:
+                    raise ValueError(f"example {i}: column {key!r} has {len(v)} entries, expected {lens[i]}")
+                buf[off[i] : off[i + 1]] = v
+        return buf
+
+    dev_t = lambda a: torch.from_numpy(a).to(device, non_blocking=True)  # noqa: E731
+    tokens = flat("input_ids", np.int32)
+    labels = flat("labels", np.int32)
+    cols = {k: flat(k, np.float32, 0.0) for k in RL_DATA_COLUMNS}
+    mv = np.fromiter((e.get("model_version", 0) for e in examples), dtype=np.int64, count=n)
+    zeros_i32 = np.zeros(n, dtype=np.int32)
+    rag = RaggedRollouts.from_numpy(
+        tokens, labels, cols["old_logprobs"], cols["ref_logprobs"], off, off, np.zeros(n), zeros_i32, zeros_i32,
+        zeros_i32, mv, np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8),
+    ).to(device)
+    prep = PreparedRollouts(
+        rollouts=rag, reward32=dev_t(cols["rewards"]), advantage=dev_t(cols["advantages"]),
+        group_tokens=dev_t(cols["group_tokens"]), num_labels=dev_t(cols["num_labels"]),
+        overflow=dev_t(cols["overflow"]), advantage64=torch.empty(0), group_tokens64=torch.empty(0),
+    )
+    return prep, sum(_PER_TOKEN_BITS.values())
+
+
+def _device_for_collate() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("pipelinerl_amd collate kernels need a HIP device; there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def collate_packed(
+    examples: list[dict[str, list[int]]],
+    tokenizer: Any,
+    seq_parallel: int,
+    label_pad_value: int = MASKED_TOKEN_ID,
+) -> PipelineBatchEncoding:
+    """Concatenate examples into one [1, T] packed batch (reference data.py:215-283).  Tensors stay
+    on the HIP device."""
+    if label_pad_value != MASKED_TOKEN_ID:
+        raise ValueError("label_pad_value other than -100 is not supported")
+    total = sum(len(e["input_ids"]) for e in examples)
+    pad = (seq_parallel - total % seq_parallel) % seq_parallel if seq_parallel > 0 else 0
+    prep, bits = _examples_to_prepared(examples, _device_for_collate())
+    batch = pack_prepared(
+        prep, [list(range(len(examples)))], eos_token_id=getattr(tokenizer, "eos_token_id", 0) or 0,
+        sentinel_pad=[pad], per_token_columns=bits,
+    )[0]
+    return batch
+
+
+def collate(
+    examples: list[dict[str, list[int]]],
+    tokenizer: Any,
+    label_mask_value: int = MASKED_TOKEN_ID,
+    pad_to_multiple_of: int = 16,
+) -> PipelineBatchEncoding:
+    """Pad examples to a common length, rounded up to `pad_to_multiple_of` (reference
+    data.py:163-212); padding side from `tokenizer.padding_side`."""
+    if label_mask_value != MASKED_TOKEN_ID:
+        raise ValueError("label_mask_value other than -100 is not supported")
+    prep, bits = _examples_to_prepared(examples, _device_for_collate())
+    return pad_prepared(
+        prep, list(range(len(examples))), padding_side=getattr(tokenizer, "padding_side", "right"),
+        pad_to_multiple_of=pad_to_multiple_of, per_token_columns=bits,
+    )
+
+
+# ---------------------------------------------------------------------------------------------
+# host helpers with the reference's signatures
+# ---------------------------------------------------------------------------------------------
+
+
+def validate_spans(text: str, predicted_spans: list[tuple[int, int]]) -> None:
+    """Spans must lie inside the text, be well-formed, ordered and non-overlapping."""
+    prev_end = None
+    for begin, end in predicted_spans:
+        if begin < 0 or end > len(text):
+            raise ValueError(f"Span {begin}:{end} is out of bounds for text {text!r}")
+        if begin > end:
+            raise ValueError(f"Span {begin}:{end} is invalid")
+        if prev_end is not None and begin < prev_end:
+            raise ValueError(f"Span {begin}:{end} overlaps the previous span ending at {prev_end}")
+        prev_end = end
+
+
+def mask_labels(
+    input_ids: Sequence[int],
+    offset_mapping: Iterable[tuple[int, int]],
+    predicted_spans: Iterable[Iterable[int]],
+    masked_token_id: int = MASKED_TOKEN_ID,
+) -> tuple[list[int], list[int]]:
+    """Labels = input ids where the token's character range overlaps a predicted span, else masked;
+    also the first overlapping token index per span (reference data.py:47-93)."""
+    offsets = list(offset_mapping)
+    labels = [masked_token_id] * len(input_ids)
+    midpoints: list[int] = []
+    for span in predicted_spans:
+        lo, hi = tuple(span)
+        first = None
+        for i, (tb, te) in enumerate(offsets):
+            if tb < hi and lo < te:
+                labels[i] = input_ids[i]
+                if first is None:
+                    first = i
+        if first is not None:
+            midpoints.append(first)
+    return labels, midpoints
+
+
+def preprocess_fn(entry: dict[str, Any], tokenizer: Any, seq_length: int, is_rl: bool = False) -> dict[str, Any]:
+    """One rollout record -> per-token python lists (reference data.py:111-160).  Compatibility
+    helper; the device path consumes `RaggedRollouts` directly."""
+    if entry.get("input_ids"):
+        n = len(entry["input_ids"])
+        encoding: dict[str, Any] = {
+            "input_ids": entry["input_ids"],
+            "labels": entry["labels"],
+            "attention_mask": [1] * n,
+        }
+    else:
+        text = entry["text"]
+        encoding = dict(tokenizer(text, return_offsets_mapping=True, max_length=seq_length, truncation=True))
+        if "predicted_spans" in entry:
+            spans = entry["predicted_spans"]
+        else:
+            n_chars = entry.get("n_predicted", len(text))
+            spans = [(len(text) - n_chars, len(text))]
+        validate_spans(text, spans)
+        encoding["labels"], _ = mask_labels(encoding["input_ids"], encoding["offset_mapping"], spans)
+    if is_rl:
+        encoding = prepare_rl_fields(encoding, entry["reward"], entry["logprobs"], entry["ref_logprobs"])
+    for key in ("pixel_values", "image_thw"):
+        if key in entry:
+            encoding[key] = entry[key]
+    return encoding
+
+
+__all__ = [
+    "MASKED_TOKEN_ID",
+    "collate",
+    "collate_packed",
+    "create_sentinel_example",
+    "mask_labels",
+    "pack_prepared",
+    "pad_prepared",
+    "preprocess_fn",
+    "validate_spans",
+]

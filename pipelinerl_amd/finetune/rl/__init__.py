@@ -1,0 +1,478 @@
+"""GRPO / PPO / REINFORCE learner step and group-baseline advantages on MI355X.
+
+Drop-in for reference pipelinerl/finetune/rl/__init__.py: same public names and signatures
+(`RLConfig`, `rl_step`, `populate_rl_data`, `prepare_rl_fields`, `RL_DATA_COLUMNS`,
+`linear_decay_coef`), same results; everything between the model's logits and the scalar
+loss runs in the hand-written HIP kernels of libprl.so:
+
+    logits --K1--> new_logprobs, entropy --K2+K3--> loss, 32 stats, d loss/d new_logprobs
+           <-------------------- K1 backward: d loss / d logits ----------------------
+
+There is one device->host copy per micro-batch (the 32-double stats vector; the reference
+does ~31 `.item()` syncs) and no CPU fallback: CPU tensors raise.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import logging
+from dataclasses import dataclass
+from typing import Any, Sequence
+
+import numpy as np
+import torch
+from pydantic import BaseModel, Field
+
+from ... import _lib
+from ..._lib import STAT_INDEX, PrlLossConfig
+from ...ragged import RaggedRollouts
+from ..types import PipelineBatchEncoding
+
+logger = logging.getLogger(__name__)
+
+RL_DATA_COLUMNS = [
+    "overflow",
+    "group_tokens",
+    "num_labels",
+    "rewards",
+    "advantages",
+    "old_logprobs",
+    "ref_logprobs",
+]
+
+
+class RLConfig(BaseModel):
+    """Hyper-parameters of the RL loss (reference rl/__init__.py:43-105, same defaults)."""
+
+    policy_loss: str = Field(default="ppo", description="ppo | reinforce | gspo")
+    use_advantages: bool = Field(default=True, description="weight log-probs by advantages instead of rewards")
+    epsilon_low: float = Field(default=0.2, description="lower clip of the importance ratio")
+    epsilon_high: float = Field(default=0.2, description="upper clip of the importance ratio")
+    batch_size: int = Field(default=0, description="samples per optimizer step; the loss normaliser")
+    reward_minus_kl_coef: float = Field(default=0.0, description="declared by the reference, unused")
+    kl_coef: float = Field(default=0.1, description="KL-to-reference penalty coefficient")
+    final_kl_coef: float = Field(default=0.1, description="KL coefficient at the last step")
+    entropy_bonus: float = Field(default=0.0, description="entropy bonus coefficient")
+    final_entropy_bonus: float = Field(default=0.0, description="entropy bonus at the last step")
+    relu_log_p_weights: bool = Field(default=False, description="clamp the log-prob weights at zero")
+    clamp_log_ratio_ref_new_value: float = Field(default=10, description="clamp of log(ref/new)")
+    divide_advantage_by_std: bool = Field(default=True, description="normalise advantages by the group std")
+    overlong_filtering: bool = Field(default=False, description="zero-weight sequences that overflowed")
+    group_normalization: bool = Field(default=False, description="weight tokens by 1/mean group tokens")
+    temperature: float = Field(default=1.0, description="sampling temperature of the rollouts")
+    filter_zero_advantage_groups: bool = Field(default=False, description="drop all-zero-advantage groups")
+    value_loss_coef: float = Field(default=0.0, description="value-head loss weight (value head unsupported)")
+    # --- MI355X extensions (absent from the reference; defaults keep its behaviour) ---
+    fused_logits_grad: bool = Field(default=False, description="single-pass logits kernel: gradient computed in forward")
+    inplace_logits_grad: bool = Field(default=False, description="write d loss/d logits over the logits buffer")
+
+
+def linear_decay_coef(current_step: int, max_step: int, initial_coef: float, final_coef: float) -> float:
+    """initial -> final, linearly in current_step / max_step (reference :119-133)."""
+    return initial_coef + (final_coef - initial_coef) * current_step / max_step
+
+
+_POLICY = {"ppo": _lib.PRL_POLICY_PPO, "reinforce": _lib.PRL_POLICY_REINFORCE}
+
+
+def make_loss_config(config: RLConfig, current_step: int, max_step: int) -> tuple[PrlLossConfig, float, float]:
+    """RLConfig -> the C struct.  Scalars are rounded to fp32 exactly where torch would do it:
+    python doubles are combined in double first (1 - eps, linear decay), then cast."""
+    if config.policy_loss not in _POLICY:
+        raise ValueError(f"Unknown algorithm {config.policy_loss}")
+    kl_coef = linear_decay_coef(current_step, max_step, config.kl_coef, config.final_kl_coef)
+    ent_coef = linear_decay_coef(current_step, max_step, config.entropy_bonus, config.final_entropy_bonus)
+    use_entropy = config.entropy_bonus != 0.0 or config.final_entropy_bonus != 0.0
+    if config.group_normalization:
+        token_weight = 0.0
+    else:
+        token_weight = float(np.float32(1.0) / np.float32(config.batch_size)) if config.batch_size else float("inf")
+    c = PrlLossConfig(
+        policy_loss=_POLICY[config.policy_loss],
+        use_advantages=int(config.use_advantages),
+        relu_log_p_weights=int(config.relu_log_p_weights),
+        group_normalization=int(config.group_normalization),
+        overlong_filtering=int(config.overlong_filtering),
+        use_entropy_loss=int(use_entropy),
+        token_weight=token_weight,
+        clip_lo=1 - config.epsilon_low,
+        clip_hi=1 + config.epsilon_high,
+        kl_coef=kl_coef,
+        entropy_coef=ent_coef,
+        clamp_log_ratio_ref_new=config.clamp_log_ratio_ref_new_value,
+    )
+    return c, kl_coef, ent_coef
+
+
+def _logits_dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return _lib.PRL_DTYPE_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.PRL_DTYPE_BF16
+    raise TypeError(f"logits must be float32 or bfloat16, got {t.dtype}")
+
+
+_workspaces: dict[Any, torch.Tensor] = {}
+
+
+def _loss_workspace(device: torch.device) -> torch.Tensor:
+    ws = _workspaces.get(device)
+    if ws is None:
+        need = ctypes.c_size_t(0)
+        _lib.check(_lib.load().prl_grpo_loss_workspace_bytes(1, 1, ctypes.byref(need)))
+        ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def grpo_loss_from_logprobs(
+    cfg: PrlLossConfig,
+    batch: PipelineBatchEncoding,
+    new_logprobs: torch.Tensor,
+    entropy: torch.Tensor,
+    want_grad: bool = True,
+) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None, torch.Tensor | None]:
+    """K2+K3 on token-aligned new_logprobs / entropy ([B, L], column 0 unused).
+    Returns (loss fp32 scalar, stats double[32], d loss/d new_logprobs, d loss/d entropy)."""
+    lib = _lib.load()
+    rows, cols = batch.labels.shape
+    cols_tensors = [
+        batch.labels, new_logprobs, entropy, batch.old_logprobs, batch.ref_logprobs, batch.advantages,
+        batch.rewards, batch.group_tokens, batch.num_labels, batch.overflow,
+    ]
+    _lib.require_device(*cols_tensors)
+    cols_tensors = [t if t.is_contiguous() else t.contiguous() for t in cols_tensors]
+    labels, nlp, ent, old, ref, adv, rew, gt, nl, ovf = cols_tensors
+    pos = None
+    if batch.is_packed and rows == 1 and batch.position_ids is not None:
+        pos = batch.position_ids if batch.position_ids.is_contiguous() else batch.position_ids.contiguous()
+    dev = labels.device
+    stats = torch.empty(_lib.PRL_NUM_STATS, dtype=torch.float64, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    g_nlp = torch.empty_like(nlp) if want_grad else None
+    g_ent = torch.empty_like(nlp) if (want_grad and cfg.use_entropy_loss) else None
+    ws = _loss_workspace(dev)
+    with torch.cuda.device(dev):
+        _lib.check(
+            lib.prl_grpo_loss_fwd_bwd(
+                ctypes.byref(cfg), rows, cols, _lib.ptr(labels), _lib.ptr(pos), _lib.ptr(nlp), _lib.ptr(ent),
+                _lib.ptr(old), _lib.ptr(ref), _lib.ptr(adv), _lib.ptr(rew), _lib.ptr(gt), _lib.ptr(nl),
+                _lib.ptr(ovf), _lib.ptr(g_nlp), _lib.ptr(g_ent), _lib.ptr(loss), _lib.ptr(stats),
+                _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr(dev),
+            )
+        )
+    return loss, stats, g_nlp, g_ent
+
+
+def logprob_entropy(logits: torch.Tensor, input_ids: torch.Tensor, temperature: float):
+    """K1 forward: token-aligned (new_logprobs, entropy, lse2), each float32 [B, L]."""
+    lib = _lib.load()
+    _lib.require_device(logits, input_ids)
+    B, L, V = logits.shape
+    if logits.stride(-1) != 1 or logits.stride(1) != logits.shape[-1] or (B > 1 and logits.stride(0) != L * V):
+        logits = logits.contiguous()
+    ids = input_ids if input_ids.is_contiguous() else input_ids.contiguous()
+    nlp = torch.empty((B, L), dtype=torch.float32, device=logits.device)
+    ent = torch.empty_like(nlp)
+    lse2 = torch.empty_like(nlp)
+    with torch.cuda.device(logits.device):
+        _lib.check(
+            lib.prl_logprob_entropy_fwd(
+                B, L, V, _lib.ptr(logits), _logits_dtype_code(logits), V, _lib.ptr(ids), float(temperature),
+                _lib.ptr(nlp), _lib.ptr(ent), _lib.ptr(lse2), _lib.current_stream_ptr(logits.device),
+            )
+        )
+    return nlp, ent, lse2, logits
+
+
+class _GrpoLossFn(torch.autograd.Function):
+    """logits -> (loss, stats) with a hand-written backward to the logits."""
+
+    @staticmethod
+    def forward(ctx, logits, batch, cfg, temperature, fused, inplace):  # type: ignore[override]
+        lib = _lib.load()
+        B, L, V = logits.shape
+        dev = logits.device
+        ids = batch.input_ids if batch.input_ids.is_contiguous() else batch.input_ids.contiguous()
+        if fused:
+            lg = logits if logits.is_contiguous() else logits.contiguous()
+            grad = lg if inplace else torch.empty_like(lg)
+            nlp = torch.empty((B, L), dtype=torch.float32, device=dev)
+            ent = torch.empty_like(nlp)
+            lse2 = torch.empty_like(nlp)
+            cont = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
+            with torch.cuda.device(dev):
+                _lib.check(
+                    lib.prl_fused_logits_loss(
+                        ctypes.byref(cfg), B, L, V, _lib.ptr(lg), _logits_dtype_code(lg), V, float(temperature),
+                        _lib.ptr(ids), _lib.ptr(cont(batch.labels)), _lib.ptr(cont(batch.old_logprobs)),
+                        _lib.ptr(cont(batch.ref_logprobs)), _lib.ptr(cont(batch.advantages)),
+                        _lib.ptr(cont(batch.rewards)), _lib.ptr(cont(batch.group_tokens)),
+                        _lib.ptr(cont(batch.overflow)), _lib.ptr(nlp), _lib.ptr(ent), _lib.ptr(lse2),
+                        _lib.ptr(grad), _lib.current_stream_ptr(dev),
+                    )
+                )
+            loss, stats, _, _ = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=False)
+            ctx.fused = True
+            ctx.grad_logits = grad
+        else:
+            nlp, ent, lse2, lg = logprob_entropy(logits, ids, temperature)
+            loss, stats, g_nlp, g_ent = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=True)
+            ctx.fused = False
+            ctx.save_for_backward(lg, ids, lse2, ent, g_nlp, g_ent if g_ent is not None else torch.empty(0, device=dev))
+            ctx.has_g_ent = g_ent is not None
+            ctx.inplace = inplace
+        ctx.temperature = float(temperature)
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_stats):  # type: ignore[override]
+        if ctx.fused:
+            grad = ctx.grad_logits
+            ctx.grad_logits = None
+            scale = float(grad_loss.item())
+            if scale != 1.0:
+                grad.mul_(scale)
+            return grad, None, None, None, None, None
+        lib = _lib.load()
+        lg, ids, lse2, ent, g_nlp, g_ent = ctx.saved_tensors
+        B, L, V = lg.shape
+        dev = lg.device
+        grad = lg if ctx.inplace else torch.empty_like(lg)
+        up = grad_loss.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(
+                lib.prl_logprob_entropy_bwd(
+                    B, L, V, _lib.ptr(lg), _logits_dtype_code(lg), V, _lib.ptr(ids), ctx.temperature,
+                    _lib.ptr(lse2), _lib.ptr(ent), _lib.ptr(g_nlp), _lib.ptr(g_ent) if ctx.has_g_ent else None,
+                    _lib.ptr(up), _lib.ptr(grad), _lib.current_stream_ptr(dev),
+                )
+            )
+        return grad, None, None, None, None, None
+
+
+_STAT_KEYS_IN_ORDER = [
+    "reward", "max_reward", "min_reward", "entropy", "old_logprobs", "new_logprobs", "ref_logprobs",
+    "advantage", "max_advantage", "min_advantage", "kl", "kl_new_old", "mean_abs_log_ratio_new_old",
+    "max_kl", "min_kl", "ratio_new_old", "ratio_new_old_sum", "ratio_new_old_squared_sum", "ratio_ref_new",
+    "ratio_ref_old", "clamp_log_ratio_ref_new_indicator", "clamp_log_ratio_new_old_indicator",
+    "token_weight", "max_token_weight", "min_token_weight",
+]
+
+
+def stats_to_dict(stats: Sequence[float], kl_coef: float, ent_coef: float, input_size: int) -> dict[str, float]:
+    """Device stats vector -> the reference's 32-key dict (rl/__init__.py:398-439), same key order."""
+    s = stats
+    loss = float(np.float32(s[STAT_INDEX["loss"]]))
+    out: dict[str, float] = {"loss": loss, "max_loss": loss, "min_loss": loss}
+    for k in _STAT_KEYS_IN_ORDER:
+        out[k] = float(np.float32(s[STAT_INDEX[k]]))
+    n_seq = int(s[STAT_INDEX["num_sequences"]])
+    out["kl_coef"] = n_seq * kl_coef
+    out["entropy_bonus_coef"] = n_seq * ent_coef
+    out["num_output_tokens_sum"] = int(s[STAT_INDEX["num_output_tokens_sum"]])
+    out["input_size"] = input_size
+    return out
+
+
+def check_finite(stats: Sequence[float]) -> None:
+    """The reference's runtime asserts (rl/__init__.py:213,247,262,291,386) from device counters."""
+    assert stats[STAT_INDEX["nonfinite_new_logprobs"]] == 0, "new_logprobs is not finite"
+    assert stats[STAT_INDEX["bad_group_tokens"]] == 0, "group_tokens must be greater than zero for group normalization"
+    assert stats[STAT_INDEX["nonfinite_log_ratio_ref_new"]] == 0, "log_ratio_ref_new is not finite"
+    assert stats[STAT_INDEX["nonfinite_kl"]] == 0, "approx_kl is not finite"
+    assert np.isfinite(stats[STAT_INDEX["loss"]]), f"Non-finite loss detected: {stats[STAT_INDEX['loss']]}"
+
+
+def rl_step(
+    model: Any,
+    batch: PipelineBatchEncoding,
+    current_step: int,
+    max_step: int,
+    config: RLConfig,
+    seq_parallel_group=None,
+) -> tuple[torch.Tensor, dict[str, float]]:
+    """One RL micro-batch: model forward + fused loss.  Signature and return value as in
+    reference rl/__init__.py:136-143: (scalar loss attached to the model's graph, stats dict)."""
+    if config.policy_loss == "gspo":
+        raise NotImplementedError("GSPO sequence-level loss is not on the MI355X hot path yet (SURVEY.md §8 a5)")
+    if hasattr(model, "value_head"):
+        raise NotImplementedError("value-head (actor-critic) batches are outside the GRPO hot path")
+    cfg, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
+
+    model_inputs = {
+        "input_ids": batch.input_ids,
+        "attention_mask": batch.attention_mask,
+        "labels": batch.labels,
+    }
+    if batch.is_packed:
+        model_inputs["position_ids"] = batch.position_ids
+    if getattr(batch, "pixel_values", None) is not None:
+        model_inputs["pixel_values"] = batch.pixel_values
+    if getattr(batch, "image_grid_thw", None) is not None:
+        model_inputs["image_grid_thw"] = batch.image_grid_thw
+    outputs = model(**model_inputs)
+    logits = outputs.logits
+    _lib.require_device(logits)
+
+    loss, stats_dev = _GrpoLossFn.apply(
+        logits, batch, cfg, config.temperature, bool(config.fused_logits_grad), bool(config.inplace_logits_grad)
+    )
+    stats = stats_dev.cpu().tolist()  # the single device->host sync of the step
+    check_finite(stats)
+    input_size = batch.input_ids.numel()
+    if int(stats[STAT_INDEX["num_output_tokens_sum"]]) == 0:
+        return loss, {"input_size": float(input_size)}
+    return loss, stats_to_dict(stats, kl_coef, ent_coef, input_size)
+
+
+# ---------------------------------------------------------------------------------------------
+# Preprocess: group-baseline advantages (K5)
+# ---------------------------------------------------------------------------------------------
+
+
+@dataclass
+class PreparedRollouts:
+    """Rollouts + the per-sequence scalars that populate_rl_data attaches (all on device)."""
+
+    rollouts: RaggedRollouts
+    reward32: torch.Tensor       # fp32 [S]   -> `rewards` column
+    advantage: torch.Tensor      # fp32 [S]
+    group_tokens: torch.Tensor   # fp32 [S]
+    num_labels: torch.Tensor     # fp32 [S]
+    overflow: torch.Tensor       # fp32 [S]
+    advantage64: torch.Tensor    # fp64 [S]   (what the reference's python lists hold)
+    group_tokens64: torch.Tensor  # fp64 [S]
+
+
+def _csr(keys: np.ndarray) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(offsets, members in dataset order, key id per member) for equal-key runs of `keys`."""
+    order = np.argsort(keys, kind="stable").astype(np.int32)
+    sorted_keys = keys[order]
+    if len(keys) == 0:
+        return np.zeros(1, dtype=np.int32), order, np.zeros(0, dtype=np.int64)
+    starts = np.flatnonzero(np.r_[True, sorted_keys[1:] != sorted_keys[:-1]])
+    off = np.r_[starts, len(keys)].astype(np.int32)
+    return off, order, sorted_keys[starts]
+
+
+def plan_groups(group_index: np.ndarray, step_index: np.ndarray, rollout_index: np.ndarray):
+    """Host-side O(S) planning for K5: CSR membership of (group, step) keys and of groups, plus
+    the number of distinct rollouts per group (reference groupby keys, rl/__init__.py:464-486)."""
+    g = group_index.astype(np.int64)
+    n_steps = int(step_index.max()) + 1 if len(step_index) else 1
+    key_off, key_members, _ = _csr(g * n_steps + step_index.astype(np.int64))
+    group_off, group_members, group_keys = _csr(g)
+    n_roll = int(rollout_index.max()) + 1 if len(rollout_index) else 1
+    pairs = np.unique(g * n_roll + rollout_index.astype(np.int64))
+    pair_group = pairs // n_roll
+    # groups are sorted ascending in both `group_keys` and `pair_group`
+    counts = np.searchsorted(pair_group, group_keys, side="right") - np.searchsorted(pair_group, group_keys, side="left")
+    return key_off, key_members, group_off, group_members, counts.astype(np.int32)
+
+
+def populate_rl_data_ragged(rollouts: RaggedRollouts, eos_token_id: int, config: RLConfig) -> PreparedRollouts:
+    """K5 on device: num_labels / overflow per sequence, leave-one-out advantages per
+    (group_id, step_index), mean rollout tokens per group (reference rl/__init__.py:453-570)."""
+    lib = _lib.load()
+    r = rollouts
+    _lib.require_device(r.tokens)
+    dev = r.device
+    S = r.n_seqs
+    key_off, key_members, group_off, group_members, n_roll = plan_groups(
+        r.host_group_index, r.host_step_index, r.host_rollout_index
+    )
+    plan = [torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True) for a in (key_off, key_members, group_off, group_members, n_roll)]
+    num_labels = torch.empty(S, dtype=torch.float32, device=dev)
+    overflow = torch.empty(S, dtype=torch.float32, device=dev)
+    adv64 = torch.empty(S, dtype=torch.float64, device=dev)
+    gt64 = torch.empty(S, dtype=torch.float64, device=dev)
+    adv32 = torch.empty(S, dtype=torch.float32, device=dev)
+    gt32 = torch.empty(S, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = _lib.current_stream_ptr(dev)
+        _lib.check(
+            lib.prl_seq_scan(
+                S, _lib.ptr(r.tokens), _lib.ptr(r.labels), _lib.ptr(r.seq_off), _lib.ptr(r.finish_code),
+                _lib.ptr(r.finished), int(eos_token_id), _lib.ptr(num_labels), _lib.ptr(overflow), stream,
+            )
+        )
+        _lib.check(
+            lib.prl_group_advantages(
+                S, len(key_off) - 1, len(group_off) - 1, *[_lib.ptr(p) for p in plan], _lib.ptr(r.reward),
+                _lib.ptr(r.seq_off), int(config.divide_advantage_by_std), _lib.ptr(adv64), _lib.ptr(gt64),
+                _lib.ptr(adv32), _lib.ptr(gt32), stream,
+            )
+        )
+    return PreparedRollouts(
+        rollouts=r, reward32=r.reward.to(torch.float32), advantage=adv32, group_tokens=gt32,
+        num_labels=num_labels, overflow=overflow, advantage64=adv64, group_tokens64=gt64,
+    )
+
+
+def populate_rl_data(dataset: list[dict[str, Any]], eos_token_id: int, config: RLConfig) -> list[dict[str, Any]]:
+    """List-of-dicts front end with the reference's contract (rl/__init__.py:453): fills the
+    per-token `advantages`, `group_tokens`, `overflow`, `num_labels` lists of every entry in place.
+    Entries are what `preprocess_fn(..., is_rl=True)` produced (+ group_id, rollout_index,
+    step_index).  The numbers come from the device kernels."""
+    if not dataset:
+        return dataset
+    entries = []
+    for e in dataset:
+        if len(e["rewards"]) == 0:
+            raise IndexError("populate_rl_data: empty sequence (the reference raises on rewards[0])")
+        if any(r != e["rewards"][0] for r in e["rewards"]):
+            raise NotImplementedError("per-token varying rewards inside one sequence are not produced on the RL path")
+        n_lp = len(e.get("logprobs", ()))
+        entries.append({
+            "input_ids": e["input_ids"], "labels": e["labels"], "logprobs": e.get("logprobs", [])[:n_lp],
+            "reward": e["rewards"][0], "group_id": e["group_id"], "rollout_index": e["rollout_index"],
+            "step_index": e["step_index"], "model_version": e.get("model_version", 0),
+            "finished": e.get("finished"), "finish_reason": e.get("finish_reason"),
+        })
+    rag = RaggedRollouts.from_entries(entries).to(_default_device())
+    prep = populate_rl_data_ragged(rag, eos_token_id, config)
+    adv = prep.advantage64.cpu().numpy()
+    gt = prep.group_tokens64.cpu().numpy()
+    ovf = prep.overflow.cpu().numpy()
+    nl = prep.num_labels.cpu().numpy()
+    for i, e in enumerate(dataset):
+        n = len(e["input_ids"])
+        e["advantages"] = [float(adv[i])] * len(e["rewards"])
+        e["group_tokens"] = [float(gt[i])] * n
+        e["overflow"] = [float(ovf[i])] * len(e["overflow"])
+        e["num_labels"] = [int(nl[i])] * n
+    return dataset
+
+
+def _default_device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("pipelinerl_amd preprocess kernels need a HIP device; there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def prepare_rl_fields(
+    encoding: dict[str, Any],
+    reward: float,
+    old_logprobs: list[float],
+    ref_logprobs: list[float],
+) -> dict[str, Any]:
+    """Per-token RL columns of one sample as python lists (reference rl/__init__.py:573-594).
+    Host-side compatibility helper: the device path never materialises these lists (the pack
+    kernel expands per-sequence scalars while writing the batch)."""
+    labels = encoding["labels"]
+    n = len(labels)
+    n_targets = n - labels.count(-100)
+    assert n_targets == len(old_logprobs), f"Target tokens: {n_targets}, old logprobs: {len(old_logprobs)}"
+    zeros = [0] * n
+    encoding.update(
+        rewards=[reward] * n,
+        advantages=[0.0] * n,
+        old_logprobs=zeros[: n - len(old_logprobs)] + old_logprobs,
+        ref_logprobs=zeros[: n - len(ref_logprobs)] + ref_logprobs,
+        overflow=list(zeros),
+        group_tokens=list(zeros),
+        num_labels=[int(lab != -100) for lab in labels],
+    )
+    return encoding

@@ -1,0 +1,62 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol that
+include/prl.h declares; the ctypes prototype table covers exactly the same set."""
+
+import ctypes
+import re
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_functions() -> dict[str, int]:
+    """name -> number of parameters, parsed from include/prl.h."""
+    text = (ROOT / "include" / "prl.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(prl_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        params = m.group(2).strip()
+        n = 0 if params in ("", "void") else len([p for p in params.split(",") if p.strip()])
+        out[m.group(1)] = n
+    return out
+
+
+def test_header_declares_the_hot_path():
+    names = declared_functions()
+    for required in ("prl_logprob_entropy_fwd", "prl_logprob_entropy_bwd", "prl_grpo_loss_fwd_bwd", "prl_fused_logits_loss",
+                     "prl_group_advantages", "prl_seq_scan", "prl_pack_collate", "prl_pad_collate", "prl_ring_create",
+                     "prl_ring_put", "prl_ring_get", "prl_wsync_init", "prl_wsync_bcast_bucket", "prl_wsync_bcast_bucket_sag"):
+        assert required in names
+
+
+def test_library_exports_every_declared_symbol(libprl):
+    from pipelinerl_amd._lib import PROTOTYPES
+
+    declared = declared_functions()
+    assert set(declared) == set(PROTOTYPES), set(declared) ^ set(PROTOTYPES)
+    for name, n_params in declared.items():
+        fn = getattr(libprl, name)  # raises AttributeError when the symbol is missing
+        assert isinstance(fn, ctypes._CFuncPtr)
+        assert len(PROTOTYPES[name][1]) == n_params, f"{name}: prototype has {len(PROTOTYPES[name][1])} params, header {n_params}"
+
+
+def test_struct_layout_matches_header():
+    from pipelinerl_amd._lib import PrlLossConfig
+
+    text = (ROOT / "include" / "prl.h").read_text()
+    body = re.search(r"typedef struct prl_loss_config \{(.*?)\} prl_loss_config;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(int32_t|float)\s+(\w+)\s*;", body)
+    assert [f for _, f in fields] == [f for f, _ in PrlLossConfig._fields_]
+    assert ctypes.sizeof(PrlLossConfig) == 4 * len(fields)
+
+
+def test_abi_version_and_error_string(libprl):
+    from pipelinerl_amd import _lib
+
+    assert libprl.prl_abi_version() == _lib.PRL_ABI_VERSION
+    # argument validation happens before any device work, so it is checkable without a GPU
+    rc = libprl.prl_grpo_loss_workspace_bytes(1, 1, None)
+    assert rc == _lib.PRL_EINVAL
+    assert b"null" in libprl.prl_last_error()
+    need = ctypes.c_size_t(0)
+    assert libprl.prl_grpo_loss_workspace_bytes(1, 8192, ctypes.byref(need)) == 0 and need.value > 0

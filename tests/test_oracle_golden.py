@@ -1,0 +1,66 @@
+"""Pin the CPU oracle against the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+
+import numpy as np
+import pytest
+
+from oracle import preprocess as opre
+from oracle import rl_loss as orl
+
+from helpers import PREPROCESS_CASES, RL_STEP_CASES, assert_batch_equal, load_preprocess_case, load_rl_case, rel_err
+
+
+@pytest.mark.parametrize("name", RL_STEP_CASES)
+def test_rl_step_oracle_matches_reference(name):
+    case = load_rl_case(name)
+    cur, mx = case["steps"]
+    res = orl.rl_step(case["logits"], case["batch"], case["config"], cur, mx, bool(case["batch"]["is_packed"]))
+    assert res["finite"]
+    # fp: loss / stats within 1e-5 relative of the reference's fp32 torch result
+    assert abs(float(res["loss"]) - case["loss"]) <= 1e-5 * max(1.0, abs(case["loss"]))
+    assert list(res["stats"].keys()) == list(case["stats"].keys())
+    for k, want in case["stats"].items():
+        got = float(res["stats"][k])
+        assert abs(got - want) <= 2e-5 * max(1.0, abs(want)), f"{k}: {got} vs {want}"
+    # closed-form gradient vs reference autograd
+    assert rel_err(res["grad_logits"], case["grad_logits"]) <= 1e-5 or np.abs(case["grad_logits"]).max() == 0
+    np.testing.assert_allclose(res["grad_logits"], case["grad_logits"], rtol=0, atol=1e-6 * max(1.0, np.abs(case["grad_logits"]).max()))
+
+
+@pytest.mark.parametrize("name", PREPROCESS_CASES)
+def test_populate_oracle_matches_reference(name):
+    case = load_preprocess_case(name)
+    data = opre.preprocess_chunk(case["raw"], case["eos_token_id"], case["divide_advantage_by_std"])
+    got = {
+        "advantage": np.array([e["advantages"][0] for e in data]),
+        "group_tokens": np.array([e["group_tokens"][0] for e in data]),
+        "overflow": np.array([e["overflow"][0] for e in data]),
+        "num_labels": np.array([e["num_labels"][0] for e in data], dtype=np.float64),
+    }
+    for k, want in case["scalars"].items():
+        np.testing.assert_allclose(got[k], want, rtol=1e-12, atol=1e-15, err_msg=k)
+
+
+@pytest.mark.parametrize("name", PREPROCESS_CASES)
+def test_collate_oracle_matches_reference(name):
+    case = load_preprocess_case(name)
+    data = opre.preprocess_chunk(case["raw"], case["eos_token_id"], case["divide_advantage_by_std"])
+    for plan, want in case["packed"].items():
+        idxs = [int(i) for i in want["__idx"]]
+        got = opre.collate_packed([data[i] for i in idxs], case["eos_token_id"], int(want["__seq_parallel"]))
+        assert_batch_equal(got, want)
+    for side, want in case["padded"].items():
+        idxs = [int(i) for i in want["__idx"]]
+        got = opre.collate([data[i] for i in idxs], padding_side=side)
+        assert_batch_equal(got, want)
+
+
+def test_sentinel_oracle_matches_reference():
+    from helpers import GOLDEN
+    import json
+
+    z = np.load(GOLDEN / "sentinel.npz")
+    got = opre.sentinel_batch(eos_token_id=7, model_version=5)
+    assert_batch_equal(got, {k: z[k] for k in z.files})
+    want_ex = json.loads((GOLDEN / "sentinel_example.json").read_text())
+    assert opre.sentinel_example(3, 7, 9) == want_ex
