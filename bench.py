@@ -125,11 +125,11 @@ def weight_sync_probe(rank: int, world: int, dev: torch.device) -> dict | None:
     bucket set over RCCL: plain broadcast vs scatter + all-gather.  Extra field, never `value`."""
     import torch.distributed as dist
 
-    from pipelinerl_amd.weight_sync import WeightSyncGroup
-
     total_bytes = int(os.environ.get("PRL_BENCH_WSYNC_BYTES", 15_231_233_024))  # 7.6B params bf16
     bucket_bytes = 1 << 30
     try:
+        from pipelinerl_amd.weight_sync import WeightSyncGroup
+
         grp = WeightSyncGroup.from_torch_distributed(rank, world, dev)
         bucket = torch.empty(bucket_bytes, dtype=torch.uint8, device=dev)
         n_buckets = (total_bytes + bucket_bytes - 1) // bucket_bytes
@@ -195,6 +195,24 @@ def main():
     logits = torch.empty((1, seq_length, vocab), dtype=torch.float32, device=dev)
     logits.normal_(0.0, 2.0, generator=gen)
     grad_logits = torch.empty_like(logits)
+
+    # Make the rollouts on-policy w.r.t. these logits (untimed setup): old_logprobs = new_logprobs +
+    # N(0, sigma) on completion tokens, so the importance ratio sits inside the PPO clip range and
+    # EVERY completion row needs its full d-logits pass (rows whose gradient is exactly zero are
+    # skipped by the kernel; sigma = 0.005 << epsilon = 0.02 keeps that shortcut out of the timing).
+    from pipelinerl_amd.finetune.rl import logprob_entropy
+
+    sigma = float(os.environ.get("PRL_BENCH_OLD_SIGMA", 0.005))
+    setup = HotPathStep(cfg, eos_token_id=2)
+    setup_batches = setup.preprocess(rag, micro_batches)
+    lo = rag_h.host_lp_off
+    for j in range(n_seq):
+        b = setup_batches[j]
+        nlp, _, _, _ = logprob_entropy(logits, b.input_ids, cfg.temperature)
+        c = int(lo[j + 1] - lo[j])
+        noise = torch.empty(c, device=dev).normal_(0.0, sigma, generator=gen)
+        rag.logprobs[int(lo[j]) : int(lo[j + 1])] = nlp[0, seq_length - c :] + noise
+    del setup, setup_batches
     torch.cuda.synchronize()
 
     timer = EventTimer()
@@ -290,7 +308,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "global_batch": bs, "seq_len": seq_length, "vocab": vocab,
                        "tokens_per_step": bs * seq_length, "parallelism": f"dp{world}", "logits_mode": args.logits_mode,
-                       "policy_loss": "ppo", "kl_coef": 0.0},
+                       "policy_loss": "ppo", "kl_coef": 0.0, "old_logprob_sigma": sigma},
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(seq_length, vocab),

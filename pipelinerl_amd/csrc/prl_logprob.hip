@@ -15,6 +15,8 @@
 // Output convention: token-aligned (see include/prl.h): out[u] is computed from logits
 // row u-1; column 0 of every batch row is written as 0.
 
+#include <cstdlib>
+
 #include "prl_common.h"
 #include "prl_token_math.h"
 
@@ -30,17 +32,15 @@ constexpr float kNegBig = -3.0e38f;  // finite "minus infinity" (keeps 0 * x wel
 struct F32 {
   using scalar = float;
   static constexpr int NV = 4;
-  struct alignas(16) vec {
-    float v[4];
-  };
+  using vec = float __attribute__((ext_vector_type(4)));
   __device__ static __forceinline__ void unpack(const vec& x, float (&o)[NV]) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) o[i] = x.v[i];
+    for (int i = 0; i < NV; ++i) o[i] = x[i];
   }
   __device__ static __forceinline__ vec pack(const float (&o)[NV]) {
     vec x;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) x.v[i] = o[i];
+    for (int i = 0; i < NV; ++i) x[i] = o[i];
     return x;
   }
   __device__ static __forceinline__ float to_float(scalar s) { return s; }
@@ -50,9 +50,7 @@ struct F32 {
 struct BF16 {
   using scalar = uint16_t;
   static constexpr int NV = 8;
-  struct alignas(16) vec {
-    uint32_t w[4];
-  };
+  using vec = uint32_t __attribute__((ext_vector_type(4)));
   __device__ static __forceinline__ float to_float(scalar s) {
     return __uint_as_float(((uint32_t)s) << 16);
   }
@@ -65,15 +63,15 @@ struct BF16 {
   __device__ static __forceinline__ void unpack(const vec& x, float (&o)[NV]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      o[2 * i] = __uint_as_float(x.w[i] << 16);
-      o[2 * i + 1] = __uint_as_float(x.w[i] & 0xffff0000u);
+      o[2 * i] = __uint_as_float(x[i] << 16);
+      o[2 * i + 1] = __uint_as_float(x[i] & 0xffff0000u);
     }
   }
   __device__ static __forceinline__ vec pack(const float (&o)[NV]) {
     vec x;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      x.w[i] = (uint32_t)from_float(o[2 * i]) | ((uint32_t)from_float(o[2 * i + 1]) << 16);
+      x[i] = (uint32_t)from_float(o[2 * i]) | ((uint32_t)from_float(o[2 * i + 1]) << 16);
     return x;
   }
 };
@@ -190,7 +188,19 @@ __device__ __forceinline__ Osm row_softmax_stats(const typename T::scalar* row, 
 
 // ---- pass 2: write d logits for one row --------------------------------------------
 //   dz_v = -g p_v - gH p_v (ln p_v + H);  d logit_v = (dz_v + g 1[v == id]) / temperature
-template <class T, int BLOCK, int UNROLL>
+template <bool NT, class V>
+__device__ __forceinline__ void store_vec(V* p, const V& v) {
+  if constexpr (NT) {
+    __builtin_nontemporal_store(v, p);
+  } else {
+    *p = v;
+  }
+}
+
+// REVERSE walks the row back to front: in the fused kernel the tail of the row is what pass 1
+// touched last, i.e. what is most likely still in L2 / Infinity Cache.  NT marks the gradient
+// stores non-temporal so they do not evict the logits lines pass 2 is about to re-read.
+template <class T, int BLOCK, int UNROLL, bool REVERSE = false, bool NT = false>
 __device__ __forceinline__ void row_write_grad(const typename T::scalar* row,
                                                typename T::scalar* out, int vocab, float k2,
                                                float inv_temp, float lse2, float H, float g,
@@ -217,7 +227,18 @@ __device__ __forceinline__ void row_write_grad(const typename T::scalar* row,
     const int nvec = vocab / NV;
     constexpr int TILE = BLOCK * UNROLL;
     const int nfull = (nvec / TILE) * TILE;
-    for (int base = 0; base < nfull; base += TILE) {
+    auto tail = [&]() {
+      for (int j = nfull + tid; j < nvec; j += BLOCK) {
+        float f[NV], o[NV];
+        T::unpack(rv[j], f);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) o[i] = one(f[i], j * NV + i);
+        store_vec<NT>(&ov[j], T::pack(o));
+      }
+    };
+    if constexpr (REVERSE) tail();
+    for (int it = 0; it < nfull; it += TILE) {
+      const int base = REVERSE ? (nfull - TILE - it) : it;
       vec v[UNROLL];
 #pragma unroll
       for (int k = 0; k < UNROLL; ++k) v[k] = rv[base + k * BLOCK + tid];
@@ -228,16 +249,10 @@ __device__ __forceinline__ void row_write_grad(const typename T::scalar* row,
         T::unpack(v[k], f);
 #pragma unroll
         for (int i = 0; i < NV; ++i) o[i] = one(f[i], j * NV + i);
-        ov[j] = T::pack(o);
+        store_vec<NT>(&ov[j], T::pack(o));
       }
     }
-    for (int j = nfull + tid; j < nvec; j += BLOCK) {
-      float f[NV], o[NV];
-      T::unpack(rv[j], f);
-#pragma unroll
-      for (int i = 0; i < NV; ++i) o[i] = one(f[i], j * NV + i);
-      ov[j] = T::pack(o);
-    }
+    if constexpr (!REVERSE) tail();
     done = nvec * NV;
   }
   for (int j = done + tid; j < vocab; j += BLOCK)
@@ -349,11 +364,14 @@ struct FusedArgs {
   float* lse2;
 };
 
-template <class T, int BLOCK, int UNROLL>
+template <class T, int BLOCK, int UNROLL, bool REVERSE, bool NT>
 __global__ __launch_bounds__(BLOCK) void fused_logits_loss_kernel(
     RowGeom geo, FusedArgs a, const typename T::scalar* logits, float k2, float inv_temp,
     typename T::scalar* grad) {
-  __shared__ Osm lds[BLOCK / kWave];
+  // The launch may request extra (unused) dynamic LDS to cap the workgroups resident per CU, so
+  // that all rows in flight (256 CUs x k x 608 KB) fit the 256 MB Infinity Cache for pass 2.
+  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+  Osm* lds = reinterpret_cast<Osm*>(dyn_lds);
   const int64_t q = blockIdx.x;
   const int64_t col = q % geo.cols;
   typename T::scalar* out = grad + q * geo.stride;
@@ -395,14 +413,15 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_kernel(
     row_write_zero<T, BLOCK>(out, geo.vocab, geo.vec_ok);
     return;
   }
-  row_write_grad<T, BLOCK, UNROLL>(row, out, geo.vocab, k2, inv_temp, lse2, H, g, gH, id,
-                                   geo.vec_ok);
+  row_write_grad<T, BLOCK, UNROLL, REVERSE, NT>(row, out, geo.vocab, k2, inv_temp, lse2, H, g, gH, id,
+                                                geo.vec_ok);
 }
 
 // ---- host-side dispatch ---------------------------------------------------------------
 constexpr int kBlock = 256;
 constexpr int kUnrollFwd = 8;
 constexpr int kUnrollBwd = 4;
+constexpr int kDefaultFusedVariant = 0;
 
 int check_geom(int64_t rows, int64_t cols, int64_t vocab, const void* logits, int32_t dtype,
                int64_t stride, RowGeom* geo) {
@@ -502,16 +521,39 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
   const float k2 = kLog2e / temperature;
   const float inv_temp = 1.0f / temperature;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)geo.n), block(kBlock);
-  if (logits_dtype == PRL_DTYPE_F32) {
-    hipLaunchKernelGGL((fused_logits_loss_kernel<F32, kBlock, kUnrollBwd>), grid, block, 0, s, geo, a,
-                       static_cast<const float*>(logits), k2, inv_temp,
-                       static_cast<float*>(grad_logits));
-  } else {
-    hipLaunchKernelGGL((fused_logits_loss_kernel<BF16, kBlock, kUnrollBwd>), grid, block, 0, s, geo, a,
-                       static_cast<const uint16_t*>(logits), k2, inv_temp,
-                       static_cast<uint16_t*>(grad_logits));
+  const dim3 grid((unsigned)geo.n);
+  // Variant selection (PRL_FUSED_VARIANT, read per call so one process can sweep them):
+  //   0: 256 threads x unroll 4, forward order          1: + reversed second pass
+  //   2: + non-temporal gradient stores                 3: 1024 threads, 1 workgroup per CU, reversed, NT
+  //   4: 512 threads, 2 workgroups per CU, reversed, NT 5: 1024 threads, 1 workgroup per CU, forward order
+  int variant = kDefaultFusedVariant;
+  if (const char* e = getenv("PRL_FUSED_VARIANT")) variant = atoi(e);
+#define PRL_FUSED_LAUNCH(TT, ST, BLK, UNR, REV, NTS, LDSB)                                            \
+  do {                                                                                              \
+    auto kfn = fused_logits_loss_kernel<TT, BLK, UNR, REV, NTS>;                                    \
+    const size_t lds_bytes = (LDSB) > 0 ? (size_t)(LDSB) : sizeof(Osm) * (BLK / kWave);             \
+    if (lds_bytes > 48 * 1024)                                                                      \
+      PRL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                         \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+    hipLaunchKernelGGL(kfn, grid, dim3(BLK), lds_bytes, s, geo, a, static_cast<const ST*>(logits), k2, \
+                       inv_temp, static_cast<ST*>(grad_logits));                                    \
+  } while (0)
+#define PRL_FUSED_DISPATCH(TT, ST)                                              \
+  switch (variant) {                                                            \
+    case 1: PRL_FUSED_LAUNCH(TT, ST, 256, 4, true, false, 0); break;            \
+    case 2: PRL_FUSED_LAUNCH(TT, ST, 256, 4, true, true, 0); break;             \
+    case 3: PRL_FUSED_LAUNCH(TT, ST, 1024, 2, true, true, 96 * 1024); break;    \
+    case 4: PRL_FUSED_LAUNCH(TT, ST, 512, 4, true, true, 64 * 1024); break;     \
+    case 5: PRL_FUSED_LAUNCH(TT, ST, 1024, 2, false, false, 96 * 1024); break;  \
+    default: PRL_FUSED_LAUNCH(TT, ST, 256, 4, false, false, 0); break;          \
   }
+  if (logits_dtype == PRL_DTYPE_F32) {
+    PRL_FUSED_DISPATCH(F32, float)
+  } else {
+    PRL_FUSED_DISPATCH(BF16, uint16_t)
+  }
+#undef PRL_FUSED_DISPATCH
+#undef PRL_FUSED_LAUNCH
   PRL_LAUNCH_CHECK("fused_logits_loss_kernel");
   return PRL_OK;
 }

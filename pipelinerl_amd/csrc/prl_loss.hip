@@ -87,15 +87,18 @@ struct LossArgs {
   double* partials;  // [gridDim.x][P_NUM]
 };
 
+// Per-lane partial sums are fp32 (a lane folds at most a few dozen tokens, so the rounding stays
+// ~1e-7 relative, below the reference's own fp32 summation error); everything across lanes,
+// waves and blocks is fp64.
 struct Acc {
-  double s[P_NUM_ADD];
+  float s[P_NUM_ADD];
   float mx[4];
   float mn[4];
 };
 
 __device__ __forceinline__ void acc_init(Acc& a) {
 #pragma unroll
-  for (int i = 0; i < P_NUM_ADD; ++i) a.s[i] = 0.0;
+  for (int i = 0; i < P_NUM_ADD; ++i) a.s[i] = 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     a.mx[i] = -INFINITY;
@@ -103,9 +106,10 @@ __device__ __forceinline__ void acc_init(Acc& a) {
   }
 }
 
-// mask_sum element: (x / num_labels * mask).nan_to_num(0) for a masked token
-__device__ __forceinline__ double per_label(float x, float nl) {
-  return (double)prl_nan_to_num0(x / nl);
+// mask_sum element: (x / num_labels * mask).nan_to_num(0) for a masked token; the division is
+// one reciprocal per token shared by the 17 per-label statistics (<= 1 ulp from x / nl).
+__device__ __forceinline__ float per_label(float x, float inv_nl) {
+  return prl_nan_to_num0(x * inv_nl);
 }
 
 // One token on the unshifted axis. `valid_pos`: column >= 1 (a shifted position exists).
@@ -116,9 +120,9 @@ __device__ __forceinline__ void token_step(const LossArgs& a, Acc& acc, bool val
                                            float& g_nlp, float& g_ent) {
   g_nlp = 0.0f;
   g_ent = 0.0f;
-  if (seq_start) acc.s[P_N_SEQ] += 1.0;
+  if (seq_start) acc.s[P_N_SEQ] += 1.0f;
   if (!valid_pos) return;
-  if (a.cfg.group_normalization && !(gt > 0.0f)) acc.s[P_BAD_GT] += 1.0;
+  if (a.cfg.group_normalization && !(gt > 0.0f)) acc.s[P_BAD_GT] += 1.0f;
   const bool m = (label != -100);
   if (!m) {
     int b0, b1, b2;
@@ -133,25 +137,26 @@ __device__ __forceinline__ void token_step(const LossArgs& a, Acc& acc, bool val
   prl_token_eval(a.cfg, x, o);
   g_nlp = o.g_nlp;
   g_ent = o.g_ent;
-  acc.s[P_LOSS] += (double)o.contrib;
-  acc.s[P_REWARD] += per_label(reward, nl);
-  acc.s[P_ENTROPY] += per_label(ent, nl);
-  acc.s[P_OLD] += per_label(old_lp, nl);
-  acc.s[P_NEW] += per_label(nlp, nl);
-  acc.s[P_REF] += per_label(ref_lp, nl);
-  acc.s[P_ADV] += per_label(adv, nl);
-  acc.s[P_KL] += per_label(o.kl, nl);
-  acc.s[P_KL_NO] += per_label(o.kl_new_old, nl);
-  acc.s[P_ABS_LR] += per_label(o.abs_lrno, nl);
-  acc.s[P_RATIO] += per_label(o.ratio_stat, nl);
-  acc.s[P_RATIO_SUM] += (double)prl_nan_to_num0(o.ratio_stat);
-  acc.s[P_RATIO_SQ] += (double)prl_nan_to_num0(o.ratio_stat * o.ratio_stat);
-  acc.s[P_RATIO_REF_NEW] += per_label(o.exp_lrrn, nl);
-  acc.s[P_RATIO_REF_OLD] += per_label(o.exp_ref_old, nl);
-  acc.s[P_CLAMP_RN] += per_label(o.clamp_rn, nl);
-  acc.s[P_CLAMP_NO] += per_label(o.clamp_no, nl);
-  acc.s[P_TW] += per_label(o.w, nl);
-  acc.s[P_N_MASKED] += 1.0;
+  const float inv_nl = 1.0f / nl;
+  acc.s[P_LOSS] += o.contrib;
+  acc.s[P_REWARD] += per_label(reward, inv_nl);
+  acc.s[P_ENTROPY] += per_label(ent, inv_nl);
+  acc.s[P_OLD] += per_label(old_lp, inv_nl);
+  acc.s[P_NEW] += per_label(nlp, inv_nl);
+  acc.s[P_REF] += per_label(ref_lp, inv_nl);
+  acc.s[P_ADV] += per_label(adv, inv_nl);
+  acc.s[P_KL] += per_label(o.kl, inv_nl);
+  acc.s[P_KL_NO] += per_label(o.kl_new_old, inv_nl);
+  acc.s[P_ABS_LR] += per_label(o.abs_lrno, inv_nl);
+  acc.s[P_RATIO] += per_label(o.ratio_stat, inv_nl);
+  acc.s[P_RATIO_SUM] += prl_nan_to_num0(o.ratio_stat);
+  acc.s[P_RATIO_SQ] += prl_nan_to_num0(o.ratio_stat * o.ratio_stat);
+  acc.s[P_RATIO_REF_NEW] += per_label(o.exp_lrrn, inv_nl);
+  acc.s[P_RATIO_REF_OLD] += per_label(o.exp_ref_old, inv_nl);
+  acc.s[P_CLAMP_RN] += per_label(o.clamp_rn, inv_nl);
+  acc.s[P_CLAMP_NO] += per_label(o.clamp_no, inv_nl);
+  acc.s[P_TW] += per_label(o.w, inv_nl);
+  acc.s[P_N_MASKED] += 1.0f;
   acc.s[P_BAD_NLP] += o.bad_nlp;
   acc.s[P_BAD_LRRN] += o.bad_lrrn;
   acc.s[P_BAD_KL] += o.bad_kl;
@@ -171,7 +176,7 @@ __device__ __forceinline__ void block_reduce_store(const Acc& acc, double* out) 
   const int wid = threadIdx.x / kWave;
 #pragma unroll
   for (int i = 0; i < P_NUM_ADD; ++i) {
-    double v = prl::wave_sum(acc.s[i]);
+    double v = prl::wave_sum((double)acc.s[i]);
     if (lane == 0) lds[wid][i] = v;
   }
 #pragma unroll

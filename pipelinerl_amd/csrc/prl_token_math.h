@@ -22,6 +22,14 @@
 #define PRL_HD static inline
 #endif
 
+// exp() of quantities that only feed statistics (never the loss or its gradient): the hardware
+// v_exp_f32 path on the device (~2 ulp), libm on the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PRL_STAT_EXPF(x) __expf(x)
+#else
+#define PRL_STAT_EXPF(x) expf(x)
+#endif
+
 struct PrlTokenIn {
   float nlp;           // new_logprobs[t]          (:212)
   float ent;           // entropy[t]               (:215-233)
@@ -152,8 +160,8 @@ PRL_HD void prl_token_eval(const prl_loss_config& c, const PrlTokenIn& x, PrlTok
   o.kl = kl;
   o.kl_new_old = kl_no;
   o.abs_lrno = fabsf(lrno);
-  o.exp_lrrn = expf(lrrn);
-  o.exp_ref_old = expf(x.ref_lp - x.old_lp);
+  o.exp_lrrn = kl_inside ? ecl : PRL_STAT_EXPF(lrrn);  // inside the clamp range cl == lrrn
+  o.exp_ref_old = PRL_STAT_EXPF(x.ref_lp - x.old_lp);
   o.clamp_rn = (fabsf(lrrn) > C) ? 1.0f : 0.0f;
   o.clamp_no = clamp_no;
   o.bad_nlp = !prl_isfinite(x.nlp);

@@ -46,50 +46,108 @@ def _alloc_outputs(total: int, dev: torch.device, packed: bool) -> dict[str, tor
     return out
 
 
+class PackedStep(Sequence):
+    """Result of one K6 launch: flat per-token buffers holding consecutive micro-batches.  Behaves
+    like a list of `PipelineBatchEncoding`; the per-micro-batch objects (12 tensor views each) are
+    only materialised when indexed, so a 4096-micro-batch step costs no host time up front."""
+
+    def __init__(self, flat: dict[str, torch.Tensor], pk_dst: np.ndarray, mb_off: np.ndarray,
+                 model_versions: np.ndarray, pads: np.ndarray | None):
+        self.flat = flat
+        self.pk_dst = pk_dst          # int64 [m + 1] token offset of every packed sequence
+        self.mb_off = mb_off          # int64 [n_mb + 1] index into pk_dst of every micro-batch
+        self.model_versions = model_versions  # int64 [n_mb]
+        self.pads = pads
+        self.token_off = pk_dst[mb_off]  # int64 [n_mb + 1] token offset of every micro-batch
+        self._cache: dict[int, PipelineBatchEncoding] = {}
+
+    def __len__(self) -> int:
+        return len(self.mb_off) - 1
+
+    @property
+    def total_tokens(self) -> int:
+        return int(self.pk_dst[-1])
+
+    def __getitem__(self, j):  # type: ignore[override]
+        if isinstance(j, slice):
+            return [self[i] for i in range(*j.indices(len(self)))]
+        if j < 0:
+            j += len(self)
+        got = self._cache.get(j)
+        if got is None:
+            a, b = int(self.mb_off[j]), int(self.mb_off[j + 1])
+            t0, t1 = int(self.pk_dst[a]), int(self.pk_dst[b])
+            bounds = (self.pk_dst[a : b + 1] - self.pk_dst[a]).astype(np.int32)
+            got = PipelineBatchEncoding(
+                **{k: v[t0:t1].unsqueeze(0) for k, v in self.flat.items()},
+                model_version=int(self.model_versions[j]),
+                is_packed=True,
+                seq_boundaries=torch.from_numpy(bounds),
+                padding=int(self.pads[j]) if self.pads is not None else 0,
+            )
+            self._cache[j] = got
+        return got
+
+    def step_batch(self) -> PipelineBatchEncoding:
+        """The whole launch as ONE [1, T_step] batch over the same buffers (no copy)."""
+        return PipelineBatchEncoding(
+            **{k: v.unsqueeze(0) for k, v in self.flat.items()},
+            model_version=int(self.model_versions.min()) if len(self.model_versions) else 0, is_packed=True,
+        )
+
+
+def plan_packing(lens: np.ndarray, micro_batches: Sequence[Sequence[int]], sentinel_pad: Sequence[int] | None):
+    """Host-side O(#sequences) plan of one K6 launch, vectorised: (pk_src, pk_seg, pk_dst, mb_off)."""
+    n_mb = len(micro_batches)
+    counts = np.fromiter((len(x) for x in micro_batches), dtype=np.int64, count=n_mb)
+    src = np.fromiter((int(s) for mb in micro_batches for s in mb), dtype=np.int64, count=int(counts.sum()))
+    pads = None if sentinel_pad is None else np.asarray(sentinel_pad, dtype=np.int64)
+    if pads is None or not pads.any():
+        mb_off = np.zeros(n_mb + 1, dtype=np.int64)
+        np.cumsum(counts, out=mb_off[1:])
+        seg = np.arange(len(src), dtype=np.int64) - np.repeat(mb_off[:-1], counts)
+        pk_len = lens[src] if len(src) else np.zeros(0, dtype=np.int64)
+        pk_src = src
+    else:
+        extra = (pads > 0).astype(np.int64)
+        counts2 = counts + extra
+        mb_off = np.zeros(n_mb + 1, dtype=np.int64)
+        np.cumsum(counts2, out=mb_off[1:])
+        m = int(mb_off[-1])
+        pk_src = np.full(m, -1, dtype=np.int64)
+        pk_len = np.zeros(m, dtype=np.int64)
+        seg = np.arange(m, dtype=np.int64) - np.repeat(mb_off[:-1], counts2)
+        real = seg < np.repeat(counts, counts2)  # the filler, when present, is the last slot
+        pk_src[real] = src
+        pk_len[real] = lens[src]
+        pk_len[~real] = pads[extra > 0]
+    pk_dst = np.zeros(len(pk_src) + 1, dtype=np.int64)
+    np.cumsum(pk_len, out=pk_dst[1:])
+    return pk_src.astype(np.int32), seg.astype(np.int32), pk_dst, mb_off
+
+
 def pack_prepared(
     prep: PreparedRollouts,
     micro_batches: Sequence[Sequence[int]],
     eos_token_id: int,
     sentinel_pad: Sequence[int] | None = None,
     per_token_columns: int = 0,
-    with_flat: bool = False,
-) -> list[PipelineBatchEncoding] | tuple[list[PipelineBatchEncoding], dict[str, torch.Tensor]]:
+) -> PackedStep:
     """Pack `micro_batches[j]` (lists of sequence indices into `prep`) into packed batches with a
     single K6 launch.  `sentinel_pad[j]` > 0 appends that many filler tokens to micro-batch j
-    (sequence-parallel padding, reference data.py:222-230).  Returns one batch per micro-batch;
-    their tensors are views of shared flat buffers (also returned, as 1-D tensors over all the
-    step's tokens, when `with_flat`)."""
+    (sequence-parallel padding, reference data.py:222-230).  Returns a list-like `PackedStep`;
+    every micro-batch is a view into shared flat buffers."""
     lib = _lib.load()
     r = prep.rollouts
     dev = r.device
     lens = r.seq_lengths()
-    pk_src: list[int] = []
-    pk_seg: list[int] = []
-    pk_len: list[int] = []
-    mb_off = [0]
-    mb_nseq = []
-    for j, idxs in enumerate(micro_batches):
-        pad = int(sentinel_pad[j]) if sentinel_pad is not None else 0
-        for k, s in enumerate(idxs):
-            pk_src.append(int(s))
-            pk_seg.append(k)
-            pk_len.append(int(lens[s]))
-        n = len(idxs)
-        if pad:
-            pk_src.append(-1)
-            pk_seg.append(n)
-            pk_len.append(pad)
-            n += 1
-        mb_nseq.append(n)
-        mb_off.append(mb_off[-1] + n)
+    pk_src, pk_seg, pk_dst, mb_off = plan_packing(lens, micro_batches, sentinel_pad)
     m = len(pk_src)
-    pk_dst = np.zeros(m + 1, dtype=np.int64)
-    np.cumsum(np.asarray(pk_len, dtype=np.int64), out=pk_dst[1:])
     total = int(pk_dst[-1])
     out = _alloc_outputs(total, dev, packed=True)
-    d_src = torch.from_numpy(np.asarray(pk_src, dtype=np.int32)).to(dev, non_blocking=True)
+    d_src = torch.from_numpy(pk_src).to(dev, non_blocking=True)
     d_dst = torch.from_numpy(pk_dst).to(dev, non_blocking=True)
-    d_seg = torch.from_numpy(np.asarray(pk_seg, dtype=np.int32)).to(dev, non_blocking=True)
+    d_seg = torch.from_numpy(pk_seg).to(dev, non_blocking=True)
     if m and total:
         with torch.cuda.device(dev):
             _lib.check(
@@ -106,24 +164,19 @@ def pack_prepared(
                     _lib.current_stream_ptr(dev),
                 )
             )
+    # model_version of a micro-batch = min over its real sequences (data.py:279)
     mv = r.host_model_version
-    batches = []
-    for j, idxs in enumerate(micro_batches):
-        a, b = mb_off[j], mb_off[j + 1]
-        t0, t1 = int(pk_dst[a]), int(pk_dst[b])
-        fields = {k: v[t0:t1].unsqueeze(0) for k, v in out.items()}
-        bounds = (pk_dst[a : b + 1] - pk_dst[a]).astype(np.int32)
-        pad = int(sentinel_pad[j]) if sentinel_pad is not None else 0
-        batches.append(
-            PipelineBatchEncoding(
-                **fields,
-                model_version=int(min(mv[list(idxs)])) if len(idxs) else 0,
-                is_packed=True,
-                seq_boundaries=torch.from_numpy(bounds),
-                padding=pad,
-            )
-        )
-    return (batches, out) if with_flat else batches
+    n_mb = len(micro_batches)
+    if n_mb:
+        real = pk_src >= 0
+        mb_of = np.repeat(np.arange(n_mb), np.diff(mb_off))
+        versions = np.full(n_mb, np.iinfo(np.int64).max, dtype=np.int64)
+        np.minimum.at(versions, mb_of[real], mv[pk_src[real]])
+        versions[versions == np.iinfo(np.int64).max] = 0
+    else:
+        versions = np.zeros(0, dtype=np.int64)
+    pads = None if sentinel_pad is None else np.asarray(sentinel_pad, dtype=np.int64)
+    return PackedStep(out, pk_dst, mb_off, versions, pads)
 
 
 def pad_prepared(
@@ -322,6 +375,7 @@ def preprocess_fn(entry: dict[str, Any], tokenizer: Any, seq_length: int, is_rl:
 
 __all__ = [
     "MASKED_TOKEN_ID",
+    "PackedStep",
     "collate",
     "collate_packed",
     "create_sentinel_example",

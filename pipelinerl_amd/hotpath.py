@@ -60,26 +60,20 @@ class HotPathStep:
         self.eos_token_id = eos_token_id
         self.cfg, self.kl_coef, self.ent_coef = make_loss_config(config, current_step, max_step)
         self.group = group
-        self.batches: list[PipelineBatchEncoding] = []
+        self.batches: Any = []
         self.step_batch: PipelineBatchEncoding | None = None
         self.buffers: StepBuffers | None = None
         self.offsets: list[int] = []
 
     # -- preprocess ---------------------------------------------------------------------------
-    def preprocess(self, rollouts: RaggedRollouts, micro_batches: Sequence[Sequence[int]]) -> list[PipelineBatchEncoding]:
+    def preprocess(self, rollouts: RaggedRollouts, micro_batches: Sequence[Sequence[int]]):
         """K5 + one K6 launch.  The returned micro-batches are views into one flat step batch."""
         prep: PreparedRollouts = populate_rl_data_ragged(rollouts, self.eos_token_id, self.config)
-        self.batches, flat = pack_prepared(prep, micro_batches, self.eos_token_id, with_flat=True)
-        self.offsets = [0]
-        for b in self.batches:
-            self.offsets.append(self.offsets[-1] + b.input_ids.shape[1])
+        self.batches = pack_prepared(prep, micro_batches, self.eos_token_id)
+        self.offsets = [int(x) for x in self.batches.token_off]
         total = self.offsets[-1]
         dev = rollouts.device
-        # the whole step as ONE [1, T_step] batch over the same buffers (no copy)
-        self.step_batch = PipelineBatchEncoding(
-            **{k: v.unsqueeze(0) for k, v in flat.items()},
-            model_version=min((b.model_version for b in self.batches), default=0), is_packed=True,
-        )
+        self.step_batch = self.batches.step_batch()
         z = lambda: torch.zeros((1, total), dtype=torch.float32, device=dev)  # noqa: E731
         self.buffers = StepBuffers(z(), z(), z())
         return self.batches
