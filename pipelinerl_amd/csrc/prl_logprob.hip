@@ -421,7 +421,7 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_kernel(
 constexpr int kBlock = 256;
 constexpr int kUnrollFwd = 8;
 constexpr int kUnrollBwd = 4;
-constexpr int kDefaultFusedVariant = 0;
+constexpr int kDefaultFusedVariant = 3;  // measured fastest on MI355X (profiles/r01_kernel_sweep.txt)
 
 int check_geom(int64_t rows, int64_t cols, int64_t vocab, const void* logits, int32_t dtype,
                int64_t stride, RowGeom* geo) {

@@ -1,0 +1,440 @@
+"""Learner loop pieces: `LearnerStep.step()`, trainer messages, weight-update manager, data loader.
+
+The reference has no `step()` function: the step is the body of the `while` loop of
+`rl_finetuning_worker` (pipelinerl/finetune_loop.py:647-957).  `LearnerStep.step(batch)` has
+exactly that contract:
+
+    dequeue micro-batch -> count samples -> decide `do_optimizer_step` -> rl_step -> backward
+    (sentinel: loss * 0) -> publish SamplesProcessed -> on boundary: optimizer step, lr step,
+    metric aggregation; `maybe_send_weights()` applies the weight_update_interval rule (:936-949).
+
+Differences, all inside the contract:
+  * the per-micro-batch `dist.all_gather` of sample counters (:709, a latency-bound sync point)
+    is a single int64 all-reduce;
+  * `SamplesProcessed` goes through a persistent writer instead of open/append/close per
+    micro-batch (:805-808);
+  * gradient synchronisation is left to the wrapped model (DDP `no_sync`) exactly like
+    `toggle_sync` (:746-755).
+"""
+
+from __future__ import annotations
+
+import contextlib
+import logging
+import threading
+import time
+from collections import defaultdict
+from concurrent.futures import ThreadPoolExecutor
+from queue import Empty, Queue
+from typing import Any, Callable, Dict, List, Literal, Optional
+
+import numpy as np
+import torch
+from pydantic import BaseModel, Field
+
+from .finetune.rl import RLConfig, rl_step as _rl_step
+from .finetune.rl.utils import aggregate_rl_stats, effective_sample_size
+from .finetune.types import PipelineBatchEncoding, TrainingMetrics
+from .streams import SingleStreamSpec, read_stream, write_to_streams
+
+logger = logging.getLogger(__name__)
+
+TRAINER_TOPIC = "weight_update_request"  # carries every trainer message, not only weight updates
+
+
+# ---------------------------------------------------------------------------------------------
+# trainer -> everyone messages (reference finetune_loop.py:141-171; same `kind` discriminators)
+# ---------------------------------------------------------------------------------------------
+
+
+class ParameterInfo(BaseModel):
+    name: str
+    shape: list[int]
+    dtype: str
+
+
+class WeightUpdateRequest(BaseModel):
+    kind: Literal["weight_update_request"] = "weight_update_request"
+    version: int
+    parameters_info: list[ParameterInfo]
+    timestamp: float = Field(default_factory=time.time)
+    # MI355X extension: how the bytes travel ("per_tensor" = reference behaviour)
+    transport: str = "bucketed"
+    bucket_bytes: int = 1 << 30
+
+
+class WeightUpdateSuccess(BaseModel):
+    kind: Literal["weight_update_success"] = "weight_update_success"
+    version: int
+    timestamp: float = Field(default_factory=time.time)
+
+
+class SamplesProcessed(BaseModel):
+    kind: Literal["samples_processed"] = "samples_processed"
+    samples_processed: int
+    timestamp: float = Field(default_factory=time.time)
+
+
+class TrainingDone(BaseModel):
+    kind: Literal["training_done"] = "training_done"
+    timestamp: float = Field(default_factory=time.time)
+
+
+TrainerMessage = WeightUpdateRequest | WeightUpdateSuccess | SamplesProcessed | TrainingDone
+
+_MESSAGE_BY_KIND = {
+    "weight_update_request": WeightUpdateRequest,
+    "weight_update_success": WeightUpdateSuccess,
+    "samples_processed": SamplesProcessed,
+    "training_done": TrainingDone,
+}
+
+
+def parse_trainer_message(record: dict) -> TrainerMessage:
+    try:
+        return _MESSAGE_BY_KIND[record["kind"]](**record)
+    except KeyError as e:
+        raise ValueError(f"not a trainer message: {record!r}") from e
+
+
+# ---------------------------------------------------------------------------------------------
+# batch accounting helpers (reference :295-312)
+# ---------------------------------------------------------------------------------------------
+
+
+def get_batch_token_count(batch: PipelineBatchEncoding) -> int:
+    """Real (non-padding) tokens of a batch."""
+    return int(batch.attention_mask.sum().item())
+
+
+def get_batch_sequence_count(batch: PipelineBatchEncoding) -> int:
+    """Sequences in a batch; the sequence-parallel filler of a packed batch does not count."""
+    if batch.position_ids is not None:
+        assert batch.seq_boundaries is not None
+        return len(batch.seq_boundaries) - (1 if batch.padding == 0 else 2)
+    return batch.input_ids.size(0)
+
+
+def calculate_train_steps(args: Any, interrupt_train_steps: int) -> int:
+    """reference :1100-1107."""
+    if interrupt_train_steps == -1:
+        assert args.interrupt_train_steps <= args.max_train_steps
+        return args.max_train_steps if args.interrupt_train_steps < 0 else args.interrupt_train_steps
+    assert interrupt_train_steps <= args.max_train_steps
+    return interrupt_train_steps
+
+
+# ---------------------------------------------------------------------------------------------
+# data loader thread (reference :92-134)
+# ---------------------------------------------------------------------------------------------
+
+
+def run_data_loader(data_stream: SingleStreamSpec, batch_queue: Queue, device: Any, stop: threading.Event | None = None) -> None:
+    """Read `training_data/<instance>/<rank>` records, rebuild the batch, move it to `device`,
+    hand it to the training thread.  Exceptions travel through the queue like in the reference."""
+    try:
+        with read_stream(data_stream) as reader:
+            for record in reader.read():
+                if stop is not None and stop.is_set():
+                    return
+                batch = PipelineBatchEncoding(**record)
+                if device is not None:
+                    batch = batch.to_device(device)
+                batch_queue.put(batch)
+    except Exception as e:  # noqa: BLE001 - forwarded to the consumer
+        logger.error(f"Error in stream reader: {e}")
+        batch_queue.put(e)
+
+
+def batch_generator(batch_queue: Queue, stop: threading.Event | None = None):
+    """Blocking iterator over the loader queue with the reference's growing poll timeout (:583-597)."""
+    while True:
+        timeout = 0.1
+        while True:
+            try:
+                item = batch_queue.get(timeout=timeout)
+                break
+            except Empty:
+                if stop is not None and stop.is_set():
+                    return
+                timeout = min(timeout * 1.5, 5.0)
+        if isinstance(item, Exception):
+            raise item
+        yield item
+
+
+# ---------------------------------------------------------------------------------------------
+# weight updates, send side (reference :174-292)
+# ---------------------------------------------------------------------------------------------
+
+
+class WeightUpdateManager:
+    """Trainer side of the in-flight weight update: rank 0 announces the parameter list to every
+    inference server over HTTP (the POST returns once the update is applied, vllm1.py:244-249),
+    streams the bytes through the RCCL update group, then publishes `WeightUpdateSuccess`.
+
+    `actor_update_group` is a `pipelinerl_amd.weight_sync.WeightSyncGroup`; `named_parameters_fn`
+    returns the full (gathered) parameters on rank 0 — e.g. `lambda: model.named_parameters()`
+    for DDP, or a FULL_STATE_DICT gather for FSDP."""
+
+    def __init__(self, llm_urls: list[str], accelerated_model: Any, update_stream: SingleStreamSpec | None,
+                 actor_update_group: Any, is_main_process: bool = True, named_parameters_fn: Callable | None = None,
+                 transport: str = "bucketed", bucket_bytes: int = 1 << 30, post: Callable | None = None):
+        self.llm_urls = llm_urls
+        self.accelerated_model = accelerated_model
+        self.update_stream = update_stream
+        self.actor_update_group = actor_update_group
+        self.is_main_process = is_main_process
+        self.named_parameters_fn = named_parameters_fn or (lambda: _unwrap(accelerated_model).named_parameters())
+        self.transport = transport
+        self.bucket_bytes = bucket_bytes
+        self.thread_pool = ThreadPoolExecutor(max_workers=max(1, len(llm_urls)))
+        self._post = post or _http_post
+        self._sender = None
+        self._shutdown = False
+
+    def _request_weight_update(self, url: str, message: WeightUpdateRequest) -> None:
+        try:
+            self._post(url + "/receive_weight_update", message.model_dump())
+        except Exception as e:  # noqa: BLE001 - logged, not raised (reference :188-192)
+            logger.error(f"Error sending weight update request to {url}: {e}")
+
+    def request_weight_updates(self, message: WeightUpdateRequest):
+        return [self.thread_pool.submit(self._request_weight_update, url, message) for url in self.llm_urls]
+
+    def shutdown(self) -> None:
+        if not self._shutdown:
+            self.thread_pool.shutdown(wait=True)
+            self._shutdown = True
+
+    def send_weight_update(self, version: int) -> None:
+        """Blocking; every trainer rank calls it, rank 0 sends."""
+        if self.is_main_process:
+            from .weight_sync import BucketedSender
+
+            params = [(n, p.detach()) for n, p in self.named_parameters_fn()]
+            info = [ParameterInfo(name=n, shape=list(p.shape), dtype=str(p.dtype)) for n, p in params]
+            message = WeightUpdateRequest(version=version, parameters_info=info, transport=self.transport, bucket_bytes=self.bucket_bytes)
+            futures = self.request_weight_updates(message)
+            if self.transport == "bucketed":
+                if self._sender is None:
+                    self._sender = BucketedSender(self.actor_update_group, self.bucket_bytes)
+                self._sender.send(params)
+            else:  # the reference's one-broadcast-per-parameter protocol
+                for _, p in params:
+                    self.actor_update_group.broadcast(p.data, src=0, stream=torch.cuda.current_stream())
+            for f in futures:
+                f.result()
+            if self.update_stream is not None:
+                with write_to_streams(self.update_stream) as writer:
+                    writer.write(WeightUpdateSuccess(version=version))
+        _barrier()
+
+
+def _http_post(url: str, payload: dict) -> None:
+    import requests
+
+    r = requests.post(url, json=payload)
+    r.raise_for_status()
+
+
+def _unwrap(model: Any) -> Any:
+    return getattr(model, "module", model)
+
+
+def _barrier() -> None:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+# ---------------------------------------------------------------------------------------------
+# LearnerStep
+# ---------------------------------------------------------------------------------------------
+
+
+class LearnerStep:
+    """One data-parallel learner rank.  `step(batch)` consumes one micro-batch."""
+
+    def __init__(
+        self,
+        model: torch.nn.Module,
+        optimizer: torch.optim.Optimizer,
+        rl_config: RLConfig,
+        train_batch_size: int,
+        gradient_accumulation_passes: int,
+        max_train_steps: int,
+        lr_scheduler: Any = None,
+        seq_parallel: int = 1,
+        weight_update_manager: WeightUpdateManager | None = None,
+        weight_update_interval: int = 1,
+        send_weight_updates: bool = True,
+        trainer_stream: SingleStreamSpec | None = None,
+        training_metrics: TrainingMetrics | None = None,
+        gradient_clipping_threshold: float | None = None,
+        max_lag: int | None = None,
+        rl_step_fn: Callable = _rl_step,
+        process_group: Any = None,
+    ):
+        import torch.distributed as dist
+
+        self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
+        self.rl_step_fn = rl_step_fn
+        self.group = process_group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self.rank = dist.get_rank(process_group) if self.distributed else 0
+        self.seq_parallel = seq_parallel
+        self.metrics = training_metrics or TrainingMetrics()
+        self.max_train_steps = max_train_steps
+        self.weight_update_manager = weight_update_manager
+        self.weight_update_interval = weight_update_interval
+        self.send_weight_updates = send_weight_updates
+        self.gradient_clipping_threshold = gradient_clipping_threshold
+        self.max_lag = max_lag
+        self.train_batch_size = train_batch_size
+
+        # sample accounting (reference :627-646)
+        num_lead = self.world // seq_parallel
+        passes_per_lead = gradient_accumulation_passes // num_lead
+        self.samples_per_lead_per_step = passes_per_lead * train_batch_size
+        self.samples_per_step = self.samples_per_lead_per_step * num_lead
+        self.start_samples = self.metrics.samples
+        self.target_samples_per_lead = self.samples_per_lead_per_step
+        self.target_samples = self.samples_per_step
+        self.local_samples = 0
+        self.total_samples = 0
+        self.rl_config = rl_config.model_copy()
+        self.rl_config.batch_size = self.samples_per_step  # the loss normaliser (:644-646)
+
+        self._rl_metrics: dict[str, list] = defaultdict(list)
+        self._micro_batch_sizes: list[int] = []
+        self._tokens: list[int] = []
+        self._lag: dict[str, int] = {}
+        self._writer_cm = None
+        self._writer = None
+        if trainer_stream is not None and self.rank == 0:
+            self._writer_cm = write_to_streams(trainer_stream)
+            self._writer = self._writer_cm.__enter__()
+        self._counter_device = next(model.parameters()).device if any(True for _ in model.parameters()) else torch.device("cpu")
+
+    # -- helpers --------------------------------------------------------------------------------
+    def _sum_over_ranks(self, value: int) -> int:
+        if not self.distributed or self.world == 1:
+            return value
+        import torch.distributed as dist
+
+        t = torch.tensor([value], dtype=torch.int64, device=self._counter_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return int(t.item())
+
+    @contextlib.contextmanager
+    def _sync_context(self, sync: bool):
+        if sync or not hasattr(self.model, "no_sync"):
+            yield
+        else:
+            with self.model.no_sync():
+                yield
+
+    def publish(self, message: BaseModel) -> None:
+        if self._writer is not None:
+            self._writer.write(message)
+
+    # -- the step -------------------------------------------------------------------------------
+    def step(self, batch: PipelineBatchEncoding) -> dict[str, Any]:
+        """Consume one micro-batch.  Returns {"loss", "did_optimizer_step", "stats", "metrics"}."""
+        m = self.metrics
+        is_sentinel = bool(batch.sentinel)
+        if self.local_samples == self.target_samples_per_lead:
+            assert is_sentinel, "We should get a sentinel batch"
+        if self.max_lag is not None and m.last_broadcasted_version - batch.model_version > self.max_lag:
+            m.samples_too_old_to_train += self.train_batch_size
+        self._lag["min_version"] = min(self._lag.get("min_version", batch.model_version), batch.model_version)
+        self._lag["max_version"] = max(self._lag.get("max_version", batch.model_version), batch.model_version)
+
+        if not is_sentinel:
+            m.passes += 1
+            n = get_batch_sequence_count(batch)
+            self._micro_batch_sizes.append(n)
+            self.local_samples += n
+            self._tokens.append(get_batch_token_count(batch))
+
+        overcounted = self._sum_over_ranks(self.local_samples)
+        assert overcounted % self.seq_parallel == 0
+        self.total_samples = overcounted // self.seq_parallel
+        do_optimizer_step = self.total_samples == self.target_samples
+
+        with self._sync_context(do_optimizer_step):
+            loss, stats = self.rl_step_fn(self.model, batch, m.completed_steps, self.max_train_steps, self.rl_config)
+            if is_sentinel:
+                loss = loss * 0.0  # keeps every rank's forward/backward count equal, adds nothing
+            else:
+                for k, v in stats.items():
+                    self._rl_metrics[k].append(v)
+            loss.backward()
+
+        self.publish(SamplesProcessed(samples_processed=self.start_samples + self.total_samples))
+        result: dict[str, Any] = {"loss": loss.detach(), "did_optimizer_step": False, "stats": stats, "metrics": {}}
+        if not do_optimizer_step:
+            return result
+
+        # ---- accumulation boundary: optimizer step (:810-857)
+        self.target_samples_per_lead += self.samples_per_lead_per_step
+        self.target_samples += self.samples_per_step
+        m.completed_steps += 1
+        m.samples = self.start_samples + self.total_samples
+        m.tokens += sum(self._tokens) * self.world
+        assert sum(self._micro_batch_sizes) == self.samples_per_lead_per_step
+        if self.gradient_clipping_threshold is not None:
+            gn = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.gradient_clipping_threshold)
+            m.grad_norm = float(gn)
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        result["did_optimizer_step"] = True
+        result["metrics"] = self._aggregate_metrics()
+        self._rl_metrics = defaultdict(list)
+        self._micro_batch_sizes, self._tokens, self._lag = [], [], {}
+        # the local counter keeps running across steps, like the reference's `local_samples`
+        return result
+
+    def _aggregate_metrics(self) -> dict[str, float]:
+        """rl/* metrics of the finished step over all ranks (reference :908-922)."""
+        gathered = dict(self._rl_metrics)
+        if self.distributed and self.world > 1:
+            import torch.distributed as dist
+
+            parts: list = [None] * self.world
+            dist.all_gather_object(parts, gathered, group=self.group)
+            merged: dict[str, list] = defaultdict(list)
+            for p in parts:
+                for k, v in p.items():
+                    merged[k].extend(x for x in v if np.isfinite(x))
+            gathered = merged
+        if not gathered:
+            return {}
+        avg = aggregate_rl_stats(gathered, self.samples_per_step)
+        if all(k in avg for k in ("rl/ratio_new_old_sum", "rl/ratio_new_old_squared_sum", "rl/num_output_tokens_sum")):
+            avg["rl/ess"] = effective_sample_size(avg)
+        return avg
+
+    def maybe_send_weights(self) -> bool:
+        """After an optimizer step: broadcast when enough samples were trained since the last
+        broadcast (`weight_update_interval`, reference :936-949).  Model version == samples trained."""
+        m = self.metrics
+        if not self.send_weight_updates or self.weight_update_manager is None:
+            return False
+        if m.samples - m.last_broadcasted_version < self.weight_update_interval:
+            return False
+        self.weight_update_manager.send_weight_update(m.samples)
+        m.last_broadcasted_version = m.samples
+        return True
+
+    def finish(self) -> None:
+        """Signal `TrainingDone` and close the trainer stream."""
+        self.publish(TrainingDone())
+        if self._writer_cm is not None:
+            self._writer_cm.__exit__(None, None, None)
+            self._writer_cm = self._writer = None

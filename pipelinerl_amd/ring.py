@@ -1,0 +1,90 @@
+"""Python handle of the shared-memory record ring (C ABI `prl_ring_*`, csrc/prl_ring.cpp)."""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import queue
+import uuid
+
+from . import _lib
+
+
+class Ring:
+    """Bounded multi-producer / multi-consumer queue of byte records in POSIX shared memory.
+    Picklable: a child process (fork or spawn) re-attaches by name."""
+
+    def __init__(self, name: str | None = None, n_slots: int = 0, slot_bytes: int = 0, create: bool = True):
+        lib = _lib.load()
+        self.name = name or f"prl_{os.getpid()}_{uuid.uuid4().hex[:12]}"
+        h = ctypes.c_void_p()
+        if create:
+            _lib.check(lib.prl_ring_create(self.name.encode(), n_slots, slot_bytes, ctypes.byref(h)))
+        else:
+            _lib.check(lib.prl_ring_attach(self.name.encode(), ctypes.byref(h)))
+        self._h = h
+        self._owner_pid = os.getpid() if create else None
+        n, sb = ctypes.c_uint32(), ctypes.c_uint64()
+        _lib.check(lib.prl_ring_capacity(self._h, ctypes.byref(n), ctypes.byref(sb)))
+        self.n_slots, self.slot_bytes = n.value, sb.value
+
+    # -- pickling: attach by name in the other process ------------------------------------------
+    def __getstate__(self):
+        return {"name": self.name}
+
+    def __setstate__(self, state):
+        self.__init__(state["name"], create=False)
+
+    @staticmethod
+    def _timeout_ms(block: bool, timeout: float | None) -> int:
+        if not block:
+            return 0
+        return -1 if timeout is None else max(0, int(timeout * 1000))
+
+    def put_bytes(self, data: bytes | bytearray | memoryview, block: bool = True, timeout: float | None = None) -> None:
+        lib = _lib.load()
+        buf = (ctypes.c_char * len(data)).from_buffer_copy(data) if not isinstance(data, bytes) else data
+        rc = lib.prl_ring_put(self._h, buf, len(data), self._timeout_ms(block, timeout))
+        if rc in (_lib.PRL_EAGAIN, _lib.PRL_ETIMEDOUT):
+            raise queue.Full()
+        if rc == _lib.PRL_EMSGSIZE:
+            raise ValueError(f"Serialized object size ({len(data)} bytes) exceeds maximum entry size ({self.slot_bytes} bytes)")
+        _lib.check(rc)
+
+    def get_bytes(self, block: bool = True, timeout: float | None = None) -> bytes:
+        lib = _lib.load()
+        p, n, ticket = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64()
+        rc = lib.prl_ring_acquire(self._h, ctypes.byref(p), ctypes.byref(n), ctypes.byref(ticket), self._timeout_ms(block, timeout))
+        if rc in (_lib.PRL_EAGAIN, _lib.PRL_ETIMEDOUT):
+            raise queue.Empty()
+        _lib.check(rc)
+        try:
+            return ctypes.string_at(p.value, n.value)
+        finally:
+            lib.prl_ring_release(self._h, ticket.value)
+
+    def qsize(self) -> int:
+        n = ctypes.c_uint64()
+        _lib.check(_lib.load().prl_ring_size(self._h, ctypes.byref(n)))
+        return n.value
+
+    def max_record_bytes(self) -> int:
+        n = ctypes.c_uint64()
+        _lib.check(_lib.load().prl_ring_max_record_bytes(self._h, ctypes.byref(n)))
+        return n.value
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h:
+            lib = _lib.load()
+            if self._owner_pid is not None and self._owner_pid != os.getpid():
+                # a forked child inherits the creator's handle: it must not unlink the segment
+                pass
+            else:
+                lib.prl_ring_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

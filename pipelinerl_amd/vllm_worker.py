@@ -1,0 +1,98 @@
+"""Receive side of the weight update: a standalone shim with the method set of the reference's
+vLLM `WorkerExtension` (pipelinerl/vllm1.py:62-134).  vLLM-ROCm is not part of this image, so the
+shim is engine-agnostic: it needs `self.device`, `self.rank` and a `load_weights(list[(name,
+tensor)]) -> iterable of loaded names` callable (vLLM's `model_runner.model.load_weights`).
+Mix it into a vLLM worker class or use `StandaloneWeightReceiver` directly.
+"""
+
+from __future__ import annotations
+
+import json
+import logging
+from typing import Any, Callable
+
+import torch
+
+from .finetune_loop import WeightUpdateRequest
+from .weight_sync import BucketedReceiver, WeightSyncGroup, string_to_dtype
+
+logger = logging.getLogger(__name__)
+
+
+class WorkerExtension:
+    device: torch.device
+    rank: int
+    pg_rank: int
+    model_update_group: Any
+
+    def _load_weights(self, weights):  # overridden / provided by the engine
+        return self.model_runner.model.load_weights(weights=weights)  # type: ignore[attr-defined]
+
+    def _after_update(self) -> None:
+        """Hook for engine caches that must be dropped after new weights land (the reference
+        invalidates its fp32 lm_head cache here, vllm1.py:126)."""
+
+    def init_actor_update_group(self, actor_idx: int, actor_ngpus: int, weight_update_group_init_method: str,
+                                weight_update_group_world_size: int) -> None:
+        # rank layout of the reference (vllm1.py:71): trainer = 0, worker = 1 + llm index * gpus + local rank
+        self.pg_rank = 1 + actor_idx * actor_ngpus + self.rank
+        logger.info(f"[INIT_ACTOR_UPDATE_GROUP]: actor {actor_idx}, ngpus {actor_ngpus}, rank {self.rank}, pg_rank {self.pg_rank}, "
+                    f"init {weight_update_group_init_method}, world {weight_update_group_world_size}")
+        self.model_update_group = WeightSyncGroup.from_init_method(
+            weight_update_group_init_method, rank=self.pg_rank, world_size=weight_update_group_world_size, device=self.device
+        )
+        self._receiver = None
+
+    def receive_weight_update(self, request_json: str) -> None:
+        request = WeightUpdateRequest.model_validate_json(request_json) if isinstance(request_json, str) else WeightUpdateRequest(**request_json)
+        torch.cuda.synchronize(self.device)
+        expected = (torch.bfloat16, torch.float32, torch.float16)
+        for info in request.parameters_info:
+            if string_to_dtype(info.dtype) not in expected:
+                logger.warning(f"Unexpected dtype for {info.name}: {info.dtype}")
+
+        def load(views):
+            loaded = list(self._load_weights(views))
+            if len(loaded) != len(views):
+                missing = [n for n, _ in views]
+                raise ValueError(f"model {missing} not found in model state dict")
+
+        if request.transport == "bucketed":
+            if getattr(self, "_receiver", None) is None or self._receiver.bucket_bytes != request.bucket_bytes:
+                self._receiver = BucketedReceiver(self.model_update_group, request.bucket_bytes)
+            self._receiver.receive([i.model_dump() for i in request.parameters_info], load)
+        else:  # reference protocol: one broadcast per parameter
+            for info in request.parameters_info:
+                buf = torch.empty(tuple(info.shape), dtype=string_to_dtype(info.dtype), device=self.device)
+                self.model_update_group.broadcast(buf, src=0, stream=torch.cuda.current_stream())
+                load([(info.name, buf)])
+        self._after_update()
+        logger.info("Weight update received")
+
+    def close_communicator(self) -> None:
+        grp = getattr(self, "model_update_group", None)
+        if grp is not None:
+            grp.close()
+            self.model_update_group = None
+            logger.info("Weight update communicator closed")
+
+
+class StandaloneWeightReceiver(WorkerExtension):
+    """WorkerExtension over a plain `torch.nn.Module` (tests, non-vLLM engines): parameters are
+    copied by name."""
+
+    def __init__(self, module: torch.nn.Module, device: torch.device, rank: int = 0):
+        self.module = module
+        self.device = device
+        self.rank = rank
+        self._params = dict(module.named_parameters())
+
+    def _load_weights(self, weights):
+        loaded = []
+        for name, tensor in weights:
+            p = self._params.get(name)
+            if p is None:
+                continue
+            p.data.copy_(tensor.to(p.dtype), non_blocking=True)
+            loaded.append(name)
+        return loaded

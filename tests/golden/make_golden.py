@@ -244,11 +244,37 @@ def gen_sentinel(ref_utils):
     (HERE / "sentinel_example.json").write_text(json.dumps(ex))
 
 
+def gen_world():
+    """GPU partition arithmetic: call the reference's WorldMap._split_gpus_by_purpose (world.py:143-192)
+    on a stub `self` (the constructor needs hydra configs and placement state we do not model)."""
+    import pipelinerl.world as ref_world
+
+    out = []
+    for total in (1, 2, 4, 8):
+        for af, pf, ff in ((4, 0, 4), (2, 0, 6), (6, 0, 2), (4, 2, 2), (1, 0, 1), (0.5, 0.25, 3)):
+            for tp, pp in ((1, 1), (2, 1), (2, 2)):
+                for replicas in (1, 2):
+                    me = types.SimpleNamespace(world_size=1, node_size=total, gpus_per_llm=tp * pp, _log_info=lambda x: None)
+                    cfg = types.SimpleNamespace(world=types.SimpleNamespace(actor_fraction=af, preprocessor_fraction=pf, finetune_fraction=ff, replicas=replicas))
+                    rec = dict(total=total, actor_fraction=af, preprocessor_fraction=pf, finetune_fraction=ff, tp=tp, pp=pp, replicas=replicas)
+                    try:
+                        ref_world.WorldMap._split_gpus_by_purpose(me, cfg)
+                        rec.update(error=None, total_finetune_gpus=me.total_finetune_gpus, gpus_per_actor=me.gpus_per_actor,
+                                   gpus_per_preprocessor=me.gpus_per_preprocessor, llms_per_actor=me.llms_per_actor,
+                                   total_actor_llms=me.total_actor_llms, weight_update_group_size=me.weight_update_group_size)
+                    except ValueError as e:
+                        rec.update(error=str(e))
+                    out.append(rec)
+    (HERE / "world.json").write_text(json.dumps(out))
+    print(f"world: {len(out)} partitions, {sum(r['error'] is not None for r in out)} rejected")
+
+
 def main():
     ref_rl, ref_data, ref_utils = import_reference()
     gen_preprocess(ref_rl, ref_data)
     gen_rl_step(ref_rl, ref_data, ref_utils)
     gen_sentinel(ref_utils)
+    gen_world()
 
 
 if __name__ == "__main__":

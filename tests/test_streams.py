@@ -1,0 +1,150 @@
+"""Stream transports (CPU only): the files backend's wire format (one JSON object per line,
+tensors as nested lists — reference streams.py:249-346), the binary shm backend, partition
+writers, and that a batch survives both transports unchanged."""
+
+import json
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import preprocess as opre
+
+
+@pytest.fixture()
+def streams(tmp_path):
+    from pipelinerl_amd import streams as s
+
+    s.reset_streams_backend()
+    yield s
+    s.reset_streams_backend()
+
+
+def _batch():
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.synthetic import make_entries
+
+    data = opre.preprocess_chunk(make_entries(1, attempts=3, seq_length=24, vocab=50, seed=1, prompt_min=2, prompt_max=5), 2, True)
+    d = opre.collate_packed(data, 2, 1)
+    return PipelineBatchEncoding(**{k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}), d
+
+
+def _same(batch_kwargs, want):
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+
+    got = PipelineBatchEncoding(**batch_kwargs)
+    for k, v in want.items():
+        g = getattr(got, k)
+        if isinstance(v, np.ndarray):
+            assert g.dtype == torch.from_numpy(v).dtype and np.array_equal(g.numpy(), v), k
+        else:
+            assert g == v, k
+
+
+def test_backend_must_be_set_once(streams, tmp_path):
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="t")
+    with pytest.raises(ValueError):
+        streams.read_stream(spec)
+    streams.set_streams_backend("files")
+    with pytest.raises(ValueError):
+        streams.set_streams_backend("files")
+    streams.reset_streams_backend()
+    with pytest.raises(ValueError):
+        streams.set_streams_backend("redis")
+    with pytest.raises(ValueError):
+        streams.set_streams_backend("carrier-pigeon")
+
+
+def test_files_wire_format_and_roundtrip(streams, tmp_path):
+    streams.set_streams_backend("files")
+    batch, want = _batch()
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data", partition=3)
+    assert str(spec) == "training_data/0/3"
+    with streams.write_to_streams(spec) as w:
+        w.write(batch)
+        w.write({"kind": "samples_processed", "samples_processed": 7})
+        with pytest.raises(ValueError):
+            w.write({}, partition=0)
+    path = tmp_path / "streams" / "training_data" / "0" / "3" / "0.jsonl"
+    lines = path.read_text().splitlines()
+    assert len(lines) == 2
+    rec = json.loads(lines[0])
+    # tensors are nested lists, scalars plain, optional tensors null — the reference's record layout
+    assert rec["input_ids"] == want["input_ids"].tolist() and rec["seq_boundaries"] == want["seq_boundaries"].tolist()
+    assert rec["is_packed"] is True and rec["pixel_values"] is None
+    assert list(rec.keys())[:5] == ["input_ids", "attention_mask", "labels", "position_ids", "segment_ids"]
+    with streams.read_stream(spec) as r:
+        it = r.read()
+        _same(next(it), want)
+        assert next(it) == {"kind": "samples_processed", "samples_processed": 7}
+
+
+def test_file_reader_tails_partial_lines(streams, tmp_path):
+    streams.set_streams_backend("files")
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="actor")
+    d = streams.stream_dir(tmp_path, "actor", 0, 0)
+    d.mkdir(parents=True)
+    f = open(d / "0.jsonl", "w")
+    f.write('{"a": 1}\n{"b"')
+    f.flush()
+    got = []
+
+    def reader():
+        rd = streams.FileStreamReader(spec, poll_delay=0.01)
+        with rd:
+            for rec in rd.read():
+                got.append(rec)
+                if len(got) == 2:
+                    return
+
+    t = threading.Thread(target=reader, daemon=True)
+    t.start()
+    import time
+
+    time.sleep(0.1)
+    assert got == [{"a": 1}]
+    f.write(': 2}\n')
+    f.flush()
+    t.join(timeout=5)
+    assert got == [{"a": 1}, {"b": 2}]
+
+
+def test_partitioned_writer(streams, tmp_path):
+    streams.set_streams_backend("files")
+    rng = streams.StreamRangeSpec(exp_path=tmp_path, topic="training_data", partition_range=(0, 3))
+    assert str(rng) == "training_data/0/0-3"
+    with streams.write_to_streams(rng) as w:
+        for i in range(4):
+            w.write({"i": i})           # round robin: 0,1,2,0
+        w.write({"i": 99}, partition=2)
+        with pytest.raises(ValueError):
+            w.write({}, partition=3)
+    def lines(p):
+        return [json.loads(x) for x in (tmp_path / "streams" / "training_data" / "0" / str(p) / "0.jsonl").read_text().splitlines()]
+    assert lines(0) == [{"i": 0}, {"i": 3}] and lines(1) == [{"i": 1}] and lines(2) == [{"i": 2}, {"i": 99}]
+
+
+def test_shm_backend_roundtrip(streams, tmp_path, libprl):
+    streams.set_streams_backend("shm", n_slots=4, slot_bytes=1 << 16)
+    batch, want = _batch()
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data", partition=1)
+    with streams.write_to_streams(spec) as w:
+        w.write(batch)
+        w.write({"kind": "training_done"})
+        with streams.read_stream(spec) as r:
+            it = r.read()
+            _same(next(it), want)
+            assert next(it) == {"kind": "training_done"}
+
+
+def test_batch_codec_is_compact(libprl):
+    from pipelinerl_amd import batch_codec
+    from pipelinerl_amd.streams import _dumps
+
+    batch, want = _batch()
+    blob = batch_codec.encode_batch(batch)
+    T = want["input_ids"].shape[1]
+    assert len(blob) <= 68 * T + 4 * len(want["seq_boundaries"]) + 2048  # 5 x i64 + 7 x f32 per token + header
+    assert len(_dumps(batch)) > len(blob) / 2  # the JSON form is of the same order or larger even on tiny batches
+    _same(batch_codec.decode(blob), want)
