@@ -288,13 +288,13 @@ def main():
         "frac": kernels[dom]["hbm_frac"], "traffic": traffic,
     }
 
-    wsync = None
-    if world > 1 and not args.no_weight_sync:
-        wsync = weight_sync_probe(rank, world, dev)
+    cpu_base = None if (args.no_cpu_baseline or world != 1) else cpu_baseline(seq_length, vocab)
 
-    if rank == 0:
+    def emit(wsync):
+        if rank != 0:
+            return
         line = {
-            "metric": "learner samples/sec (post-model hot path: K5+K6 preprocess, fused logits->GRPO loss->dlogits, stats), 7B GRPO bs=4096",
+            "metric": "learner samples/sec, 7B GRPO bs=4096 (post-model hot path: K5+K6 preprocess, fused logits->GRPO loss->dlogits, step stats; trainer->actor weight-sync ms in weight_sync)",
             "value": bs / (elapsed / args.steps),
             "unit": "samples/s",
             "n_gpus": world,
@@ -311,11 +311,29 @@ def main():
                        "policy_loss": "ppo", "kl_coef": 0.0, "old_logprob_sigma": sigma},
             "roofline": roofline,
             "kernels": kernels,
-            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(seq_length, vocab),
+            "cpu_baseline": cpu_base,
             "weight_sync": wsync,
             "loss": stats_host[0],
         }
         print(json.dumps(line), flush=True)
+
+    # The weight-sync probe creates its own RCCL communicator; a hang there must not cost the
+    # benchmark line, so a watchdog prints the line without it and ends the process.
+    wsync = None
+    if world > 1 and not args.no_weight_sync and os.environ.get("PRL_BENCH_WSYNC", "1") != "0":
+        import threading
+
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(float(os.environ.get("PRL_BENCH_WSYNC_TIMEOUT", 180))):
+                emit({"error": "weight-sync probe timed out"})
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        wsync = weight_sync_probe(rank, world, dev)
+        done.set()
+    emit(wsync)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_kernel(
 constexpr int kBlock = 256;
 constexpr int kUnrollFwd = 8;
 constexpr int kUnrollBwd = 4;
-constexpr int kDefaultFusedVariant = 3;  // measured fastest on MI355X (profiles/r01_kernel_sweep.txt)
+constexpr int kDefaultFusedVariant = 6;  // measured fastest on MI355X (profiles/r01_kernel_sweep.txt)
 
 int check_geom(int64_t rows, int64_t cols, int64_t vocab, const void* logits, int32_t dtype,
                int64_t stride, RowGeom* geo) {
@@ -526,6 +526,7 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
   //   0: 256 threads x unroll 4, forward order          1: + reversed second pass
   //   2: + non-temporal gradient stores                 3: 1024 threads, 1 workgroup per CU, reversed, NT
   //   4: 512 threads, 2 workgroups per CU, reversed, NT 5: 1024 threads, 1 workgroup per CU, forward order
+  //   6: as 3 with unroll 4   7: as 3 with plain stores   8: 512 threads, 1 per CU   9: as 3 with unroll 1
   int variant = kDefaultFusedVariant;
   if (const char* e = getenv("PRL_FUSED_VARIANT")) variant = atoi(e);
 #define PRL_FUSED_LAUNCH(TT, ST, BLK, UNR, REV, NTS, LDSB)                                            \
@@ -545,6 +546,10 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
     case 3: PRL_FUSED_LAUNCH(TT, ST, 1024, 2, true, true, 96 * 1024); break;    \
     case 4: PRL_FUSED_LAUNCH(TT, ST, 512, 4, true, true, 64 * 1024); break;     \
     case 5: PRL_FUSED_LAUNCH(TT, ST, 1024, 2, false, false, 96 * 1024); break;  \
+    case 6: PRL_FUSED_LAUNCH(TT, ST, 1024, 4, true, true, 96 * 1024); break;    \
+    case 7: PRL_FUSED_LAUNCH(TT, ST, 1024, 2, true, false, 96 * 1024); break;   \
+    case 8: PRL_FUSED_LAUNCH(TT, ST, 512, 4, true, true, 96 * 1024); break;     \
+    case 9: PRL_FUSED_LAUNCH(TT, ST, 1024, 1, true, true, 96 * 1024); break;    \
     default: PRL_FUSED_LAUNCH(TT, ST, 256, 4, false, false, 0); break;          \
   }
   if (logits_dtype == PRL_DTYPE_F32) {

@@ -286,41 +286,46 @@ __global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
   block_reduce_store(acc, a.partials + (int64_t)blockIdx.x * P_NUM);
 }
 
-// Reduce the per-block records in a fixed order and emit the public stats vector.
-__global__ __launch_bounds__(kBlock) void grpo_loss_finalize_kernel(const double* partials,
-                                                                    int nblocks, int64_t rows,
-                                                                    int packed_counted,
-                                                                    double* stats,
-                                                                    float* loss_out) {
-  __shared__ double lds[8][P_NUM];
+// Reduce the per-block records in a fixed order and emit the public stats vector.  1024 threads:
+// 32 entries x 32 sub-lanes, each sub-lane folds every 32nd record with 4 independent partial
+// accumulators so the (L2-resident) loads overlap instead of forming one latency chain.
+constexpr int kFinalBlock = 1024;
+constexpr int kFinalLanes = kFinalBlock / P_NUM;  // 32
+
+__device__ __forceinline__ double combine(int i, double a, double b) {
+  if (i < P_NUM_ADD) return a + b;
+  if (i < P_MIN_REWARD) return fmax(a, b);
+  return fmin(a, b);
+}
+
+__global__ __launch_bounds__(kFinalBlock) void grpo_loss_finalize_kernel(const double* partials,
+                                                                         int nblocks, int64_t rows,
+                                                                         int packed_counted,
+                                                                         double* stats,
+                                                                         float* loss_out) {
+  __shared__ double lds[kFinalLanes][P_NUM];
   __shared__ double red[P_NUM];
   const int i = threadIdx.x & (P_NUM - 1);  // entry
-  const int k = threadIdx.x / P_NUM;        // sub-lane 0..7
-  double v = (i < P_NUM_ADD) ? 0.0 : ((i < P_MIN_REWARD) ? -INFINITY : INFINITY);
-  for (int b = k; b < nblocks; b += 8) {
-    const double o = partials[(int64_t)b * P_NUM + i];
-    if (i < P_NUM_ADD) {
-      v += o;
-    } else if (i < P_MIN_REWARD) {
-      v = fmax(v, o);
-    } else {
-      v = fmin(v, o);
-    }
+  const int k = threadIdx.x / P_NUM;        // sub-lane 0..31
+  const double ident = (i < P_NUM_ADD) ? 0.0 : ((i < P_MIN_REWARD) ? -INFINITY : INFINITY);
+  double v0 = ident, v1 = ident, v2 = ident, v3 = ident;
+  int b = k;
+  for (; b + 3 * kFinalLanes < nblocks; b += 4 * kFinalLanes) {
+    const double o0 = partials[(int64_t)b * P_NUM + i];
+    const double o1 = partials[(int64_t)(b + kFinalLanes) * P_NUM + i];
+    const double o2 = partials[(int64_t)(b + 2 * kFinalLanes) * P_NUM + i];
+    const double o3 = partials[(int64_t)(b + 3 * kFinalLanes) * P_NUM + i];
+    v0 = combine(i, v0, o0);
+    v1 = combine(i, v1, o1);
+    v2 = combine(i, v2, o2);
+    v3 = combine(i, v3, o3);
   }
-  lds[k][i] = v;
+  for (; b < nblocks; b += kFinalLanes) v0 = combine(i, v0, partials[(int64_t)b * P_NUM + i]);
+  lds[k][i] = combine(i, combine(i, v0, v1), combine(i, v2, v3));
   __syncthreads();
   if (threadIdx.x < P_NUM) {
     double r = lds[0][i];
-    for (int j = 1; j < 8; ++j) {
-      const double o = lds[j][i];
-      if (i < P_NUM_ADD) {
-        r += o;
-      } else if (i < P_MIN_REWARD) {
-        r = fmax(r, o);
-      } else {
-        r = fmin(r, o);
-      }
-    }
+    for (int j = 1; j < kFinalLanes; ++j) r = combine(i, r, lds[j][i]);
     red[i] = r;
   }
   __syncthreads();
@@ -448,7 +453,7 @@ extern "C" int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, i
   }
   PRL_LAUNCH_CHECK("grpo_loss_partial_kernel");
   const int packed_counted = (a.packed && position_ids != nullptr) ? 1 : 0;
-  hipLaunchKernelGGL(grpo_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, a.partials, nblocks,
+  hipLaunchKernelGGL(grpo_loss_finalize_kernel, dim3(1), dim3(kFinalBlock), 0, s, a.partials, nblocks,
                      rows, packed_counted, stats, loss_out);
   PRL_LAUNCH_CHECK("grpo_loss_finalize_kernel");
   return PRL_OK;

@@ -36,13 +36,14 @@ timeout 900 python bench.py --steps 2 --warmup 1 > $OUT/bench_full.log 2>&1
 echo "bench full exit $?" | tee -a $OUT/bench_full.log
 tail -2 $OUT/bench_full.log | cut -c1-1500
 
-echo "== rocprof stats (0.5B workload: same kernels, shorter run)"
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_stats -o stats -- python $GRAFT_REPO_ROOT/bench.py --workload 0p5b_grpo_bs512_seq2048 --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_stats.log 2>&1
+echo "== rocprof stats of the default bench command"
+cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_stats -o stats -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_stats.log 2>&1
 echo "rocprof exit $?" | tee -a $GRAFT_REPO_ROOT/$OUT/rocprof_stats.log
 cd $GRAFT_REPO_ROOT
 find $OUT/prof_stats -name "*kernel_stats*" | head; for f in $(find $OUT/prof_stats -name "*kernel_stats.csv" | head -1); do head -12 $f; done
 # keep the merge-back small: the raw kernel trace can be large
-find $OUT/prof_stats -name "*kernel_trace.csv" -size +20M -delete
+find $OUT/prof_stats -name "*kernel_trace.csv" -size +2M -delete
+tail -3 $OUT/rocprof_stats.log | cut -c1-1200
 echo "== pmc passes (separate runs, kernel-trace only)"
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o pmc -- python $GRAFT_REPO_ROOT/scripts/kernel_sweep.py --quick > $GRAFT_REPO_ROOT/$OUT/pmc_$C.log 2>&1; echo "pmc $C exit $?")
