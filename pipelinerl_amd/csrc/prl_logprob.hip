@@ -417,11 +417,170 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_kernel(
                                                 geo.vec_ok);
 }
 
+// ---------------------------------------------------------------------------------------
+// fused, row-resident variant: the head of the row stays ON CHIP between the two passes.
+//
+// A 608 KB fp32 row does not fit one CU (512 KB of VGPRs + 160 KB of LDS minus working set), but
+// most of it does: every lane keeps KREG 16-byte vectors in registers and KLDS more in LDS
+// (1024 lanes x (16 + 9) x 16 B = 400 KB = 67 % of the row).  Pass 2 recomputes the gradient of
+// that part from the chip-resident copy and re-reads only the tail - which pass 1 touched last,
+// so it is the part most likely still in L2 / Infinity Cache.  HBM-side traffic drops from
+// 3 x V x 4 to about (2 + 0.33) x V x 4 bytes per token.
+// ---------------------------------------------------------------------------------------
+struct GradParams {
+  float k2, lse2, H, ngi, nhi, gi;
+  int id;
+  bool use_h;
+};
+
+__device__ __forceinline__ float grad_one(const GradParams& p, float x, int v) {
+  const float d2 = __builtin_fmaf(x, p.k2, -p.lse2);  // log2 p_v
+  const float pv = fast_exp2(d2);
+  float r = p.ngi * pv;
+  if (p.use_h) r = __builtin_fmaf(p.nhi * pv, __builtin_fmaf(d2, kLn2, p.H), r);
+  if (v == p.id) r += p.gi;
+  return r;
+}
+
+template <class T>
+__device__ __forceinline__ typename T::vec grad_vec(const GradParams& p, const typename T::vec& in, int j) {
+  constexpr int NV = T::NV;
+  float f[NV], o[NV];
+  T::unpack(in, f);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) o[i] = grad_one(p, f[i], j * NV + i);
+  return T::pack(o);
+}
+
+template <class T>
+__device__ __forceinline__ void push_vec(Osm& st, const typename T::vec& v, float k2) {
+  constexpr int NV = T::NV;
+  float f[NV], y[NV];
+  T::unpack(v, f);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) y[i] = f[i] * k2;
+  osm_push<NV>(st, y);
+}
+
+template <class T, int BLOCK, int UNROLL, int KREG, int KLDS>
+__global__ __launch_bounds__(BLOCK) void fused_logits_loss_keep_kernel(
+    RowGeom geo, FusedArgs a, const typename T::scalar* logits, float k2, float inv_temp,
+    typename T::scalar* grad) {
+  using vec = typename T::vec;
+  constexpr int NV = T::NV;
+  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+  Osm* red = reinterpret_cast<Osm*>(dyn_lds);                 // [BLOCK / 64] (<= 256 bytes)
+  vec* lds_keep = reinterpret_cast<vec*>(dyn_lds + 256);      // [KLDS][BLOCK]
+  const int tid = threadIdx.x;
+  const int64_t q = blockIdx.x;
+  const int64_t col = q % geo.cols;
+  typename T::scalar* out = grad + q * geo.stride;
+  if (col == 0 && tid == 0) {
+    a.nlp[q] = 0.0f;
+    a.ent[q] = 0.0f;
+    a.lse2[q] = 0.0f;
+  }
+  if (col == geo.cols - 1) {
+    row_write_zero<T, BLOCK>(out, geo.vocab, true);
+    return;
+  }
+  const int64_t u = q + 1;
+  const typename T::scalar* row = logits + q * geo.stride;
+  const int64_t id64 = a.ids[u];
+  const int id = (id64 >= 0 && id64 < geo.vocab) ? (int)id64 : -1;
+  float y_sel = __builtin_nanf("");
+  if (id >= 0) y_sel = T::to_float(row[id]) * k2;
+
+  const vec* rv = reinterpret_cast<const vec*>(row);
+  vec* ov = reinterpret_cast<vec*>(out);
+  const int nvec = geo.vocab / NV;                 // host guarantees nvec >= (KREG + KLDS) * BLOCK
+  constexpr int HEAD = (KREG + KLDS) * BLOCK;      // vectors kept on chip
+  constexpr int TILE = BLOCK * UNROLL;
+
+  // ---- pass 1 -------------------------------------------------------------------------
+  Osm st;
+  osm_init(st);
+  vec keep[KREG > 0 ? KREG : 1];
+#pragma unroll
+  for (int k = 0; k < KREG; ++k) keep[k] = rv[k * BLOCK + tid];
+#pragma unroll
+  for (int k = 0; k < KREG; ++k) push_vec<T>(st, keep[k], k2);
+#pragma unroll
+  for (int k = 0; k < KLDS; ++k) {
+    const vec v = rv[(KREG + k) * BLOCK + tid];
+    lds_keep[k * BLOCK + tid] = v;
+    push_vec<T>(st, v, k2);
+  }
+  const int ntail = nvec - HEAD;
+  const int nfull = (ntail / TILE) * TILE;
+  for (int base = 0; base < nfull; base += TILE) {
+    vec v[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) v[k] = rv[HEAD + base + k * BLOCK + tid];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) push_vec<T>(st, v[k], k2);
+  }
+  for (int j = HEAD + nfull + tid; j < nvec; j += BLOCK) push_vec<T>(st, rv[j], k2);
+  for (int j = nvec * NV + tid; j < geo.vocab; j += BLOCK) {
+    float y[1] = {T::to_float(row[j]) * k2};
+    osm_push<1>(st, y);
+  }
+  st = osm_block_reduce<BLOCK>(st, red);
+
+  const float l2s = __log2f(st.S);
+  const float nlp = (y_sel - st.M - l2s) * kLn2;
+  const float H = kLn2 * (l2s - st.W / st.S);
+  const float lse2 = st.M + l2s;
+  if (tid == 0) {
+    a.nlp[u] = nlp;
+    a.ent[u] = H;
+    a.lse2[u] = lse2;
+  }
+  const bool m = a.labels[u] != -100;
+  float g = 0.0f, gH = 0.0f;
+  if (m) {
+    PrlTokenIn x{nlp,      H,           a.old_lp[u],       a.ref_lp[u], a.adv[u],
+                 a.reward[u], a.group_tokens[u], 1.0f, a.overflow[u]};
+    prl_token_grad(a.cfg, x, 1, &g, &gH);
+  }
+  if (g == 0.0f && gH == 0.0f) {
+    row_write_zero<T, BLOCK>(out, geo.vocab, true);
+    return;
+  }
+
+  // ---- pass 2: tail (re-read, back to front) -> LDS part -> register part ------------------
+  GradParams p{k2, lse2, H, -g * inv_temp, -gH * inv_temp, g * inv_temp, id, gH != 0.0f};
+  for (int j = nvec * NV + tid; j < geo.vocab; j += BLOCK)
+    out[j] = T::from_float(grad_one(p, T::to_float(row[j]), j));
+  for (int j = HEAD + nfull + tid; j < nvec; j += BLOCK) store_vec<true>(&ov[j], grad_vec<T>(p, rv[j], j));
+  for (int it = 0; it < nfull; it += TILE) {
+    const int base = HEAD + (nfull - TILE - it);
+    vec v[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) v[k] = rv[base + k * BLOCK + tid];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+      const int j = base + k * BLOCK + tid;
+      store_vec<true>(&ov[j], grad_vec<T>(p, v[k], j));
+    }
+  }
+#pragma unroll
+  for (int k = KLDS - 1; k >= 0; --k) {
+    const int j = (KREG + k) * BLOCK + tid;
+    store_vec<true>(&ov[j], grad_vec<T>(p, lds_keep[k * BLOCK + tid], j));
+  }
+#pragma unroll
+  for (int k = KREG - 1; k >= 0; --k) {
+    const int j = k * BLOCK + tid;
+    store_vec<true>(&ov[j], grad_vec<T>(p, keep[k], j));
+  }
+}
+
 // ---- host-side dispatch ---------------------------------------------------------------
 constexpr int kBlock = 256;
 constexpr int kUnrollFwd = 8;
 constexpr int kUnrollBwd = 4;
-constexpr int kDefaultFusedVariant = 6;  // measured fastest on MI355X (profiles/r01_kernel_sweep.txt)
+constexpr int kDefaultFusedVariant = 11;  // measured fastest on MI355X (profiles/r01_kernel_sweep.txt)
 
 int check_geom(int64_t rows, int64_t cols, int64_t vocab, const void* logits, int32_t dtype,
                int64_t stride, RowGeom* geo) {
@@ -527,6 +686,7 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
   //   2: + non-temporal gradient stores                 3: 1024 threads, 1 workgroup per CU, reversed, NT
   //   4: 512 threads, 2 workgroups per CU, reversed, NT 5: 1024 threads, 1 workgroup per CU, forward order
   //   6: as 3 with unroll 4   7: as 3 with plain stores   8: 512 threads, 1 per CU   9: as 3 with unroll 1
+  //   10-14: row-resident variants (KREG vectors per lane in VGPRs + KLDS in LDS stay on chip)
   int variant = kDefaultFusedVariant;
   if (const char* e = getenv("PRL_FUSED_VARIANT")) variant = atoi(e);
 #define PRL_FUSED_LAUNCH(TT, ST, BLK, UNR, REV, NTS, LDSB)                                            \
@@ -539,8 +699,33 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
     hipLaunchKernelGGL(kfn, grid, dim3(BLK), lds_bytes, s, geo, a, static_cast<const ST*>(logits), k2, \
                        inv_temp, static_cast<ST*>(grad_logits));                                    \
   } while (0)
+#define PRL_KEEP_LAUNCH(TT, ST, BLK, UNR, KR, KL)                                                     \
+  do {                                                                                              \
+    if (!geo.vec_ok || geo.vocab / TT::NV < (KR + KL) * BLK) {                                      \
+      PRL_FUSED_LAUNCH(TT, ST, 1024, 4, true, true, 96 * 1024); /* row too short / unaligned */     \
+      break;                                                                                        \
+    }                                                                                               \
+    auto kfn = fused_logits_loss_keep_kernel<TT, BLK, UNR, KR, KL>;                                 \
+    size_t lds_bytes = 256 + (size_t)(KL) * BLK * 16;                                               \
+    if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024; /* keep ONE workgroup per CU */               \
+    PRL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+    hipLaunchKernelGGL(kfn, grid, dim3(BLK), lds_bytes, s, geo, a, static_cast<const ST*>(logits), k2, \
+                       inv_temp, static_cast<ST*>(grad_logits));                                    \
+  } while (0)
 #define PRL_FUSED_DISPATCH(TT, ST)                                              \
   switch (variant) {                                                            \
+    case 10: PRL_KEEP_LAUNCH(TT, ST, 1024, 2, 16, 0); break;                    \
+    case 11: PRL_KEEP_LAUNCH(TT, ST, 1024, 2, 16, 9); break;                    \
+    case 12: PRL_KEEP_LAUNCH(TT, ST, 1024, 2, 20, 9); break;                    \
+    case 13: PRL_KEEP_LAUNCH(TT, ST, 1024, 2, 12, 9); break;                    \
+    case 14: PRL_KEEP_LAUNCH(TT, ST, 1024, 4, 16, 9); break;                    \
+    case 15: PRL_KEEP_LAUNCH(TT, ST, 512, 2, 44, 19); break;                    \
+    case 16: PRL_KEEP_LAUNCH(TT, ST, 512, 2, 46, 19); break;                    \
+    case 17: PRL_KEEP_LAUNCH(TT, ST, 256, 2, 96, 38); break;                    \
+    case 18: PRL_KEEP_LAUNCH(TT, ST, 768, 2, 26, 12); break;                    \
+    case 19: PRL_KEEP_LAUNCH(TT, ST, 512, 1, 48, 19); break;                    \
+    case 20: PRL_KEEP_LAUNCH(TT, ST, 512, 2, 40, 19); break;                    \
     case 1: PRL_FUSED_LAUNCH(TT, ST, 256, 4, true, false, 0); break;            \
     case 2: PRL_FUSED_LAUNCH(TT, ST, 256, 4, true, true, 0); break;             \
     case 3: PRL_FUSED_LAUNCH(TT, ST, 1024, 2, true, true, 96 * 1024); break;    \
@@ -558,6 +743,7 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
     PRL_FUSED_DISPATCH(BF16, uint16_t)
   }
 #undef PRL_FUSED_DISPATCH
+#undef PRL_KEEP_LAUNCH
 #undef PRL_FUSED_LAUNCH
   PRL_LAUNCH_CHECK("fused_logits_loss_kernel");
   return PRL_OK;
