@@ -462,7 +462,18 @@ __device__ __forceinline__ void push_vec(Osm& st, const typename T::vec& v, floa
   osm_push<NV>(st, y);
 }
 
-template <class T, int BLOCK, int UNROLL, int KREG, int KLDS>
+template <bool NT, class V>
+__device__ __forceinline__ V load_vec(const V* p) {
+  if constexpr (NT) {
+    return __builtin_nontemporal_load(p);
+  } else {
+    return *p;
+  }
+}
+
+// NTHEAD: the chip-resident head is read exactly once -> stream it past the caches so that the
+// tail (which IS re-read) keeps its lines in L2 / Infinity Cache.
+template <class T, int BLOCK, int UNROLL, int KREG, int KLDS, bool NTHEAD = false>
 __global__ __launch_bounds__(BLOCK) void fused_logits_loss_keep_kernel(
     RowGeom geo, FusedArgs a, const typename T::scalar* logits, float k2, float inv_temp,
     typename T::scalar* grad) {
@@ -502,12 +513,12 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_keep_kernel(
   osm_init(st);
   vec keep[KREG > 0 ? KREG : 1];
 #pragma unroll
-  for (int k = 0; k < KREG; ++k) keep[k] = rv[k * BLOCK + tid];
+  for (int k = 0; k < KREG; ++k) keep[k] = load_vec<NTHEAD>(&rv[k * BLOCK + tid]);
 #pragma unroll
   for (int k = 0; k < KREG; ++k) push_vec<T>(st, keep[k], k2);
 #pragma unroll
   for (int k = 0; k < KLDS; ++k) {
-    const vec v = rv[(KREG + k) * BLOCK + tid];
+    const vec v = load_vec<NTHEAD>(&rv[(KREG + k) * BLOCK + tid]);
     lds_keep[k * BLOCK + tid] = v;
     push_vec<T>(st, v, k2);
   }
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_keep_kernel(
 constexpr int kBlock = 256;
 constexpr int kUnrollFwd = 8;
 constexpr int kUnrollBwd = 4;
-constexpr int kDefaultFusedVariant = 11;  // measured fastest on MI355X (profiles/r01_kernel_sweep.txt)
+constexpr int kDefaultFusedVariant = 21;  // measured fastest on MI355X (profiles/r01_kernel_sweep.txt)
 
 int check_geom(int64_t rows, int64_t cols, int64_t vocab, const void* logits, int32_t dtype,
                int64_t stride, RowGeom* geo) {
@@ -699,13 +710,14 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
     hipLaunchKernelGGL(kfn, grid, dim3(BLK), lds_bytes, s, geo, a, static_cast<const ST*>(logits), k2, \
                        inv_temp, static_cast<ST*>(grad_logits));                                    \
   } while (0)
-#define PRL_KEEP_LAUNCH(TT, ST, BLK, UNR, KR, KL)                                                     \
+#define PRL_KEEP_LAUNCH(TT, ST, BLK, UNR, KR, KL) PRL_KEEP_LAUNCH2(TT, ST, BLK, UNR, KR, KL, false)
+#define PRL_KEEP_LAUNCH2(TT, ST, BLK, UNR, KR, KL, NTH)                                                     \
   do {                                                                                              \
     if (!geo.vec_ok || geo.vocab / TT::NV < (KR + KL) * BLK) {                                      \
       PRL_FUSED_LAUNCH(TT, ST, 1024, 4, true, true, 96 * 1024); /* row too short / unaligned */     \
       break;                                                                                        \
     }                                                                                               \
-    auto kfn = fused_logits_loss_keep_kernel<TT, BLK, UNR, KR, KL>;                                 \
+    auto kfn = fused_logits_loss_keep_kernel<TT, BLK, UNR, KR, KL, NTH>;                                 \
     size_t lds_bytes = 256 + (size_t)(KL) * BLK * 16;                                               \
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024; /* keep ONE workgroup per CU */               \
     PRL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                           \
@@ -726,6 +738,8 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
     case 18: PRL_KEEP_LAUNCH(TT, ST, 768, 2, 26, 12); break;                    \
     case 19: PRL_KEEP_LAUNCH(TT, ST, 512, 1, 48, 19); break;                    \
     case 20: PRL_KEEP_LAUNCH(TT, ST, 512, 2, 40, 19); break;                    \
+    case 21: PRL_KEEP_LAUNCH2(TT, ST, 1024, 2, 16, 9, true); break;             \
+    case 22: PRL_KEEP_LAUNCH2(TT, ST, 1024, 2, 16, 0, true); break;             \
     case 1: PRL_FUSED_LAUNCH(TT, ST, 256, 4, true, false, 0); break;            \
     case 2: PRL_FUSED_LAUNCH(TT, ST, 256, 4, true, true, 0); break;             \
     case 3: PRL_FUSED_LAUNCH(TT, ST, 1024, 2, true, true, 96 * 1024); break;    \
@@ -744,6 +758,7 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
   }
 #undef PRL_FUSED_DISPATCH
 #undef PRL_KEEP_LAUNCH
+#undef PRL_KEEP_LAUNCH2
 #undef PRL_FUSED_LAUNCH
   PRL_LAUNCH_CHECK("fused_logits_loss_kernel");
   return PRL_OK;

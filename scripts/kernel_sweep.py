@@ -116,7 +116,7 @@ def main():
         b0.ref_logprobs.data_ptr(), b0.advantages.data_ptr(), b0.rewards.data_ptr(), b0.group_tokens.data_ptr(), b0.overflow.data_ptr(),
         o_nlp.data_ptr(), o_ent.data_ptr(), o_lse.data_ptr(), grad.data_ptr(), stream))
     print("advantage of sequence 0:", float(b0.advantages[0, 0]))
-    for variant in (11, 15, 16, 17, 18, 19, 20, 11):
+    for variant in (11, 21, 22, 11, 21):
         os.environ["PRL_FUSED_VARIANT"] = str(variant)
         med, mn = timeit(fused, iters=8)
         report(f"fused K1+grad+K1' variant {variant} [algorithmic: read+write V*4/token]", 2 * T * V * 4, med, mn)

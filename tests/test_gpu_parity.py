@@ -431,7 +431,7 @@ def test_wsync_single_rank_group(libprl, cuda_device):
     grp.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_fused_kernel_variants_agree(libprl, cuda_device, variant, monkeypatch):
     """The launch-geometry variants of the fused logits kernel (block size, reversed second pass,
     non-temporal stores, residency cap) are the same arithmetic per element: bitwise equal."""
@@ -471,3 +471,59 @@ def test_fused_kernel_variants_agree(libprl, cuda_device, variant, monkeypatch):
     # block-size changes alter the reduction tree of the online softmax: fp32-rounding-level differences
     assert torch.allclose(n0, n1, rtol=1e-6, atol=1e-6) and torch.allclose(e0, e1, rtol=1e-5, atol=1e-6)
     assert rel_err(g1.cpu().numpy(), g0.cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_ragged_pipeline_vs_oracle(libprl, cuda_device, seed):
+    """Randomised ragged shapes (sequence lengths 1..70, random grouping / steps / finish flags,
+    random micro-batch plans with sequence-parallel fillers): K5 + K6 against the oracle,
+    bit-exact on every integer field and fp32 copy."""
+    from pipelinerl_amd.finetune.data import pack_prepared
+    from pipelinerl_amd.finetune.rl import RLConfig, populate_rl_data_ragged
+    from pipelinerl_amd.ragged import RaggedRollouts
+
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 60))
+    raw = []
+    for i in range(n):
+        p, c = int(rng.integers(1, 20)), int(rng.integers(0, 50))
+        ids = rng.integers(2, 40, size=p + c).tolist()  # 2 == EOS may appear anywhere
+        e = {
+            "input_ids": ids, "labels": [-100] * p + ids[p:], "logprobs": (-rng.random(c)).astype(np.float32).tolist(),
+            "ref_logprobs": (-rng.random(c)).astype(np.float32).tolist() if seed % 2 else [],
+            "reward": float(rng.integers(0, 3)) if seed % 3 else float(rng.normal()),
+            "group_id": f"g{int(rng.integers(0, max(1, n // 4) + 1))}", "finished": bool(rng.integers(0, 2)),
+            "metadata": {"model_version": int(rng.integers(0, 9)), "rollout_index": int(rng.integers(0, 4)), "step_index": int(rng.integers(0, 2))},
+        }
+        fr = rng.integers(0, 4)
+        if fr == 1:
+            e["finish_reason"] = " Length "
+        elif fr == 2:
+            e["finish_reason"] = "stop"
+        raw.append(e)
+    divide = bool(seed % 2)
+    rag = RaggedRollouts.from_entries(raw).to(cuda_device)
+    prep = populate_rl_data_ragged(rag, 2, RLConfig(divide_advantage_by_std=divide))
+    data = opre.preprocess_chunk(raw, 2, divide)
+    want_scalars = opre.sequence_scalars(data, 2, divide)
+    np.testing.assert_allclose(prep.advantage64.cpu().numpy(), [s[0] for s in want_scalars], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(prep.group_tokens64.cpu().numpy(), [s[1] for s in want_scalars], rtol=1e-12)
+    assert prep.overflow.cpu().tolist() == [s[2] for s in want_scalars]
+    assert prep.num_labels.cpu().tolist() == [float(s[3]) for s in want_scalars]
+    # random partition of a random permutation into micro-batches
+    order = rng.permutation(n).tolist()
+    mbs, k = [], 0
+    while k < n:
+        m = int(rng.integers(1, 8))
+        mbs.append(order[k:k + m])
+        k += m
+    sp = int(rng.choice([1, 1, 2, 4, 8]))
+    pads = [(sp - sum(len(raw[i]["input_ids"]) for i in mb) % sp) % sp for mb in mbs]
+    got = pack_prepared(prep, mbs, eos_token_id=2, sentinel_pad=pads)
+    for mb, g in zip(mbs, got):
+        # the fp32 scalar columns come from the device fp64 results: compare against the oracle's
+        # fp64 -> fp32 cast (identical unless the fp64 values differ in the last bit)
+        want = opre.collate_packed([data[i] for i in mb], 2, sp)
+        assert_batch_equal(_batch_to_np(g), want, float_tol=1e-6)
+        for key in ("input_ids", "labels", "position_ids", "segment_ids", "attention_mask", "seq_boundaries"):
+            assert np.array_equal(np.asarray(_batch_to_np(g)[key]), want[key]), key
