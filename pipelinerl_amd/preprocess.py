@@ -16,8 +16,15 @@ from typing import Any, Iterable, Sequence
 
 import numpy as np
 
+import logging
+import time
+
+import torch
+
 from .finetune.rl import PreparedRollouts, RLConfig, populate_rl_data_ragged
-from .ragged import RaggedRollouts
+from .ragged import RaggedRollouts, concat_ragged
+
+logger = logging.getLogger(__name__)
 
 
 @dataclass
@@ -170,3 +177,160 @@ def preprocess_chunk(entries: Sequence[dict], eos_token_id: int, rl_config: RLCo
     (reference preprocess.py:160-161)."""
     rag = RaggedRollouts.from_entries(entries).to(device)
     return populate_rl_data_ragged(rag, eos_token_id, rl_config)
+
+
+def concat_prepared(parts: Sequence[PreparedRollouts]) -> PreparedRollouts:
+    """Merge preprocessed chunks (a micro-batch may span chunk boundaries)."""
+    if len(parts) == 1:
+        return parts[0]
+    cat = lambda name: torch.cat([getattr(p, name) for p in parts])  # noqa: E731
+    return PreparedRollouts(
+        rollouts=concat_ragged([p.rollouts for p in parts]), reward32=cat("reward32"), advantage=cat("advantage"),
+        group_tokens=cat("group_tokens"), num_labels=cat("num_labels"), overflow=cat("overflow"),
+        advantage64=cat("advantage64"), group_tokens64=cat("group_tokens64"),
+    )
+
+
+@dataclass
+class PreprocessorConfig:
+    """The keys of the reference config the preprocessor loop consumes (conf/base.yaml:25-44,
+    conf/finetune/base.yaml; SURVEY.md §5 "config")."""
+
+    exp_path: Any
+    num_trainers: int
+    train_batch_size: int
+    gradient_accumulation_passes: int
+    seq_length: int
+    attempts: int
+    rl: RLConfig
+    eos_token_id: int
+    seq_parallel: int = 1
+    chunk_n_groups: int = 2
+    max_ready_samples_per_lead: int = 64
+    input_topic: str = "actor"
+    output_topic: str = "training_data"
+
+
+@dataclass
+class _Sample:
+    chunk: int
+    index: int
+    length: int
+
+
+class PreprocessorLoop:
+    """`run_preprocessing_loop` of the reference (preprocess.py:370-704) without worker processes:
+    the per-chunk work that needed N CPU workers is two kernel launches here.
+
+        actor stream -> chunks of `chunk_n_groups` groups -> K5 on device -> MicroBatchScheduler
+        -> ONE K6 launch per drain -> per-trainer `training_data` partitions (+ sentinels)
+
+    Back-pressure as in the reference (:587-592): publishing pauses while
+    published - trainer_state.samples_processed exceeds max_ready_samples_per_lead * num_trainers."""
+
+    def __init__(self, cfg: PreprocessorConfig, device, trainer_state=None):
+        from .streams import SingleStreamSpec, StreamRangeSpec
+
+        self.cfg = cfg
+        self.device = device
+        self.trainer_state = trainer_state
+        self.sched = MicroBatchScheduler(cfg.num_trainers, cfg.train_batch_size, cfg.gradient_accumulation_passes,
+                                         cfg.seq_length, seq_parallel=cfg.seq_parallel, length_of=lambda s: s.length)
+        self.in_spec = SingleStreamSpec(exp_path=cfg.exp_path, topic=cfg.input_topic)
+        self.out_spec = StreamRangeSpec(exp_path=cfg.exp_path, topic=cfg.output_topic, partition_range=(0, max(cfg.num_trainers, 1)))
+        self.chunks: dict[int, PreparedRollouts] = {}
+        self._next_chunk = 0
+        self.filtered_out = 0
+        self.max_model_version = 0
+
+    def _ingest(self, groups: list[list[dict]]) -> None:
+        entries = [e for g in groups for e in g]
+        if not check_group_sizes(entries, self.cfg.attempts):
+            raise ValueError("Group sizes are wrong")
+        prep = preprocess_chunk(entries, self.cfg.eos_token_id, self.cfg.rl, self.device)
+        keep = np.ones(prep.rollouts.n_seqs, dtype=bool)
+        if self.cfg.rl.filter_zero_advantage_groups:
+            keep = nonzero_advantage_mask(prep)
+            self.filtered_out += int((~keep).sum())
+        cid = self._next_chunk
+        self._next_chunk += 1
+        self.chunks[cid] = prep
+        lens = prep.rollouts.seq_lengths()
+        self.max_model_version = max(self.max_model_version, int(prep.rollouts.host_model_version.max()))
+        self.sched.push(_Sample(cid, i, int(lens[i])) for i in range(len(lens)) if keep[i])
+
+    def _publish(self, writer) -> bool:
+        """Drain the scheduler once and write what it emitted.  Returns batch_done."""
+        from .finetune.data import pack_prepared
+        from .finetune.utils import create_sentinel_batch
+
+        mbs, done = self.sched.drain()
+        real = [mb for mb in mbs if not mb.sentinel]
+        packed = None
+        if real:
+            used = sorted({s.chunk for mb in real for s in mb.samples})
+            merged = concat_prepared([self.chunks[c] for c in used])
+            base, acc = {}, 0
+            for c in used:
+                base[c] = acc
+                acc += self.chunks[c].rollouts.n_seqs
+            packed = pack_prepared(merged, [[base[s.chunk] + s.index for s in mb.samples] for mb in real], self.cfg.eos_token_id)
+        k = 0
+        for mb in mbs:
+            if mb.sentinel:
+                batch = create_sentinel_batch(None, tokenizer=type("T", (), {"eos_token_id": self.cfg.eos_token_id})(), model_version=self.max_model_version)
+            else:
+                batch = packed[k]
+                k += 1
+            slices = batch.make_slices(self.cfg.seq_parallel) if self.cfg.seq_parallel > 1 else [batch]
+            for off, piece in enumerate(slices):
+                writer.write(piece, partition=mb.trainer_id + off)
+        # chunks whose samples have all been scheduled can be dropped
+        alive = {s.chunk for s in self.sched.queue} | {s.chunk for s in self.sched._current}
+        for c in [c for c in self.chunks if c not in alive]:
+            del self.chunks[c]
+        return done
+
+    def run(self, max_published_samples: int | None = None, idle_timeout: float = 5.0) -> int:
+        """Consume the actor stream until `max_published_samples` were published (or the stream stays
+        silent for `idle_timeout` seconds).  Returns the number of published samples."""
+        import queue
+        import threading
+
+        from .streams import read_stream, write_to_streams
+
+        groups_q: queue.Queue = queue.Queue()
+
+        def reader():
+            with read_stream(self.in_spec) as r:
+                for record in r.read():
+                    groups_q.put(record)
+
+        threading.Thread(target=reader, daemon=True).start()
+        pending: list[list[dict]] = []
+        start = self.sched.published_samples
+        last_data = time.time()
+        with write_to_streams(self.out_spec) as writer:
+            while max_published_samples is None or self.sched.published_samples - start < max_published_samples:
+                try:
+                    pending.append(groups_q.get(timeout=0.01))
+                    last_data = time.time()
+                except queue.Empty:
+                    if time.time() - last_data > idle_timeout and not self.sched.queue:
+                        break
+                if len(pending) >= self.cfg.chunk_n_groups:
+                    self._ingest(pending)
+                    pending = []
+                ts = self.trainer_state
+                if ts is not None and ts.samples_processed is not None:
+                    limit = self.cfg.max_ready_samples_per_lead * self.cfg.num_trainers
+                    if self.sched.published_samples - ts.samples_processed > limit:
+                        continue
+                while self.sched.queue:
+                    before = self.sched.published_samples
+                    done = self._publish(writer)
+                    if self.sched.published_samples == before and not done:
+                        break
+                    if max_published_samples is not None and self.sched.published_samples - start >= max_published_samples:
+                        break
+        return self.sched.published_samples - start

@@ -177,3 +177,30 @@ class RaggedRollouts:
             tokens, labels, logprobs, ref, seq_off, lp_off, reward, group_index, step_index, rollout_index,
             model_version, finished, finish_code, group_ids=[str(g) for g in gid_to_idx],
         )
+
+
+def concat_ragged(parts: Sequence["RaggedRollouts"]) -> "RaggedRollouts":
+    """Concatenate rollouts that live on the same device (offsets and group indices are rebased)."""
+    if len(parts) == 1:
+        return parts[0]
+    dev = parts[0].device
+    tok_base = np.cumsum([0] + [p.n_tokens for p in parts])
+    lp_base = np.cumsum([0] + [int(p.logprobs.shape[0]) for p in parts])
+    grp_base = np.cumsum([0] + [len(p.group_ids) if p.group_ids else (int(p.host_group_index.max()) + 1 if p.n_seqs else 0) for p in parts])
+    cat = lambda name: torch.cat([getattr(p, name) for p in parts])  # noqa: E731
+    seq_off = np.concatenate([[0]] + [p.host_seq_off[1:] + tok_base[i] for i, p in enumerate(parts)]).astype(np.int64)
+    lp_off = np.concatenate([[0]] + [p.host_lp_off[1:] + lp_base[i] for i, p in enumerate(parts)]).astype(np.int64)
+    gi = np.concatenate([p.host_group_index + grp_base[i] for i, p in enumerate(parts)]).astype(np.int32)
+    have_ref = all(p.ref_logprobs is not None for p in parts)
+    return RaggedRollouts(
+        tokens=cat("tokens"), labels=cat("labels"), logprobs=cat("logprobs"),
+        ref_logprobs=torch.cat([p.ref_logprobs if p.ref_logprobs is not None else p.logprobs for p in parts]) if (have_ref or any(p.ref_logprobs is not None for p in parts)) else None,
+        seq_off=torch.from_numpy(seq_off).to(dev), lp_off=torch.from_numpy(lp_off).to(dev), reward=cat("reward"),
+        group_index=torch.from_numpy(gi).to(dev), step_index=cat("step_index"), rollout_index=cat("rollout_index"),
+        model_version=cat("model_version"), finished=cat("finished"), finish_code=cat("finish_code"),
+        group_ids=[g for p in parts for g in p.group_ids],
+        host_seq_off=seq_off, host_lp_off=lp_off, host_group_index=gi,
+        host_step_index=np.concatenate([p.host_step_index for p in parts]),
+        host_rollout_index=np.concatenate([p.host_rollout_index for p in parts]),
+        host_model_version=np.concatenate([p.host_model_version for p in parts]),
+    )

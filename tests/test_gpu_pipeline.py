@@ -1,0 +1,99 @@
+"""End-to-end replay on the GPU: recorded `actor` stream -> PreprocessorLoop (K5, scheduler, K6)
+-> `training_data` stream -> LearnerStep.step() with the HIP rl_step on a small torch model.
+Mirrors the reference's stage-isolation test mode (`debug.mode=finetune+preprocessor` with
+`debug.streams_from`, launch.py:554-564,692-693)."""
+
+import queue
+import threading
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rl_loss as orl
+
+pytestmark = pytest.mark.gpu
+
+
+class TinyLM(torch.nn.Module):
+    def __init__(self, vocab=64, dim=16):
+        super().__init__()
+        self.emb = torch.nn.Embedding(vocab, dim)
+        self.head = torch.nn.Linear(dim, vocab)
+
+    def forward(self, input_ids=None, **kw):
+        return types.SimpleNamespace(logits=self.head(self.emb(input_ids)).float())
+
+
+@pytest.mark.parametrize("backend", ["files", "shm"])
+def test_replay_actor_stream_through_preprocessor_and_learner(libprl, cuda_device, tmp_path, backend):
+    from pipelinerl_amd import streams
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.finetune_loop import TRAINER_TOPIC, LearnerStep, batch_generator, run_data_loader
+    from pipelinerl_amd.preprocess import PreprocessorConfig, PreprocessorLoop
+    from pipelinerl_amd.state import TrainerState
+    from pipelinerl_amd.synthetic import make_entries
+
+    streams.reset_streams_backend()
+    streams.set_streams_backend(backend, **({"n_slots": 64, "slot_bytes": 1 << 20} if backend == "shm" else {}))
+    try:
+        attempts, V = 4, 64
+        raw = make_entries(6, attempts=attempts, seq_length=48, vocab=V, seed=21, prompt_min=3, prompt_max=8)
+        rl = RLConfig(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0,
+                      divide_advantage_by_std=False, clamp_log_ratio_ref_new_value=5)
+        cfg = PreprocessorConfig(exp_path=tmp_path, num_trainers=1, train_batch_size=1, gradient_accumulation_passes=8,
+                                 seq_length=96, attempts=attempts, rl=rl, eos_token_id=2, chunk_n_groups=2)
+        actor_spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="actor")
+        published = {}
+
+        def preprocessor():
+            # the ring of the shm backend must exist before the reader attaches: writer first
+            with streams.write_to_streams(actor_spec) as w:
+                for g in range(6):
+                    w.write(raw[g * attempts:(g + 1) * attempts])
+                loop = PreprocessorLoop(cfg, cuda_device)
+                published["n"] = loop.run(max_published_samples=16, idle_timeout=3.0)
+
+        t = threading.Thread(target=preprocessor, daemon=True)
+        t.start()
+
+        torch.manual_seed(0)
+        model = TinyLM(V).to(cuda_device)
+        before = [p.detach().clone() for p in model.parameters()]
+        step = LearnerStep(model, torch.optim.SGD(model.parameters(), lr=0.5), rl, train_batch_size=1, gradient_accumulation_passes=8,
+                           max_train_steps=10, send_weight_updates=False,
+                           trainer_stream=streams.SingleStreamSpec(exp_path=tmp_path, topic=TRAINER_TOPIC))
+        q: queue.Queue = queue.Queue(maxsize=2)
+        data_spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data", partition=0)
+        threading.Thread(target=run_data_loader, args=(data_spec, q, cuda_device), daemon=True).start()
+        gen = batch_generator(q)
+        steps, first = 0, None
+        while steps < 2:
+            batch = next(gen)
+            assert batch.input_ids.is_cuda and batch.input_ids.shape[1] <= 96
+            if first is None:
+                # oracle check of the very first micro-batch with the model's own logits
+                with torch.no_grad():
+                    logits = model(input_ids=batch.input_ids).logits
+                b = {k: v.cpu().numpy() for k, v in batch.tensors()}
+                ocfg = rl.model_copy()
+                ocfg.batch_size = 8
+                first = orl.rl_step(logits.cpu().numpy(), b, ocfg, 0, 10, True)
+            res = step.step(batch)
+            if first is not None and "checked" not in first:
+                assert abs(res["stats"]["loss"] - float(first["loss"])) <= 1e-4 * max(abs(float(first["loss"])), 1e-6)
+                first["checked"] = True
+            assert torch.isfinite(res["loss"]).item()
+            steps += int(res["did_optimizer_step"])
+        assert step.metrics.samples == 16 and step.metrics.completed_steps == 2
+        assert any(not torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+        step.finish()
+        t.join(timeout=20)
+        assert published["n"] == 16
+        if backend == "files":
+            st = TrainerState(tmp_path)
+            st.start_listening()
+            assert st.wait_for_training_done(timeout=10) and st.samples_processed == 16
+    finally:
+        streams.reset_streams_backend()
