@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 1
+#define PRL_ABI_VERSION 2
 
 #define PRL_OK 0
 #define PRL_EINVAL (-22)   /* bad argument                                  */
@@ -107,6 +107,9 @@ int prl_logprob_entropy_bwd(int64_t rows, int64_t cols, int64_t vocab,
 
 #define PRL_POLICY_PPO 0
 #define PRL_POLICY_REINFORCE 1
+#define PRL_POLICY_GSPO 2 /* sequence-level ratio: the per-token policy gradient and clip indicator
+                              come from the caller (ext_token_grad / ext_clamp_indicator); the
+                              kernel produces the statistics and routes the gradient           */
 
 typedef struct prl_loss_config {
   int32_t policy_loss;         /* PRL_POLICY_*                      (RLConfig.policy_loss) */
@@ -176,6 +179,9 @@ int prl_grpo_loss_workspace_bytes(int64_t rows, int64_t cols, size_t* bytes);
  * Outputs: grad_new_logprobs / grad_entropy (token-aligned d loss / d x, nullable),
  * stats (double[PRL_NUM_STATS]).  loss = stats[PRL_STAT_LOSS], also written as a
  * float to loss_out (device, nullable).
+ * ext_token_grad / ext_clamp_indicator: token-aligned float32 [rows, cols], required for
+ * PRL_POLICY_GSPO (rl/__init__.py:310-352: the gradient coefficient and clip indicator of a
+ * token's segment), NULL otherwise.
  */
 int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, int64_t cols,
                           const int64_t* labels, const int64_t* position_ids,
@@ -183,7 +189,8 @@ int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, int64_t cols
                           const float* old_logprobs, const float* ref_logprobs,
                           const float* advantages, const float* rewards,
                           const float* group_tokens, const float* num_labels,
-                          const float* overflow, float* grad_new_logprobs,
+                          const float* overflow, const float* ext_token_grad,
+                          const float* ext_clamp_indicator, float* grad_new_logprobs,
                           float* grad_entropy, float* loss_out, double* stats,
                           void* workspace, size_t workspace_bytes,
                           prl_stream_t stream);

@@ -141,21 +141,62 @@ def token_loss(batch: dict[str, np.ndarray], new_logprobs: np.ndarray, entropy: 
             pol = (nlp * A * crr).astype(F32)
             dpol = (A * crr).astype(F32)
             ratio_stat = crr
+        elif algo == "gspo":
+            # sequence-level ratio (rl/__init__.py:310-352, rl/utils.py:106-208): per-segment masked
+            # sums on the shifted axis, segment of shifted position t = segment_ids[t + 1]
+            if segments is None:
+                raise ValueError("GSPO loss requires packed sequences with segments")
+            seg = batch["segment_ids"][0, 1:]
+            n_seg = int(seg.max()) + 1 if seg.size else 0
+            mm = fm[0]
+            cnt = np.zeros(n_seg, dtype=F32)
+            lrn_sum = np.zeros(n_seg, dtype=F32)
+            adv_sum = np.zeros(n_seg, dtype=F32)
+            w_sum = np.zeros(n_seg, dtype=F32)
+            np.add.at(cnt, seg, mm)
+            np.add.at(lrn_sum, seg, lrno[0] * mm)
+            np.add.at(adv_sum, seg, advantages[0] * mm)
+            np.add.at(w_sum, seg, w[0] * mm)
+            den = np.maximum(cnt, F32(1e-6))
+            g_ratio = np.exp(lrn_sum / den, dtype=F32)
+            g_adv = (adv_sum / den).astype(F32)
+            valid = (cnt > 0) & (w_sum > 0)
+            s1 = (g_ratio * g_adv).astype(F32)
+            cr = np.clip(g_ratio, lo, hi).astype(F32)
+            seg_clamped = (cr != g_ratio) & valid
+            s2 = (cr * g_adv).astype(F32)
+            if batch.get("sentinel") or n_seg == 0:
+                gspo_loss = F32(0)
+            else:
+                gspo_loss = F32(-(np.minimum(s1, s2) * valid.astype(F32) * w_sum).sum(dtype=F32))
+            inside = (g_ratio >= lo) & (g_ratio <= hi)
+            dmin = np.where(s1 < s2, g_adv, np.where(s2 < s1, np.where(inside, g_adv, F32(0)),
+                                                      F32(0.5) * g_adv + F32(0.5) * np.where(inside, g_adv, F32(0)))).astype(F32)
+            coef = (-(w_sum * valid.astype(F32)) * dmin * g_ratio / den).astype(F32)
+            clamp_no = seg_clamped[seg][None, :]
+            ratio_stat = ratio
+            pol = dpol = None
         else:
             raise ValueError(f"Unknown algorithm {algo}")
 
-        tok = (pol - F32(kl_coef) * kl).astype(F32)
-        if use_entropy:
-            tok = (tok + F32(ent_coef) * entropy.astype(F32)).astype(F32)
-        tok = (tok * w).astype(F32)
-        loss = F32(-sum_sum(tok, mask, segments))
+        if algo == "gspo":
+            loss = gspo_loss
+            tok = np.zeros_like(w)
+            g_nlp = (coef[seg] * mm)[None, :].astype(F32) if not batch.get("sentinel") else np.zeros_like(w)
+            g_ent = np.zeros_like(w)
+        else:
+            tok = (pol - F32(kl_coef) * kl).astype(F32)
+            if use_entropy:
+                tok = (tok + F32(ent_coef) * entropy.astype(F32)).astype(F32)
+            tok = (tok * w).astype(F32)
+            loss = F32(-sum_sum(tok, mask, segments))
 
-        # closed-form backward (App. A): nan_to_num passes gradient only where finite
-        kl_inside = (lrrn >= -C) & (lrrn <= C)
-        dkl = np.where(kl_inside, F32(1) - ecl, F32(0)).astype(F32)
-        finite = np.isfinite(tok * fm)
-        g_nlp = np.where(finite, -((dpol - F32(kl_coef) * dkl) * w) * fm, F32(0)).astype(F32)
-        g_ent = (np.where(finite, -(F32(ent_coef) * w) * fm, F32(0)) if use_entropy else np.zeros_like(tok)).astype(F32)
+            # closed-form backward (App. A): nan_to_num passes gradient only where finite
+            kl_inside = (lrrn >= -C) & (lrrn <= C)
+            dkl = np.where(kl_inside, F32(1) - ecl, F32(0)).astype(F32)
+            finite = np.isfinite(tok * fm)
+            g_nlp = np.where(finite, -((dpol - F32(kl_coef) * dkl) * w) * fm, F32(0)).astype(F32)
+            g_ent = (np.where(finite, -(F32(ent_coef) * w) * fm, F32(0)) if use_entropy else np.zeros_like(tok)).astype(F32)
 
     out: dict[str, Any] = {"loss": loss, "g_nlp": g_nlp, "g_ent": g_ent, "num_sequences": num_sequences,
                            "finite": bool(np.isfinite(nlp).all() and np.isfinite(lrrn).all() and np.isfinite(kl).all() and np.isfinite(loss))}

@@ -13,7 +13,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl.so"
 
-PRL_ABI_VERSION = 1
+PRL_ABI_VERSION = 2
 PRL_OK = 0
 PRL_EINVAL = -22
 PRL_ENOMEM = -12
@@ -27,6 +27,7 @@ PRL_DTYPE_F32 = 0
 PRL_DTYPE_BF16 = 1
 PRL_POLICY_PPO = 0
 PRL_POLICY_REINFORCE = 1
+PRL_POLICY_GSPO = 2
 PRL_FINISH_NONE = 0
 PRL_FINISH_LENGTH = 1
 PRL_FINISH_STOP = 2
@@ -107,7 +108,7 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_logprob_entropy_fwd": (c_int32, [c_int64, c_int64, c_int64, _P, c_int32, c_int64, _P, c_float, _P, _P, _P, _P]),
     "prl_logprob_entropy_bwd": (c_int32, [c_int64, c_int64, c_int64, _P, c_int32, c_int64, _P, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "prl_grpo_loss_workspace_bytes": (c_int32, [c_int64, c_int64, POINTER(c_size_t)]),
-    "prl_grpo_loss_fwd_bwd": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64] + [_P] * 11 + [_P, _P, _P, _P, _P, c_size_t, _P]),
+    "prl_grpo_loss_fwd_bwd": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64] + [_P] * 13 + [_P, _P, _P, _P, _P, c_size_t, _P]),
     "prl_fused_logits_loss": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64, c_int64, _P, c_int32, c_int64, c_float] + [_P] * 8 + [_P, _P, _P, _P, _P]),
     "prl_segment_sums": (c_int32, [c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prl_seq_scan": (c_int32, [c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),

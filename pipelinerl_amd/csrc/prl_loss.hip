@@ -82,6 +82,8 @@ struct LossArgs {
   const float* group_tokens;
   const float* num_labels;
   const float* overflow;
+  const float* ext_g;      // GSPO: per-token gradient coefficient of the token's segment
+  const float* ext_clamp;  // GSPO: per-token clip indicator of the token's segment
   float* g_nlp;
   float* g_ent;
   double* partials;  // [gridDim.x][P_NUM]
@@ -117,7 +119,8 @@ __device__ __forceinline__ void token_step(const LossArgs& a, Acc& acc, bool val
                                            int64_t label, bool seq_start, float nlp,
                                            float ent, float old_lp, float ref_lp, float adv,
                                            float reward, float gt, float nl, float ovf,
-                                           float& g_nlp, float& g_ent) {
+                                           float ext_g, float ext_clamp, float& g_nlp,
+                                           float& g_ent) {
   g_nlp = 0.0f;
   g_ent = 0.0f;
   if (seq_start) acc.s[P_N_SEQ] += 1.0f;
@@ -137,6 +140,10 @@ __device__ __forceinline__ void token_step(const LossArgs& a, Acc& acc, bool val
   prl_token_eval(a.cfg, x, o);
   g_nlp = o.g_nlp;
   g_ent = o.g_ent;
+  if (a.cfg.policy_loss == PRL_POLICY_GSPO) {
+    g_nlp = ext_g;
+    o.clamp_no = ext_clamp;
+  }
   const float inv_nl = 1.0f / nl;
   acc.s[P_LOSS] += o.contrib;
   acc.s[P_REWARD] += per_label(reward, inv_nl);
@@ -217,6 +224,7 @@ __global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
   const int64_t nthreads = (int64_t)gridDim.x * kBlock;
   const bool count_pos = a.packed && a.position_ids != nullptr;
   const bool flat = count_pos && a.cfg.flat_micro_batches;
+  const bool gspo = a.cfg.policy_loss == PRL_POLICY_GSPO;
 
   if constexpr (VEC == 4) {
     const int64_t n4 = a.n >> 2;
@@ -238,6 +246,11 @@ __global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
       const float4 gt = *reinterpret_cast<const float4*>(a.group_tokens + u0);
       const float4 nl = *reinterpret_cast<const float4*>(a.num_labels + u0);
       const float4 ov = *reinterpret_cast<const float4*>(a.overflow + u0);
+      float4 xg = make_float4(0.f, 0.f, 0.f, 0.f), xc = xg;
+      if (gspo) {
+        xg = *reinterpret_cast<const float4*>(a.ext_g + u0);
+        xc = *reinterpret_cast<const float4*>(a.ext_clamp + u0);
+      }
 
       const int64_t lab[4] = {lab01.x, lab01.y, lab23.x, lab23.y};
       const int64_t pos[4] = {pos01.x, pos01.y, pos23.x, pos23.y};
@@ -250,6 +263,8 @@ __global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
       const float f_gt[4] = {gt.x, gt.y, gt.z, gt.w};
       const float f_nl[4] = {nl.x, nl.y, nl.z, nl.w};
       const float f_ov[4] = {ov.x, ov.y, ov.z, ov.w};
+      const float f_xg[4] = {xg.x, xg.y, xg.z, xg.w};
+      const float f_xc[4] = {xc.x, xc.y, xc.z, xc.w};
       // column of the first element of the group (cols may be any value >= 1)
       int64_t col = a.packed ? u0 : (u0 % a.cols);
       float g[4], gh[4];
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
         const bool valid_pos = (col != 0) && !(flat && pos[k] == 0);
         const bool seq_start = count_pos && (pos[k] == 0 || (u0 + k) == 0);
         token_step(a, acc, valid_pos, lab[k], seq_start, f_nlp[k], f_ent[k], f_old[k],
-                   f_ref[k], f_adv[k], f_rew[k], f_gt[k], f_nl[k], f_ov[k], g[k], gh[k]);
+                   f_ref[k], f_adv[k], f_rew[k], f_gt[k], f_nl[k], f_ov[k], f_xg[k], f_xc[k], g[k], gh[k]);
         ++col;
         if (!a.packed && col == a.cols) col = 0;
       }
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
       float g, gh;
       token_step(a, acc, (col != 0) && !(flat && a.position_ids[u] == 0), a.labels[u], seq_start, a.nlp[u], a.ent[u], a.old_lp[u],
                  a.ref_lp[u], a.adv[u], a.reward[u], a.group_tokens[u], a.num_labels[u],
-                 a.overflow[u], g, gh);
+                 a.overflow[u], gspo ? a.ext_g[u] : 0.0f, gspo ? a.ext_clamp[u] : 0.0f, g, gh);
       if (a.g_nlp) a.g_nlp[u] = g;
       if (a.g_ent) a.g_ent[u] = gh;
     }
@@ -394,15 +409,19 @@ extern "C" int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, i
                                      const float* old_logprobs, const float* ref_logprobs,
                                      const float* advantages, const float* rewards,
                                      const float* group_tokens, const float* num_labels,
-                                     const float* overflow, float* grad_new_logprobs,
+                                     const float* overflow, const float* ext_token_grad,
+                                     const float* ext_clamp_indicator, float* grad_new_logprobs,
                                      float* grad_entropy, float* loss_out, double* stats,
                                      void* workspace, size_t workspace_bytes,
                                      prl_stream_t stream) {
   PRL_CHECK_ARG(cfg != nullptr, "cfg is null");
   PRL_CHECK_ARG(rows >= 1 && cols >= 1, "rows and cols must be >= 1 (got %lld x %lld)",
                 (long long)rows, (long long)cols);
-  PRL_CHECK_ARG(cfg->policy_loss == PRL_POLICY_PPO || cfg->policy_loss == PRL_POLICY_REINFORCE,
+  PRL_CHECK_ARG(cfg->policy_loss == PRL_POLICY_PPO || cfg->policy_loss == PRL_POLICY_REINFORCE ||
+                    cfg->policy_loss == PRL_POLICY_GSPO,
                 "unknown policy_loss %d", cfg->policy_loss);
+  PRL_CHECK_ARG(cfg->policy_loss != PRL_POLICY_GSPO || (ext_token_grad && ext_clamp_indicator),
+                "PRL_POLICY_GSPO needs ext_token_grad and ext_clamp_indicator");
   PRL_CHECK_ARG(labels && new_logprobs && entropy && old_logprobs && ref_logprobs && advantages &&
                     rewards && group_tokens && num_labels && overflow && stats,
                 "null input pointer");
@@ -430,6 +449,8 @@ extern "C" int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, i
   a.group_tokens = group_tokens;
   a.num_labels = num_labels;
   a.overflow = overflow;
+  a.ext_g = ext_token_grad;
+  a.ext_clamp = ext_clamp_indicator;
   a.g_nlp = grad_new_logprobs;
   a.g_ent = grad_entropy;
   a.partials = static_cast<double*>(workspace);
@@ -440,6 +461,8 @@ extern "C" int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, i
                       prl::aligned16(advantages) && prl::aligned16(rewards) &&
                       prl::aligned16(group_tokens) && prl::aligned16(num_labels) &&
                       prl::aligned16(overflow) &&
+                      (!ext_token_grad || prl::aligned16(ext_token_grad)) &&
+                      (!ext_clamp_indicator || prl::aligned16(ext_clamp_indicator)) &&
                       (!grad_new_logprobs || prl::aligned16(grad_new_logprobs)) &&
                       (!grad_entropy || prl::aligned16(grad_entropy));
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -133,12 +133,17 @@ PRL_HD void prl_token_eval(const prl_loss_config& c, const PrlTokenIn& x, PrlTok
       dpol = pol;
     }
     ratio_stat = ratio;
-  } else {  // REINFORCE (:304-309)
+  } else if (c.policy_loss == PRL_POLICY_REINFORCE) {  // (:304-309)
     clamp_no = (ratio > c.clip_hi) ? 1.0f : 0.0f;
     const float crr = prl_clampf(ratio, 0.0f, c.clip_hi);
     pol = x.nlp * A * crr;
     dpol = A * crr;  // ratio is detached
     ratio_stat = crr;
+  } else {  // GSPO (:310-352): the loss lives at segment level; tokens only feed the statistics
+    clamp_no = 0.0f;
+    pol = 0.0f;
+    dpol = 0.0f;
+    ratio_stat = ratio;
   }
 
   // combine (:355-359): loss = policy_loss - kl_coef*approx_kl [+ ent_coef*entropy]
@@ -146,8 +151,9 @@ PRL_HD void prl_token_eval(const prl_loss_config& c, const PrlTokenIn& x, PrlTok
   if (c.use_entropy_loss) loss_t = loss_t + c.entropy_coef * x.ent;
   const float v = loss_t * w;  // (:363), mask == 1 here
 
-  const int finite = prl_isfinite(v);
-  o.contrib = prl_nan_to_num0(v);
+  const int gspo = (c.policy_loss == PRL_POLICY_GSPO);
+  const int finite = prl_isfinite(v) && !gspo;
+  o.contrib = gspo ? 0.0f : prl_nan_to_num0(v);
   // d kl / d nlp = (1 - exp(cl)) inside the clamp range, else 0
   const float dkl = kl_inside ? (1.0f - ecl) : 0.0f;
   const float dl = dpol - c.kl_coef * dkl;

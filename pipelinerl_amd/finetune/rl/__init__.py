@@ -72,7 +72,7 @@ def linear_decay_coef(current_step: int, max_step: int, initial_coef: float, fin
     return initial_coef + (final_coef - initial_coef) * current_step / max_step
 
 
-_POLICY = {"ppo": _lib.PRL_POLICY_PPO, "reinforce": _lib.PRL_POLICY_REINFORCE}
+_POLICY = {"ppo": _lib.PRL_POLICY_PPO, "reinforce": _lib.PRL_POLICY_REINFORCE, "gspo": _lib.PRL_POLICY_GSPO}
 
 
 def make_loss_config(config: RLConfig, current_step: int, max_step: int) -> tuple[PrlLossConfig, float, float]:
@@ -131,9 +131,12 @@ def grpo_loss_from_logprobs(
     new_logprobs: torch.Tensor,
     entropy: torch.Tensor,
     want_grad: bool = True,
+    ext_token_grad: torch.Tensor | None = None,
+    ext_clamp_indicator: torch.Tensor | None = None,
 ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None, torch.Tensor | None]:
     """K2+K3 on token-aligned new_logprobs / entropy ([B, L], column 0 unused).
-    Returns (loss fp32 scalar, stats double[32], d loss/d new_logprobs, d loss/d entropy)."""
+    Returns (loss fp32 scalar, stats double[32], d loss/d new_logprobs, d loss/d entropy).
+    `ext_*`: GSPO only, the per-token view of the segment-level gradient / clip indicator."""
     lib = _lib.load()
     rows, cols = batch.labels.shape
     cols_tensors = [
@@ -157,7 +160,8 @@ def grpo_loss_from_logprobs(
             lib.prl_grpo_loss_fwd_bwd(
                 ctypes.byref(cfg), rows, cols, _lib.ptr(labels), _lib.ptr(pos), _lib.ptr(nlp), _lib.ptr(ent),
                 _lib.ptr(old), _lib.ptr(ref), _lib.ptr(adv), _lib.ptr(rew), _lib.ptr(gt), _lib.ptr(nl),
-                _lib.ptr(ovf), _lib.ptr(g_nlp), _lib.ptr(g_ent), _lib.ptr(loss), _lib.ptr(stats),
+                _lib.ptr(ovf), _lib.ptr(ext_token_grad), _lib.ptr(ext_clamp_indicator), _lib.ptr(g_nlp), _lib.ptr(g_ent),
+                _lib.ptr(loss), _lib.ptr(stats),
                 _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr(dev),
             )
         )
@@ -183,6 +187,68 @@ def logprob_entropy(logits: torch.Tensor, input_ids: torch.Tensor, temperature: 
             )
         )
     return nlp, ent, lse2, logits
+
+
+def segment_sums(segment_ids: torch.Tensor, labels: torch.Tensor, a: torch.Tensor, b: torch.Tensor, n_segments: int):
+    """Masked per-segment sums of two token-aligned columns + token counts (float64 [n_segments] x 3)."""
+    lib = _lib.load()
+    dev = a.device
+    out = [torch.empty(n_segments, dtype=torch.float64, device=dev) for _ in range(3)]
+    cont = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
+    with torch.cuda.device(dev):
+        _lib.check(lib.prl_segment_sums(a.shape[-1], n_segments, _lib.ptr(cont(segment_ids)), _lib.ptr(cont(labels)),
+                                        _lib.ptr(cont(a)), _lib.ptr(cont(b)), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]),
+                                        _lib.current_stream_ptr(dev)))
+    return out
+
+
+def gspo_segment_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, new_logprobs: torch.Tensor):
+    """Sequence-level (GSPO) policy term, reference rl/__init__.py:310-352 + rl/utils.py:106-208:
+    per-segment masked means of log(new/old) and of the advantages (segment-sum kernel), clipped
+    sequence ratio, loss = -sum_s min(r_s A_s, clip(r_s) A_s) * (sum of the segment's token weights).
+    Returns (loss scalar, per-token d loss/d new_logprobs coefficient, per-token clip indicator);
+    the O(#segments) arithmetic runs as a handful of device tensor ops."""
+    seg_ids = batch.segment_ids
+    if seg_ids is None:
+        raise ValueError("segment_ids must be provided for per-segment reductions")
+    if batch.seq_boundaries is not None:
+        n_seg = int(batch.seq_boundaries.shape[0]) - 1
+    else:
+        n_seg = int(seg_ids.max().item()) + 1
+    f32 = torch.float32
+    lrno = new_logprobs - batch.old_logprobs
+    if cfg.group_normalization:
+        w = 1.0 / batch.group_tokens
+    else:
+        w = torch.full_like(batch.group_tokens, cfg.token_weight)
+    if cfg.overlong_filtering:
+        w = w * (1 - batch.overflow)
+    lrn_sum, adv_sum, cnt = segment_sums(seg_ids, batch.labels, lrno, batch.advantages, n_seg)
+    w_sum, _, _ = segment_sums(seg_ids, batch.labels, w, torch.zeros_like(w), n_seg)
+    cnt32 = cnt.to(f32)
+    den = cnt32.clamp(min=1e-6)
+    ratio = torch.exp(lrn_sum.to(f32) / den)
+    adv = adv_sum.to(f32) / den
+    w_sum = w_sum.to(f32)
+    valid = (cnt32 > 0) & (w_sum > 0)
+    s1 = ratio * adv
+    clipped = ratio.clamp(cfg.clip_lo, cfg.clip_hi)
+    indicator = (clipped != ratio) & valid
+    s2 = clipped * adv
+    T = new_logprobs.shape[-1]
+    if batch.sentinel or T <= 1:
+        loss = torch.zeros((), dtype=f32, device=new_logprobs.device)
+    else:
+        loss = -(torch.minimum(s1, s2) * valid.to(f32) * w_sum).sum()
+    inside = ((ratio >= cfg.clip_lo) & (ratio <= cfg.clip_hi)).to(f32)
+    dmin = torch.where(s1 < s2, adv, torch.where(s2 < s1, adv * inside, 0.5 * adv + 0.5 * adv * inside))
+    coef = -(w_sum * valid.to(f32)) * dmin * ratio / den
+    if batch.sentinel:
+        coef = torch.zeros_like(coef)
+    idx = seg_ids.reshape(-1).clamp(0, max(n_seg - 1, 0))
+    ext_g = coef[idx].reshape(new_logprobs.shape).contiguous()
+    ext_c = indicator.to(f32)[idx].reshape(new_logprobs.shape).contiguous()
+    return loss, ext_g, ext_c
 
 
 class _GrpoLossFn(torch.autograd.Function):
@@ -217,7 +283,14 @@ class _GrpoLossFn(torch.autograd.Function):
             ctx.grad_logits = grad
         else:
             nlp, ent, lse2, lg = logprob_entropy(logits, ids, temperature)
-            loss, stats, g_nlp, g_ent = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=True)
+            if cfg.policy_loss == _lib.PRL_POLICY_GSPO:
+                seg_loss, ext_g, ext_c = gspo_segment_terms(cfg, batch, nlp)
+                _, stats, g_nlp, g_ent = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=True,
+                                                                  ext_token_grad=ext_g, ext_clamp_indicator=ext_c)
+                loss = seg_loss
+                stats[STAT_INDEX["loss"]] = seg_loss.double()
+            else:
+                loss, stats, g_nlp, g_ent = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=True)
             ctx.fused = False
             ctx.save_for_backward(lg, ids, lse2, ent, g_nlp, g_ent if g_ent is not None else torch.empty(0, device=dev))
             ctx.has_g_ent = g_ent is not None
@@ -296,7 +369,10 @@ def rl_step(
     """One RL micro-batch: model forward + fused loss.  Signature and return value as in
     reference rl/__init__.py:136-143: (scalar loss attached to the model's graph, stats dict)."""
     if config.policy_loss == "gspo":
-        raise NotImplementedError("GSPO sequence-level loss is not on the MI355X hot path yet (SURVEY.md §8 a5)")
+        if not batch.is_packed:
+            raise ValueError("GSPO loss requires packed sequences with segments")
+        if seq_parallel_group is not None:
+            raise NotImplementedError("GSPO across sequence-parallel slices is not supported")
     if hasattr(model, "value_head"):
         raise NotImplementedError("value-head (actor-critic) batches are outside the GRPO hot path")
     cfg, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
@@ -317,7 +393,8 @@ def rl_step(
     _lib.require_device(logits)
 
     loss, stats_dev = _GrpoLossFn.apply(
-        logits, batch, cfg, config.temperature, bool(config.fused_logits_grad), bool(config.inplace_logits_grad)
+        logits, batch, cfg, config.temperature, bool(config.fused_logits_grad) and config.policy_loss != "gspo",
+        bool(config.inplace_logits_grad),
     )
     stats = stats_dev.cpu().tolist()  # the single device->host sync of the step
     check_finite(stats)

@@ -186,20 +186,24 @@ RL_CASES = {
     "c8_offpolicy": (dict(vocab=97, with_ref=True, on_policy=False), dict(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.05, final_kl_coef=0.05, clamp_log_ratio_ref_new_value=5, batch_size=16), (0, 10)),
     "c9_sp_padding": (dict(vocab=97, seq_parallel=8), dict(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0, batch_size=16), (0, 10)),
     "c10_reinforce_rewards": (dict(vocab=64), dict(policy_loss="reinforce", epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0, use_advantages=False, batch_size=16, temperature=1.3), (0, 10)),
+    "c11_gspo": (dict(vocab=97, with_ref=True, seed_offset=40), dict(policy_loss="gspo", epsilon_low=0.05, epsilon_high=0.05, kl_coef=0.1, final_kl_coef=0.1, batch_size=16), (0, 10)),
+    "c12_gspo_groupnorm_sp": (dict(vocab=64, seq_parallel=8, on_policy=True), dict(policy_loss="gspo", epsilon_low=0.002, epsilon_high=0.002, kl_coef=0.0, final_kl_coef=0.0, group_normalization=True, overlong_filtering=True, batch_size=16), (0, 10)),
 }
 
 
-def gen_rl_step(ref_rl, ref_data, ref_utils):
+def gen_rl_step(ref_rl, ref_data, ref_utils, only=None, index=None):
     from pipelinerl_amd.synthetic import make_entries
 
     for i, (name, (bk, ck, (cur, mx))) in enumerate(RL_CASES.items()):
+        if only is not None and name not in only:
+            continue
         torch.manual_seed(100 + i)
         V = bk["vocab"]
         cfg = ref_rl.RLConfig(**ck)
         if bk.get("sentinel"):
             batch = ref_utils.create_sentinel_batch(device=None, tokenizer=Tok(EOS), model_version=3)
         else:
-            raw = make_entries(2, attempts=3, seq_length=40, vocab=V, seed=200 + i, prompt_min=3, prompt_max=9,
+            raw = make_entries(2, attempts=3, seq_length=40, vocab=V, seed=200 + i + bk.get("seed_offset", 0), prompt_min=3, prompt_max=9,
                                with_ref=bk.get("with_ref", False))
             data = ref_preprocess(ref_rl, ref_data, raw, cfg)
             if bk.get("unpacked"):
@@ -271,6 +275,13 @@ def gen_world():
 
 def main():
     ref_rl, ref_data, ref_utils = import_reference()
+    if "--only-new" in sys.argv:  # add cases without rewriting the committed fixtures
+        global RL_CASES
+        have = {p.stem[len("rl_step_"):] for p in HERE.glob("rl_step_*.npz")}
+        idx = {name: i for i, name in enumerate(RL_CASES)}
+        todo = {k: v for k, v in RL_CASES.items() if k not in have}
+        gen_rl_step(ref_rl, ref_data, ref_utils, only=todo, index=idx)
+        return
     gen_preprocess(ref_rl, ref_data)
     gen_rl_step(ref_rl, ref_data, ref_utils)
     gen_sentinel(ref_utils)
