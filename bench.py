@@ -52,6 +52,8 @@ def parse_args():
     p.add_argument("--logits-mode", default=os.environ.get("PRL_BENCH_LOGITS_MODE", "fused"), choices=["fused", "two_pass"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-weight-sync", action="store_true")
+    p.add_argument("--backend", default=os.environ.get("PRL_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                   help="gloo + PRL_BENCH_SHARE_DEVICE=1 runs N ranks on ONE GPU (dry run of the N > 1 logic)")
     return p.parse_args()
 
 
@@ -162,11 +164,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if os.environ.get("PRL_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from pipelinerl_amd import _lib
@@ -254,7 +261,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     ms_per_step = 1e3 * elapsed / args.steps
@@ -278,7 +285,7 @@ def main():
     dom = "fused_logits_loss" if "fused_logits_loss" in kernels else max(kernels, key=lambda n: kernels[n]["avg_us"] * kernels[n]["launches"])
     traffic = None
     pmc = ROOT / "profiles" / "pmc_traffic.json"
-    if pmc.exists():
+    if pmc.exists() and (seq_length, vocab) == (8192, 152064):  # the PMC passes were taken at this shape
         try:
             traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:
@@ -290,11 +297,13 @@ def main():
 
     cpu_base = None if (args.no_cpu_baseline or world != 1) else cpu_baseline(seq_length, vocab)
 
+    label = {"7b_grpo_bs4096_seq8192": "7B GRPO bs=4096", "0p5b_grpo_bs512_seq2048": "0.5B GRPO bs=512 seq=2048"}.get(args.workload, args.workload)
+
     def emit(wsync):
         if rank != 0:
             return
         line = {
-            "metric": "learner samples/sec, 7B GRPO bs=4096 (post-model hot path: K5+K6 preprocess, fused logits->GRPO loss->dlogits, step stats; trainer->actor weight-sync ms in weight_sync)",
+            "metric": f"learner samples/sec, {label} (post-model hot path: K5+K6 preprocess, fused logits->GRPO loss->dlogits, step stats; trainer->actor weight-sync ms in weight_sync)",
             "value": bs / (elapsed / args.steps),
             "unit": "samples/s",
             "n_gpus": world,
@@ -320,7 +329,7 @@ def main():
     # The weight-sync probe creates its own RCCL communicator; a hang there must not cost the
     # benchmark line, so a watchdog prints the line without it and ends the process.
     wsync = None
-    if world > 1 and not args.no_weight_sync and os.environ.get("PRL_BENCH_WSYNC", "1") != "0":
+    if world > 1 and args.backend == "nccl" and not args.no_weight_sync and os.environ.get("PRL_BENCH_WSYNC", "1") != "0":
         import threading
 
         done = threading.Event()

@@ -144,8 +144,12 @@ class HotPathStep:
         if self.group is None and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return stats
         world = dist.get_world_size(self.group)
+        dev = stats.device
+        if dist.get_backend(self.group) == "gloo":  # CPU collectives (tests / single-GPU dry runs)
+            stats = stats.cpu()
         gathered = torch.empty((world, stats.numel()), dtype=stats.dtype, device=stats.device)
-        dist.all_gather_into_tensor(gathered, stats.unsqueeze(0), group=self.group)
+        dist.all_gather_into_tensor(gathered, stats.unsqueeze(0).contiguous(), group=self.group)
+        gathered = gathered.to(dev)
         out = gathered.sum(dim=0)
         out[_MAX_LANES] = gathered[:, _MAX_LANES].max(dim=0).values
         out[_MIN_LANES] = gathered[:, _MIN_LANES].min(dim=0).values

@@ -55,6 +55,17 @@ class TrainingText(BaseModel):
     def output_text(self) -> str:
         return self.text[-self.n_predicted :]
 
+    def check_consistency(self) -> None:
+        """What the preprocess path relies on (rl/__init__.py:582-585, preprocess.py:90-92):
+        one label per token, one logprob per target token, targets form the tail of the sequence."""
+        if len(self.labels) != len(self.input_ids):
+            raise ValueError(f"labels ({len(self.labels)}) and input_ids ({len(self.input_ids)}) differ in length")
+        n_targets = sum(1 for x in self.labels if x != -100)
+        if n_targets != len(self.logprobs):
+            raise ValueError(f"Target tokens: {n_targets}, old logprobs: {len(self.logprobs)}")
+        if self.ref_logprobs and len(self.ref_logprobs) != len(self.logprobs):
+            raise ValueError(f"{len(self.ref_logprobs)} != {len(self.logprobs)}")
+
 
 class RolloutResult(BaseModel):
     training_texts: list[TrainingText]
@@ -65,6 +76,21 @@ class RolloutResult(BaseModel):
     dataset_name: Optional[str] = None
     group_id: Optional[str] = None
     domain: Optional[str] = None
+
+
+def stamp_group(results: Sequence["RolloutResult"], group_id: str, model_version: int) -> list[dict]:
+    """What the actor does to a finished group before publishing it (reference actor.py:210-225,
+    648-652): every training text gets `group_id` and metadata {model_version, rollout_index,
+    step_index}; the returned list of plain dicts is ONE record of the `actor` stream."""
+    record: list[dict] = []
+    for rollout_index, result in enumerate(results):
+        result.model_version = model_version
+        result.group_id = group_id
+        for step_index, text in enumerate(result.training_texts):
+            text.group_id = group_id
+            text.metadata.update(model_version=model_version, rollout_index=rollout_index, step_index=step_index)
+            record.append(text.model_dump())
+    return record
 
 
 @dataclass(frozen=True)

@@ -1,9 +1,10 @@
-"""`TrainerState`: a follower of the trainer's message topic (reference pipelinerl/state.py:20-65).
+"""`TrainerState`: a follower of the trainer's message topic (role of reference
+pipelinerl/state.py:20-65).
 
-Actor, rollout workers, preprocessor and launcher each keep one; a daemon thread tails the
-`weight_update_request` topic and tracks the last propagated weight version, the number of samples
-the trainer has consumed (back-pressure input of the preprocessor, preprocess.py:587-592) and the
-end of training.
+Actor, rollout workers, preprocessor and launcher each keep one.  A daemon thread tails the
+`weight_update_request` topic and folds every message into three facts: the last weight version
+that reached the inference servers, how many samples the trainer has consumed (the
+preprocessor's back-pressure input, preprocess.py:587-592) and whether training has ended.
 """
 
 from __future__ import annotations
@@ -12,69 +13,83 @@ import logging
 import threading
 import time
 from pathlib import Path
+from typing import Callable
 
-from .finetune_loop import (
-    TRAINER_TOPIC,
-    SamplesProcessed,
-    TrainingDone,
-    WeightUpdateSuccess,
-    parse_trainer_message,
-)
+from . import finetune_loop as fl
 from .streams import SingleStreamSpec, read_stream
 
 logger = logging.getLogger(__name__)
 
 
 class TrainerState:
+    #: how often the blocking waits re-check / log
+    POLL_S = 0.05
+    LOG_EVERY_S = 1.0
+
     def __init__(self, exp_path: Path):
         self.exp_path = exp_path
         self.propagated_weight_version: int | None = None
         self.samples_processed: int | None = None
         self.training_done: bool = False
-        self._training_done_event = threading.Event()
+        self._done = threading.Event()
         self._thread: threading.Thread | None = None
+        self._handlers: dict[type, Callable] = {
+            fl.WeightUpdateSuccess: self._on_weights,
+            fl.SamplesProcessed: self._on_samples,
+            fl.TrainingDone: self._on_done,
+        }
 
-    def debug_mode_init(self) -> None:
-        """No trainer around (debug.mode actor / preprocessor): pretend version 0, nothing consumed."""
-        self.propagated_weight_version = 0
-        self.samples_processed = 0
+    # -- message handlers ------------------------------------------------------------------------
+    def _on_weights(self, m: "fl.WeightUpdateSuccess") -> None:
+        self.propagated_weight_version = m.version
+
+    def _on_samples(self, m: "fl.SamplesProcessed") -> None:
+        self.samples_processed = m.samples_processed
+
+    def _on_done(self, _m: "fl.TrainingDone") -> None:
         self.training_done = True
-        self._training_done_event.set()
+        self._done.set()
 
-    def _apply(self, message) -> None:
-        if isinstance(message, WeightUpdateSuccess):
-            self.propagated_weight_version = message.version
-        elif isinstance(message, SamplesProcessed):
-            self.samples_processed = message.samples_processed
-        elif isinstance(message, TrainingDone):
-            self.training_done = True
-            self._training_done_event.set()
+    def apply(self, message) -> None:
+        handler = self._handlers.get(type(message))
+        if handler is not None:  # WeightUpdateRequest and unknown kinds are not state
+            handler(message)
+
+    # -- lifecycle -------------------------------------------------------------------------------
+    def debug_mode_init(self) -> None:
+        """Stage-isolation modes without a trainer (debug.mode actor / preprocessor): version 0,
+        nothing consumed, training over."""
+        self.apply(fl.WeightUpdateSuccess(version=0))
+        self.apply(fl.SamplesProcessed(samples_processed=0))
+        self.apply(fl.TrainingDone())
 
     def start_listening(self) -> None:
-        stream = SingleStreamSpec(exp_path=self.exp_path, topic=TRAINER_TOPIC)
+        spec = SingleStreamSpec(exp_path=self.exp_path, topic=fl.TRAINER_TOPIC)
 
-        def listen():
-            with read_stream(stream) as reader:
+        def follow() -> None:
+            with read_stream(spec) as reader:
                 for record in reader.read():
-                    self._apply(parse_trainer_message(record))
+                    self.apply(fl.parse_trainer_message(record))
 
-        self._thread = threading.Thread(target=listen, daemon=True)
+        self._thread = threading.Thread(target=follow, name="trainer-state", daemon=True)
         self._thread.start()
 
+    # -- blocking accessors ------------------------------------------------------------------------
     def wait_for_training_done(self, timeout: float | None = None) -> bool:
-        return self._training_done_event.wait(timeout=timeout)
+        return self._done.wait(timeout=timeout)
 
-    def _wait_for(self, attr: str, what: str, poll: float = 0.05, log_every: float = 1.0):
-        last = 0.0
-        while getattr(self, attr) is None:
-            if time.time() - last >= log_every:
-                logger.info(f"Waiting for the trainer to declare {what}")
-                last = time.time()
-            time.sleep(poll)
-        return getattr(self, attr)
+    def _block_until_known(self, attr: str, what: str):
+        logged = 0.0
+        while (value := getattr(self, attr)) is None:
+            now = time.time()
+            if now - logged >= self.LOG_EVERY_S:
+                logger.info("Waiting for the trainer to declare %s", what)
+                logged = now
+            time.sleep(self.POLL_S)
+        return value
 
-    def wait_for_processed_samples(self):
-        return self._wait_for("samples_processed", "the number of processed samples")
+    def wait_for_processed_samples(self) -> int:
+        return self._block_until_known("samples_processed", "the number of processed samples")
 
-    def wait_for_model_version(self):
-        return self._wait_for("propagated_weight_version", "the initial weight version")
+    def wait_for_model_version(self) -> int:
+        return self._block_until_known("propagated_weight_version", "the initial weight version")
