@@ -26,7 +26,7 @@ import time
 from collections import defaultdict
 from concurrent.futures import ThreadPoolExecutor
 from queue import Empty, Queue
-from typing import Any, Callable, Dict, List, Literal, Optional
+from typing import Any, Callable, Literal
 
 import numpy as np
 import torch

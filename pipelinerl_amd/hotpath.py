@@ -17,9 +17,8 @@ from __future__ import annotations
 
 import ctypes
 from dataclasses import dataclass
-from typing import Any, Callable, Sequence
+from typing import Any, Sequence
 
-import numpy as np
 import torch
 
 from . import _lib

@@ -7,9 +7,8 @@ Mix it into a vLLM worker class or use `StandaloneWeightReceiver` directly.
 
 from __future__ import annotations
 
-import json
 import logging
-from typing import Any, Callable
+from typing import Any
 
 import torch
 

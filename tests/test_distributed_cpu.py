@@ -9,7 +9,6 @@ import types
 from pathlib import Path
 
 import numpy as np
-import pytest
 import torch
 import torch.multiprocessing as mp
 

@@ -7,7 +7,6 @@ import queue
 import threading
 import types
 
-import numpy as np
 import pytest
 import torch
 

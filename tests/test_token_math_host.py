@@ -5,7 +5,6 @@ checks the device MATH on a machine without a GPU; the kernels themselves are co
 
 import ctypes
 import subprocess
-import sys
 from pathlib import Path
 
 import numpy as np

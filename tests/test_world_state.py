@@ -2,7 +2,6 @@
 trainer messages over the files stream (CPU only)."""
 
 import json
-import time
 
 import pytest
 
