@@ -438,3 +438,61 @@ class LearnerStep:
         if self._writer_cm is not None:
             self._writer_cm.__exit__(None, None, None)
             self._writer_cm = self._writer = None
+
+
+class NativeLearnerStep:
+    """The MI355X-native optimizer step: consumes a whole step's rollouts at once.
+
+        K5 + ONE K6 launch  ->  per micro-batch: model forward, fused logits kernel (loss gradient
+        straight into d logits), model backward  ->  ONE K2+K3 launch for loss + 32 statistics
+        ->  one stats all-gather  ->  optimizer step
+
+    No host synchronisation happens inside the step; `step()` returns device tensors and only
+    `stats_dict()` copies 256 bytes to the host.  Numerically identical to running the drop-in
+    `rl_step` per micro-batch and summing (tests/test_gpu_pipeline.py)."""
+
+    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, rl_config: RLConfig, eos_token_id: int,
+                 samples_per_step: int, max_train_steps: int, lr_scheduler: Any = None,
+                 gradient_clipping_threshold: float | None = None, process_group: Any = None):
+        self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
+        self.rl_config = rl_config.model_copy()
+        self.rl_config.batch_size = samples_per_step
+        self.eos_token_id = eos_token_id
+        self.max_train_steps = max_train_steps
+        self.gradient_clipping_threshold = gradient_clipping_threshold
+        self.group = process_group
+        self.metrics = TrainingMetrics()
+        self._last = None
+
+    def step(self, rollouts, micro_batches) -> dict[str, Any]:
+        from .hotpath import HotPathStep
+
+        hp = HotPathStep(self.rl_config, self.eos_token_id, self.metrics.completed_steps, self.max_train_steps, group=self.group)
+        batches = hp.preprocess(rollouts, micro_batches)
+        n = len(batches)
+        for j in range(n):
+            b = batches[j]
+            ctx = self.model.no_sync() if (hasattr(self.model, "no_sync") and j < n - 1) else contextlib.nullcontext()
+            with ctx:
+                logits = self.model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits
+                lg = logits.detach()
+                if lg.dtype not in (torch.float32, torch.bfloat16) or not lg.is_contiguous():
+                    lg = lg.float().contiguous()
+                dlogits = hp.logits_backward(j, lg)
+                logits.backward(dlogits.to(logits.dtype))
+        loss, stats = hp.finish()
+        if self.gradient_clipping_threshold is not None:
+            self.metrics.grad_norm = float(torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.gradient_clipping_threshold))
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        m = self.metrics
+        m.completed_steps += 1
+        m.passes += n
+        m.samples += self.rl_config.batch_size
+        self._last = hp
+        return {"loss": loss, "stats": stats, "micro_batches": n}
+
+    def stats_dict(self, stats: torch.Tensor) -> dict[str, float]:
+        return self._last.stats_dict(stats)
