@@ -345,6 +345,7 @@ int prl_ring_size(prl_ring* r, uint64_t* n_ready);
 int prl_ring_capacity(prl_ring* r, uint32_t* n_slots, uint64_t* slot_bytes);
 int prl_ring_max_record_bytes(prl_ring* r, uint64_t* nbytes);
 int prl_ring_close(prl_ring* r);           /* detach (creator also unlinks) */
+int prl_ring_detach(prl_ring* r);          /* detach only: the segment stays for late readers */
 int prl_ring_unlink(const char* name);
 
 /* ------------------------------------------------------------------------- */

@@ -127,6 +127,7 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_ring_capacity": (c_int32, [c_void_p, POINTER(c_uint32), POINTER(c_uint64)]),
     "prl_ring_max_record_bytes": (c_int32, [c_void_p, POINTER(c_uint64)]),
     "prl_ring_close": (c_int32, [c_void_p]),
+    "prl_ring_detach": (c_int32, [c_void_p]),
     "prl_ring_unlink": (c_int32, [c_char_p]),
     "prl_wsync_unique_id": (c_int32, [POINTER(c_uint8)]),
     "prl_wsync_init": (c_int32, [POINTER(c_uint8), c_int32, c_int32, c_int32, POINTER(c_void_p)]),

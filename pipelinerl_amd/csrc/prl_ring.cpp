@@ -324,6 +324,13 @@ extern "C" int prl_ring_close(prl_ring* r) {
   return PRL_OK;
 }
 
+extern "C" int prl_ring_detach(prl_ring* r) {
+  if (!r) return PRL_OK;
+  munmap(r->base, r->map_bytes);
+  delete r;
+  return PRL_OK;
+}
+
 extern "C" int prl_ring_unlink(const char* name) {
   PRL_CHECK_ARG(name, "null name");
   shm_unlink(shm_name(name).c_str());

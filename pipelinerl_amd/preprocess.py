@@ -243,11 +243,21 @@ class PreprocessorLoop:
         self.filtered_out = 0
         self.max_model_version = 0
 
-    def _ingest(self, groups: list[list[dict]]) -> None:
-        entries = [e for g in groups for e in g]
-        if not check_group_sizes(entries, self.cfg.attempts):
-            raise ValueError("Group sizes are wrong")
-        prep = preprocess_chunk(entries, self.cfg.eos_token_id, self.cfg.rl, self.device)
+    def _ingest(self, groups: list) -> None:
+        """`groups`: stream records, each either a list of TrainingText dicts (the reference's text
+        record) or a `RaggedRollouts` (binary record of the shm backend)."""
+        if all(isinstance(g, RaggedRollouts) for g in groups):
+            rag = concat_ragged(groups).to(self.device)
+            sizes = np.bincount(rag.host_group_index)
+            pairs = np.unique(np.stack([rag.host_group_index, rag.host_rollout_index]), axis=1)
+            if not (np.bincount(pairs[0], minlength=len(sizes)) == self.cfg.attempts).all():
+                raise ValueError("Group sizes are wrong")
+            prep = populate_rl_data_ragged(rag, self.cfg.eos_token_id, self.cfg.rl)
+        else:
+            entries = [e for g in groups for e in g]
+            if not check_group_sizes(entries, self.cfg.attempts):
+                raise ValueError("Group sizes are wrong")
+            prep = preprocess_chunk(entries, self.cfg.eos_token_id, self.cfg.rl, self.device)
         keep = np.ones(prep.rollouts.n_seqs, dtype=bool)
         if self.cfg.rl.filter_zero_advantage_groups:
             keep = nonzero_advantage_mask(prep)

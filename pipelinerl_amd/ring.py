@@ -73,15 +73,23 @@ class Ring:
         _lib.check(_lib.load().prl_ring_max_record_bytes(self._h, ctypes.byref(n)))
         return n.value
 
-    def close(self) -> None:
+    def close(self, unlink: bool = True) -> None:
+        """Detach.  The creator also removes the shared-memory name unless `unlink=False` (stream
+        writers keep the segment for readers that attach later and unlink at process exit)."""
         if getattr(self, "_h", None) and self._h:
             lib = _lib.load()
             if self._owner_pid is not None and self._owner_pid != os.getpid():
                 # a forked child inherits the creator's handle: it must not unlink the segment
                 pass
-            else:
+            elif unlink:
                 lib.prl_ring_close(self._h)
+            else:
+                lib.prl_ring_detach(self._h)
             self._h = ctypes.c_void_p()
+
+    @staticmethod
+    def unlink_name(name: str) -> None:
+        _lib.load().prl_ring_unlink(name.encode())
 
     def __del__(self):
         try:

@@ -34,6 +34,7 @@ from pydantic import BaseModel
 
 from . import batch_codec
 from .finetune.types import PipelineBatchEncoding
+from .ragged import RaggedRollouts
 
 logger = logging.getLogger(__name__)
 
@@ -119,6 +120,10 @@ class StreamReader(ABC):
 
 def to_jsonable(data: Any) -> Any:
     """pydantic models / batches -> plain dicts; tensors and arrays -> nested lists."""
+    if isinstance(data, RaggedRollouts):  # text form = the reference's list-of-dicts group record
+        from .synthetic import ragged_to_entries
+
+        return ragged_to_entries(data)
     if isinstance(data, (BaseModel, PipelineBatchEncoding)):
         data = data.model_dump()
     if isinstance(data, dict):
@@ -249,17 +254,25 @@ class ShmStreamWriter(StreamWriter):
     def __enter__(self):
         from .ring import Ring
 
-        self._ring = Ring(ring_name(self.stream), n_slots=self.n_slots, slot_bytes=self.slot_bytes, create=True)
+        import atexit
+
+        name = ring_name(self.stream)
+        self._ring = Ring(name, n_slots=self.n_slots, slot_bytes=self.slot_bytes, create=True)
+        # Streams outlive their writer (a reader may attach after the producer finished, like a
+        # file on disk): the segment is only unlinked when the creating process exits.
+        atexit.register(Ring.unlink_name, name)
         return self
 
     def __exit__(self, exc_type, exc_value, traceback):
-        self._ring.close()
+        self._ring.close(unlink=False)
 
     def write(self, data, partition: int | None = None):
         if partition is not None:
             raise ValueError()
         if isinstance(data, PipelineBatchEncoding):
             payload = batch_codec.encode_batch(data)
+        elif isinstance(data, RaggedRollouts):
+            payload = batch_codec.encode_rollouts(data)
         else:
             payload = batch_codec.encode_json(_dumps(data))
         self._ring.put_bytes(payload)

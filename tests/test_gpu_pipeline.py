@@ -29,8 +29,9 @@ class TinyLM(torch.nn.Module):
 def test_replay_actor_stream_through_preprocessor_and_learner(libprl, cuda_device, tmp_path, backend):
     from pipelinerl_amd import streams
     from pipelinerl_amd.finetune.rl import RLConfig
-    from pipelinerl_amd.finetune_loop import TRAINER_TOPIC, LearnerStep, batch_generator, run_data_loader
+    from pipelinerl_amd.finetune_loop import TRAINER_TOPIC, LearnerStep, run_data_loader
     from pipelinerl_amd.preprocess import PreprocessorConfig, PreprocessorLoop
+    from pipelinerl_amd.ragged import RaggedRollouts
     from pipelinerl_amd.state import TrainerState
     from pipelinerl_amd.synthetic import make_entries
 
@@ -46,11 +47,24 @@ def test_replay_actor_stream_through_preprocessor_and_learner(libprl, cuda_devic
         actor_spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="actor")
         published = {}
 
+        errors = []
+
         def preprocessor():
+            try:
+                _preprocessor()
+            except Exception as e:  # noqa: BLE001 - surfaced by the main thread
+                import traceback
+
+                errors.append(traceback.format_exc())
+                raise e
+
+        def _preprocessor():
             # the ring of the shm backend must exist before the reader attaches: writer first
             with streams.write_to_streams(actor_spec) as w:
                 for g in range(6):
-                    w.write(raw[g * attempts:(g + 1) * attempts])
+                    group = raw[g * attempts:(g + 1) * attempts]
+                    # shm backend: rollouts travel as binary ragged SoA records; files: the text record
+                    w.write(RaggedRollouts.from_entries(group) if backend == "shm" else group)
                 loop = PreprocessorLoop(cfg, cuda_device)
                 published["n"] = loop.run(max_published_samples=16, idle_timeout=3.0)
 
@@ -66,10 +80,17 @@ def test_replay_actor_stream_through_preprocessor_and_learner(libprl, cuda_devic
         q: queue.Queue = queue.Queue(maxsize=2)
         data_spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data", partition=0)
         threading.Thread(target=run_data_loader, args=(data_spec, q, cuda_device), daemon=True).start()
-        gen = batch_generator(q)
         steps, first = 0, None
         while steps < 2:
-            batch = next(gen)
+            while True:  # poll so that a dead preprocessor fails the test instead of hanging it
+                try:
+                    batch = q.get(timeout=0.5)
+                    break
+                except queue.Empty:
+                    assert not errors, errors[0]
+                    assert t.is_alive() or not q.empty(), "preprocessor exited without producing the expected batches"
+            if isinstance(batch, Exception):
+                raise batch
             assert batch.input_ids.is_cuda and batch.input_ids.shape[1] <= 96
             if first is None:
                 # oracle check of the very first micro-batch with the model's own logits

@@ -148,3 +148,31 @@ def test_batch_codec_is_compact(libprl):
     assert len(blob) <= 68 * T + 4 * len(want["seq_boundaries"]) + 2048  # 5 x i64 + 7 x f32 per token + header
     assert len(_dumps(batch)) > len(blob) / 2  # the JSON form is of the same order or larger even on tiny batches
     _same(batch_codec.decode(blob), want)
+
+
+def test_rollouts_binary_record_roundtrip(streams, tmp_path, libprl):
+    """The `actor` hop in binary: RaggedRollouts -> shm ring -> RaggedRollouts, field for field; and
+    the text form written by the files backend is the reference's list-of-dicts group record."""
+    from pipelinerl_amd import batch_codec
+    from pipelinerl_amd.ragged import RaggedRollouts
+    from pipelinerl_amd.synthetic import make_ragged, ragged_to_entries
+
+    rag, reasons = make_ragged(2, attempts=3, seq_length=30, vocab=40, seed=8, prompt_min=2, prompt_max=6, with_ref=True)
+    got = batch_codec.decode(batch_codec.encode_rollouts(rag))
+    assert isinstance(got, RaggedRollouts) and got.group_ids == rag.group_ids
+    for name in ("tokens", "labels", "logprobs", "ref_logprobs", "seq_off", "lp_off", "reward", "group_index", "step_index",
+                 "rollout_index", "model_version", "finished", "finish_code"):
+        a, b = getattr(rag, name), getattr(got, name)
+        assert a.dtype == b.dtype and torch.equal(a, b), name
+    assert np.array_equal(got.host_seq_off, rag.host_seq_off)
+    blob = batch_codec.encode_rollouts(rag)
+    assert len(blob) < 20 * rag.n_tokens + 4096  # ~16 B/token + header
+    streams.set_streams_backend("files")
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="actor")
+    with streams.write_to_streams(spec) as w:
+        w.write(rag)
+    with streams.read_stream(spec) as r:
+        rec = next(r.read())
+    want = ragged_to_entries(rag)
+    assert [e["input_ids"] for e in rec] == [e["input_ids"] for e in want]
+    assert [e["metadata"] for e in rec] == [e["metadata"] for e in want]
