@@ -136,5 +136,45 @@ def main():
     (HERE / "schedule.json").write_text(json.dumps(out))
 
 
+
+
+def reference_function_source(name: str) -> str:
+    """Source text of a top-level function of the reference's preprocess.py."""
+    lines = SRC.read_text().splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith(f"def {name}("))
+    end = start + 1
+    while end < len(lines) and (not lines[end].strip() or lines[end].startswith((" ", "\t"))):
+        end += 1
+    return "\n".join(lines[start:end])
+
+
+def gen_filter_golden():
+    """filter_zero_advantage_groups (preprocess.py:316-353) and _check_group_sizes (:70-83), executed
+    from the reference source on small hand-made datasets."""
+    ns = {"defaultdict": __import__("collections").defaultdict, "logger": types.SimpleNamespace(error=lambda *a, **k: None)}
+    exec(compile(reference_function_source("filter_zero_advantage_groups"), "ref_filter", "exec"), ns)
+    exec(compile(reference_function_source("_check_group_sizes"), "ref_check", "exec"), ns)
+    rng = np.random.default_rng(1)
+    cases = []
+    for c in range(6):
+        data = []
+        for g in range(int(rng.integers(1, 5))):
+            zero = bool(rng.integers(0, 2))
+            for r in range(int(rng.integers(1, 4))):
+                adv = 0.0 if zero else float(np.round(rng.normal(), 3))
+                if not zero and r == 0 and rng.random() < 0.3:
+                    adv = 5e-7  # below the epsilon
+                data.append({"group_id": f"g{g}", "advantages": [adv] * int(rng.integers(1, 4)), "uid": len(data),
+                             "metadata": {"rollout_index": r if rng.random() < 0.9 else 0}})
+        order = rng.permutation(len(data)).tolist()
+        data = [data[i] for i in order]
+        kept, dropped = ns["filter_zero_advantage_groups"](list(data))
+        sizes = {gs: bool(ns["_check_group_sizes"](data, gs)) for gs in (1, 2, 3)}
+        cases.append({"data": data, "kept_uids": [e["uid"] for e in kept], "dropped": dropped, "group_size_ok": sizes})
+    (HERE / "filter_groups.json").write_text(json.dumps(cases))
+    print("filter_groups:", len(cases), "cases")
+
+
 if __name__ == "__main__":
     main()
+    gen_filter_golden()

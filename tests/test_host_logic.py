@@ -1,0 +1,117 @@
+"""Host-side logic of the path (CPU only): group filtering / group-size check against outputs of
+the reference functions (executed from source, tests/golden/make_schedule_golden.py),
+PipelineBatchEncoding slicing, stats aggregation rules, rollout plugin types."""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+
+
+@pytest.mark.parametrize("case", json.loads((GOLDEN / "filter_groups.json").read_text()), ids=lambda c: f"n{len(c['data'])}")
+def test_group_filter_and_size_check_match_reference(case):
+    from pipelinerl_amd.preprocess import check_group_sizes, filter_zero_advantage_groups
+
+    kept, dropped = filter_zero_advantage_groups(list(case["data"]))
+    assert [e["uid"] for e in kept] == case["kept_uids"] and dropped == case["dropped"]
+    for gs, ok in case["group_size_ok"].items():
+        assert check_group_sizes(case["data"], int(gs)) == ok
+
+
+def _packed_batch(T=16, n_seq=3):
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+
+    i64 = lambda: torch.arange(T, dtype=torch.long).unsqueeze(0)  # noqa: E731
+    f32 = lambda: torch.arange(T, dtype=torch.float32).unsqueeze(0) / 7  # noqa: E731
+    return PipelineBatchEncoding(
+        input_ids=i64(), attention_mask=torch.ones(1, T, dtype=torch.long), labels=i64(), position_ids=i64(), segment_ids=i64() // 6,
+        rewards=f32(), advantages=f32(), ref_logprobs=f32(), old_logprobs=f32(), group_tokens=f32() + 1, num_labels=f32() + 1,
+        overflow=f32() * 0, model_version=4, is_packed=True, seq_boundaries=[0, 6, 12, 16], padding=0)
+
+
+def test_batch_encoding_slices_and_coercion():
+    """make_slices (types.py:145-180): equal token ranges, metadata shared; list inputs coerced to
+    the reference's dtypes; unknown keys ignored; missing required fields rejected."""
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+
+    b = _packed_batch()
+    parts = b.make_slices(4)
+    assert len(parts) == 4 and all(p.input_ids.shape == (1, 4) for p in parts)
+    assert torch.equal(torch.cat([p.old_logprobs for p in parts], dim=1), b.old_logprobs)
+    assert all(p.model_version == 4 and p.is_packed and torch.equal(p.seq_boundaries, b.seq_boundaries) for p in parts)
+    with pytest.raises(ValueError):
+        b.make_slices(5)  # 16 % 5 != 0
+    with pytest.raises(ValueError):
+        b.make_slices(32)
+    d = {k: (v.tolist() if isinstance(v, torch.Tensor) else v) for k, v in b.model_dump().items()}
+    d["some_future_field"] = 1
+    c = PipelineBatchEncoding(**d)
+    assert c.input_ids.dtype == torch.long and c.rewards.dtype == torch.float32 and c.seq_boundaries.dtype == torch.int32
+    assert torch.equal(c.labels, b.labels) and c.pixel_values is None and c.sentinel is False
+    e = PipelineBatchEncoding.from_dict({"extra": 3}, **{k: v for k, v in d.items() if k != "some_future_field"})
+    assert e.model_extra == {"extra": 3}
+    with pytest.raises(ValueError):
+        PipelineBatchEncoding(input_ids=[[1]], attention_mask=[[1]], labels=[[1]], model_version=0)
+    unpacked = PipelineBatchEncoding(**{**d, "position_ids": None, "is_packed": False})
+    with pytest.raises(ValueError):
+        unpacked.make_slices(2)
+
+
+def test_sequence_count_and_token_count():
+    from pipelinerl_amd.finetune_loop import get_batch_sequence_count, get_batch_token_count
+    from pipelinerl_amd.finetune.utils import create_sentinel_batch
+
+    b = _packed_batch()
+    assert get_batch_sequence_count(b) == 3 and get_batch_token_count(b) == 16
+    b.padding = 4  # the last "sequence" is the sequence-parallel filler (finetune_loop.py:302-312)
+    assert get_batch_sequence_count(b) == 2
+    s = create_sentinel_batch(None)
+    assert get_batch_sequence_count(s) == 1 and s.sentinel and int((s.labels != -100).sum()) == 0
+
+
+def test_aggregate_rl_stats_rules():
+    """Aggregation op by key substring, in the reference's precedence (rl/utils.py:9-23)."""
+    from pipelinerl_amd.finetune.rl.utils import aggregate_rl_stats, effective_sample_size
+
+    stats = {"min_loss": [3.0, -1.0], "max_kl": [0.5, 2.0], "loss": [1.0, 2.0], "ratio_new_old_sum": [10.0, 30.0],
+             "ratio_new_old_squared_sum": [12.0, 28.0], "num_output_tokens_sum": [20, 20], "reward": [4.0, 8.0], "max_loss": [1.0, 5.0]}
+    out = aggregate_rl_stats(stats, num_samples=4)
+    assert out["rl/min_loss"] == -1.0 and out["rl/max_kl"] == 2.0 and out["rl/max_loss"] == 5.0
+    assert out["rl/loss"] == 3.0 and out["rl/ratio_new_old_sum"] == 40.0 and out["rl/reward"] == 3.0
+    assert effective_sample_size(out) == pytest.approx(40.0 ** 2 / 40.0 / 40.0)
+
+
+def test_linear_decay_and_loss_config():
+    from pipelinerl_amd.finetune.rl import RLConfig, linear_decay_coef, make_loss_config
+
+    assert linear_decay_coef(3, 10, 0.3, 0.1) == pytest.approx(0.3 + (0.1 - 0.3) * 0.3)
+    c, kl, ent = make_loss_config(RLConfig(policy_loss="reinforce", epsilon_low=0.1, epsilon_high=0.3, kl_coef=0.3, final_kl_coef=0.1, batch_size=8), 3, 10)
+    assert c.policy_loss == 1 and c.clip_lo == np.float32(0.9) and c.clip_hi == np.float32(1.3) and c.token_weight == np.float32(0.125)
+    assert kl == pytest.approx(0.24) and ent == 0 and c.use_entropy_loss == 0
+    with pytest.raises(ValueError):
+        make_loss_config(RLConfig(policy_loss="dpo"), 0, 1)
+    assert RLConfig(**{"policy_loss": "ppo", "aggregate_loss": "sum"}).policy_loss == "ppo"  # unknown yaml keys are ignored
+
+
+def test_rollout_plugin_types_and_stamping():
+    from pipelinerl_amd.ragged import RaggedRollouts
+    from pipelinerl_amd.rollouts import BaseMetrics, RolloutResult, TrainingText, resolve_plugin, stamp_group, summarize_training_texts
+
+    t = TrainingText(text="prompt answer", n_predicted=6, input_ids=[5, 6, 7, 8], labels=[-100, -100, 7, 8], logprobs=[-0.1, -0.2], reward=1.0, finished=True)
+    t.check_consistency()
+    assert t.prompt_text == "prompt " and t.output_text == "answer"
+    bad = t.model_copy(update={"logprobs": [-0.1]})
+    with pytest.raises(ValueError):
+        bad.check_consistency()
+    results = [RolloutResult(training_texts=[t.model_copy(deep=True)], metrics=BaseMetrics(reward=1, success=True, no_error=True, no_answer=False), latency=0.1) for _ in range(3)]
+    record = stamp_group(results, "problem-7", model_version=48)
+    assert [e["metadata"]["rollout_index"] for e in record] == [0, 1, 2] and all(e["group_id"] == "problem-7" for e in record)
+    rag = RaggedRollouts.from_entries(record)  # the stream record is directly ingestible
+    assert rag.n_seqs == 3 and rag.host_model_version.tolist() == [48, 48, 48] and rag.finished.tolist() == [1, 1, 1]
+    assert summarize_training_texts([t]).overflow is False
+    assert resolve_plugin("pipelinerl_amd.rollouts.stamp_group") is stamp_group
+    with pytest.raises(ValueError):
+        resolve_plugin("nodots")
