@@ -699,6 +699,8 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
   //   6: as 3 with unroll 4   7: as 3 with plain stores   8: 512 threads, 1 per CU   9: as 3 with unroll 1
   //   10-14: row-resident variants (KREG vectors per lane in VGPRs + KLDS in LDS stay on chip)
   int variant = kDefaultFusedVariant;
+  // a bf16 row of the same vocabulary is half as long: 16 + 2 vectors per lane hold 97 % of it
+  if (logits_dtype == PRL_DTYPE_BF16) variant = 23;
   if (const char* e = getenv("PRL_FUSED_VARIANT")) variant = atoi(e);
 #define PRL_FUSED_LAUNCH(TT, ST, BLK, UNR, REV, NTS, LDSB)                                            \
   do {                                                                                              \
@@ -740,6 +742,7 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
     case 20: PRL_KEEP_LAUNCH(TT, ST, 512, 2, 40, 19); break;                    \
     case 21: PRL_KEEP_LAUNCH2(TT, ST, 1024, 2, 16, 9, true); break;             \
     case 22: PRL_KEEP_LAUNCH2(TT, ST, 1024, 2, 16, 0, true); break;             \
+    case 23: PRL_KEEP_LAUNCH2(TT, ST, 1024, 2, 16, 2, true); break;             \
     case 1: PRL_FUSED_LAUNCH(TT, ST, 256, 4, true, false, 0); break;            \
     case 2: PRL_FUSED_LAUNCH(TT, ST, 256, 4, true, true, 0); break;             \
     case 3: PRL_FUSED_LAUNCH(TT, ST, 1024, 2, true, true, 96 * 1024); break;    \

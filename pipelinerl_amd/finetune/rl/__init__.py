@@ -251,6 +251,22 @@ def gspo_segment_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, new_log
     return loss, ext_g, ext_c
 
 
+def annotate_ref_logprobs(ref_model: Any, batch: PipelineBatchEncoding, temperature: float = 1.0) -> PipelineBatchEncoding:
+    """Fill `batch.ref_logprobs` with a no-grad forward of a frozen reference model that lives on
+    the learner GPU.  The reference pipeline instead asks a second vLLM server
+    for `prompt_logprobs` over HTTP per chunk (preprocess.py:86-104, llm.py:606-648) and stores
+    the completion-token logprobs left-zero-padded; here the same values come out of the K1 kernel:
+    ref_logprobs[u] = log p_ref(token u | prefix) on labelled tokens, 0 elsewhere."""
+    model_inputs = {"input_ids": batch.input_ids, "attention_mask": batch.attention_mask}
+    if batch.is_packed:
+        model_inputs["position_ids"] = batch.position_ids
+    with torch.no_grad():
+        logits = ref_model(**model_inputs).logits
+        nlp, _, _, _ = logprob_entropy(logits, batch.input_ids, temperature)
+        batch.ref_logprobs = torch.where(batch.labels != -100, nlp, torch.zeros_like(nlp))
+    return batch
+
+
 class _GrpoLossFn(torch.autograd.Function):
     """logits -> (loss, stats) with a hand-written backward to the logits."""
 

@@ -527,3 +527,39 @@ def test_random_ragged_pipeline_vs_oracle(libprl, cuda_device, seed):
         assert_batch_equal(_batch_to_np(g), want, float_tol=1e-6)
         for key in ("input_ids", "labels", "position_ids", "segment_ids", "attention_mask", "seq_boundaries"):
             assert np.array_equal(np.asarray(_batch_to_np(g)[key]), want[key]), key
+
+
+def test_annotate_ref_logprobs(libprl, cuda_device):
+    """Reference-model logprobs computed on the learner GPU equal torch log_softmax on labelled
+    tokens and are zero elsewhere (the layout prepare_rl_fields gives ref_logprobs)."""
+    from pipelinerl_amd.finetune.rl import annotate_ref_logprobs
+
+    case = load_rl_case("c1_ppo_kl_temp")
+    batch = _batch_from_np(case["batch"], cuda_device)
+    logits = torch.from_numpy(case["logits"]).to(cuda_device)
+    ref_model = lambda **kw: types.SimpleNamespace(logits=logits)  # noqa: E731
+    annotate_ref_logprobs(ref_model, batch)
+    lp = torch.log_softmax(logits[:, :-1].double(), -1).gather(2, batch.input_ids[:, 1:, None])[..., 0]
+    mask = batch.labels[:, 1:] != -100
+    got = batch.ref_logprobs[:, 1:]
+    assert torch.allclose(got[mask].double(), lp[mask], rtol=1e-5, atol=1e-5)
+    assert torch.count_nonzero(got[~mask]).item() == 0 and batch.ref_logprobs[0, 0].item() == 0
+
+
+def test_rl_step_bf16_logits(libprl, cuda_device):
+    """bf16 logits (a model whose lm_head is not forced to fp32): both logits kernels accept them;
+    compare with the oracle evaluated on the bf16-rounded values."""
+    from pipelinerl_amd.finetune.rl import RLConfig, rl_step
+
+    case = load_rl_case("c1_ppo_kl_temp")
+    cur, mx = case["steps"]
+    lg16 = torch.from_numpy(case["logits"]).to(cuda_device).to(torch.bfloat16)
+    want = orl.rl_step(lg16.float().cpu().numpy(), case["batch"], case["config"], cur, mx, True)
+    for fused in (False, True):
+        batch = _batch_from_np(case["batch"], cuda_device)
+        model = FakeModel(lg16.clone())
+        loss, stats = rl_step(model, batch, cur, mx, RLConfig(**case["config"], fused_logits_grad=fused))
+        loss.backward()
+        assert abs(loss.item() - float(want["loss"])) <= 1e-4 * max(abs(float(want["loss"])), 1e-6)
+        g = model.logits.grad.float().cpu().numpy()
+        assert rel_err(g, want["grad_logits"]) <= 1e-2  # the gradient itself is rounded to bf16
