@@ -222,7 +222,7 @@ class WeightUpdateManager:
                 self._sender.send(params)
             else:  # the reference's one-broadcast-per-parameter protocol
                 for _, p in params:
-                    self.actor_update_group.broadcast(p.data, src=0, stream=torch.cuda.current_stream())
+                    self.actor_update_group.broadcast(p.data, src=0)
             for f in futures:
                 f.result()
             if self.update_stream is not None:

@@ -44,7 +44,8 @@ class WorkerExtension:
 
     def receive_weight_update(self, request_json: str) -> None:
         request = WeightUpdateRequest.model_validate_json(request_json) if isinstance(request_json, str) else WeightUpdateRequest(**request_json)
-        torch.cuda.synchronize(self.device)
+        if torch.device(self.device).type == "cuda":
+            torch.cuda.synchronize(self.device)
         expected = (torch.bfloat16, torch.float32, torch.float16)
         for info in request.parameters_info:
             if string_to_dtype(info.dtype) not in expected:
@@ -63,7 +64,7 @@ class WorkerExtension:
         else:  # reference protocol: one broadcast per parameter
             for info in request.parameters_info:
                 buf = torch.empty(tuple(info.shape), dtype=string_to_dtype(info.dtype), device=self.device)
-                self.model_update_group.broadcast(buf, src=0, stream=torch.cuda.current_stream())
+                self.model_update_group.broadcast(buf, src=0)
                 load([(info.name, buf)])
         self._after_update()
         logger.info("Weight update received")

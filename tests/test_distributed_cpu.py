@@ -9,6 +9,7 @@ import types
 from pathlib import Path
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -187,3 +188,86 @@ def test_bucketed_weight_transfer_two_ranks(tmp_path):
     mp.spawn(_wsync_rank, args=(2, port, tmp_path), nprocs=2, join=True)
     res = json.loads((tmp_path / "wsync.json").read_text())
     assert res["ok"] and res["n"] == 3
+
+
+class GlooGroup(GlooBucketGroup):
+    """+ the per-tensor `broadcast` of the reference protocol."""
+
+    def broadcast(self, tensor, src=0, stream=None):
+        import torch.distributed as dist
+
+        dist.broadcast(tensor, src=src)
+
+
+def _weight_update_rank(rank, world, port, exp_path, transport):
+    """rank 0: trainer with WeightUpdateManager; rank 1: an inference worker (WorkerExtension shim).
+    The HTTP POST of the reference is replaced by a file drop that the worker polls."""
+    import time
+
+    import torch.distributed as dist
+
+    from pipelinerl_amd import streams
+    from pipelinerl_amd.finetune_loop import TRAINER_TOPIC, WeightUpdateManager
+    from pipelinerl_amd.vllm_worker import StandaloneWeightReceiver
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    streams.set_streams_backend("files")
+    request_file = Path(exp_path) / "request.json"
+    torch.manual_seed(rank)  # different initial weights on the two sides
+    model = TinyLM(vocab=50, dim=12)
+    group = GlooGroup(torch.device("cpu"))
+    if rank == 0:
+        model.head.weight.data = model.head.weight.data.to(torch.bfloat16).float()
+        named = lambda: [(n, p.to(torch.bfloat16) if n == "head.weight" else p) for n, p in model.named_parameters()]  # noqa: E731
+        mgr = WeightUpdateManager(
+            ["http://worker0"], model, streams.SingleStreamSpec(exp_path=exp_path, topic=TRAINER_TOPIC), group,
+            is_main_process=True, named_parameters_fn=named, transport=transport, bucket_bytes=4096,
+            post=lambda url, payload: request_file.write_text(json.dumps(payload)),
+        )
+        mgr.send_weight_update(version=32)
+        mgr.shutdown()
+        Path(exp_path, "trainer_checksum.json").write_text(json.dumps({n: float(p.double().sum()) for n, p in model.named_parameters()}))
+    else:
+        worker = StandaloneWeightReceiver(model, torch.device("cpu"), rank=0)
+        worker.model_update_group = group
+        worker.pg_rank = 1
+        while not request_file.exists() or not request_file.read_text().endswith("}"):
+            time.sleep(0.01)
+        worker.receive_weight_update(request_file.read_text())
+        Path(exp_path, "worker_checksum.json").write_text(json.dumps({n: float(p.double().sum()) for n, p in model.named_parameters()}))
+        from pipelinerl_amd.finetune_loop import _barrier
+
+        _barrier()  # matches the trainer-side barrier at the end of send_weight_update
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport", ["bucketed", "per_tensor"])
+def test_weight_update_protocol_two_ranks(tmp_path, transport):
+    """WeightUpdateRequest -> bytes -> load_weights -> WeightUpdateSuccess, for the bucketed transport
+    and for the reference's one-broadcast-per-parameter protocol."""
+    import pytest as _pytest  # noqa: F401
+
+    from pipelinerl_amd import streams
+    from pipelinerl_amd.state import TrainerState
+
+    port = _free_port()
+    mp.spawn(_weight_update_rank, args=(2, port, tmp_path, transport), nprocs=2, join=True)
+    a = json.loads((tmp_path / "trainer_checksum.json").read_text())
+    b = json.loads((tmp_path / "worker_checksum.json").read_text())
+    assert a.keys() == b.keys()
+    for k in a:
+        assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(a[k])), k
+    req = json.loads((tmp_path / "request.json").read_text())
+    assert req["kind"] == "weight_update_request" and req["version"] == 32 and req["transport"] == transport
+    assert {p["name"]: p["dtype"] for p in req["parameters_info"]}["head.weight"] == "torch.bfloat16"
+    streams.reset_streams_backend()
+    streams.set_streams_backend("files")
+    try:
+        st = TrainerState(tmp_path)
+        st.start_listening()
+        assert st.wait_for_model_version() == 32
+    finally:
+        streams.reset_streams_backend()

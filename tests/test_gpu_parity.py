@@ -563,3 +563,21 @@ def test_rl_step_bf16_logits(libprl, cuda_device):
         assert abs(loss.item() - float(want["loss"])) <= 1e-4 * max(abs(float(want["loss"])), 1e-6)
         g = model.logits.grad.float().cpu().numpy()
         assert rel_err(g, want["grad_logits"]) <= 1e-2  # the gradient itself is rounded to bf16
+
+
+@pytest.mark.parametrize("name", PREPROCESS_CASES)
+def test_zero_advantage_group_mask(libprl, cuda_device, name):
+    """Device-path group filter == the reference's list-based filter_zero_advantage_groups."""
+    from pipelinerl_amd.finetune.rl import RLConfig, populate_rl_data_ragged
+    from pipelinerl_amd.preprocess import filter_zero_advantage_groups, nonzero_advantage_mask
+    from pipelinerl_amd.ragged import RaggedRollouts
+
+    case = load_preprocess_case(name)
+    rag = RaggedRollouts.from_entries(case["raw"]).to(cuda_device)
+    prep = populate_rl_data_ragged(rag, case["eos_token_id"], RLConfig(divide_advantage_by_std=case["divide_advantage_by_std"]))
+    keep = nonzero_advantage_mask(prep)
+    data = opre.preprocess_chunk(case["raw"], case["eos_token_id"], case["divide_advantage_by_std"])
+    for i, e in enumerate(data):
+        e["uid"] = i
+    kept, dropped = filter_zero_advantage_groups(data)
+    assert sorted(e["uid"] for e in kept) == np.flatnonzero(keep).tolist() and dropped == int((~keep).sum())
