@@ -93,8 +93,8 @@ def cpu_baseline(seq_length: int, vocab: int) -> dict:
     from oracle import rl_loss as orl
     from pipelinerl_amd.synthetic import make_ragged, ragged_to_entries
 
-    n_seq, t_logits = 8, 192
-    rag, reasons = make_ragged(1, attempts=n_seq, seq_length=seq_length, vocab=vocab, seed=99, dense=True)
+    n_seq, t_logits = 64, min(seq_length, 2048)  # a few seconds of single-thread numpy at the 7B shape
+    rag, reasons = make_ragged(n_seq // 8, attempts=8, seq_length=seq_length, vocab=vocab, seed=99, dense=True)
     entries = ragged_to_entries(rag, reasons)
     cfg = dict(policy_loss="ppo", epsilon_low=0.02, epsilon_high=0.02, kl_coef=0.0, final_kl_coef=0.0,
                clamp_log_ratio_ref_new_value=5, divide_advantage_by_std=False, batch_size=4096, temperature=1.0)
