@@ -99,11 +99,11 @@ class WeightSyncGroup:
         _lib.check(lib.prl_wsync_unique_id(arr))
         return bytes(arr)
 
-    @classmethod
-    def from_init_method(cls, init_method: str, rank: int, world_size: int, device: torch.device,
-                         timeout_s: float = 300.0) -> "WeightSyncGroup":
-        """`tcp://host:port` rendezvous like the reference's `stateless_init_process_group`: rank 0
-        hosts a TCPStore and publishes the RCCL unique id, the others fetch it."""
+    @staticmethod
+    def exchange_unique_id(init_method: str, rank: int, world_size: int, timeout_s: float = 300.0):
+        """`tcp://host:port` rendezvous like the reference's `stateless_init_process_group`
+        (torch_utils.py:70-94): rank 0 hosts a TCPStore and publishes the RCCL unique id, the others
+        fetch it.  Returns (uid bytes, store); keep the store alive while peers may still join."""
         from torch.distributed import TCPStore
 
         u = urlparse(init_method)
@@ -111,11 +111,17 @@ class WeightSyncGroup:
         store = TCPStore(host, port, world_size, is_master=(rank == 0), timeout=datetime.timedelta(seconds=timeout_s),
                          wait_for_workers=False)
         if rank == 0:
-            uid = cls._new_uid()
+            uid = WeightSyncGroup._new_uid()
             store.set("prl_wsync_uid", uid)
         else:
             uid = store.get("prl_wsync_uid")
-        grp = cls._init(bytes(uid), rank, world_size, device)
+        return bytes(uid), store
+
+    @classmethod
+    def from_init_method(cls, init_method: str, rank: int, world_size: int, device: torch.device,
+                         timeout_s: float = 300.0) -> "WeightSyncGroup":
+        uid, store = cls.exchange_unique_id(init_method, rank, world_size, timeout_s)
+        grp = cls._init(uid, rank, world_size, device)
         grp._store = store  # keep the server alive for late joiners
         return grp
 

@@ -271,3 +271,26 @@ def test_weight_update_protocol_two_ranks(tmp_path, transport):
         assert st.wait_for_model_version() == 32
     finally:
         streams.reset_streams_backend()
+
+
+def test_unique_id_rendezvous_over_tcpstore(libprl):
+    """Bootstrap of the weight-update group: rank 0 creates the RCCL unique id (no GPU needed for
+    that) and publishes it through a TCPStore at `tcp://127.0.0.1:port`; the other ranks fetch the
+    same 128 bytes (the communicator itself is created on GPUs only)."""
+    import threading
+
+    from pipelinerl_amd.weight_sync import WeightSyncGroup
+
+    port = _free_port()
+    out = {}
+
+    def rank_fn(rank):
+        out[rank] = WeightSyncGroup.exchange_unique_id(f"tcp://127.0.0.1:{port}", rank, 3, timeout_s=30)
+
+    threads = [threading.Thread(target=rank_fn, args=(r,)) for r in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+    uids = [out[r][0] for r in range(3)]
+    assert len(uids[0]) == 128 and uids[0] == uids[1] == uids[2] and any(uids[0])
