@@ -192,7 +192,12 @@ def main():
     # synthetic rollouts of this rank's shard, resident in HBM before the timed region (§8d: dense)
     rag_h, _ = make_ragged(groups_per_rank, attempts=attempts, seq_length=seq_length, vocab=vocab,
                            seed=1234 + 2 + 1000 * rank, dense=True)
+    torch.cuda.synchronize()
+    t_h2d = time.perf_counter()
     rag = rag_h.to(dev)
+    torch.cuda.synchronize()
+    t_h2d = time.perf_counter() - t_h2d
+    h2d_bytes = sum(t.numel() * t.element_size() for t in (rag.tokens, rag.labels, rag.logprobs, rag.seq_off, rag.lp_off, rag.reward))
     n_seq = rag.n_seqs
     micro_batches = [[i] for i in range(n_seq)]  # dense: every sequence fills one seq_length budget
     tokens_per_rank = int(rag_h.host_seq_off[-1])
@@ -317,7 +322,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "global_batch": bs, "seq_len": seq_length, "vocab": vocab,
                        "tokens_per_step": bs * seq_length, "parallelism": f"dp{world}", "logits_mode": args.logits_mode,
-                       "policy_loss": "ppo", "kl_coef": 0.0, "old_logprob_sigma": sigma},
+                       "policy_loss": "ppo", "kl_coef": 0.0, "old_logprob_sigma": sigma,
+                       "h2d_ragged_input": {"bytes": h2d_bytes, "ms": 1e3 * t_h2d, "note": "pageable host memory, not part of value"}},
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu_base,
