@@ -93,12 +93,14 @@ struct LossArgs {
 // ~1e-7 relative, below the reference's own fp32 summation error); everything across lanes,
 // waves and blocks is fp64.
 struct Acc {
+  double loss;  // the loss lane alone stays fp64 end to end (it is the number that trains the model)
   float s[P_NUM_ADD];
   float mx[4];
   float mn[4];
 };
 
 __device__ __forceinline__ void acc_init(Acc& a) {
+  a.loss = 0.0;
 #pragma unroll
   for (int i = 0; i < P_NUM_ADD; ++i) a.s[i] = 0.0f;
 #pragma unroll
@@ -145,7 +147,7 @@ __device__ __forceinline__ void token_step(const LossArgs& a, Acc& acc, bool val
     o.clamp_no = ext_clamp;
   }
   const float inv_nl = 1.0f / nl;
-  acc.s[P_LOSS] += o.contrib;
+  acc.loss += (double)o.contrib;
   acc.s[P_REWARD] += per_label(reward, inv_nl);
   acc.s[P_ENTROPY] += per_label(ent, inv_nl);
   acc.s[P_OLD] += per_label(old_lp, inv_nl);
@@ -183,7 +185,7 @@ __device__ __forceinline__ void block_reduce_store(const Acc& acc, double* out) 
   const int wid = threadIdx.x / kWave;
 #pragma unroll
   for (int i = 0; i < P_NUM_ADD; ++i) {
-    double v = prl::wave_sum((double)acc.s[i]);
+    double v = prl::wave_sum(i == P_LOSS ? acc.loss : (double)acc.s[i]);
     if (lane == 0) lds[wid][i] = v;
   }
 #pragma unroll
