@@ -188,6 +188,11 @@ RL_CASES = {
     "c10_reinforce_rewards": (dict(vocab=64), dict(policy_loss="reinforce", epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0, use_advantages=False, batch_size=16, temperature=1.3), (0, 10)),
     "c11_gspo": (dict(vocab=97, with_ref=True, seed_offset=40), dict(policy_loss="gspo", epsilon_low=0.05, epsilon_high=0.05, kl_coef=0.1, final_kl_coef=0.1, batch_size=16), (0, 10)),
     "c12_gspo_groupnorm_sp": (dict(vocab=64, seq_parallel=8, on_policy=True), dict(policy_loss="gspo", epsilon_low=0.002, epsilon_high=0.002, kl_coef=0.0, final_kl_coef=0.0, group_normalization=True, overlong_filtering=True, batch_size=16), (0, 10)),
+    "c13_ppo_all_terms": (dict(vocab=128, with_ref=True), dict(policy_loss="ppo", epsilon_low=0.03, epsilon_high=0.05, kl_coef=0.2, final_kl_coef=0.05, entropy_bonus=0.02, final_entropy_bonus=0.0, temperature=0.9, clamp_log_ratio_ref_new_value=0.08, batch_size=12), (4, 9)),
+    "c14_reinforce_all_terms": (dict(vocab=64, with_ref=True, seed_offset=7), dict(policy_loss="reinforce", epsilon_high=0.01, kl_coef=0.05, final_kl_coef=0.05, entropy_bonus=0.005, final_entropy_bonus=0.005, group_normalization=True, temperature=1.2, batch_size=6), (1, 3)),
+    "c15_unpacked_left_reinforce": (dict(vocab=97, with_ref=True, unpacked=True, padding_side="left"), dict(policy_loss="reinforce", epsilon_high=0.2, kl_coef=0.01, final_kl_coef=0.01, batch_size=16), (0, 10)),
+    "c16_ppo_final_step": (dict(vocab=97, with_ref=True, seed_offset=3), dict(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.28, kl_coef=0.5, final_kl_coef=0.0, entropy_bonus=0.0, final_entropy_bonus=0.03, batch_size=16), (10, 10)),
+    "c17_ppo_overlong_only": (dict(vocab=64, seed_offset=11), dict(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0, overlong_filtering=True, divide_advantage_by_std=False, batch_size=16), (0, 10)),
 }
 
 
@@ -207,7 +212,7 @@ def gen_rl_step(ref_rl, ref_data, ref_utils, only=None, index=None):
                                with_ref=bk.get("with_ref", False))
             data = ref_preprocess(ref_rl, ref_data, raw, cfg)
             if bk.get("unpacked"):
-                batch = ref_data.collate([{k: v for k, v in e.items() if k != "finish_reason"} for e in data[:4]], Tok(EOS))
+                batch = ref_data.collate([{k: v for k, v in e.items() if k != "finish_reason"} for e in data[:4]], Tok(EOS, bk.get("padding_side", "right")))
             else:
                 batch = ref_data.collate_packed(data, Tok(EOS), seq_parallel=bk.get("seq_parallel", 1))
         B, L = batch.input_ids.shape
