@@ -116,12 +116,16 @@ _workspaces: dict[Any, torch.Tensor] = {}
 
 
 def _loss_workspace(device: torch.device) -> torch.Tensor:
-    ws = _workspaces.get(device)
+    """Scratch for the per-block partial records of K2+K3: one per (device, stream), because two
+    streams may run the loss kernel concurrently and the finalize kernel reads what the partial
+    kernel of the SAME launch wrote."""
+    key = (device, _lib.current_stream_ptr(device))
+    ws = _workspaces.get(key)
     if ws is None:
         need = ctypes.c_size_t(0)
         _lib.check(_lib.load().prl_grpo_loss_workspace_bytes(1, 1, ctypes.byref(need)))
         ws = torch.empty(need.value, dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+        _workspaces[key] = ws
     return ws
 
 
