@@ -9,6 +9,8 @@
 // 16 B read per token): every lane owns 4 consecutive output tokens, so each of the
 // 12 output arrays is written with full 16/32-byte stores, wave-contiguous.
 
+#include <cstdlib>
+
 #include "prl_common.h"
 
 namespace {
@@ -16,6 +18,7 @@ namespace {
 using prl::kWave;
 constexpr int kBlock = 256;
 constexpr int kMaxBlocks = 4096;
+constexpr bool kPackNtDefault = true;  // +3 % at 33.5 M tokens (scripts/pack_bench.py)
 
 // ---------------------------------------------------------------------------------------
 // K5a: per-sequence scan (num_labels, overflow flag).  One workgroup per sequence.
@@ -252,7 +255,7 @@ __device__ __forceinline__ void make_token(const PackArgs& a, const SeqCtx& c, i
   }
 }
 
-template <bool VEC>
+template <bool VEC, bool NT>
 __global__ __launch_bounds__(kBlock) void pack_collate_kernel(PackArgs a) {
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * kBlock;
@@ -278,12 +281,25 @@ __global__ __launch_bounds__(kBlock) void pack_collate_kernel(PackArgs a) {
       }
     }
     if (VEC && cnt == 4) {
+      using l2 = long __attribute__((ext_vector_type(2)));
+      using f4 = float __attribute__((ext_vector_type(4)));
       auto st2 = [&](int64_t* p, int64_t x0, int64_t x1, int64_t x2, int64_t x3) {
-        *reinterpret_cast<longlong2*>(p + t0) = make_longlong2(x0, x1);
-        *reinterpret_cast<longlong2*>(p + t0 + 2) = make_longlong2(x2, x3);
+        l2 a01 = {x0, x1}, a23 = {x2, x3};
+        if constexpr (NT) {  // the batch is written once and read much later: keep it out of L2
+          __builtin_nontemporal_store(a01, reinterpret_cast<l2*>(p + t0));
+          __builtin_nontemporal_store(a23, reinterpret_cast<l2*>(p + t0 + 2));
+        } else {
+          *reinterpret_cast<l2*>(p + t0) = a01;
+          *reinterpret_cast<l2*>(p + t0 + 2) = a23;
+        }
       };
       auto stf = [&](float* p, float x0, float x1, float x2, float x3) {
-        *reinterpret_cast<float4*>(p + t0) = make_float4(x0, x1, x2, x3);
+        f4 v = {x0, x1, x2, x3};
+        if constexpr (NT) {
+          __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p + t0));
+        } else {
+          *reinterpret_cast<f4*>(p + t0) = v;
+        }
       };
       st2(a.o_ids, tk[0].id, tk[1].id, tk[2].id, tk[3].id);
       st2(a.o_labels, tk[0].label, tk[1].label, tk[2].label, tk[3].label);
@@ -478,10 +494,14 @@ extern "C" int prl_pack_collate(int32_t m, int64_t total_tokens, const int32_t* 
                    prl::aligned16(out_num_labels) && prl::aligned16(out_overflow);
   const int nb = blocks_for((total_tokens + 3) / 4);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (vec) {
-    hipLaunchKernelGGL(pack_collate_kernel<true>, dim3(nb), dim3(kBlock), 0, s, a);
+  const char* nt_env = getenv("PRL_PACK_NT");
+  const bool nt = nt_env ? (atoi(nt_env) != 0) : kPackNtDefault;
+  if (vec && nt) {
+    hipLaunchKernelGGL((pack_collate_kernel<true, true>), dim3(nb), dim3(kBlock), 0, s, a);
+  } else if (vec) {
+    hipLaunchKernelGGL((pack_collate_kernel<true, false>), dim3(nb), dim3(kBlock), 0, s, a);
   } else {
-    hipLaunchKernelGGL(pack_collate_kernel<false>, dim3(nb), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((pack_collate_kernel<false, false>), dim3(nb), dim3(kBlock), 0, s, a);
   }
   PRL_LAUNCH_CHECK("pack_collate_kernel");
   return PRL_OK;
