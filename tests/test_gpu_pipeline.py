@@ -168,3 +168,46 @@ def test_native_step_equals_per_micro_batch_rl_step(libprl, cuda_device):
         assert abs(stats_a[k] - max(agg[k])) <= 1e-6 * max(1.0, abs(max(agg[k]))), k
     assert stats_a["num_output_tokens_sum"] == sum(agg["num_output_tokens_sum"])
     assert res["micro_batches"] == len(mbs) and native.metrics.completed_steps == 1
+
+
+def test_rl_step_drives_a_huggingface_causal_lm(libprl, cuda_device):
+    """Drop-in check with the model class the reference trains (transformers Qwen2ForCausalLM,
+    random init, tiny config): `rl_step(model, batch, ...)` calls `model(**inputs)`, reads
+    `outputs.logits`, and the backward reaches every parameter.  Loss / gradients equal a plain
+    torch implementation of the same PPO objective on the model's own logits."""
+    transformers = pytest.importorskip("transformers")
+    from pipelinerl_amd.finetune.data import collate
+    from pipelinerl_amd.finetune.rl import RLConfig, rl_step
+    from pipelinerl_amd.synthetic import make_entries
+    from oracle import preprocess as opre
+
+    V = 512
+    cfg_m = transformers.Qwen2Config(vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                                     num_key_value_heads=2, max_position_embeddings=256, tie_word_embeddings=False)
+    torch.manual_seed(0)
+    model = transformers.Qwen2ForCausalLM(cfg_m).to(cuda_device).float()
+    raw = make_entries(2, attempts=4, seq_length=40, vocab=V, seed=17, prompt_min=4, prompt_max=10)
+    data = opre.preprocess_chunk(raw, 2, False)
+    tok = types.SimpleNamespace(eos_token_id=2, padding_side="right")
+    batch = collate([{k: v for k, v in e.items() if k != "finish_reason"} for e in data], tok)  # [8, Lp] padded batch on the GPU
+    rl = RLConfig(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0, batch_size=8,
+                  divide_advantage_by_std=False)
+    loss, stats = rl_step(model, batch, 0, 10, rl)
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    assert all(g is not None and torch.isfinite(g).all() for g in grads.values())
+    assert any(g.abs().max() > 0 for g in grads.values())
+    # plain torch reference of the same objective
+    model.zero_grad()
+    logits = model(input_ids=batch.input_ids, attention_mask=batch.attention_mask).logits.float()
+    lp = torch.log_softmax(logits[:, :-1], -1).gather(2, batch.input_ids[:, 1:, None])[..., 0]
+    m = (batch.labels[:, 1:] != -100).float()
+    ratio = torch.exp(lp - batch.old_logprobs[:, 1:])
+    adv = batch.advantages[:, 1:]
+    pol = torch.minimum(ratio * adv, ratio.clamp(0.8, 1.2) * adv)
+    ref_loss = -(pol * m / 8).sum()
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * max(abs(ref_loss.item()), 1e-6)
+    for n, p in model.named_parameters():
+        assert torch.allclose(grads[n], p.grad, rtol=2e-3, atol=1e-6), n
+    assert stats["num_output_tokens_sum"] == int(m.sum().item()) and stats["input_size"] == batch.input_ids.numel()
