@@ -67,6 +67,13 @@ class RLConfig(BaseModel):
     inplace_logits_grad: bool = Field(default=False, description="write d loss/d logits over the logits buffer")
 
 
+def make_rl_data_callback(args: Any, current_dir: Any, rl_config: "RLConfig | None", model: Any):
+    """`populate_rl_data` bound to a config, or None without one (reference rl/__init__.py:108-116)."""
+    from functools import partial
+
+    return partial(populate_rl_data, config=rl_config) if rl_config else None
+
+
 def linear_decay_coef(current_step: int, max_step: int, initial_coef: float, final_coef: float) -> float:
     """initial -> final, linearly in current_step / max_step (reference :119-133)."""
     return initial_coef + (final_coef - initial_coef) * current_step / max_step

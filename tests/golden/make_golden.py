@@ -278,8 +278,56 @@ def gen_world():
     print(f"world: {len(out)} partitions, {sum(r['error'] is not None for r in out)} rejected")
 
 
+def gen_text_path(ref_data):
+    """SFT/text branch helpers of preprocess_fn: mask_labels / validate_spans (data.py:47-108) and
+    preprocess_fn on a text entry with a toy whitespace tokenizer."""
+    rng = np.random.default_rng(3)
+
+    class ToyTok:
+        eos_token_id, padding_side = 2, "right"
+
+        def __call__(self, text, return_offsets_mapping=True, max_length=None, truncation=True):
+            ids, offs, pos = [], [], 0
+            for w in text.split(" "):
+                if w:
+                    ids.append(3 + (sum(map(ord, w)) % 50))
+                    offs.append((pos, pos + len(w)))
+                pos += len(w) + 1
+            if max_length is not None:
+                ids, offs = ids[:max_length], offs[:max_length]
+            return {"input_ids": ids, "attention_mask": [1] * len(ids), "offset_mapping": offs}
+
+    cases = []
+    for c in range(8):
+        words = ["w" * int(rng.integers(1, 6)) for _ in range(int(rng.integers(3, 12)))]
+        text = " ".join(words)
+        enc = ToyTok()(text)
+        n_spans = int(rng.integers(1, 3))
+        cuts = sorted(rng.choice(np.arange(len(text) + 1), size=2 * n_spans, replace=False).tolist())
+        spans = [(cuts[2 * i], cuts[2 * i + 1]) for i in range(n_spans)]
+        labels, mids = ref_data.mask_labels(enc["input_ids"], enc["offset_mapping"], spans)
+        entry = {"text": text, "predicted_spans": spans} if c % 2 else {"text": text, "n_predicted": int(rng.integers(0, len(text) + 1))}
+        sl = int(rng.integers(3, 20))
+        out = ref_data.preprocess_fn(dict(entry), ToyTok(), seq_length=sl, is_rl=False)
+        cases.append({"text": text, "spans": spans, "input_ids": enc["input_ids"], "offset_mapping": enc["offset_mapping"],
+                      "labels": labels, "midpoints": mids, "entry": entry, "seq_length": sl,
+                      "preprocess": {k: out[k] for k in ("input_ids", "labels", "attention_mask")}})
+    bad = []
+    for spans in ([(-1, 2)], [(0, 99)], [(3, 1)], [(0, 4), (2, 6)]):
+        try:
+            ref_data.validate_spans("hello world", spans)
+            bad.append({"spans": spans, "error": None})
+        except ValueError as e:
+            bad.append({"spans": spans, "error": str(e)[:20]})
+    (HERE / "text_path.json").write_text(json.dumps({"cases": cases, "invalid": bad}))
+    print("text_path:", len(cases), "cases")
+
+
 def main():
     ref_rl, ref_data, ref_utils = import_reference()
+    if "--text-only" in sys.argv:
+        gen_text_path(ref_data)
+        return
     if "--only-new" in sys.argv:  # add cases without rewriting the committed fixtures
         global RL_CASES
         have = {p.stem[len("rl_step_"):] for p in HERE.glob("rl_step_*.npz")}
@@ -291,6 +339,7 @@ def main():
     gen_rl_step(ref_rl, ref_data, ref_utils)
     gen_sentinel(ref_utils)
     gen_world()
+    gen_text_path(ref_data)
 
 
 if __name__ == "__main__":

@@ -115,3 +115,53 @@ def test_rollout_plugin_types_and_stamping():
     assert resolve_plugin("pipelinerl_amd.rollouts.stamp_group") is stamp_group
     with pytest.raises(ValueError):
         resolve_plugin("nodots")
+
+
+class _ToyTok:
+    """Whitespace tokenizer with offsets (the generator of tests/golden/text_path.json uses the same)."""
+
+    eos_token_id, padding_side = 2, "right"
+
+    def __call__(self, text, return_offsets_mapping=True, max_length=None, truncation=True):
+        ids, offs, pos = [], [], 0
+        for w in text.split(" "):
+            if w:
+                ids.append(3 + (sum(map(ord, w)) % 50))
+                offs.append((pos, pos + len(w)))
+            pos += len(w) + 1
+        if max_length is not None:
+            ids, offs = ids[:max_length], offs[:max_length]
+        return {"input_ids": ids, "attention_mask": [1] * len(ids), "offset_mapping": offs}
+
+
+def test_text_path_helpers_match_reference():
+    """mask_labels / validate_spans / preprocess_fn on text entries (data.py:47-160) against outputs
+    of the reference functions."""
+    from pipelinerl_amd.finetune.data import mask_labels, preprocess_fn, validate_spans
+
+    g = json.loads((GOLDEN / "text_path.json").read_text())
+    for c in g["cases"]:
+        spans = [tuple(s) for s in c["spans"]]
+        labels, mids = mask_labels(c["input_ids"], [tuple(o) for o in c["offset_mapping"]], spans)
+        assert labels == c["labels"] and mids == c["midpoints"]
+        entry = dict(c["entry"])
+        if "predicted_spans" in entry:
+            entry["predicted_spans"] = [tuple(s) for s in entry["predicted_spans"]]
+        out = preprocess_fn(entry, _ToyTok(), seq_length=c["seq_length"], is_rl=False)
+        for k, v in c["preprocess"].items():
+            assert out[k] == v, k
+    for b in g["invalid"]:
+        spans = [tuple(s) for s in b["spans"]]
+        if b["error"] is None:
+            validate_spans("hello world", spans)
+        else:
+            with pytest.raises(ValueError):
+                validate_spans("hello world", spans)
+
+
+def test_make_rl_data_callback():
+    from pipelinerl_amd.finetune.rl import RLConfig, make_rl_data_callback, populate_rl_data
+
+    cb = make_rl_data_callback(None, None, RLConfig(divide_advantage_by_std=False), None)
+    assert cb.func is populate_rl_data and cb.keywords["config"].divide_advantage_by_std is False
+    assert make_rl_data_callback(None, None, None, None) is None
