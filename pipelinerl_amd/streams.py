@@ -5,8 +5,9 @@ Public API as in the reference (:33-69, :390-423): `set_streams_backend`, `Singl
 `write_to_streams(spec, mode)` -> context manager with `.write(data, partition=None)`.
 
 Backends
-  files  the reference's on-disk layout and wire format, kept byte-compatible so recorded runs can
-         be replayed (`debug.streams_from`): `<exp>/streams/<topic>/<instance>/<partition>/0.jsonl`,
+  files  the reference's on-disk layout and wire format, kept structurally identical so recorded runs can
+         be replayed (same keys, nesting and line framing; numbers are printed by the stdlib
+         encoder instead of orjson, so files are parse-compatible, not byte-identical) (`debug.streams_from`): `<exp>/streams/<topic>/<instance>/<partition>/0.jsonl`,
          one JSON object per line, tensors as nested lists, flush per record (:238-278).  The
          reader tails the file and never sees EOF (:281-346).
   shm    MI355X-native transport for the hot `training_data` hop: one `prl_ring` per
