@@ -706,9 +706,12 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
   do {                                                                                              \
     auto kfn = fused_logits_loss_kernel<TT, BLK, UNR, REV, NTS>;                                    \
     const size_t lds_bytes = (LDSB) > 0 ? (size_t)(LDSB) : sizeof(Osm) * (BLK / kWave);             \
-    if (lds_bytes > 48 * 1024)                                                                      \
+    static bool attr_set = false; /* one process drives one GPU: set the LDS opt-in once */         \
+    if (lds_bytes > 48 * 1024 && !attr_set) {                                                       \
       PRL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                         \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+      attr_set = true;                                                                              \
+    }                                                                                               \
     hipLaunchKernelGGL(kfn, grid, dim3(BLK), lds_bytes, s, geo, a, static_cast<const ST*>(logits), k2, \
                        inv_temp, static_cast<ST*>(grad_logits));                                    \
   } while (0)
@@ -722,8 +725,12 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
     auto kfn = fused_logits_loss_keep_kernel<TT, BLK, UNR, KR, KL, NTH>;                                 \
     size_t lds_bytes = 256 + (size_t)(KL) * BLK * 16;                                               \
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024; /* keep ONE workgroup per CU */               \
-    PRL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+    static bool attr_set = false;                                                                   \
+    if (!attr_set) {                                                                                \
+      PRL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                         \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+      attr_set = true;                                                                              \
+    }                                                                                               \
     hipLaunchKernelGGL(kfn, grid, dim3(BLK), lds_bytes, s, geo, a, static_cast<const ST*>(logits), k2, \
                        inv_temp, static_cast<ST*>(grad_logits));                                    \
   } while (0)
