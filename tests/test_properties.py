@@ -1,0 +1,105 @@
+"""Property tests (hypothesis) of the host-side planning code: the O(#sequences) plans that drive
+the K5 / K6 launches, the micro-batch scheduler and the weight-sync bucket plan.  CPU only."""
+
+import numpy as np
+import torch
+from hypothesis import given, settings
+from hypothesis import strategies as st
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(st.integers(0, 30), min_size=0, max_size=40), st.data())
+def test_plan_packing_matches_bruteforce(lens, data):
+    from pipelinerl_amd.finetune.data import plan_packing
+
+    lens = np.asarray(lens, dtype=np.int64)
+    n = len(lens)
+    order = data.draw(st.permutations(list(range(n)))) if n else []
+    mbs, k = [], 0
+    while k < n:
+        m = data.draw(st.integers(0, 5))
+        mbs.append(order[k:k + m])
+        k += m
+    pads = data.draw(st.one_of(st.none(), st.lists(st.integers(0, 7), min_size=len(mbs), max_size=len(mbs))))
+    src, seg, dst, off = plan_packing(lens, mbs, pads)
+    # brute force
+    e_src, e_seg, e_len, e_off = [], [], [], [0]
+    for j, mb in enumerate(mbs):
+        for q, s in enumerate(mb):
+            e_src.append(s); e_seg.append(q); e_len.append(int(lens[s]))
+        cnt = len(mb)
+        if pads is not None and pads[j] > 0:
+            e_src.append(-1); e_seg.append(cnt); e_len.append(pads[j]); cnt += 1
+        e_off.append(e_off[-1] + cnt)
+    assert src.tolist() == e_src and seg.tolist() == e_seg and off.tolist() == e_off
+    assert dst.tolist() == [0] + np.cumsum(e_len).tolist()
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(st.tuples(st.integers(0, 5), st.integers(0, 2), st.integers(0, 3)), min_size=1, max_size=40))
+def test_plan_groups_matches_bruteforce(rows):
+    from pipelinerl_amd.finetune.rl import plan_groups
+
+    g = np.array([r[0] for r in rows], dtype=np.int32)
+    s = np.array([r[1] for r in rows], dtype=np.int32)
+    r = np.array([r[2] for r in rows], dtype=np.int32)
+    key_off, key_members, group_off, group_members, n_roll = plan_groups(g, s, r)
+    keys = sorted(set(zip(g.tolist(), s.tolist())))
+    assert len(key_off) - 1 == len(keys)
+    for k, (gg, ss) in enumerate(keys):
+        members = key_members[key_off[k]:key_off[k + 1]].tolist()
+        assert members == [i for i in range(len(rows)) if g[i] == gg and s[i] == ss]  # dataset order
+    groups = sorted(set(g.tolist()))
+    for k, gg in enumerate(groups):
+        members = group_members[group_off[k]:group_off[k + 1]].tolist()
+        assert members == [i for i in range(len(rows)) if g[i] == gg]
+        assert n_roll[k] == len({int(r[i]) for i in members})
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 4), st.integers(1, 3), st.integers(1, 4), st.integers(8, 64), st.lists(st.integers(1, 8), min_size=1, max_size=80))
+def test_scheduler_invariants(num_lead, tbs, passes_per_lead, seq_length, lens):
+    """For any arrival sequence: samples leave in arrival order exactly once, every micro-batch fits
+    the token budget, trainers are served round-robin, quotas are never exceeded, and at every step
+    boundary all lead trainers hold the same number of samples."""
+    from pipelinerl_amd.preprocess import MicroBatchScheduler
+
+    lens = [min(x, seq_length) for x in lens]
+    sched = MicroBatchScheduler(num_trainers=num_lead, train_batch_size=tbs, gradient_accumulation_passes=passes_per_lead * num_lead,
+                                seq_length=seq_length, length_of=lambda e: e[1])
+    sched.push(list(enumerate(lens)))
+    emitted = []
+    while sched.queue:
+        mbs, done = sched.drain()
+        emitted += mbs
+        if done:
+            counts = set(sched.samples_per_trainer.values())
+            assert len(counts) == 1
+        if not mbs and not done:
+            break
+    flat = [s[0] for mb in emitted for s in mb.samples]
+    assert flat == list(range(len(flat)))
+    assert [mb.trainer_id for mb in emitted] == [i % num_lead for i in range(len(emitted))]
+    for mb in emitted:
+        assert mb.sentinel == (len(mb.samples) == 0)
+        assert sum(s[1] for s in mb.samples) <= seq_length
+    assert all(v <= sched.target_samples_per_lead for v in sched.samples_per_trainer.values())
+    assert sched.published_samples == len(flat)
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(st.tuples(st.integers(1, 5000), st.sampled_from([torch.bfloat16, torch.float32, torch.float16])), min_size=1, max_size=30),
+       st.integers(256, 20000))
+def test_bucket_plan_invariants(params, bucket_bytes):
+    from pipelinerl_amd.weight_sync import ParamSpec, bucket_nbytes, plan_buckets
+
+    specs = [ParamSpec(f"p{i}", (n,), dt) for i, (n, dt) in enumerate(params)]
+    plan = plan_buckets(specs, bucket_bytes)
+    assert [sp.name for b in plan for sp, _ in b] == [sp.name for sp in specs]  # order preserved, nothing lost
+    for b in plan:
+        end = 0
+        for sp, off in b:
+            assert off % 256 == 0 and off >= end
+            end = off + sp.nbytes
+        assert bucket_nbytes(b) >= end
+        assert len(b) == 1 or bucket_nbytes(b) <= bucket_bytes  # only a single oversized tensor may exceed the budget
