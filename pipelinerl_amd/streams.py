@@ -15,7 +15,8 @@ Backends
          (header + raw int64 / fp32 buffers, see `batch_codec`) instead of ~114 bytes of JSON text
          per token, and blocked readers park on a futex instead of polling every 100 ms.
          Non-batch records (trainer messages, stats dicts) travel as JSON bytes.
-  redis  not implemented (the image has no redis); selecting it raises.
+  redis  accepted for config compatibility and served by `shm` (the image has no redis server or
+         client; single-node semantics are the same: ordered topics, blocking readers).
 """
 
 from __future__ import annotations
@@ -52,9 +53,13 @@ def set_streams_backend(backend: Literal["files", "shm", "redis"], **kwargs: Any
     if _backend is not None:
         raise ValueError("Backend already set. Cannot change it.")
     if backend == "redis":
-        raise ValueError("The redis backend is not available in pipelinerl_amd; use 'files' or 'shm'.")
+        # conf/streams/redis.yaml of the reference: a single-node run gets the same semantics
+        # (ordered topics, blocking readers) from the shared-memory rings, so the option keeps
+        # working; host/port are ignored.  Rings are bounded: a full ring back-pressures the writer.
+        logger.warning("streams backend 'redis' is served by the shared-memory ring backend ('shm') in pipelinerl_amd")
+        backend, kwargs = "shm", {"n_slots": kwargs.get("n_slots", 1024), "slot_bytes": kwargs.get("slot_bytes", 16 << 20)}
     if backend not in ("files", "shm"):
-        raise ValueError(f"Invalid backend: {backend}. Only 'files' and 'shm' are supported.")
+        raise ValueError(f"Invalid backend: {backend}. Only 'redis', 'files' and 'shm' are supported.")
     _backend, _backend_options = backend, dict(kwargs)
 
 

@@ -50,8 +50,9 @@ def test_backend_must_be_set_once(streams, tmp_path):
     with pytest.raises(ValueError):
         streams.set_streams_backend("files")
     streams.reset_streams_backend()
-    with pytest.raises(ValueError):
-        streams.set_streams_backend("redis")
+    streams.set_streams_backend("redis", host="localhost", port=6379)  # config compatibility: served by shm
+    assert streams._backend == "shm" and streams._backend_options["n_slots"] == 1024
+    streams.reset_streams_backend()
     with pytest.raises(ValueError):
         streams.set_streams_backend("carrier-pigeon")
 
