@@ -5,6 +5,10 @@ reference file:line it follows).  Only `tests/`, `__graft_entry__.smoke()` and t
 leg of `bench.py` may import this package, and only as the checker: the product
 (`pipelinerl_amd/`) never imports it and has no CPU fallback.
 
+Form: the reference is pure Python (no C/C++ sources to compile into `oracle/_ref`), so the
+restatement is numpy / pure Python rather than C, and `__graft_entry__.build()` has no oracle
+binary to build (it builds the test-only host harness of the device token math instead).
+
 Pinning: the reference ships no tests or golden vectors for this path, so
 the oracle is pinned against outputs of the reference's own functions run in the build
 container: `tests/golden/make_golden.py` imports `/root/reference/pipelinerl` and writes the
