@@ -33,7 +33,7 @@
  *   prl_pad_collate               pipelinerl/finetune/data.py:163-212
  *   prl_ring_*                    pipelinerl/shared_memory_array.py:9-196,
  *                                 pipelinerl/streams.py:249-346
- *   prl_wsync_*                   pipelinerl/finetune_loop.py:205-292,
+ *   prl_wsync_* / prl_ipc_*       pipelinerl/finetune_loop.py:205-292,
  *                                 pipelinerl/vllm1.py:62-134,
  *                                 pipelinerl/torch_utils.py:70-94
  */
@@ -371,6 +371,17 @@ int prl_wsync_bcast_bucket(prl_wsync* w, void* bucket, uint64_t nbytes, int32_t 
 int prl_wsync_bcast_bucket_sag(prl_wsync* w, void* bucket, uint64_t nbytes,
                                prl_stream_t stream);
 int prl_wsync_destroy(prl_wsync* w);
+
+/* Colocated hand-off (trainer and inference worker are two processes on ONE GPU, BASELINE config
+ * "actor+learner colocated"): a device bucket allocated by the library is exported as a HIP IPC
+ * handle; the peer maps the same memory and copies it into its own weights.  Replaces the
+ * per-parameter broadcast of finetune_loop.py:279-282 / vllm1.py:118-122 for that topology. */
+#define PRL_IPC_HANDLE_BYTES 64
+int prl_ipc_alloc(uint64_t nbytes, void** dev_ptr);
+int prl_ipc_free(void* dev_ptr);
+int prl_ipc_export(const void* dev_ptr, uint8_t handle[PRL_IPC_HANDLE_BYTES]);
+int prl_ipc_open(const uint8_t handle[PRL_IPC_HANDLE_BYTES], void** dev_ptr);
+int prl_ipc_close(void* dev_ptr);
 
 #ifdef __cplusplus
 }

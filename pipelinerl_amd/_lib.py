@@ -33,6 +33,7 @@ PRL_FINISH_LENGTH = 1
 PRL_FINISH_STOP = 2
 PRL_NUM_STATS = 32
 PRL_WSYNC_UID_BYTES = 128
+PRL_IPC_HANDLE_BYTES = 64
 
 # index of every public statistic in the device stats vector (enum in include/prl.h)
 STAT_INDEX = {
@@ -134,6 +135,11 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_wsync_bcast_bucket": (c_int32, [c_void_p, c_void_p, c_uint64, c_int32, c_void_p]),
     "prl_wsync_bcast_bucket_sag": (c_int32, [c_void_p, c_void_p, c_uint64, c_void_p]),
     "prl_wsync_destroy": (c_int32, [c_void_p]),
+    "prl_ipc_alloc": (c_int32, [c_uint64, POINTER(c_void_p)]),
+    "prl_ipc_free": (c_int32, [c_void_p]),
+    "prl_ipc_export": (c_int32, [c_void_p, POINTER(c_uint8)]),
+    "prl_ipc_open": (c_int32, [POINTER(c_uint8), POINTER(c_void_p)]),
+    "prl_ipc_close": (c_int32, [c_void_p]),
 }
 
 _lib: ctypes.CDLL | None = None

@@ -33,6 +33,7 @@ SOURCES = [
     "prl_api.cpp",
     "prl_ring.cpp",
     "prl_wsync.cpp",
+    "prl_ipc.cpp",
     "prl_loss.hip",
     "prl_logprob.hip",
     "prl_pack.hip",

@@ -58,9 +58,12 @@ class WeightUpdateRequest(BaseModel):
     version: int
     parameters_info: list[ParameterInfo]
     timestamp: float = Field(default_factory=time.time)
-    # MI355X extension: how the bytes travel ("per_tensor" = reference behaviour)
+    # MI355X extensions: how the bytes travel ("per_tensor" = reference behaviour, "bucketed" = RCCL
+    # buckets, "ipc" = trainer and worker share one GPU: the request carries HIP IPC handles)
     transport: str = "bucketed"
     bucket_bytes: int = 1 << 30
+    ipc_handles: list[str] = Field(default_factory=list)
+    ipc_nbytes: list[int] = Field(default_factory=list)
 
 
 class WeightUpdateSuccess(BaseModel):
@@ -215,8 +218,18 @@ class WeightUpdateManager:
             params = [(n, p.detach()) for n, p in self.named_parameters_fn()]
             info = [ParameterInfo(name=n, shape=list(p.shape), dtype=str(p.dtype)) for n, p in params]
             message = WeightUpdateRequest(version=version, parameters_info=info, transport=self.transport, bucket_bytes=self.bucket_bytes)
+            if self.transport == "ipc":
+                # colocated: fill the exported buckets first, the request then carries their handles
+                from .weight_sync import ColocatedSender
+
+                if self._sender is None:
+                    self._sender = ColocatedSender(params[0][1].device, self.bucket_bytes)
+                desc = self._sender.publish(params)
+                message.ipc_handles, message.ipc_nbytes = desc["ipc_handles"], desc["ipc_nbytes"]
             futures = self.request_weight_updates(message)
-            if self.transport == "bucketed":
+            if self.transport == "ipc":
+                pass  # the POST returns when the worker has copied the buckets
+            elif self.transport == "bucketed":
                 if self._sender is None:
                     self._sender = BucketedSender(self.actor_update_group, self.bucket_bytes)
                 self._sender.send(params)

@@ -57,7 +57,13 @@ class WorkerExtension:
                 missing = [n for n, _ in views]
                 raise ValueError(f"model {missing} not found in model state dict")
 
-        if request.transport == "bucketed":
+        if request.transport == "ipc":
+            from .weight_sync import ColocatedReceiver
+
+            if getattr(self, "_ipc_receiver", None) is None:
+                self._ipc_receiver = ColocatedReceiver(self.device, request.bucket_bytes)
+            self._ipc_receiver.receive([i.model_dump() for i in request.parameters_info], request.ipc_handles, request.ipc_nbytes, load)
+        elif request.transport == "bucketed":
             if getattr(self, "_receiver", None) is None or self._receiver.bucket_bytes != request.bucket_bytes:
                 self._receiver = BucketedReceiver(self.model_update_group, request.bucket_bytes)
             self._receiver.receive([i.model_dump() for i in request.parameters_info], load)
@@ -70,6 +76,10 @@ class WorkerExtension:
         logger.info("Weight update received")
 
     def close_communicator(self) -> None:
+        ipc = getattr(self, "_ipc_receiver", None)
+        if ipc is not None:
+            ipc.close()
+            self._ipc_receiver = None
         grp = getattr(self, "model_update_group", None)
         if grp is not None:
             grp.close()

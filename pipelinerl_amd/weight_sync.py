@@ -232,3 +232,160 @@ class BucketedReceiver:
             load_weights(views)
             n += len(views)
         return n
+
+
+# ---------------------------------------------------------------------------------------------
+# Colocated hand-off over HIP IPC (trainer and inference worker share ONE GPU)
+# ---------------------------------------------------------------------------------------------
+
+
+class _RawDeviceMemory:
+    """Exposes a raw device pointer through the CUDA array interface so torch can view it."""
+
+    def __init__(self, ptr: int, nbytes: int, owner: Any):
+        self._owner = owner  # keeps the allocation / mapping alive as long as a tensor views it
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class DeviceBucket:
+    """A hipMalloc'ed byte bucket whose memory can be exported to another process on the same GPU."""
+
+    def __init__(self, nbytes: int, device: torch.device):
+        lib = _lib.load()
+        self.nbytes = int(nbytes)
+        self.device = device
+        out = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.prl_ipc_alloc(self.nbytes, ctypes.byref(out)))
+        self.ptr = out.value
+        self._tensor = torch.as_tensor(_RawDeviceMemory(self.ptr, self.nbytes, self), device=device)
+
+    def tensor(self) -> torch.Tensor:
+        return self._tensor
+
+    def handle(self) -> bytes:
+        arr = (ctypes.c_uint8 * _lib.PRL_IPC_HANDLE_BYTES)()
+        _lib.check(_lib.load().prl_ipc_export(self.ptr, arr))
+        return bytes(arr)
+
+    def free(self) -> None:
+        if self.ptr:
+            self._tensor = None
+            _lib.load().prl_ipc_free(self.ptr)
+            self.ptr = None
+
+
+class MappedBucket:
+    """The peer's view of a `DeviceBucket` (hipIpcOpenMemHandle)."""
+
+    def __init__(self, handle: bytes, nbytes: int, device: torch.device):
+        lib = _lib.load()
+        arr = (ctypes.c_uint8 * _lib.PRL_IPC_HANDLE_BYTES).from_buffer_copy(handle)
+        out = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.prl_ipc_open(arr, ctypes.byref(out)))
+        self.ptr, self.nbytes, self.device = out.value, int(nbytes), device
+        self._tensor = torch.as_tensor(_RawDeviceMemory(self.ptr, self.nbytes, self), device=device)
+
+    def tensor(self) -> torch.Tensor:
+        return self._tensor
+
+    def close(self) -> None:
+        if self.ptr:
+            self._tensor = None
+            _lib.load().prl_ipc_close(self.ptr)
+            self.ptr = None
+
+
+class ColocatedSender:
+    """Trainer side when the inference worker lives on the same GPU: flatten the parameters into
+    IPC-exportable device buckets and describe them; nothing travels over any link."""
+
+    def __init__(self, device: torch.device, bucket_bytes: int = DEFAULT_BUCKET_BYTES):
+        self.device = device
+        self.bucket_bytes = bucket_bytes
+        self._buckets: list[DeviceBucket] = []
+
+    def _ensure_buckets(self, params: list[tuple[str, torch.Tensor]]):
+        specs = [ParamSpec(n, tuple(p.shape), p.dtype) for n, p in params]
+        plan = plan_buckets(specs, self.bucket_bytes)
+        sizes = [bucket_nbytes(b) for b in plan]
+        if [b.nbytes for b in self._buckets] != sizes:
+            for b in self._buckets:
+                b.free()
+            self._buckets = [DeviceBucket(n, self.device) for n in sizes]
+        return plan, sizes
+
+    def rehome(self, named_parameters: Iterable[tuple[str, torch.nn.Parameter]]) -> None:
+        """Move the parameters' storage INTO the exported buckets (`p.data` becomes a bucket view), so
+        every later `publish` is zero-copy: the optimizer updates the shared memory in place.
+        Call once after the model is built (before optimizer state captures `p.data` pointers)."""
+        params = list(named_parameters)
+        plan, _ = self._ensure_buckets([(n, p.data) for n, p in params])
+        by_name = dict(params)
+        for bucket, dev_bucket in zip(plan, self._buckets):
+            buf = dev_bucket.tensor()
+            for sp, off in bucket:
+                view = buf[off : off + sp.nbytes].view(sp.dtype).view(sp.shape)
+                view.copy_(by_name[sp.name].data)
+                by_name[sp.name].data = view
+        torch.cuda.synchronize(self.device)
+
+    def publish(self, named_parameters: Iterable[tuple[str, torch.Tensor]]) -> dict:
+        """Returns {"ipc_handles": [hex...], "ipc_nbytes": [...]} for the update request; the buckets
+        are complete (device-synchronised) when this returns.  Parameters that already live in their
+        bucket slot (`rehome`) are not copied."""
+        params = [(n, p.detach()) for n, p in named_parameters]
+        plan, sizes = self._ensure_buckets(params)
+        tensors = dict(params)
+        for bucket, dev_bucket in zip(plan, self._buckets):
+            buf = dev_bucket.tensor()
+            base = dev_bucket.ptr
+            for sp, off in bucket:
+                src = tensors[sp.name]
+                if src.data_ptr() == base + off and src.is_contiguous():
+                    continue
+                buf[off : off + sp.nbytes].view(sp.dtype).view(sp.shape).copy_(src, non_blocking=True)
+        torch.cuda.synchronize(self.device)
+        return {"ipc_handles": [b.handle().hex() for b in self._buckets], "ipc_nbytes": sizes}
+
+    def close(self) -> None:
+        for b in self._buckets:
+            b.free()
+        self._buckets = []
+
+
+class ColocatedReceiver:
+    """Worker side: map the trainer's buckets (once per handle) and hand (name, view) pairs to
+    `load_weights`, which copies them into the engine's own weights device-to-device."""
+
+    def __init__(self, device: torch.device, bucket_bytes: int = DEFAULT_BUCKET_BYTES):
+        self.device = device
+        self.bucket_bytes = bucket_bytes
+        self._mapped: dict[str, MappedBucket] = {}
+
+    def receive(self, parameters_info: Sequence[dict | ParamSpec], ipc_handles: Sequence[str], ipc_nbytes: Sequence[int],
+                load_weights: Callable[[list[tuple[str, torch.Tensor]]], Any]) -> int:
+        specs = [
+            p if isinstance(p, ParamSpec) else ParamSpec(p["name"], tuple(p["shape"]), string_to_dtype(p["dtype"]))
+            for p in parameters_info
+        ]
+        plan = plan_buckets(specs, self.bucket_bytes)
+        if len(plan) != len(ipc_handles):
+            raise ValueError(f"{len(ipc_handles)} IPC buckets announced, the parameter list implies {len(plan)}")
+        n = 0
+        for bucket, hx, nb in zip(plan, ipc_handles, ipc_nbytes):
+            mapped = self._mapped.get(hx)
+            if mapped is None:
+                mapped = self._mapped[hx] = MappedBucket(bytes.fromhex(hx), nb, self.device)
+            buf = mapped.tensor()
+            views = [(sp.name, buf[off : off + sp.nbytes].view(sp.dtype).view(sp.shape)) for sp, off in bucket]
+            load_weights(views)
+            n += len(views)
+        torch.cuda.synchronize(self.device)  # the trainer may overwrite the buckets after the ack
+        return n
+
+    def close(self) -> None:
+        for m in self._mapped.values():
+            m.close()
+        self._mapped = {}

@@ -1,0 +1,80 @@
+"""Colocated weight hand-off (trainer and inference worker on ONE GPU) over HIP IPC.
+
+Reference behaviour being replaced: `pipelinerl/finetune_loop.py:205-292` + `pipelinerl/vllm1.py:83-134`
+(the same NCCL broadcast is used even when both ends share a device).  Here the request carries
+IPC handles of the trainer's buckets and the worker copies device-to-device.
+"""
+
+from __future__ import annotations
+
+import multiprocessing as mp
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _param_set(seed: int, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    shapes = [("embed.weight", (1000, 64), torch.bfloat16), ("l0.w", (64, 64), torch.bfloat16),
+              ("l0.b", (63,), torch.float32), ("l1.w", (129, 7), torch.bfloat16), ("norm", (1,), torch.float32)]
+    return [(n, torch.randn(s, generator=g).to(dt).to(device)) for n, s, dt in shapes]
+
+
+def _worker(req_q, ack_q):
+    import torch
+
+    from pipelinerl_amd.vllm_worker import StandaloneWeightReceiver
+
+    device = torch.device("cuda:0")
+    torch.cuda.set_device(device)
+    module = torch.nn.Module()
+    own = {}
+    for n, p in _param_set(0, device):
+        own[n] = torch.nn.Parameter(torch.zeros_like(p), requires_grad=False)
+        module.register_parameter(n.replace(".", "__"), own[n])
+    module.named_parameters = lambda: own.items()  # keep the dotted names
+    recv = StandaloneWeightReceiver(module, device)
+    ack_q.put("ready")
+    while True:
+        raw = req_q.get()
+        if raw is None:
+            break
+        recv.receive_weight_update(raw)
+        ack_q.put({n: t.float().double().sum().item() for n, t in own.items()})
+    recv.close_communicator()
+
+
+def test_colocated_ipc_weight_update(cuda_device):
+    from pipelinerl_amd.finetune_loop import WeightUpdateManager
+
+    ctx = mp.get_context("spawn")
+    req_q, ack_q = ctx.Queue(), ctx.Queue()
+    proc = ctx.Process(target=_worker, args=(req_q, ack_q), daemon=True)
+    proc.start()
+    try:
+        assert ack_q.get(timeout=300) == "ready"
+        acks = []
+
+        def post(url, payload):
+            assert url.endswith("/receive_weight_update")
+            req_q.put(payload)
+            acks.append(ack_q.get(timeout=120))
+
+        params = _param_set(1, cuda_device)
+        mgr = WeightUpdateManager(llm_urls=["ipc://worker"], accelerated_model=None, update_stream=None, actor_update_group=None,
+                                  named_parameters_fn=lambda: params, transport="ipc", post=post)
+        for version in (1, 2):
+            if version == 2:  # in-place optimizer step; same buckets and handles are reused
+                for _, p in params:
+                    p.mul_(0.5).add_(1.0)
+            mgr.send_weight_update(version)
+            want = {n: p.float().double().sum().item() for n, p in params}
+            assert acks[-1] == pytest.approx(want, rel=0, abs=0)
+        mgr.shutdown()
+    finally:
+        req_q.put(None)
+        proc.join(timeout=60)
+        if proc.is_alive():
+            proc.kill()
