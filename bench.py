@@ -335,6 +335,17 @@ def main():
     # The weight-sync probe creates its own RCCL communicator; a hang there must not cost the
     # benchmark line, so a watchdog prints the line without it and ends the process.
     wsync = None
+    if world == 1 and not args.no_weight_sync and os.environ.get("PRL_BENCH_WSYNC", "1") != "0":
+        # one GPU: the only trainer -> actor layout is colocated; hand the 7B / 0.5B parameter set to a
+        # second process on this GPU over HIP IPC (request-to-ack of send_weight_update, median of 5)
+        del logits, grad_logits
+        torch.cuda.empty_cache()
+        try:
+            from pipelinerl_amd.weight_sync_probe import colocated_probe
+
+            wsync = colocated_probe("7b" if args.workload.startswith("7b") else "0p5b", iters=5, rehome=True, ready_timeout=240.0)
+        except Exception as e:  # noqa: BLE001 - the probe must never take the benchmark line down
+            wsync = {"error": f"{type(e).__name__}: {e}"}
     if world > 1 and args.backend == "nccl" and not args.no_weight_sync and os.environ.get("PRL_BENCH_WSYNC", "1") != "0":
         import threading
 

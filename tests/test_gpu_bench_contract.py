@@ -32,3 +32,6 @@ def test_bench_json_contract(libprl, cuda_device):
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert {"fused_logits_loss", "grpo_loss_step", "preprocess_K5_K6"} <= set(d["kernels"])
+    w = d["weight_sync"]  # N = 1: colocated hand-off over HIP IPC
+    assert "error" not in w, w
+    assert w["metric"] == "trainer_to_actor_weight_sync_ms" and w["median_ms"] > 0 and w["gbytes"] > 0.9
