@@ -33,7 +33,8 @@
  *   prl_pad_collate               pipelinerl/finetune/data.py:163-212
  *   prl_ring_*                    pipelinerl/shared_memory_array.py:9-196,
  *                                 pipelinerl/streams.py:249-346
- *   prl_wsync_* / prl_ipc_*       pipelinerl/finetune_loop.py:205-292,
+ *   prl_wsync_* / prl_ipc_* /
+ *   prl_bucket_*                  pipelinerl/finetune_loop.py:205-292,
  *                                 pipelinerl/vllm1.py:62-134,
  *                                 pipelinerl/torch_utils.py:70-94
  */
@@ -382,6 +383,19 @@ int prl_ipc_free(void* dev_ptr);
 int prl_ipc_export(const void* dev_ptr, uint8_t handle[PRL_IPC_HANDLE_BYTES]);
 int prl_ipc_open(const uint8_t handle[PRL_IPC_HANDLE_BYTES], void** dev_ptr);
 int prl_ipc_close(void* dev_ptr);
+
+/* ---- bucket <-> parameter copies ---------------------------------------------------------
+ * Flatten the trainer's parameters into a bucket (gather) / hand a received bucket out to the
+ * engine's weights (scatter) in one launch per 64 segments, replacing the per-parameter
+ * staging of finetune_loop.py:262-282 and vllm1.py:110-127.  `segments` is a HOST array;
+ * `tensor` and `bucket` are device pointers; regions must not overlap.  Enqueued on `stream`. */
+struct prl_segment {
+  void* tensor;          /* device address of the parameter's (contiguous) storage */
+  int64_t bucket_offset; /* byte offset of its slot inside the bucket */
+  int64_t nbytes;
+};
+int prl_bucket_gather(void* bucket, int64_t bucket_bytes, const struct prl_segment* segments, int64_t n_segments, void* stream);
+int prl_bucket_scatter(const void* bucket, int64_t bucket_bytes, const struct prl_segment* segments, int64_t n_segments, void* stream);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,12 @@ class PrlLossConfig(ctypes.Structure):
     ]
 
 
+class PrlSegment(ctypes.Structure):
+    """Mirror of `struct prl_segment` (include/prl.h)."""
+
+    _fields_ = [("tensor", c_void_p), ("bucket_offset", c_int64), ("nbytes", c_int64)]
+
+
 class PrlError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"libprl error {code}: {message}")
@@ -140,6 +146,8 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_ipc_export": (c_int32, [c_void_p, POINTER(c_uint8)]),
     "prl_ipc_open": (c_int32, [POINTER(c_uint8), POINTER(c_void_p)]),
     "prl_ipc_close": (c_int32, [c_void_p]),
+    "prl_bucket_gather": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "prl_bucket_scatter": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
 }
 
 _lib: ctypes.CDLL | None = None

@@ -37,6 +37,7 @@ SOURCES = [
     "prl_loss.hip",
     "prl_logprob.hip",
     "prl_pack.hip",
+    "prl_copy.hip",
 ]
 
 

@@ -27,6 +27,12 @@ class WorkerExtension:
     def _load_weights(self, weights):  # overridden / provided by the engine
         return self.model_runner.model.load_weights(weights=weights)  # type: ignore[attr-defined]
 
+    def _weight_destinations(self) -> dict[str, torch.Tensor] | None:
+        """Optional: name -> the engine's own weight tensor for parameters that are stored exactly
+        as the trainer names and shapes them.  Those are filled by one scatter-copy launch per bucket
+        instead of going through `load_weights` (which stays in charge of fused / sharded weights)."""
+        return None
+
     def _after_update(self) -> None:
         """Hook for engine caches that must be dropped after new weights land (the reference
         invalidates its fp32 lm_head cache here, vllm1.py:126)."""
@@ -62,11 +68,12 @@ class WorkerExtension:
 
             if getattr(self, "_ipc_receiver", None) is None:
                 self._ipc_receiver = ColocatedReceiver(self.device, request.bucket_bytes)
-            self._ipc_receiver.receive([i.model_dump() for i in request.parameters_info], request.ipc_handles, request.ipc_nbytes, load)
+            self._ipc_receiver.receive([i.model_dump() for i in request.parameters_info], request.ipc_handles, request.ipc_nbytes, load,
+                                       destinations=self._weight_destinations())
         elif request.transport == "bucketed":
             if getattr(self, "_receiver", None) is None or self._receiver.bucket_bytes != request.bucket_bytes:
                 self._receiver = BucketedReceiver(self.model_update_group, request.bucket_bytes)
-            self._receiver.receive([i.model_dump() for i in request.parameters_info], load)
+            self._receiver.receive([i.model_dump() for i in request.parameters_info], load, destinations=self._weight_destinations())
         else:  # reference protocol: one broadcast per parameter
             for info in request.parameters_info:
                 buf = torch.empty(tuple(info.shape), dtype=string_to_dtype(info.dtype), device=self.device)
@@ -96,6 +103,9 @@ class StandaloneWeightReceiver(WorkerExtension):
         self.device = device
         self.rank = rank
         self._params = dict(module.named_parameters())
+
+    def _weight_destinations(self):
+        return {n: p.data for n, p in self._params.items()}
 
     def _load_weights(self, weights):
         loaded = []

@@ -177,6 +177,66 @@ def string_to_dtype(name: str) -> torch.dtype:
     return d
 
 
+def _segment_table(bucket: Sequence[tuple[ParamSpec, int]], tensors: dict[str, torch.Tensor], writable: bool):
+    """ctypes `prl_segment[]` for one bucket plus the contiguous temporaries made for it."""
+    segs = (_lib.PrlSegment * len(bucket))()
+    keep = []
+    for i, (sp, off) in enumerate(bucket):
+        t = tensors[sp.name]
+        if t.dtype != sp.dtype or tuple(t.shape) != tuple(sp.shape):
+            raise ValueError(f"{sp.name}: tensor is {t.dtype}{tuple(t.shape)}, the update announces {sp.dtype}{tuple(sp.shape)}")
+        if not t.is_contiguous():
+            if writable:
+                raise ValueError(f"{sp.name}: destination tensor must be contiguous")
+            t = t.contiguous()
+            keep.append(t)
+        segs[i].tensor, segs[i].bucket_offset, segs[i].nbytes = t.data_ptr(), off, sp.nbytes
+    return segs, keep
+
+
+def gather_into_bucket(buf: torch.Tensor, bucket: Sequence[tuple[ParamSpec, int]], tensors: dict[str, torch.Tensor]) -> None:
+    """Flatten the bucket's parameters into `buf` (uint8): one `prl_bucket_gather` launch per 64
+    parameters on the current stream.  Host tensors (the gloo protocol tests) use torch copies."""
+    if not buf.is_cuda:
+        for sp, off in bucket:
+            buf[off : off + sp.nbytes].view(sp.dtype).view(sp.shape).copy_(tensors[sp.name])
+        return
+    segs, keep = _segment_table(bucket, tensors, writable=False)
+    _lib.check(_lib.load().prl_bucket_gather(buf.data_ptr(), buf.numel(), segs, len(bucket), _lib.current_stream_ptr(buf.device)))
+    for t in keep:  # temporaries made contiguous above: free only after the copy on this stream
+        t.record_stream(torch.cuda.current_stream(buf.device))
+
+
+def scatter_from_bucket(buf: torch.Tensor, bucket: Sequence[tuple[ParamSpec, int]], tensors: dict[str, torch.Tensor]) -> None:
+    """Copy every slot of `buf` into the same-named destination tensor (the engine's own weights)
+    with one `prl_bucket_scatter` launch per 64 parameters."""
+    if not buf.is_cuda:
+        for sp, off in bucket:
+            tensors[sp.name].copy_(buf[off : off + sp.nbytes].view(sp.dtype).view(sp.shape))
+        return
+    segs, _ = _segment_table(bucket, tensors, writable=True)
+    _lib.check(_lib.load().prl_bucket_scatter(buf.data_ptr(), buf.numel(), segs, len(bucket), _lib.current_stream_ptr(buf.device)))
+
+
+def _deliver(buf: torch.Tensor, bucket: Sequence[tuple[ParamSpec, int]], load_weights: Callable | None,
+             destinations: dict[str, torch.Tensor] | None) -> int:
+    """Hand one received bucket to the engine: parameters with a registered same-dtype/shape
+    destination are scattered by the copy kernel, the rest go through `load_weights` as views."""
+    direct = []
+    if destinations:
+        direct = [(sp, off) for sp, off in bucket
+                  if (d := destinations.get(sp.name)) is not None and d.dtype == sp.dtype and tuple(d.shape) == tuple(sp.shape) and d.is_contiguous()]
+        if direct:
+            scatter_from_bucket(buf, direct, destinations)
+    if len(direct) < len(bucket):
+        taken = {sp.name for sp, _ in direct}
+        views = [(sp.name, buf[off : off + sp.nbytes].view(sp.dtype).view(sp.shape)) for sp, off in bucket if sp.name not in taken]
+        if load_weights is None:
+            raise ValueError(f"no destination registered for {[n for n, _ in views][:4]}... and no load_weights callback")
+        load_weights(views)
+    return len(bucket)
+
+
 class BucketedSender:
     """Trainer side: flatten named parameters into reusable device buckets and broadcast them."""
 
@@ -197,9 +257,7 @@ class BucketedSender:
         tensors = dict(params)
         for k, bucket in enumerate(plan):
             buf = self._staging[k % 2][: bucket_nbytes(bucket)]
-            for sp, off in bucket:
-                dst = buf[off : off + sp.nbytes].view(sp.dtype).view(sp.shape)
-                dst.copy_(tensors[sp.name], non_blocking=True)
+            gather_into_bucket(buf, bucket, tensors)
             self.group.broadcast_bucket(buf, mode=self.mode)
         return specs
 
@@ -215,7 +273,8 @@ class BucketedReceiver:
         self.mode = mode
         self._staging: list[torch.Tensor] = []
 
-    def receive(self, parameters_info: Sequence[dict | ParamSpec], load_weights: Callable[[list[tuple[str, torch.Tensor]]], Any]) -> int:
+    def receive(self, parameters_info: Sequence[dict | ParamSpec], load_weights: Callable[[list[tuple[str, torch.Tensor]]], Any] | None,
+                destinations: dict[str, torch.Tensor] | None = None) -> int:
         specs = [
             p if isinstance(p, ParamSpec) else ParamSpec(p["name"], tuple(p["shape"]), string_to_dtype(p["dtype"]))
             for p in parameters_info
@@ -228,9 +287,7 @@ class BucketedReceiver:
         for k, bucket in enumerate(plan):
             buf = self._staging[k % 2][: bucket_nbytes(bucket)]
             self.group.broadcast_bucket(buf, mode=self.mode)
-            views = [(sp.name, buf[off : off + sp.nbytes].view(sp.dtype).view(sp.shape)) for sp, off in bucket]
-            load_weights(views)
-            n += len(views)
+            n += _deliver(buf, bucket, load_weights, destinations)
         return n
 
 
@@ -339,13 +396,11 @@ class ColocatedSender:
         plan, sizes = self._ensure_buckets(params)
         tensors = dict(params)
         for bucket, dev_bucket in zip(plan, self._buckets):
-            buf = dev_bucket.tensor()
             base = dev_bucket.ptr
-            for sp, off in bucket:
-                src = tensors[sp.name]
-                if src.data_ptr() == base + off and src.is_contiguous():
-                    continue
-                buf[off : off + sp.nbytes].view(sp.dtype).view(sp.shape).copy_(src, non_blocking=True)
+            moving = [(sp, off) for sp, off in bucket
+                      if not (tensors[sp.name].data_ptr() == base + off and tensors[sp.name].is_contiguous())]
+            if moving:
+                gather_into_bucket(dev_bucket.tensor(), moving, tensors)
         torch.cuda.synchronize(self.device)
         return {"ipc_handles": [b.handle().hex() for b in self._buckets], "ipc_nbytes": sizes}
 
@@ -365,7 +420,8 @@ class ColocatedReceiver:
         self._mapped: dict[str, MappedBucket] = {}
 
     def receive(self, parameters_info: Sequence[dict | ParamSpec], ipc_handles: Sequence[str], ipc_nbytes: Sequence[int],
-                load_weights: Callable[[list[tuple[str, torch.Tensor]]], Any]) -> int:
+                load_weights: Callable[[list[tuple[str, torch.Tensor]]], Any] | None,
+                destinations: dict[str, torch.Tensor] | None = None) -> int:
         specs = [
             p if isinstance(p, ParamSpec) else ParamSpec(p["name"], tuple(p["shape"]), string_to_dtype(p["dtype"]))
             for p in parameters_info
@@ -378,10 +434,7 @@ class ColocatedReceiver:
             mapped = self._mapped.get(hx)
             if mapped is None:
                 mapped = self._mapped[hx] = MappedBucket(bytes.fromhex(hx), nb, self.device)
-            buf = mapped.tensor()
-            views = [(sp.name, buf[off : off + sp.nbytes].view(sp.dtype).view(sp.shape)) for sp, off in bucket]
-            load_weights(views)
-            n += len(views)
+            n += _deliver(mapped.tensor(), bucket, load_weights, destinations)
         torch.cuda.synchronize(self.device)  # the trainer may overwrite the buckets after the ack
         return n
 

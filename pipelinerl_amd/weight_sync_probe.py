@@ -30,7 +30,7 @@ def qwen25_shapes(which: str):
     return out
 
 
-def _worker(which, req_q, ack_q):
+def _worker(which, req_q, ack_q, direct=True):
     import torch
 
     from pipelinerl_amd.vllm_worker import WorkerExtension
@@ -41,6 +41,9 @@ def _worker(which, req_q, ack_q):
 
     class Engine(WorkerExtension):
         device, rank = dev, 0
+
+        def _weight_destinations(self):
+            return own if direct else None
 
         def _load_weights(self, weights):
             names = [n for n, _ in weights]
@@ -74,7 +77,7 @@ def _get(q, proc, timeout: float):
                 raise TimeoutError("weight-sync worker did not answer in time") from None
 
 
-def colocated_probe(which: str = "7b", iters: int = 5, rehome: bool = True, ready_timeout: float = 600.0) -> dict:
+def colocated_probe(which: str = "7b", iters: int = 5, rehome: bool = True, ready_timeout: float = 600.0, direct: bool = True) -> dict:
     """Median request-to-ack time of `WeightUpdateManager.send_weight_update` over `iters` updates of
     the Qwen2.5 `which` parameter set (bf16), the worker being a second process on cuda:0."""
     from pipelinerl_amd.finetune_loop import WeightUpdateManager
@@ -83,7 +86,7 @@ def colocated_probe(which: str = "7b", iters: int = 5, rehome: bool = True, read
     dev = torch.device("cuda", 0)
     ctx = mp.get_context("spawn")
     req_q, ack_q = ctx.Queue(), ctx.Queue()
-    proc = ctx.Process(target=_worker, args=(which, req_q, ack_q), daemon=True)
+    proc = ctx.Process(target=_worker, args=(which, req_q, ack_q, direct), daemon=True)
     proc.start()
     mgr = None
     try:
@@ -120,7 +123,7 @@ def colocated_probe(which: str = "7b", iters: int = 5, rehome: bool = True, read
         recv = sorted(a["recv_ms"] for a in acks[1:])
         med, rmed = steady[len(steady) // 2], recv[len(recv) // 2]
         return {"metric": "trainer_to_actor_weight_sync_ms", "layout": "colocated (1 GPU, 2 processes, HIP IPC)", "params": which,
-                "tensors": len(params), "gbytes": round(nbytes / 1e9, 3), "zero_copy_publish": rehome,
+                "tensors": len(params), "gbytes": round(nbytes / 1e9, 3), "zero_copy_publish": rehome, "worker_scatter_kernel": direct,
                 "first_ms": round(times[0], 2), "median_ms": round(med, 2), "min_ms": round(steady[0], 2),
                 "worker_copy_ms": round(rmed, 2), "effective_GBps": round(nbytes / med / 1e6, 1)}
     finally:

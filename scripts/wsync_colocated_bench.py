@@ -22,8 +22,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     args = ap.parse_args()
     for which in args.sets.split(","):
-        for rehome in (False, True):
-            print(json.dumps(colocated_probe(which, args.iters, rehome)), flush=True)
+        for rehome, direct in ((False, False), (True, False), (False, True), (True, True)):
+            print(json.dumps(colocated_probe(which, args.iters, rehome, direct=direct)), flush=True)
 
 
 if __name__ == "__main__":

@@ -80,3 +80,21 @@ def test_ring_and_wsync_reject_bad_arguments(libprl):
     uid = (ctypes.c_uint8 * _lib.PRL_WSYNC_UID_BYTES)()
     assert lib.prl_wsync_init(uid, 3, 2, 0, ctypes.byref(h)) == _lib.PRL_EINVAL and "rank" in _err(lib)
     assert lib.prl_wsync_destroy(None) == _lib.PRL_OK
+
+
+def test_bucket_copy_rejects_bad_segments(libprl):
+    lib = libprl
+    segs = (_lib.PrlSegment * 2)()
+    segs[0].tensor, segs[0].bucket_offset, segs[0].nbytes = P, 0, 64
+    segs[1].tensor, segs[1].bucket_offset, segs[1].nbytes = P, 64, 65
+    for fn in (lib.prl_bucket_gather, lib.prl_bucket_scatter):
+        assert fn(P, 128, segs, 2, None) == _lib.PRL_EINVAL and "exceeds" in _err(lib)
+        assert fn(P, 128, segs, -1, None) == _lib.PRL_EINVAL
+        assert fn(None, 128, segs, 2, None) == _lib.PRL_EINVAL
+        assert fn(P, 128, None, 2, None) == _lib.PRL_EINVAL
+        assert fn(P, 128, segs, 0, None) == _lib.PRL_OK  # nothing to do, no launch
+    segs[1].nbytes = 64
+    segs[1].tensor = None
+    assert lib.prl_bucket_gather(P, 128, segs, 2, None) == _lib.PRL_EINVAL and "null tensor" in _err(lib)
+    segs[1].tensor, segs[1].bucket_offset = P, -8
+    assert lib.prl_bucket_scatter(P, 128, segs, 2, None) == _lib.PRL_EINVAL and "negative" in _err(lib)
