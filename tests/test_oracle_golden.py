@@ -27,6 +27,22 @@ def test_rl_step_oracle_matches_reference(name):
     np.testing.assert_allclose(res["grad_logits"], case["grad_logits"], rtol=0, atol=1e-6 * max(1.0, np.abs(case["grad_logits"]).max()))
 
 
+@pytest.mark.parametrize("leg", ["rl_step", "rl_step_closed_form"])
+@pytest.mark.parametrize("name", RL_STEP_CASES)
+def test_rl_step_torch_legs_match_reference(name, leg):
+    """The multi-threaded torch legs (autograd / closed form; the latter is bench.py's cpu_baseline): same pins."""
+    from oracle import rl_loss_torch as orlt
+
+    case = load_rl_case(name)
+    cur, mx = case["steps"]
+    res = getattr(orlt, leg)(case["logits"], case["batch"], case["config"], cur, mx, bool(case["batch"]["is_packed"]))
+    assert abs(float(res["loss"]) - case["loss"]) <= 1e-5 * max(1.0, abs(case["loss"]))
+    for k, want in case["stats"].items():
+        assert abs(float(res["stats"][k]) - want) <= 2e-5 * max(1.0, abs(want)), k
+    got = res["grad_logits"].numpy()
+    np.testing.assert_allclose(got, case["grad_logits"], rtol=0, atol=1e-6 * max(1.0, np.abs(case["grad_logits"]).max()))
+
+
 @pytest.mark.parametrize("name", PREPROCESS_CASES)
 def test_populate_oracle_matches_reference(name):
     case = load_preprocess_case(name)
