@@ -15,6 +15,8 @@
 // plain masked sum; position_ids are still read to count sequence starts
 // (num_sequences scales the kl_coef / entropy_bonus_coef stats, rl/__init__.py:431-432).
 
+#include <cstdlib>
+
 #include "prl_common.h"
 #include "prl_token_math.h"
 
@@ -117,6 +119,7 @@ __device__ __forceinline__ float per_label(float x, float inv_nl) {
 }
 
 // One token on the unshifted axis. `valid_pos`: column >= 1 (a shifted position exists).
+template <bool FAST>
 __device__ __forceinline__ void token_step(const LossArgs& a, Acc& acc, bool valid_pos,
                                            int64_t label, bool seq_start, float nlp,
                                            float ent, float old_lp, float ref_lp, float adv,
@@ -148,23 +151,62 @@ __device__ __forceinline__ void token_step(const LossArgs& a, Acc& acc, bool val
   }
   const float inv_nl = 1.0f / nl;
   acc.loss += (double)o.contrib;
-  acc.s[P_REWARD] += per_label(reward, inv_nl);
-  acc.s[P_ENTROPY] += per_label(ent, inv_nl);
-  acc.s[P_OLD] += per_label(old_lp, inv_nl);
-  acc.s[P_NEW] += per_label(nlp, inv_nl);
-  acc.s[P_REF] += per_label(ref_lp, inv_nl);
-  acc.s[P_ADV] += per_label(adv, inv_nl);
-  acc.s[P_KL] += per_label(o.kl, inv_nl);
-  acc.s[P_KL_NO] += per_label(o.kl_new_old, inv_nl);
-  acc.s[P_ABS_LR] += per_label(o.abs_lrno, inv_nl);
-  acc.s[P_RATIO] += per_label(o.ratio_stat, inv_nl);
-  acc.s[P_RATIO_SUM] += prl_nan_to_num0(o.ratio_stat);
-  acc.s[P_RATIO_SQ] += prl_nan_to_num0(o.ratio_stat * o.ratio_stat);
-  acc.s[P_RATIO_REF_NEW] += per_label(o.exp_lrrn, inv_nl);
-  acc.s[P_RATIO_REF_OLD] += per_label(o.exp_ref_old, inv_nl);
-  acc.s[P_CLAMP_RN] += per_label(o.clamp_rn, inv_nl);
-  acc.s[P_CLAMP_NO] += per_label(o.clamp_no, inv_nl);
-  acc.s[P_TW] += per_label(o.w, inv_nl);
+  // Every per-label statistic is nan_to_num(x / num_labels).  `0 * x` is 0 for finite x and NaN
+  // otherwise, so one fused chain over the 14 values tells whether nan_to_num can change anything
+  // for this token; with num_labels >= 1 the products cannot overflow either.  Finite tokens (all of
+  // them in a healthy run) then cost a multiply and an add per statistic instead of three
+  // compare/select pairs each.
+  const float ratio_sq = o.ratio_stat * o.ratio_stat;
+  float probe = __builtin_fmaf(0.0f, reward, 0.0f);
+  probe = __builtin_fmaf(0.0f, ent, probe);
+  probe = __builtin_fmaf(0.0f, old_lp, probe);
+  probe = __builtin_fmaf(0.0f, nlp, probe);
+  probe = __builtin_fmaf(0.0f, ref_lp, probe);
+  probe = __builtin_fmaf(0.0f, adv, probe);
+  probe = __builtin_fmaf(0.0f, o.kl, probe);
+  probe = __builtin_fmaf(0.0f, o.kl_new_old, probe);
+  probe = __builtin_fmaf(0.0f, o.abs_lrno, probe);
+  probe = __builtin_fmaf(0.0f, ratio_sq, probe);  // finite => ratio_stat finite
+  probe = __builtin_fmaf(0.0f, o.exp_lrrn, probe);
+  probe = __builtin_fmaf(0.0f, o.exp_ref_old, probe);
+  probe = __builtin_fmaf(0.0f, o.w, probe);
+  if (FAST && probe == 0.0f && nl >= 1.0f) {
+    acc.s[P_REWARD] += reward * inv_nl;
+    acc.s[P_ENTROPY] += ent * inv_nl;
+    acc.s[P_OLD] += old_lp * inv_nl;
+    acc.s[P_NEW] += nlp * inv_nl;
+    acc.s[P_REF] += ref_lp * inv_nl;
+    acc.s[P_ADV] += adv * inv_nl;
+    acc.s[P_KL] += o.kl * inv_nl;
+    acc.s[P_KL_NO] += o.kl_new_old * inv_nl;
+    acc.s[P_ABS_LR] += o.abs_lrno * inv_nl;
+    acc.s[P_RATIO] += o.ratio_stat * inv_nl;
+    acc.s[P_RATIO_SUM] += o.ratio_stat;
+    acc.s[P_RATIO_SQ] += ratio_sq;
+    acc.s[P_RATIO_REF_NEW] += o.exp_lrrn * inv_nl;
+    acc.s[P_RATIO_REF_OLD] += o.exp_ref_old * inv_nl;
+    acc.s[P_CLAMP_RN] += o.clamp_rn * inv_nl;
+    acc.s[P_CLAMP_NO] += o.clamp_no * inv_nl;
+    acc.s[P_TW] += o.w * inv_nl;
+  } else {
+    acc.s[P_REWARD] += per_label(reward, inv_nl);
+    acc.s[P_ENTROPY] += per_label(ent, inv_nl);
+    acc.s[P_OLD] += per_label(old_lp, inv_nl);
+    acc.s[P_NEW] += per_label(nlp, inv_nl);
+    acc.s[P_REF] += per_label(ref_lp, inv_nl);
+    acc.s[P_ADV] += per_label(adv, inv_nl);
+    acc.s[P_KL] += per_label(o.kl, inv_nl);
+    acc.s[P_KL_NO] += per_label(o.kl_new_old, inv_nl);
+    acc.s[P_ABS_LR] += per_label(o.abs_lrno, inv_nl);
+    acc.s[P_RATIO] += per_label(o.ratio_stat, inv_nl);
+    acc.s[P_RATIO_SUM] += prl_nan_to_num0(o.ratio_stat);
+    acc.s[P_RATIO_SQ] += prl_nan_to_num0(ratio_sq);
+    acc.s[P_RATIO_REF_NEW] += per_label(o.exp_lrrn, inv_nl);
+    acc.s[P_RATIO_REF_OLD] += per_label(o.exp_ref_old, inv_nl);
+    acc.s[P_CLAMP_RN] += per_label(o.clamp_rn, inv_nl);
+    acc.s[P_CLAMP_NO] += per_label(o.clamp_no, inv_nl);
+    acc.s[P_TW] += per_label(o.w, inv_nl);
+  }
   acc.s[P_N_MASKED] += 1.0f;
   acc.s[P_BAD_NLP] += o.bad_nlp;
   acc.s[P_BAD_LRRN] += o.bad_lrrn;
@@ -216,9 +258,48 @@ __device__ __forceinline__ void block_reduce_store(const Acc& acc, double* out) 
   }
 }
 
+// Four consecutive tokens of every input column (16-byte loads; 52 VGPRs without the GSPO columns).
+struct TokVec4 {
+  longlong2 lab01, lab23, pos01, pos23;
+  float4 nlp, ent, old, ref, adv, rew, gt, nl, ov, xg, xc;
+};
+
+template <bool GSPO>
+__device__ __forceinline__ void load_vec4(const LossArgs& a, bool count_pos, int64_t u0, TokVec4& v) {
+  v.lab01 = *reinterpret_cast<const longlong2*>(a.labels + u0);
+  v.lab23 = *reinterpret_cast<const longlong2*>(a.labels + u0 + 2);
+  v.pos01 = make_longlong2(1, 1);
+  v.pos23 = make_longlong2(1, 1);
+  if (count_pos) {
+    v.pos01 = *reinterpret_cast<const longlong2*>(a.position_ids + u0);
+    v.pos23 = *reinterpret_cast<const longlong2*>(a.position_ids + u0 + 2);
+  }
+  v.nlp = *reinterpret_cast<const float4*>(a.nlp + u0);
+  v.ent = *reinterpret_cast<const float4*>(a.ent + u0);
+  v.old = *reinterpret_cast<const float4*>(a.old_lp + u0);
+  v.ref = *reinterpret_cast<const float4*>(a.ref_lp + u0);
+  v.adv = *reinterpret_cast<const float4*>(a.adv + u0);
+  v.rew = *reinterpret_cast<const float4*>(a.reward + u0);
+  v.gt = *reinterpret_cast<const float4*>(a.group_tokens + u0);
+  v.nl = *reinterpret_cast<const float4*>(a.num_labels + u0);
+  v.ov = *reinterpret_cast<const float4*>(a.overflow + u0);
+  if constexpr (GSPO) {
+    v.xg = *reinterpret_cast<const float4*>(a.ext_g + u0);
+    v.xc = *reinterpret_cast<const float4*>(a.ext_clamp + u0);
+  } else {
+    v.xg = make_float4(0.f, 0.f, 0.f, 0.f);
+    v.xc = v.xg;
+  }
+}
+
 // VEC = 4: all base pointers 16-byte aligned; the n % 4 tail is handled by block 0's
 // first lanes with scalar accesses.  VEC = 1: fully scalar fallback for odd views.
-template <int VEC>
+//
+// The per-token math is ~290 VALU instructions, and the accumulators plus one group of inputs
+// already take ~140 VGPRs (3 waves per SIMD), so the loads of the NEXT group are issued before
+// the current group is evaluated: the SQ counters of the unpipelined loop showed the waves
+// parked on s_waitcnt for 47 % of their cycles with the VALU 32 % busy.
+template <int VEC, bool FAST, bool GSPO>
 __global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
   Acc acc;
   acc_init(acc);
@@ -226,47 +307,31 @@ __global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
   const int64_t nthreads = (int64_t)gridDim.x * kBlock;
   const bool count_pos = a.packed && a.position_ids != nullptr;
   const bool flat = count_pos && a.cfg.flat_micro_batches;
-  const bool gspo = a.cfg.policy_loss == PRL_POLICY_GSPO;
+  const bool gspo = GSPO;
 
   if constexpr (VEC == 4) {
     const int64_t n4 = a.n >> 2;
-    for (int64_t i = tid; i < n4; i += nthreads) {
+    TokVec4 cur, nxt;
+    int64_t i = tid;
+    if (i < n4) load_vec4<GSPO>(a, count_pos, i << 2, cur);
+    for (; i < n4; i += nthreads) {
       const int64_t u0 = i << 2;
-      const longlong2 lab01 = *reinterpret_cast<const longlong2*>(a.labels + u0);
-      const longlong2 lab23 = *reinterpret_cast<const longlong2*>(a.labels + u0 + 2);
-      longlong2 pos01 = make_longlong2(1, 1), pos23 = make_longlong2(1, 1);
-      if (count_pos) {
-        pos01 = *reinterpret_cast<const longlong2*>(a.position_ids + u0);
-        pos23 = *reinterpret_cast<const longlong2*>(a.position_ids + u0 + 2);
-      }
-      const float4 nlp = *reinterpret_cast<const float4*>(a.nlp + u0);
-      const float4 ent = *reinterpret_cast<const float4*>(a.ent + u0);
-      const float4 old = *reinterpret_cast<const float4*>(a.old_lp + u0);
-      const float4 ref = *reinterpret_cast<const float4*>(a.ref_lp + u0);
-      const float4 adv = *reinterpret_cast<const float4*>(a.adv + u0);
-      const float4 rew = *reinterpret_cast<const float4*>(a.reward + u0);
-      const float4 gt = *reinterpret_cast<const float4*>(a.group_tokens + u0);
-      const float4 nl = *reinterpret_cast<const float4*>(a.num_labels + u0);
-      const float4 ov = *reinterpret_cast<const float4*>(a.overflow + u0);
-      float4 xg = make_float4(0.f, 0.f, 0.f, 0.f), xc = xg;
-      if (gspo) {
-        xg = *reinterpret_cast<const float4*>(a.ext_g + u0);
-        xc = *reinterpret_cast<const float4*>(a.ext_clamp + u0);
-      }
+      const int64_t inext = i + nthreads;
+      if (inext < n4) load_vec4<GSPO>(a, count_pos, inext << 2, nxt);
 
-      const int64_t lab[4] = {lab01.x, lab01.y, lab23.x, lab23.y};
-      const int64_t pos[4] = {pos01.x, pos01.y, pos23.x, pos23.y};
-      const float f_nlp[4] = {nlp.x, nlp.y, nlp.z, nlp.w};
-      const float f_ent[4] = {ent.x, ent.y, ent.z, ent.w};
-      const float f_old[4] = {old.x, old.y, old.z, old.w};
-      const float f_ref[4] = {ref.x, ref.y, ref.z, ref.w};
-      const float f_adv[4] = {adv.x, adv.y, adv.z, adv.w};
-      const float f_rew[4] = {rew.x, rew.y, rew.z, rew.w};
-      const float f_gt[4] = {gt.x, gt.y, gt.z, gt.w};
-      const float f_nl[4] = {nl.x, nl.y, nl.z, nl.w};
-      const float f_ov[4] = {ov.x, ov.y, ov.z, ov.w};
-      const float f_xg[4] = {xg.x, xg.y, xg.z, xg.w};
-      const float f_xc[4] = {xc.x, xc.y, xc.z, xc.w};
+      const int64_t lab[4] = {cur.lab01.x, cur.lab01.y, cur.lab23.x, cur.lab23.y};
+      const int64_t pos[4] = {cur.pos01.x, cur.pos01.y, cur.pos23.x, cur.pos23.y};
+      const float f_nlp[4] = {cur.nlp.x, cur.nlp.y, cur.nlp.z, cur.nlp.w};
+      const float f_ent[4] = {cur.ent.x, cur.ent.y, cur.ent.z, cur.ent.w};
+      const float f_old[4] = {cur.old.x, cur.old.y, cur.old.z, cur.old.w};
+      const float f_ref[4] = {cur.ref.x, cur.ref.y, cur.ref.z, cur.ref.w};
+      const float f_adv[4] = {cur.adv.x, cur.adv.y, cur.adv.z, cur.adv.w};
+      const float f_rew[4] = {cur.rew.x, cur.rew.y, cur.rew.z, cur.rew.w};
+      const float f_gt[4] = {cur.gt.x, cur.gt.y, cur.gt.z, cur.gt.w};
+      const float f_nl[4] = {cur.nl.x, cur.nl.y, cur.nl.z, cur.nl.w};
+      const float f_ov[4] = {cur.ov.x, cur.ov.y, cur.ov.z, cur.ov.w};
+      const float f_xg[4] = {cur.xg.x, cur.xg.y, cur.xg.z, cur.xg.w};
+      const float f_xc[4] = {cur.xc.x, cur.xc.y, cur.xc.z, cur.xc.w};
       // column of the first element of the group (cols may be any value >= 1)
       int64_t col = a.packed ? u0 : (u0 % a.cols);
       float g[4], gh[4];
@@ -274,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
       for (int k = 0; k < 4; ++k) {
         const bool valid_pos = (col != 0) && !(flat && pos[k] == 0);
         const bool seq_start = count_pos && (pos[k] == 0 || (u0 + k) == 0);
-        token_step(a, acc, valid_pos, lab[k], seq_start, f_nlp[k], f_ent[k], f_old[k],
+        token_step<FAST>(a, acc, valid_pos, lab[k], seq_start, f_nlp[k], f_ent[k], f_old[k],
                    f_ref[k], f_adv[k], f_rew[k], f_gt[k], f_nl[k], f_ov[k], f_xg[k], f_xc[k], g[k], gh[k]);
         ++col;
         if (!a.packed && col == a.cols) col = 0;
@@ -282,6 +347,7 @@ __global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
       if (a.g_nlp) *reinterpret_cast<float4*>(a.g_nlp + u0) = make_float4(g[0], g[1], g[2], g[3]);
       if (a.g_ent)
         *reinterpret_cast<float4*>(a.g_ent + u0) = make_float4(gh[0], gh[1], gh[2], gh[3]);
+      cur = nxt;
     }
   }
 
@@ -292,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
       const int64_t col = a.packed ? u : (u % a.cols);
       const bool seq_start = count_pos && (a.position_ids[u] == 0 || u == 0);
       float g, gh;
-      token_step(a, acc, (col != 0) && !(flat && a.position_ids[u] == 0), a.labels[u], seq_start, a.nlp[u], a.ent[u], a.old_lp[u],
+      token_step<FAST>(a, acc, (col != 0) && !(flat && a.position_ids[u] == 0), a.labels[u], seq_start, a.nlp[u], a.ent[u], a.old_lp[u],
                  a.ref_lp[u], a.adv[u], a.reward[u], a.group_tokens[u], a.num_labels[u],
                  a.overflow[u], gspo ? a.ext_g[u] : 0.0f, gspo ? a.ext_clamp[u] : 0.0f, g, gh);
       if (a.g_nlp) a.g_nlp[u] = g;
@@ -386,12 +452,37 @@ __global__ __launch_bounds__(kFinalBlock) void grpo_loss_finalize_kernel(const d
   }
 }
 
+// PRL_LOSS_FAST_STATS=0 selects the always-nan_to_num statistics path (A/B measurements only).
+bool fast_stats() {
+  static const bool on = [] {
+    const char* e = getenv("PRL_LOSS_FAST_STATS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 int grid_for(int64_t n, int vec) {
   const int64_t items = (n + vec - 1) / vec;
   int64_t blocks = (items + kBlock - 1) / kBlock;
   if (blocks < 1) blocks = 1;
   if (blocks > kMaxBlocks) blocks = kMaxBlocks;
   return (int)blocks;
+}
+
+// min(wanted, CUs x resident blocks per CU) for `kernel`; the occupancy query runs once per kernel.
+template <typename K>
+int resident_grid(K kernel, int wanted) {
+  static const int cap = [&] {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return kMaxBlocks;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return kMaxBlocks;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu <= 0) return kMaxBlocks;
+    const char* e = getenv("PRL_LOSS_BLOCKS_PER_CU");  // measurement override
+    if (e && atoi(e) > 0) per_cu = atoi(e);
+    const int64_t c = (int64_t)cus * per_cu;
+    return (int)(c < kMaxBlocks ? c : kMaxBlocks);
+  }();
+  return wanted < cap ? wanted : cap;
 }
 
 }  // namespace
@@ -470,11 +561,25 @@ extern "C" int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, i
   hipStream_t s = static_cast<hipStream_t>(stream);
   int nblocks;
   if (vec_ok) {
-    nblocks = grid_for(a.n, 4);
-    hipLaunchKernelGGL(grpo_loss_partial_kernel<4>, dim3(nblocks), dim3(kBlock), 0, s, a);
+    // grid = what is co-resident (the loop is grid-stride and software-pipelined): a grid of more
+    // blocks than fit runs in rounds and leaves the last round partly empty
+    const bool is_gspo = a.cfg.policy_loss == PRL_POLICY_GSPO;
+    if (is_gspo) {
+      nblocks = resident_grid(grpo_loss_partial_kernel<4, true, true>, grid_for(a.n, 4));
+      hipLaunchKernelGGL((grpo_loss_partial_kernel<4, true, true>), dim3(nblocks), dim3(kBlock), 0, s, a);
+    } else if (fast_stats()) {
+      nblocks = resident_grid(grpo_loss_partial_kernel<4, true, false>, grid_for(a.n, 4));
+      hipLaunchKernelGGL((grpo_loss_partial_kernel<4, true, false>), dim3(nblocks), dim3(kBlock), 0, s, a);
+    } else {
+      nblocks = resident_grid(grpo_loss_partial_kernel<4, false, false>, grid_for(a.n, 4));
+      hipLaunchKernelGGL((grpo_loss_partial_kernel<4, false, false>), dim3(nblocks), dim3(kBlock), 0, s, a);
+    }
   } else {
     nblocks = grid_for(a.n, 1);
-    hipLaunchKernelGGL(grpo_loss_partial_kernel<1>, dim3(nblocks), dim3(kBlock), 0, s, a);
+    if (a.cfg.policy_loss == PRL_POLICY_GSPO)
+      hipLaunchKernelGGL((grpo_loss_partial_kernel<1, false, true>), dim3(nblocks), dim3(kBlock), 0, s, a);
+    else
+      hipLaunchKernelGGL((grpo_loss_partial_kernel<1, false, false>), dim3(nblocks), dim3(kBlock), 0, s, a);
   }
   PRL_LAUNCH_CHECK("grpo_loss_partial_kernel");
   const int packed_counted = (a.packed && position_ids != nullptr) ? 1 : 0;
