@@ -13,6 +13,7 @@ Pinning: the reference ships no tests or golden vectors for this path (SURVEY.md
 the oracle is pinned against outputs of the reference's own functions run in the build
 container: `tests/golden/make_golden.py` imports `/root/reference/pipelinerl` and writes the
 fixtures under `tests/golden/`; `tests/test_oracle_golden.py` checks every oracle function
-against them.  The micro-batch schedule and the stream wire format could not be imported
-(missing third-party deps) and are restated from the source; see DESIGN.md "parity status".
+against them.  The micro-batch schedule loop is cut from the reference source and executed with
+recording stubs; the `files` stream backend is executed with stand-ins for its two missing imports;
+the weight-update protocol is restated from the source (vllm absent); see DESIGN.md "parity status".
 """

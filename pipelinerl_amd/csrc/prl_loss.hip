@@ -470,9 +470,9 @@ int grid_for(int64_t n, int vec) {
 }
 
 // min(wanted, CUs x resident blocks per CU) for `kernel`; the occupancy query runs once per kernel.
-template <typename K>
-int resident_grid(K kernel, int wanted) {
-  static const int cap = [&] {
+template <void (*kernel)(LossArgs)>
+int resident_grid(int wanted) {
+  static const int cap = [] {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return kMaxBlocks;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return kMaxBlocks;
@@ -565,13 +565,13 @@ extern "C" int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, i
     // blocks than fit runs in rounds and leaves the last round partly empty
     const bool is_gspo = a.cfg.policy_loss == PRL_POLICY_GSPO;
     if (is_gspo) {
-      nblocks = resident_grid(grpo_loss_partial_kernel<4, true, true>, grid_for(a.n, 4));
+      nblocks = resident_grid<grpo_loss_partial_kernel<4, true, true>>(grid_for(a.n, 4));
       hipLaunchKernelGGL((grpo_loss_partial_kernel<4, true, true>), dim3(nblocks), dim3(kBlock), 0, s, a);
     } else if (fast_stats()) {
-      nblocks = resident_grid(grpo_loss_partial_kernel<4, true, false>, grid_for(a.n, 4));
+      nblocks = resident_grid<grpo_loss_partial_kernel<4, true, false>>(grid_for(a.n, 4));
       hipLaunchKernelGGL((grpo_loss_partial_kernel<4, true, false>), dim3(nblocks), dim3(kBlock), 0, s, a);
     } else {
-      nblocks = resident_grid(grpo_loss_partial_kernel<4, false, false>, grid_for(a.n, 4));
+      nblocks = resident_grid<grpo_loss_partial_kernel<4, false, false>>(grid_for(a.n, 4));
       hipLaunchKernelGGL((grpo_loss_partial_kernel<4, false, false>), dim3(nblocks), dim3(kBlock), 0, s, a);
     }
   } else {

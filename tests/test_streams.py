@@ -177,3 +177,83 @@ def test_rollouts_binary_record_roundtrip(streams, tmp_path, libprl):
     want = ragged_to_entries(rag)
     assert [e["input_ids"] for e in rec] == [e["input_ids"] for e in want]
     assert [e["metadata"] for e in rec] == [e["metadata"] for e in want]
+
+
+# ---- interop with files written / read by the reference's own `files` backend -------------------
+# tests/golden/streams_files.json comes from tests/golden/make_streams_golden.py, which runs
+# pipelinerl/streams.py (reference :249-423) itself with stand-ins for the two missing imports.
+
+
+def _golden_streams():
+    from helpers import GOLDEN
+
+    return json.loads((GOLDEN / "streams_files.json").read_text())
+
+
+def _replay_scenario(s, exp):
+    """The same writes as make_streams_golden.scenario, through this package's API."""
+    from pydantic import BaseModel
+
+    class Msg(BaseModel):
+        kind: str = "samples_processed"
+        samples_processed: int = 0
+
+    class WithTensor(BaseModel):
+        model_config = {"arbitrary_types_allowed": True}
+        input_ids: torch.Tensor
+        rewards: torch.Tensor
+        model_version: int = 3
+        is_packed: bool = True
+
+    with s.write_to_streams(s.SingleStreamSpec(exp_path=exp, topic="actor")) as w:
+        w.write([{"input_ids": [1, 2, 3], "labels": [-100, 2, 3], "reward": 1.0, "logprobs": [-0.5, -0.25], "metadata": {"group_id": "g0"}}])
+        w.write([{"input_ids": [4], "labels": [4], "reward": 0.0, "logprobs": [-1.5], "metadata": {"group_id": "g1", "nested": [1, {"a": None}]}}])
+    rng = s.StreamRangeSpec(exp_path=exp, topic="training_data", partition_range=(0, 3))
+    with s.write_to_streams(rng) as w:
+        for i in range(5):
+            w.write({"i": i})
+        w.write({"i": "explicit"}, partition=2)
+        w.write(WithTensor(input_ids=torch.tensor([[5, 6, 7]]), rewards=torch.tensor([[0.5, 0.0, 1.0]])), partition=1)
+    spec = s.SingleStreamSpec(exp_path=exp, topic="stats", instance=2, partition=1)
+    with s.write_to_streams(spec) as w:
+        w.write(Msg(samples_processed=8))
+    with s.write_to_streams(spec) as w:
+        w.write(Msg(samples_processed=16))
+    spec_w = s.SingleStreamSpec(exp_path=exp, topic="weight_update_request")
+    with s.write_to_streams(spec_w) as w:
+        w.write({"version": 1})
+    with s.write_to_streams(spec_w, mode="w") as w:
+        w.write({"version": 2, "np": np.arange(3)})
+    return str(spec), str(rng)
+
+
+def test_files_backend_writes_what_the_reference_writes(streams, tmp_path):
+    """Same directory tree, same number of lines per file, same parsed record per line."""
+    g = _golden_streams()
+    streams.set_streams_backend("files")
+    str_single, str_range = _replay_scenario(streams, tmp_path)
+    assert str_single == g["str_single"] and str_range == g["str_range"]
+    mine = {str(p.relative_to(tmp_path)): p.read_text() for p in sorted(tmp_path.rglob("*")) if p.is_file()}
+    assert sorted(mine) == sorted(g["files"])
+    for rel, want_text in g["files"].items():
+        got_lines, want_lines = mine[rel].split("\n"), want_text.split("\n")
+        assert got_lines[-1] == "" and len(got_lines) == len(want_lines), rel  # newline-terminated, one record per line
+        assert [json.loads(l) for l in got_lines[:-1]] == [json.loads(l) for l in want_lines[:-1]], rel
+
+
+def test_files_backend_reads_reference_written_files(streams, tmp_path):
+    """Files produced by the reference are consumed record for record (debug.streams_from replay),
+    and the reader yields exactly what the reference's own reader yielded."""
+    g = _golden_streams()
+    for rel, text in g["files"].items():
+        p = tmp_path / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_text(text)
+    streams.set_streams_backend("files")
+    for rel, want in g["records"].items():
+        _, topic, instance, partition, _ = rel.split("/")
+        spec = streams.SingleStreamSpec(exp_path=tmp_path, topic=topic, instance=int(instance), partition=int(partition))
+        with streams.read_stream(spec) as r:
+            it = r.read()
+            got = [next(it) for _ in range(len(want))]
+        assert got == want, rel
