@@ -29,8 +29,12 @@ class SharedMemoryQueue:
         self._ring = Ring(n_slots=max_size, slot_bytes=max_entry_size)
 
     def put(self, item: Any, block: bool = True, timeout: float | None = None) -> None:
-        """Raises queue.Full when no slot frees up, ValueError when the pickle exceeds a slot."""
-        self._ring.put_bytes(pickle.dumps(item, protocol=pickle.HIGHEST_PROTOCOL), block=block, timeout=timeout)
+        """Raises queue.Full when no slot frees up, ValueError when the pickle exceeds a slot.
+        (The reference takes the slot before it checks the size and never returns it, so every
+        oversize put permanently shrinks its queue by one slot — shared_memory_array.py:150-158,
+        pinned in tests/golden/queue_trace.json; here the capacity is unchanged.)"""
+        # default pickle protocol, as the reference: the oversize threshold is on the pickled size
+        self._ring.put_bytes(pickle.dumps(item), block=block, timeout=timeout)
 
     def get(self, block: bool = True, timeout: float | None = None) -> Any:
         """Raises queue.Empty when nothing arrives in time."""

@@ -85,3 +85,52 @@ def test_shared_memory_queue_interface(libprl):
     with pytest.raises(ValueError):
         SharedMemoryQueue(None, 0, 10)
     q.close()
+
+
+def test_shared_memory_queue_matches_reference_trace(libprl):
+    """Differential test against the operation trace of the reference's own SharedMemoryQueue
+    (tests/golden/make_queue_golden.py): results, exceptions, qsize/full/max_actual_entry_size after
+    every operation.  One deliberate divergence: the reference leaks a slot on an oversize put."""
+    import json
+    import pickle
+    import sys
+    from queue import Empty, Full
+
+    from helpers import GOLDEN
+    from pipelinerl_amd.shared_memory_array import SharedMemoryQueue
+
+    sys.path.insert(0, str(GOLDEN))
+    from make_queue_golden import SCRIPT
+
+    g = json.loads((GOLDEN / "queue_trace.json").read_text())
+    for name, args in (("zero_size", (0, 16)), ("zero_entry", (4, 0))):
+        assert g["ctor"][name] == "ValueError"
+        with pytest.raises(ValueError):
+            SharedMemoryQueue(None, *args)
+    q = SharedMemoryQueue(None, 3, 256)
+    mine = []
+    for op, arg in SCRIPT:
+        try:
+            if op == "put":
+                q.put(arg, block=False)
+                res = "ok"
+            else:
+                res = {"item": q.get(block=True, timeout=0.05)}
+        except Full:
+            res = "Full"
+        except Empty:
+            res = "Empty"
+        except ValueError:
+            res = "ValueError"
+        mine.append({"op": op, "result": res, "qsize": q.qsize(), "full": q.full(), "max_actual_entry_size": q.max_actual_entry_size()})
+    q.close()
+    leak = next(i for i, r in enumerate(g["trace"]) if r["result"] == "ValueError")
+    for i in range(leak + 1):  # identical up to and including the oversize put
+        want = {k: g["trace"][i][k] for k in ("op", "result", "qsize", "full", "max_actual_entry_size")}
+        assert mine[i] == want, (i, mine[i], want)
+    assert len(pickle.dumps(SCRIPT[leak][1])) == g["trace"][leak]["pickled_size"] > 256
+    # afterwards the reference runs with 2 usable slots (put/put -> ok/Full); this queue keeps all 3
+    assert [r["result"] for r in g["trace"][leak + 1 : leak + 4]] == ["ok", "Full", "Full"]
+    assert [r["result"] for r in mine[leak + 1 : leak + 4]] == ["ok", "ok", "Full"]
+    assert [r["result"] for r in mine[leak + 4 :]] == [{"item": {"nested": {"k": [1.5, None, True]}}}, {"item": 9}, {"item": 10}, "Empty", "Empty"]
+    assert mine[-1]["qsize"] == 0 and mine[-1]["full"] is False
