@@ -68,3 +68,57 @@ def test_trainer_state_follows_messages(tmp_path):
         assert dbg.propagated_weight_version == 0 and dbg.samples_processed == 0 and dbg.wait_for_training_done(0)
     finally:
         streams.reset_streams_backend()
+
+
+def test_trainer_messages_and_state_match_reference(tmp_path):
+    """tests/golden/trainer_messages.json: the reference's own message models, files backend and
+    TrainerState executed on a message sequence.  (a) this package's models dump the same fields,
+    (b) its TrainerState, following the file the REFERENCE wrote, passes through the same states."""
+    import json
+    import time
+
+    from helpers import GOLDEN
+    from pipelinerl_amd import finetune_loop as fl
+    from pipelinerl_amd import streams
+    from pipelinerl_amd.state import TrainerState
+
+    g = json.loads((GOLDEN / "trainer_messages.json").read_text())
+    assert fl.TRAINER_TOPIC == g["topic"]
+    # (a) every reference dump parses into the same-kind model, and our dump carries the reference's
+    # fields with equal values (extra keys are the MI355X transport extensions with defaults)
+    extensions = {"transport", "bucket_bytes", "ipc_handles", "ipc_nbytes"}
+    for want in g["dumps"]:
+        msg = fl.parse_trainer_message(want)
+        got = msg.model_dump()
+        assert got["kind"] == want["kind"]
+        assert {k: got[k] for k in want} == want
+        assert set(got) - set(want) <= extensions
+    # (b) follow the reference-written stream line by line
+    rel, text = next(iter(g["files"].items()))
+    lines = text.splitlines(keepends=True)
+    path = tmp_path / rel
+    path.parent.mkdir(parents=True)
+    streams.reset_streams_backend()
+    streams.set_streams_backend("files")
+    try:
+        st = TrainerState(tmp_path)
+        snap = lambda: {"propagated_weight_version": st.propagated_weight_version, "samples_processed": st.samples_processed,  # noqa: E731
+                        "training_done": st.training_done}
+        trace = g["state_trace"]
+        assert snap() == {k: trace[0][k] for k in snap()}
+        with open(path, "a") as f:
+            f.write(lines[0])
+            f.flush()
+            st.start_listening()
+            for i, want in enumerate(trace[1:]):
+                if i > 0:
+                    f.write(lines[i])
+                    f.flush()
+                want_state = {k: want[k] for k in ("propagated_weight_version", "samples_processed", "training_done")}
+                deadline = time.monotonic() + 5.0
+                while snap() != want_state and time.monotonic() < deadline:
+                    time.sleep(0.02)
+                assert snap() == want_state, (i, snap(), want_state)
+        assert st.wait_for_training_done(timeout=1.0) == g["wait_for_training_done"]
+    finally:
+        streams.reset_streams_backend()
