@@ -15,5 +15,6 @@ container: `tests/golden/make_golden.py` imports `/root/reference/pipelinerl` an
 fixtures under `tests/golden/`; `tests/test_oracle_golden.py` checks every oracle function
 against them.  The micro-batch schedule loop is cut from the reference source and executed with
 recording stubs; the `files` stream backend is executed with stand-ins for its two missing imports;
-the weight-update protocol is restated from the source (vllm absent); see DESIGN.md "parity status".
+the weight-update sender / receiver, the trainer messages and TrainerState are cut from the source and
+executed with recording stubs for their absent dependencies; see DESIGN.md "parity status".
 """

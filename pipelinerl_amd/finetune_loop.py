@@ -59,8 +59,10 @@ class WeightUpdateRequest(BaseModel):
     parameters_info: list[ParameterInfo]
     timestamp: float = Field(default_factory=time.time)
     # MI355X extensions: how the bytes travel ("per_tensor" = reference behaviour, "bucketed" = RCCL
-    # buckets, "ipc" = trainer and worker share one GPU: the request carries HIP IPC handles)
-    transport: str = "bucketed"
+    # buckets, "ipc" = trainer and worker share one GPU: the request carries HIP IPC handles).
+    # A request WITHOUT the field comes from an unmodified reference trainer, hence the default;
+    # this package's WeightUpdateManager always states its transport.
+    transport: str = "per_tensor"
     bucket_bytes: int = 1 << 30
     ipc_handles: list[str] = Field(default_factory=list)
     ipc_nbytes: list[int] = Field(default_factory=list)

@@ -163,18 +163,23 @@ class WeightSyncGroup:
             self._h = ctypes.c_void_p()
 
 
-_DTYPES = {str(d): d for d in (torch.bfloat16, torch.float32, torch.float16)}
+_DTYPE_NAMES = {
+    torch.bfloat16: ("bfloat16", "bf16"),
+    torch.float32: ("float32", "fp32", "float"),
+    torch.float16: ("float16", "fp16", "half"),
+}
+_DTYPES = {alias: dt for dt, aliases in _DTYPE_NAMES.items() for alias in aliases}
 
 
 def string_to_dtype(name: str) -> torch.dtype:
-    """'torch.bfloat16' -> torch.bfloat16; the dtype string travels in ParameterInfo.dtype
-    (finetune_loop.py:226,273) and the receiver must honour whatever arrives."""
-    if name in _DTYPES:
-        return _DTYPES[name]
-    d = getattr(torch, name.split(".")[-1], None)
-    if not isinstance(d, torch.dtype):
-        raise ValueError(f"unknown dtype string {name!r}")
-    return d
+    """'torch.bfloat16' -> torch.bfloat16: the dtype string travels in ParameterInfo.dtype
+    (finetune_loop.py:226,273).  Accepts what the reference's receiver accepts
+    (vllm_quantization.py:64-82: case-insensitive, optional `torch.` prefix, the three floating
+    types and their short names) and raises ValueError for anything else."""
+    key = name.lower().replace("torch.", "").strip()
+    if key not in _DTYPES:
+        raise ValueError(f"Unsupported dtype string: {name!r}. Supported values: {sorted(_DTYPES)}")
+    return _DTYPES[key]
 
 
 def _segment_table(bucket: Sequence[tuple[ParamSpec, int]], tensors: dict[str, torch.Tensor], writable: bool):

@@ -60,7 +60,7 @@ def test_trainer_state_follows_messages(tmp_path):
             assert st.wait_for_training_done(timeout=5)
             assert st.samples_processed == 32 and st.training_done
         msg = parse_trainer_message({"kind": "weight_update_request", "version": 3, "parameters_info": [{"name": "w", "shape": [2, 3], "dtype": "torch.bfloat16"}]})
-        assert msg.parameters_info[0].shape == [2, 3] and msg.transport == "bucketed"
+        assert msg.parameters_info[0].shape == [2, 3] and msg.transport == "per_tensor"  # no field = reference trainer
         with pytest.raises(ValueError):
             parse_trainer_message({"kind": "nope"})
         dbg = TrainerState(tmp_path)
