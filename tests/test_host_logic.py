@@ -165,3 +165,46 @@ def test_make_rl_data_callback():
     cb = make_rl_data_callback(None, None, RLConfig(divide_advantage_by_std=False), None)
     assert cb.func is populate_rl_data and cb.keywords["config"].divide_advantage_by_std is False
     assert make_rl_data_callback(None, None, None, None) is None
+
+
+def test_sample_accounting_matches_reference():
+    """get_batch_token_count / get_batch_sequence_count / calculate_train_steps against the
+    reference's own functions (tests/golden/make_counts_golden.py executes them on the batches its
+    collate functions produced - the same batches stored in preprocess_*.npz)."""
+    import json
+    import types
+
+    import torch
+
+    from helpers import GOLDEN, PREPROCESS_CASES, load_preprocess_case
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.finetune.utils import create_sentinel_batch
+    from pipelinerl_amd.finetune_loop import calculate_train_steps, get_batch_sequence_count, get_batch_token_count
+
+    g = json.loads((GOLDEN / "batch_counts.json").read_text())
+
+    def build(d):
+        kw = {}
+        for k, v in d.items():
+            if k.startswith("__"):
+                continue
+            kw[k] = torch.from_numpy(v) if v.ndim > 0 else v.item()
+        return PipelineBatchEncoding(**kw)
+
+    seen = 0
+    for name in PREPROCESS_CASES:
+        case = load_preprocess_case(name)
+        for kind in ("packed", "padded"):
+            for plan, arrays in case[kind].items():
+                want = g["batches"][f"{name}/{kind}/{plan}"]
+                b = build(arrays)
+                assert get_batch_token_count(b) == want["tokens"] and get_batch_sequence_count(b) == want["sequences"], (name, kind, plan)
+                if "padding" in want:
+                    assert int(b.padding) == want["padding"]
+                seen += 1
+    assert seen == len(g["batches"]) - 1
+    s = create_sentinel_batch(device="cpu", tokenizer=types.SimpleNamespace(eos_token_id=7), model_version=5)
+    assert get_batch_token_count(s) == g["batches"]["sentinel"]["tokens"] and get_batch_sequence_count(s) == g["batches"]["sentinel"]["sequences"]
+    for rec in g["train_steps"]:
+        args = types.SimpleNamespace(interrupt_train_steps=rec["cfg_interrupt"], max_train_steps=rec["max"])
+        assert calculate_train_steps(args, rec["arg"]) == rec["result"], rec
