@@ -37,7 +37,7 @@ echo "bench full exit $?" | tee -a $OUT/bench_full.log
 tail -2 $OUT/bench_full.log | cut -c1-1500
 
 echo "== rocprof stats of the default bench command"
-cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_stats -o stats -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_stats.log 2>&1
+cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_stats -o stats -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-weight-sync > $GRAFT_REPO_ROOT/$OUT/rocprof_stats.log 2>&1
 echo "rocprof exit $?" | tee -a $GRAFT_REPO_ROOT/$OUT/rocprof_stats.log
 cd $GRAFT_REPO_ROOT
 find $OUT/prof_stats -name "*kernel_stats*" | head; for f in $(find $OUT/prof_stats -name "*kernel_stats.csv" | head -1); do head -12 $f; done
