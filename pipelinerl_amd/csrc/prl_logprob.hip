@@ -67,11 +67,17 @@ struct BF16 {
       o[2 * i + 1] = __uint_as_float(x[i] & 0xffff0000u);
     }
   }
+  // gfx950 converts two fp32 to packed bf16 (round to nearest even) in one instruction
+  // (v_cvt_pk_bf16_f32) - the software RNE above costs ~7 VALU operations per element.
   __device__ static __forceinline__ vec pack(const float (&o)[NV]) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     vec x;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      x[i] = (uint32_t)from_float(o[2 * i]) | ((uint32_t)from_float(o[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 pair = {o[2 * i], o[2 * i + 1]};
+      x[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pair, bf16x2));
+    }
     return x;
   }
 };
@@ -699,8 +705,10 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
   //   6: as 3 with unroll 4   7: as 3 with plain stores   8: 512 threads, 1 per CU   9: as 3 with unroll 1
   //   10-14: row-resident variants (KREG vectors per lane in VGPRs + KLDS in LDS stay on chip)
   int variant = kDefaultFusedVariant;
-  // a bf16 row of the same vocabulary is half as long: 16 + 2 vectors per lane hold 97 % of it
-  if (logits_dtype == PRL_DTYPE_BF16) variant = 23;
+  // bf16 rows carry twice the exp/convert work per byte and a whole step's rows (304 KB x 256 CUs)
+  // sit in the Infinity Cache, so the row-resident structure loses to the two-sweep kernel with two
+  // 512-thread workgroups per CU (profiles/r01r_kernel_sweep_bf16.txt: 1091 vs 1664 us)
+  if (logits_dtype == PRL_DTYPE_BF16) variant = 4;
   if (const char* e = getenv("PRL_FUSED_VARIANT")) variant = atoi(e);
 #define PRL_FUSED_LAUNCH(TT, ST, BLK, UNR, REV, NTS, LDSB)                                            \
   do {                                                                                              \

@@ -121,6 +121,25 @@ def main():
         med, mn = timeit(fused, iters=8)
         report(f"fused K1+grad+K1' variant {variant} [algorithmic: read+write V*4/token]", 2 * T * V * 4, med, mn)
     os.environ.pop("PRL_FUSED_VARIANT", None)
+    # ---- the same micro-batch with bf16 logits in and bf16 d-logits out (a bf16 lm_head): a 304 KB row,
+    #      97 % of it stays on chip between the two passes (variant 23: 16 + 2 vectors per lane)
+    if not quick:
+        lb = logits.to(torch.bfloat16)
+        gb = torch.empty_like(lb)
+        fused_bf16 = lambda: _lib.check(lib.prl_fused_logits_loss(  # noqa: E731
+            ctypes.byref(c_cfg), 1, T, V, lb.data_ptr(), 1, V, 1.0, ids.data_ptr(), b0.labels.data_ptr(), b0.old_logprobs.data_ptr(),
+            b0.ref_logprobs.data_ptr(), b0.advantages.data_ptr(), b0.rewards.data_ptr(), b0.group_tokens.data_ptr(), b0.overflow.data_ptr(),
+            o_nlp.data_ptr(), o_ent.data_ptr(), o_lse.data_ptr(), gb.data_ptr(), stream))
+        fused_bf16()  # new logprobs of the bf16 logits -> make the rollouts on-policy w.r.t. THEM
+        b0.old_logprobs[:, 1:] = torch.where(b0.labels[:, 1:] != -100, o_nlp[:, 1:] + 0.005 * torch.randn_like(o_nlp[:, 1:]), b0.old_logprobs[:, 1:])
+        b0.ref_logprobs.copy_(b0.old_logprobs)
+        fused_bf16()
+        print("bf16 rows with non-zero gradient:", int((gb.float().abs().amax(dim=-1) != 0).sum()), "of", T)
+        for variant in (23, 6, 4, 3, 4):
+            os.environ["PRL_FUSED_VARIANT"] = str(variant)
+            med, mn = timeit(fused_bf16, iters=8)
+            report(f"fused bf16 logits variant {variant} [algorithmic: read+write V*2/token]", 2 * T * V * 2, med, mn)
+        os.environ.pop("PRL_FUSED_VARIANT", None)
     t0 = time.perf_counter()
     print("done", time.perf_counter() - t0)
 
