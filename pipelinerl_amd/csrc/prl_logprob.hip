@@ -701,9 +701,12 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
   // Variant selection (PRL_FUSED_VARIANT, read per call so one process can sweep them):
   //   0: 256 threads x unroll 4, forward order          1: + reversed second pass
   //   2: + non-temporal gradient stores                 3: 1024 threads, 1 workgroup per CU, reversed, NT
-  //   4: 512 threads, 2 workgroups per CU, reversed, NT 5: 1024 threads, 1 workgroup per CU, forward order
-  //   6: as 3 with unroll 4   7: as 3 with plain stores   8: 512 threads, 1 per CU   9: as 3 with unroll 1
-  //   10-14: row-resident variants (KREG vectors per lane in VGPRs + KLDS in LDS stay on chip)
+  //   4: 512 threads, 2 workgroups per CU, reversed, NT 6: as 3 with unroll 4
+  //   11 / 21 / 22 / 23: row-resident (KREG vectors per lane in VGPRs + KLDS in LDS stay on chip);
+  //   21 = 11 with non-temporal head loads, 22 = registers only, 23 = 16 + 2 vectors
+  // The other geometries of the round-1 sweeps (5, 7-10, 12-20: forward order, plain stores, 256 /
+  // 512 / 768-thread retention shapes) measured slower and were removed from the build; their
+  // numbers stay in profiles/r01[c-f]_kernel_sweep*.txt.
   int variant = kDefaultFusedVariant;
   // bf16 rows carry twice the exp/convert work per byte and a whole step's rows (304 KB x 256 CUs)
   // sit in the Infinity Cache, so the row-resident structure loses to the two-sweep kernel with two
@@ -744,17 +747,7 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
   } while (0)
 #define PRL_FUSED_DISPATCH(TT, ST)                                              \
   switch (variant) {                                                            \
-    case 10: PRL_KEEP_LAUNCH(TT, ST, 1024, 2, 16, 0); break;                    \
     case 11: PRL_KEEP_LAUNCH(TT, ST, 1024, 2, 16, 9); break;                    \
-    case 12: PRL_KEEP_LAUNCH(TT, ST, 1024, 2, 20, 9); break;                    \
-    case 13: PRL_KEEP_LAUNCH(TT, ST, 1024, 2, 12, 9); break;                    \
-    case 14: PRL_KEEP_LAUNCH(TT, ST, 1024, 4, 16, 9); break;                    \
-    case 15: PRL_KEEP_LAUNCH(TT, ST, 512, 2, 44, 19); break;                    \
-    case 16: PRL_KEEP_LAUNCH(TT, ST, 512, 2, 46, 19); break;                    \
-    case 17: PRL_KEEP_LAUNCH(TT, ST, 256, 2, 96, 38); break;                    \
-    case 18: PRL_KEEP_LAUNCH(TT, ST, 768, 2, 26, 12); break;                    \
-    case 19: PRL_KEEP_LAUNCH(TT, ST, 512, 1, 48, 19); break;                    \
-    case 20: PRL_KEEP_LAUNCH(TT, ST, 512, 2, 40, 19); break;                    \
     case 21: PRL_KEEP_LAUNCH2(TT, ST, 1024, 2, 16, 9, true); break;             \
     case 22: PRL_KEEP_LAUNCH2(TT, ST, 1024, 2, 16, 0, true); break;             \
     case 23: PRL_KEEP_LAUNCH2(TT, ST, 1024, 2, 16, 2, true); break;             \
@@ -762,11 +755,7 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
     case 2: PRL_FUSED_LAUNCH(TT, ST, 256, 4, true, true, 0); break;             \
     case 3: PRL_FUSED_LAUNCH(TT, ST, 1024, 2, true, true, 96 * 1024); break;    \
     case 4: PRL_FUSED_LAUNCH(TT, ST, 512, 4, true, true, 64 * 1024); break;     \
-    case 5: PRL_FUSED_LAUNCH(TT, ST, 1024, 2, false, false, 96 * 1024); break;  \
     case 6: PRL_FUSED_LAUNCH(TT, ST, 1024, 4, true, true, 96 * 1024); break;    \
-    case 7: PRL_FUSED_LAUNCH(TT, ST, 1024, 2, true, false, 96 * 1024); break;   \
-    case 8: PRL_FUSED_LAUNCH(TT, ST, 512, 4, true, true, 96 * 1024); break;     \
-    case 9: PRL_FUSED_LAUNCH(TT, ST, 1024, 1, true, true, 96 * 1024); break;    \
     default: PRL_FUSED_LAUNCH(TT, ST, 256, 4, false, false, 0); break;          \
   }
   if (logits_dtype == PRL_DTYPE_F32) {

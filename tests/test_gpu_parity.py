@@ -431,7 +431,7 @@ def test_wsync_single_rank_group(libprl, cuda_device):
     grp.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 11, 21, 22, 23])
 def test_fused_kernel_variants_agree(libprl, cuda_device, variant, monkeypatch):
     """The launch-geometry variants of the fused logits kernel (block size, reversed second pass,
     non-temporal stores, residency cap) are the same arithmetic per element: bitwise equal."""
