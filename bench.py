@@ -52,6 +52,8 @@ def parse_args():
     p.add_argument("--logits-mode", default=os.environ.get("PRL_BENCH_LOGITS_MODE", "fused"), choices=["fused", "two_pass"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-weight-sync", action="store_true")
+    p.add_argument("--cpu-baseline-threads", default=None,
+                   help="comma-separated thread counts: time ONLY the cpu_baseline loss leg at each count and exit (no GPU work)")
     p.add_argument("--backend", default=os.environ.get("PRL_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                    help="gloo + PRL_BENCH_SHARE_DEVICE=1 runs N ranks on ONE GPU (dry run of the N > 1 logic)")
     return p.parse_args()
@@ -97,6 +99,31 @@ def usable_host_cores() -> int:
     except (OSError, ValueError):
         pass
     return n
+
+
+def cpu_baseline_thread_sweep(counts: list[int], seq_length: int, vocab: int, t_logits: int = 1024) -> None:
+    """Thread sweep of the cpu_baseline loss leg (profiles/r01p_cpu_baseline_threads.txt): which
+    thread count is fair to report on this host."""
+    from oracle import preprocess as opre
+    from oracle import rl_loss_torch as orlt
+    from pipelinerl_amd.synthetic import make_ragged, ragged_to_entries
+
+    print("nproc", os.cpu_count(), "usable", usable_host_cores(), flush=True)
+    t_logits = min(t_logits, seq_length)
+    rag, reasons = make_ragged(1, attempts=8, seq_length=seq_length, vocab=vocab, seed=99, dense=True)
+    batch = opre.collate_packed([opre.preprocess_chunk(ragged_to_entries(rag, reasons), 2, False)[0]], 2, 1)
+    b = {k: (v[:, :t_logits] if isinstance(v, np.ndarray) and v.ndim == 2 else v) for k, v in batch.items()}
+    cfg = dict(policy_loss="ppo", epsilon_low=0.02, epsilon_high=0.02, kl_coef=0.0, final_kl_coef=0.0,
+               clamp_log_ratio_ref_new_value=5, divide_advantage_by_std=False, batch_size=4096, temperature=1.0)
+    logits = (np.random.default_rng(0).standard_normal((1, t_logits, vocab)) * 2).astype(np.float32)
+    for n in counts:
+        torch.set_num_threads(n)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            orlt.rl_step_closed_form(logits, b, cfg, 0, 10, True)
+            ts.append(time.perf_counter() - t0)
+        print(f"threads {n:4d}: {min(ts[1:]) / t_logits * 1e6:8.1f} us/token", flush=True)
 
 
 def cpu_baseline(seq_length: int, vocab: int) -> dict:
@@ -195,6 +222,10 @@ def weight_sync_probe(rank: int, world: int, dev: torch.device) -> dict | None:
 
 def main():
     args = parse_args()
+    if args.cpu_baseline_threads:
+        _, seq_length, vocab, _ = WORKLOADS[args.workload]
+        cpu_baseline_thread_sweep([int(x) for x in args.cpu_baseline_threads.split(",")], seq_length, vocab)
+        return
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", 0))
