@@ -213,19 +213,43 @@ def segment_sums(segment_ids: torch.Tensor, labels: torch.Tensor, a: torch.Tenso
     return out
 
 
-def gspo_segment_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, new_logprobs: torch.Tensor):
+def _group_all_reduce(t: torch.Tensor, group: Any, op: Any) -> torch.Tensor:
+    """All-reduce a small device tensor over `group`; a gloo group gets it through host memory."""
+    import torch.distributed as dist
+
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        return h.to(t.device)
+    dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def gspo_segment_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, new_logprobs: torch.Tensor, seq_parallel_group: Any = None):
     """Sequence-level (GSPO) policy term, reference rl/__init__.py:310-352 + rl/utils.py:106-208:
     per-segment masked means of log(new/old) and of the advantages (segment-sum kernel), clipped
     sequence ratio, loss = -sum_s min(r_s A_s, clip(r_s) A_s) * (sum of the segment's token weights).
     Returns (loss scalar, per-token d loss/d new_logprobs coefficient, per-token clip indicator);
-    the O(#segments) arithmetic runs as a handful of device tensor ops."""
+    the O(#segments) arithmetic runs as a handful of device tensor ops.
+
+    With `seq_parallel_group` the batch is one `make_slices` slice of a packed sequence: the four
+    per-segment sums are added over the group in ONE all-reduce (the reference issues one per
+    column, rl/utils.py:194-206), every rank then holds the full loss, and - as with the reference's
+    differentiable all-reduce, whose backward sums the identical gradients of all ranks - the token
+    gradient carries a factor `group size`."""
+    import torch.distributed as dist
+
+    sp = seq_parallel_group is not None and dist.is_available() and dist.is_initialized()
     seg_ids = batch.segment_ids
     if seg_ids is None:
         raise ValueError("segment_ids must be provided for per-segment reductions")
     if batch.seq_boundaries is not None:
-        n_seg = int(batch.seq_boundaries.shape[0]) - 1
+        n_seg = int(batch.seq_boundaries.shape[0]) - 1  # slices carry the boundaries of the whole sequence
     else:
-        n_seg = int(seg_ids.max().item()) + 1
+        top = seg_ids.max().to(torch.int64).reshape(1) if seg_ids.numel() else torch.full((1,), -1, dtype=torch.int64, device=seg_ids.device)
+        if sp:
+            top = _group_all_reduce(top, seq_parallel_group, dist.ReduceOp.MAX)
+        n_seg = int(top.item()) + 1
     f32 = torch.float32
     lrno = new_logprobs - batch.old_logprobs
     if cfg.group_normalization:
@@ -236,6 +260,10 @@ def gspo_segment_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, new_log
         w = w * (1 - batch.overflow)
     lrn_sum, adv_sum, cnt = segment_sums(seg_ids, batch.labels, lrno, batch.advantages, n_seg)
     w_sum, _, _ = segment_sums(seg_ids, batch.labels, w, torch.zeros_like(w), n_seg)
+    grad_scale = 1.0
+    if sp:
+        lrn_sum, adv_sum, cnt, w_sum = _group_all_reduce(torch.stack([lrn_sum, adv_sum, cnt, w_sum]), seq_parallel_group, dist.ReduceOp.SUM)
+        grad_scale = float(dist.get_world_size(seq_parallel_group))
     cnt32 = cnt.to(f32)
     den = cnt32.clamp(min=1e-6)
     ratio = torch.exp(lrn_sum.to(f32) / den)
@@ -253,12 +281,17 @@ def gspo_segment_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, new_log
         loss = -(torch.minimum(s1, s2) * valid.to(f32) * w_sum).sum()
     inside = ((ratio >= cfg.clip_lo) & (ratio <= cfg.clip_hi)).to(f32)
     dmin = torch.where(s1 < s2, adv, torch.where(s2 < s1, adv * inside, 0.5 * adv + 0.5 * adv * inside))
-    coef = -(w_sum * valid.to(f32)) * dmin * ratio / den
+    coef = -(w_sum * valid.to(f32)) * dmin * ratio / den * grad_scale
     if batch.sentinel:
         coef = torch.zeros_like(coef)
     idx = seg_ids.reshape(-1).clamp(0, max(n_seg - 1, 0))
     ext_g = coef[idx].reshape(new_logprobs.shape).contiguous()
-    ext_c = indicator.to(f32)[idx].reshape(new_logprobs.shape).contiguous()
+    # The reference expands the clip indicator with zip(local segments, per-segment values)
+    # (rl/__init__.py:347-350): the j-th sequence STARTING OR CONTINUING in this slice takes the
+    # value of global segment j.  Identical to indexing by segment id when the slice starts at 0.
+    first = seg_ids.reshape(-1)[:1] if seg_ids.numel() else seg_ids.reshape(-1)
+    local_idx = (seg_ids.reshape(-1) - first).clamp(0, max(n_seg - 1, 0)) if seg_ids.numel() else idx
+    ext_c = indicator.to(f32)[local_idx].reshape(new_logprobs.shape).contiguous()
     return loss, ext_g, ext_c
 
 
@@ -282,7 +315,7 @@ class _GrpoLossFn(torch.autograd.Function):
     """logits -> (loss, stats) with a hand-written backward to the logits."""
 
     @staticmethod
-    def forward(ctx, logits, batch, cfg, temperature, fused, inplace):  # type: ignore[override]
+    def forward(ctx, logits, batch, cfg, temperature, fused, inplace, sp_group=None):  # type: ignore[override]
         lib = _lib.load()
         B, L, V = logits.shape
         dev = logits.device
@@ -311,7 +344,7 @@ class _GrpoLossFn(torch.autograd.Function):
         else:
             nlp, ent, lse2, lg = logprob_entropy(logits, ids, temperature)
             if cfg.policy_loss == _lib.PRL_POLICY_GSPO:
-                seg_loss, ext_g, ext_c = gspo_segment_terms(cfg, batch, nlp)
+                seg_loss, ext_g, ext_c = gspo_segment_terms(cfg, batch, nlp, sp_group)
                 _, stats, g_nlp, g_ent = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=True,
                                                                   ext_token_grad=ext_g, ext_clamp_indicator=ext_c)
                 loss = seg_loss
@@ -334,7 +367,7 @@ class _GrpoLossFn(torch.autograd.Function):
             scale = float(grad_loss.item())
             if scale != 1.0:
                 grad.mul_(scale)
-            return grad, None, None, None, None, None
+            return grad, None, None, None, None, None, None
         lib = _lib.load()
         lg, ids, lse2, ent, g_nlp, g_ent = ctx.saved_tensors
         B, L, V = lg.shape
@@ -349,7 +382,7 @@ class _GrpoLossFn(torch.autograd.Function):
                     _lib.ptr(up), _lib.ptr(grad), _lib.current_stream_ptr(dev),
                 )
             )
-        return grad, None, None, None, None, None
+        return grad, None, None, None, None, None, None
 
 
 _STAT_KEYS_IN_ORDER = [
@@ -398,8 +431,6 @@ def rl_step(
     if config.policy_loss == "gspo":
         if not batch.is_packed:
             raise ValueError("GSPO loss requires packed sequences with segments")
-        if seq_parallel_group is not None:
-            raise NotImplementedError("GSPO across sequence-parallel slices is not supported")
     if hasattr(model, "value_head"):
         raise NotImplementedError("value-head (actor-critic) batches are outside the GRPO hot path")
     cfg, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
@@ -421,7 +452,7 @@ def rl_step(
 
     loss, stats_dev = _GrpoLossFn.apply(
         logits, batch, cfg, config.temperature, bool(config.fused_logits_grad) and config.policy_loss != "gspo",
-        bool(config.inplace_logits_grad),
+        bool(config.inplace_logits_grad), seq_parallel_group if config.policy_loss == "gspo" else None,
     )
     stats = stats_dev.cpu().tolist()  # the single device->host sync of the step
     check_finite(stats)

@@ -20,7 +20,11 @@ INT_KEYS = ("input_ids", "attention_mask", "labels", "position_ids", "segment_id
 
 
 def load_rl_case(name: str) -> dict:
-    z = np.load(GOLDEN / f"rl_step_{name}.npz", allow_pickle=False)
+    """`name`: an rl_step case name, or the stem of any fixture with the same layout (gspo_sp2_*)."""
+    path = GOLDEN / f"rl_step_{name}.npz"
+    if not path.exists():
+        path = GOLDEN / f"{name}.npz"
+    z = np.load(path, allow_pickle=False)
     batch = {k[len("batch/"):]: z[k] for k in z.files if k.startswith("batch/")}
     for k in ("model_version", "sentinel", "padding", "is_packed"):
         if k in batch:
