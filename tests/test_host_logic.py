@@ -208,3 +208,22 @@ def test_sample_accounting_matches_reference():
     for rec in g["train_steps"]:
         args = types.SimpleNamespace(interrupt_train_steps=rec["cfg_interrupt"], max_train_steps=rec["max"])
         assert calculate_train_steps(args, rec["arg"]) == rec["result"], rec
+
+
+def test_aggregate_rl_stats_matches_reference():
+    """tests/golden/aggregate.json: the reference's aggregate_rl_stats / linear_decay_coef run on the
+    statistics of the rl_step fixtures."""
+    import json
+
+    from helpers import GOLDEN
+    from pipelinerl_amd.finetune.rl import linear_decay_coef
+    from pipelinerl_amd.finetune.rl.utils import aggregate_rl_stats
+
+    g = json.loads((GOLDEN / "aggregate.json").read_text())
+    for case in g["cases"]:
+        got = aggregate_rl_stats(case["stats"], case["num_samples"])
+        assert list(got) == list(case["out"])
+        for k, want in case["out"].items():
+            assert got[k] == pytest.approx(want, rel=2e-6, abs=1e-9), k  # fp32 summation order only
+    for rec in g["linear_decay"]:
+        assert linear_decay_coef(*rec["args"]) == rec["out"]
