@@ -227,3 +227,19 @@ def test_aggregate_rl_stats_matches_reference():
             assert got[k] == pytest.approx(want, rel=2e-6, abs=1e-9), k  # fp32 summation order only
     for rec in g["linear_decay"]:
         assert linear_decay_coef(*rec["args"]) == rec["out"]
+
+
+def test_rollout_models_match_reference():
+    """tests/golden/rollouts_models.json: field tables and dumps of the reference's own plugin models."""
+    import json
+    import sys
+
+    from helpers import GOLDEN
+    from pipelinerl_amd import rollouts
+
+    sys.path.insert(0, str(GOLDEN))
+    from make_rollouts_golden import describe
+
+    want = json.loads((GOLDEN / "rollouts_models.json").read_text())
+    got = json.loads(json.dumps(describe(rollouts)))
+    assert got == want
