@@ -1,6 +1,7 @@
 """Golden description of the rollout-plugin data models: the reference's `pipelinerl/rollouts.py`
 (`BaseMetrics`, `TrainingText`, `RolloutResult`) imported, their pydantic field tables (name, required,
-default) and the `model_dump()` of example instances recorded.
+default) and the `model_dump()` of example instances recorded; plus the field table of `RLConfig`
+(rl/__init__.py:43-105) -> rlconfig_fields.json.
 
     python tests/golden/make_rollouts_golden.py
 """
@@ -43,6 +44,12 @@ def main() -> None:
 
     out = describe(rollouts)
     (HERE / "rollouts_models.json").write_text(json.dumps(out, indent=1))
+    # RLConfig (rl/__init__.py:43-105): every yaml key of conf/finetune/*.yaml `rl:` and its default
+    sys.path.insert(0, str(HERE))
+    import make_golden as mg
+
+    ref_rl, _, _ = mg.import_reference()
+    (HERE / "rlconfig_fields.json").write_text(json.dumps(field_table(ref_rl.RLConfig), indent=1))
     print(json.dumps(out["fields"]["RolloutResult"]))
 
 

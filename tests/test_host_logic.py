@@ -243,3 +243,19 @@ def test_rollout_models_match_reference():
     want = json.loads((GOLDEN / "rollouts_models.json").read_text())
     got = json.loads(json.dumps(describe(rollouts)))
     assert got == want
+
+
+def test_rlconfig_accepts_the_reference_keys_with_the_reference_defaults():
+    import json
+    import sys
+
+    from helpers import GOLDEN
+    from pipelinerl_amd.finetune.rl import RLConfig
+
+    sys.path.insert(0, str(GOLDEN))
+    from make_rollouts_golden import field_table
+
+    want = json.loads((GOLDEN / "rlconfig_fields.json").read_text())
+    got = json.loads(json.dumps(field_table(RLConfig)))
+    assert {k: got[k] for k in want} == want
+    assert set(got) - set(want) == {"fused_logits_grad", "inplace_logits_grad"}  # MI355X extensions
