@@ -265,6 +265,13 @@ def main():
     rag = rag_h.to(dev)
     torch.cuda.synchronize()
     t_h2d = time.perf_counter() - t_h2d
+    rag_pinned = rag_h.pin_memory()
+    torch.cuda.synchronize()
+    t_h2d_pinned = time.perf_counter()
+    rag = rag_pinned.to(dev)
+    torch.cuda.synchronize()
+    t_h2d_pinned = time.perf_counter() - t_h2d_pinned
+    del rag_pinned
     h2d_bytes = sum(t.numel() * t.element_size() for t in (rag.tokens, rag.labels, rag.logprobs, rag.seq_off, rag.lp_off, rag.reward))
     n_seq = rag.n_seqs
     micro_batches = [[i] for i in range(n_seq)]  # dense: every sequence fills one seq_length budget
@@ -391,7 +398,8 @@ def main():
             "config": {"workload": args.workload, "global_batch": bs, "seq_len": seq_length, "vocab": vocab,
                        "tokens_per_step": bs * seq_length, "parallelism": f"dp{world}", "logits_mode": args.logits_mode,
                        "policy_loss": "ppo", "kl_coef": 0.0, "old_logprob_sigma": sigma,
-                       "h2d_ragged_input": {"bytes": h2d_bytes, "ms": 1e3 * t_h2d, "note": "pageable host memory, not part of value"}},
+                       "h2d_ragged_input": {"bytes": h2d_bytes, "ms": 1e3 * t_h2d, "ms_pinned": 1e3 * t_h2d_pinned,
+                                            "note": "one step's ragged rollouts, pageable vs page-locked host memory; not part of value"}},
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu_base,

@@ -77,10 +77,21 @@ class RaggedRollouts:
         return np.diff(self.host_seq_off)
 
     def to(self, device: str | torch.device) -> "RaggedRollouts":
+        """Copies are enqueued `non_blocking` on the current stream: with `pin_memory()`ed sources
+        they are true asynchronous DMAs that overlap the previous step's kernels."""
         kw = {}
         for f in fields(self):
             v = getattr(self, f.name)
             kw[f.name] = v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) else v
+        return RaggedRollouts(**kw)
+
+    def pin_memory(self) -> "RaggedRollouts":
+        """Page-locked host copy (one memcpy per column) so that `.to(device)` runs at PCIe rate
+        instead of through the driver's pageable staging path."""
+        kw = {}
+        for f in fields(self):
+            v = getattr(self, f.name)
+            kw[f.name] = v.pin_memory() if isinstance(v, torch.Tensor) and not v.is_cuda else v
         return RaggedRollouts(**kw)
 
     @classmethod
