@@ -468,8 +468,13 @@ class NativeLearnerStep:
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, rl_config: RLConfig, eos_token_id: int,
                  samples_per_step: int, max_train_steps: int, lr_scheduler: Any = None,
-                 gradient_clipping_threshold: float | None = None, process_group: Any = None):
+                 gradient_clipping_threshold: float | None = None, process_group: Any = None,
+                 ref_model: torch.nn.Module | None = None):
+        """`ref_model`: a frozen reference policy on this GPU.  When given, the KL-to-reference term
+        uses ITS log-probabilities, computed per micro-batch right before the policy forward (SURVEY
+        §8f-3: replaces the HTTP round trip to a second inference server for KL-enabled configs)."""
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
+        self.ref_model = ref_model
         self.rl_config = rl_config.model_copy()
         self.rl_config.batch_size = samples_per_step
         self.eos_token_id = eos_token_id
@@ -488,6 +493,13 @@ class NativeLearnerStep:
         for j in range(n):
             b = batches[j]
             ctx = self.model.no_sync() if (hasattr(self.model, "no_sync") and j < n - 1) else contextlib.nullcontext()
+            if self.ref_model is not None:
+                with torch.no_grad():
+                    ref_logits = self.ref_model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits
+                    if ref_logits.dtype not in (torch.float32, torch.bfloat16) or not ref_logits.is_contiguous():
+                        ref_logits = ref_logits.float().contiguous()
+                    hp.annotate_ref_logprobs(j, ref_logits)
+                    del ref_logits
             with ctx:
                 logits = self.model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits
                 lg = logits.detach()

@@ -102,6 +102,20 @@ class HotPathStep:
             )
         return grad
 
+    def annotate_ref_logprobs(self, j: int, ref_logits: torch.Tensor, temperature: float | None = None) -> None:
+        """Fill micro-batch j's `ref_logprobs` column from the logits of a frozen reference model that
+        lives on this GPU (K1 forward, no graph): log p_ref(token | prefix) on labelled tokens, 0
+        elsewhere - the values the reference pipeline fetches from a second inference server over HTTP
+        (preprocess.py:86-104, llm.py:606-648).  Writes in place: the step-level statistics launch
+        (`finish`) reads the same storage."""
+        from .finetune.rl import logprob_entropy
+
+        b = self.batches[j]
+        temp = float(self.config.temperature if temperature is None else temperature)
+        with torch.no_grad():
+            nlp, _, _, _ = logprob_entropy(ref_logits, b.input_ids, temp)
+            b.ref_logprobs.copy_(torch.where(b.labels != -100, nlp, torch.zeros_like(nlp)))
+
     def logits_two_pass(self, j: int, logits: torch.Tensor, grad_out: torch.Tensor | None = None) -> torch.Tensor:
         """Unfused alternative: K1 forward, K2+K3 on the micro-batch, K1 backward (three launches)."""
         lib = _lib.load()

@@ -211,3 +211,58 @@ def test_rl_step_drives_a_huggingface_causal_lm(libprl, cuda_device):
     for n, p in model.named_parameters():
         assert torch.allclose(grads[n], p.grad, rtol=2e-3, atol=1e-6), n
     assert stats["num_output_tokens_sum"] == int(m.sum().item()) and stats["input_size"] == batch.input_ids.numel()
+
+
+def test_native_step_with_reference_model_on_the_learner(libprl, cuda_device):
+    """KL-to-reference with the reference policy living on the learner GPU: NativeLearnerStep(ref_model=...)
+    must equal the drop-in loop in which every batch was annotated by `annotate_ref_logprobs`, and the
+    annotated column must equal a plain torch log_softmax of the reference model's logits."""
+    import copy
+
+    from pipelinerl_amd.finetune.rl import RLConfig, annotate_ref_logprobs, rl_step
+    from pipelinerl_amd.finetune_loop import NativeLearnerStep
+    from pipelinerl_amd.hotpath import HotPathStep, dense_micro_batches
+    from pipelinerl_amd.synthetic import make_ragged
+
+    V = 96
+    rag_h, _ = make_ragged(3, attempts=4, seq_length=36, vocab=V, seed=9, prompt_min=3, prompt_max=8)
+    rag = rag_h.to(cuda_device)
+    mbs = dense_micro_batches(rag_h, 90)
+    rl = RLConfig(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.3, final_kl_coef=0.3, clamp_log_ratio_ref_new_value=5,
+                  divide_advantage_by_std=False)
+    torch.manual_seed(1)
+    model_a = TinyLM(V).to(cuda_device)
+    model_b = copy.deepcopy(model_a)
+    torch.manual_seed(2)
+    ref_model = TinyLM(V).to(cuda_device).eval()  # a DIFFERENT policy: the KL term is not zero
+
+    captured = {}
+    opt_a = torch.optim.SGD(model_a.parameters(), lr=0.0)
+    orig_zero = opt_a.zero_grad
+    opt_a.zero_grad = lambda *a, **k: captured.update(g=[p.grad.detach().clone() for p in model_a.parameters()]) or orig_zero(*a, **k)
+    native = NativeLearnerStep(model_a, opt_a, rl, eos_token_id=2, samples_per_step=12, max_train_steps=10, ref_model=ref_model)
+    res = native.step(rag, mbs)
+    stats_a = native.stats_dict(res["stats"])
+    assert stats_a["kl"] > 1e-4  # the reference policy really differs
+
+    cfg_b = rl.model_copy()
+    cfg_b.batch_size = 12
+    hp = HotPathStep(cfg_b, 2, 0, 10)
+    batches = hp.preprocess(rag, mbs)
+    agg = {}
+    for b in batches:
+        annotate_ref_logprobs(ref_model, b, cfg_b.temperature)
+        with torch.no_grad():
+            lp = torch.log_softmax(ref_model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits.float(), -1)
+            want = torch.zeros_like(b.ref_logprobs)
+            want[:, 1:] = lp[:, :-1].gather(-1, b.input_ids[:, 1:, None])[..., 0]
+            want = torch.where(b.labels != -100, want, torch.zeros_like(want))
+        assert torch.allclose(b.ref_logprobs, want, rtol=1e-5, atol=1e-5)
+        loss, st = rl_step(model_b, b, 0, 10, cfg_b)
+        loss.backward()
+        for k, v in st.items():
+            agg.setdefault(k, []).append(v)
+    for ga, pb in zip(captured["g"], model_b.parameters()):
+        assert torch.allclose(ga, pb.grad, rtol=1e-4, atol=1e-7)
+    for k in ("loss", "kl", "ref_logprobs", "ratio_ref_new"):
+        assert abs(stats_a[k] - sum(agg[k])) <= 1e-4 * max(1.0, abs(sum(agg[k]))), k
