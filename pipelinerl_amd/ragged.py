@@ -94,6 +94,48 @@ class RaggedRollouts:
             kw[f.name] = v.pin_memory() if isinstance(v, torch.Tensor) and not v.is_cuda else v
         return RaggedRollouts(**kw)
 
+    def to_entries(self, finish_reasons: Sequence[Any] | None = None) -> list[dict[str, Any]]:
+        """The same rollouts as `actor`-stream dicts (`TrainingText.model_dump()` layout, reference
+        actor.py:648-652) - what the reference's preprocessor reads and what the JSONL mirror of the
+        binary stream stores for `debug.streams_from` replay.  `finish_reasons` overrides the
+        strings derived from `finish_code` (None = key absent)."""
+        tokens = self.tokens.cpu().numpy()
+        labels = self.labels.cpu().numpy()
+        lp = self.logprobs.cpu().numpy()
+        ref = None if self.ref_logprobs is None else self.ref_logprobs.cpu().numpy()
+        so, lo = self.host_seq_off, self.host_lp_off
+        reward = self.reward.cpu().numpy()
+        fin = self.finished.cpu().numpy()
+        codes = self.finish_code.cpu().numpy()
+        names = {PRL_FINISH_LENGTH: "length", PRL_FINISH_STOP: "stop"}
+        out = []
+        for i in range(self.n_seqs):
+            n_out = int(lo[i + 1] - lo[i])
+            e: dict[str, Any] = {
+                "text": "",
+                "n_predicted": n_out,
+                "reward": float(reward[i]),
+                "logprobs": lp[lo[i] : lo[i + 1]].tolist(),
+                "ref_logprobs": [] if ref is None else ref[lo[i] : lo[i + 1]].tolist(),
+                "input_ids": tokens[so[i] : so[i + 1]].tolist(),
+                "labels": labels[so[i] : so[i + 1]].tolist(),
+                "group_id": self.group_ids[int(self.host_group_index[i])] if self.group_ids else str(int(self.host_group_index[i])),
+                "finished": bool(fin[i]),
+                "prompt_tokens": int((so[i + 1] - so[i]) - n_out),
+                "output_tokens": n_out,
+                "visual_features": None,
+                "metadata": {
+                    "model_version": int(self.host_model_version[i]),
+                    "rollout_index": int(self.host_rollout_index[i]),
+                    "step_index": int(self.host_step_index[i]),
+                },
+            }
+            reason = finish_reasons[i] if finish_reasons is not None else names.get(int(codes[i]))
+            if reason is not None:
+                e["finish_reason"] = reason
+            out.append(e)
+        return out
+
     @classmethod
     def from_numpy(
         cls,

@@ -14,7 +14,9 @@ Backends
          (topic, instance, partition); a `PipelineBatchEncoding` travels as a binary SoA record
          (header + raw int64 / fp32 buffers, see `batch_codec`) instead of ~114 bytes of JSON text
          per token, and blocked readers park on a futex instead of polling every 100 ms.
-         Non-batch records (trainer messages, stats dicts) travel as JSON bytes.
+         Non-batch records (trainer messages, stats dicts) travel as JSON bytes.  With
+         `mirror_jsonl=True` (or a list of topics) every record is also appended to the files-backend
+         location, so the run can be replayed with `backend: files` (`debug.streams_from`).
   redis  accepted for config compatibility and served by `shm` (the image has no redis server or
          client; single-node semantics are the same: ordered topics, blocking readers).
 """
@@ -254,8 +256,14 @@ class ShmStreamWriter(StreamWriter):
 
     def __init__(self, stream: SingleStreamSpec, mode: Literal["w", "a"] = "a"):
         self.stream = stream
+        self.mode = mode
         self.n_slots = int(_backend_options.get("n_slots", 64))
         self.slot_bytes = int(_backend_options.get("slot_bytes", 16 << 20))
+        # `mirror_jsonl`: True or a list of topics - every record also goes to the files-backend
+        # location as one JSON line, so a run can be replayed later with `backend: files`
+        # (`debug.streams_from`); rollouts are mirrored as the actor's list-of-dicts record.
+        mirror = _backend_options.get("mirror_jsonl", False)
+        self._mirror = FileStreamWriter(stream, mode) if (mirror is True or (isinstance(mirror, (list, tuple, set)) and stream.topic in mirror)) else None
 
     def __enter__(self):
         from .ring import Ring
@@ -267,10 +275,14 @@ class ShmStreamWriter(StreamWriter):
         # Streams outlive their writer (a reader may attach after the producer finished, like a
         # file on disk): the segment is only unlinked when the creating process exits.
         atexit.register(Ring.unlink_name, name)
+        if self._mirror is not None:
+            self._mirror.__enter__()
         return self
 
     def __exit__(self, exc_type, exc_value, traceback):
         self._ring.close(unlink=False)
+        if self._mirror is not None:
+            self._mirror.__exit__(exc_type, exc_value, traceback)
 
     def write(self, data, partition: int | None = None):
         if partition is not None:
@@ -282,6 +294,8 @@ class ShmStreamWriter(StreamWriter):
         else:
             payload = batch_codec.encode_json(_dumps(data))
         self._ring.put_bytes(payload)
+        if self._mirror is not None:
+            self._mirror.write(data.to_entries() if isinstance(data, RaggedRollouts) else data)
 
 
 class ShmStreamReader(StreamReader):

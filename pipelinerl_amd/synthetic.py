@@ -90,39 +90,11 @@ def make_ragged(
 
 
 def ragged_to_entries(rag: RaggedRollouts, finish_reasons: list[Any] | None = None) -> list[dict[str, Any]]:
-    """The same rollouts as `actor`-stream dicts (what the reference's preprocessor reads)."""
-    tokens = rag.tokens.cpu().numpy()
-    labels = rag.labels.cpu().numpy()
-    lp = rag.logprobs.cpu().numpy()
-    ref = None if rag.ref_logprobs is None else rag.ref_logprobs.cpu().numpy()
-    so, lo = rag.host_seq_off, rag.host_lp_off
-    reward = rag.reward.cpu().numpy()
-    fin = rag.finished.cpu().numpy()
-    out = []
-    for i in range(rag.n_seqs):
-        e: dict[str, Any] = {
-            "text": "",
-            "n_predicted": int(lo[i + 1] - lo[i]),
-            "reward": float(reward[i]),
-            "logprobs": [float(x) for x in lp[lo[i] : lo[i + 1]]],
-            "ref_logprobs": [] if ref is None else [float(x) for x in ref[lo[i] : lo[i + 1]]],
-            "input_ids": [int(x) for x in tokens[so[i] : so[i + 1]]],
-            "labels": [int(x) for x in labels[so[i] : so[i + 1]]],
-            "group_id": rag.group_ids[int(rag.host_group_index[i])],
-            "finished": bool(fin[i]),
-            "prompt_tokens": int((so[i + 1] - so[i]) - (lo[i + 1] - lo[i])),
-            "output_tokens": int(lo[i + 1] - lo[i]),
-            "visual_features": None,
-            "metadata": {
-                "model_version": int(rag.host_model_version[i]),
-                "rollout_index": int(rag.host_rollout_index[i]),
-                "step_index": int(rag.host_step_index[i]),
-            },
-        }
-        if finish_reasons is not None and finish_reasons[i] is not None:
-            e["finish_reason"] = finish_reasons[i]
-        out.append(e)
-    return out
+    """The same rollouts as `actor`-stream dicts (what the reference's preprocessor reads); the
+    synthetic `finish_reasons` (mixed case, absent keys) replace the canonical strings."""
+    if finish_reasons is None:
+        finish_reasons = [None] * rag.n_seqs
+    return rag.to_entries(finish_reasons)
 
 
 def make_entries(n_groups: int, **kw: Any) -> list[dict[str, Any]]:

@@ -257,3 +257,36 @@ def test_files_backend_reads_reference_written_files(streams, tmp_path):
             it = r.read()
             got = [next(it) for _ in range(len(want))]
         assert got == want, rel
+
+
+def test_shm_backend_jsonl_mirror_allows_replay(streams, tmp_path):
+    """shm transport with `mirror_jsonl`: the binary ring feeds the live reader, the JSONL mirror
+    under <exp>/streams/... replays the same records later through the files backend."""
+    from pipelinerl_amd.ragged import RaggedRollouts
+    from pipelinerl_amd.synthetic import make_ragged
+
+    rag, _ = make_ragged(2, attempts=3, seq_length=40, vocab=60, seed=4, prompt_min=3, prompt_max=8, with_ref=True)
+    batch, want_batch = _batch()
+    streams.set_streams_backend("shm", n_slots=8, slot_bytes=1 << 20, mirror_jsonl=["actor", "training_data"])
+    a = streams.SingleStreamSpec(exp_path=tmp_path, topic="actor")
+    t = streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data")
+    s = streams.SingleStreamSpec(exp_path=tmp_path, topic="stats")
+    with streams.write_to_streams(a) as wa, streams.write_to_streams(t) as wt, streams.write_to_streams(s) as ws:
+        wa.write(rag)
+        wt.write(batch)
+        ws.write({"x": 1})
+        with streams.read_stream(a) as r:
+            live = next(iter(r.read()))
+        assert isinstance(live, RaggedRollouts) and torch.equal(live.tokens, rag.tokens)
+    assert not (tmp_path / "streams" / "stats").exists()  # topic not mirrored
+    streams.reset_streams_backend()
+    streams.set_streams_backend("files")
+    with streams.read_stream(a) as r:
+        entries = next(iter(r.read()))
+    back = RaggedRollouts.from_entries(entries)
+    for name in ("tokens", "labels", "logprobs", "ref_logprobs", "seq_off", "lp_off", "reward", "step_index", "rollout_index",
+                 "model_version", "finished", "finish_code"):
+        assert torch.equal(getattr(back, name), getattr(rag, name)), name
+    assert [back.group_ids[i] for i in back.host_group_index] == [rag.group_ids[i] for i in rag.host_group_index]
+    with streams.read_stream(t) as r:
+        _same(next(iter(r.read())), want_batch)
