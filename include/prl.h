@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 2
+#define PRL_ABI_VERSION 3
 
 #define PRL_OK 0
 #define PRL_EINVAL (-22)   /* bad argument                                  */

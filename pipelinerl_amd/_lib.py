@@ -13,7 +13,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl.so"
 
-PRL_ABI_VERSION = 2
+PRL_ABI_VERSION = 3
 PRL_OK = 0
 PRL_EINVAL = -22
 PRL_ENOMEM = -12
