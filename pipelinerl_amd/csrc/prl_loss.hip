@@ -119,6 +119,9 @@ __device__ __forceinline__ float per_label(float x, float inv_nl) {
 }
 
 // One token on the unshifted axis. `valid_pos`: column >= 1 (a shifted position exists).
+// Written without early returns: on real batches ~95 % of the tokens are labelled, so evaluating
+// every token and selecting the results keeps the wave convergent (the branchy form of this
+// function compiled to ~250 exec-mask save/restore pairs and ~170 branches per 4-token group).
 template <bool FAST>
 __device__ __forceinline__ void token_step(const LossArgs& a, Acc& acc, bool valid_pos,
                                            int64_t label, bool seq_start, float nlp,
@@ -126,36 +129,28 @@ __device__ __forceinline__ void token_step(const LossArgs& a, Acc& acc, bool val
                                            float reward, float gt, float nl, float ovf,
                                            float ext_g, float ext_clamp, float& g_nlp,
                                            float& g_ent) {
-  g_nlp = 0.0f;
-  g_ent = 0.0f;
-  if (seq_start) acc.s[P_N_SEQ] += 1.0f;
-  if (!valid_pos) return;
-  if (a.cfg.group_normalization && !(gt > 0.0f)) acc.s[P_BAD_GT] += 1.0f;
-  const bool m = (label != -100);
-  if (!m) {
-    int b0, b1, b2;
-    prl_token_flags(a.cfg, nlp, ref_lp, &b0, &b1, &b2);
-    acc.s[P_BAD_NLP] += b0;
-    acc.s[P_BAD_LRRN] += b1;
-    acc.s[P_BAD_KL] += b2;
-    return;
-  }
+  acc.s[P_N_SEQ] += seq_start ? 1.0f : 0.0f;
+  const bool m = valid_pos && (label != -100);
+  const float vf = valid_pos ? 1.0f : 0.0f;
   PrlTokenIn x{nlp, ent, old_lp, ref_lp, adv, reward, gt, nl, ovf};
   PrlTokenOut o;
   prl_token_eval(a.cfg, x, o);
-  g_nlp = o.g_nlp;
-  g_ent = o.g_ent;
-  if (a.cfg.policy_loss == PRL_POLICY_GSPO) {
-    g_nlp = ext_g;
-    o.clamp_no = ext_clamp;
-  }
+  // the reference's finiteness asserts look at every shifted position, labelled or not
+  acc.s[P_BAD_NLP] += vf * (float)o.bad_nlp;
+  acc.s[P_BAD_LRRN] += vf * (float)o.bad_lrrn;
+  acc.s[P_BAD_KL] += vf * (float)o.bad_kl;
+  acc.s[P_BAD_GT] += (a.cfg.group_normalization && valid_pos && !(gt > 0.0f)) ? 1.0f : 0.0f;
+  const bool gspo = a.cfg.policy_loss == PRL_POLICY_GSPO;
+  g_nlp = m ? (gspo ? ext_g : o.g_nlp) : 0.0f;
+  g_ent = m ? o.g_ent : 0.0f;
+  if (gspo) o.clamp_no = ext_clamp;
+
+  // Every per-label statistic is nan_to_num(x / num_labels) on labelled tokens.  `0 * x` is 0 for
+  // finite x and NaN otherwise, so one fused chain over the 14 values tells whether nan_to_num
+  // can change anything for this token; with num_labels >= 1 the products cannot overflow either.
+  // Finite tokens (all of them in a healthy run) then cost a multiply and an add per statistic;
+  // unlabelled tokens ride along with a zero weight.
   const float inv_nl = 1.0f / nl;
-  acc.loss += (double)o.contrib;
-  // Every per-label statistic is nan_to_num(x / num_labels).  `0 * x` is 0 for finite x and NaN
-  // otherwise, so one fused chain over the 14 values tells whether nan_to_num can change anything
-  // for this token; with num_labels >= 1 the products cannot overflow either.  Finite tokens (all of
-  // them in a healthy run) then cost a multiply and an add per statistic instead of three
-  // compare/select pairs each.
   const float ratio_sq = o.ratio_stat * o.ratio_stat;
   float probe = __builtin_fmaf(0.0f, reward, 0.0f);
   probe = __builtin_fmaf(0.0f, ent, probe);
@@ -170,25 +165,31 @@ __device__ __forceinline__ void token_step(const LossArgs& a, Acc& acc, bool val
   probe = __builtin_fmaf(0.0f, o.exp_lrrn, probe);
   probe = __builtin_fmaf(0.0f, o.exp_ref_old, probe);
   probe = __builtin_fmaf(0.0f, o.w, probe);
+  probe = __builtin_fmaf(0.0f, o.contrib, probe);
   if (FAST && probe == 0.0f && nl >= 1.0f) {
-    acc.s[P_REWARD] += reward * inv_nl;
-    acc.s[P_ENTROPY] += ent * inv_nl;
-    acc.s[P_OLD] += old_lp * inv_nl;
-    acc.s[P_NEW] += nlp * inv_nl;
-    acc.s[P_REF] += ref_lp * inv_nl;
-    acc.s[P_ADV] += adv * inv_nl;
-    acc.s[P_KL] += o.kl * inv_nl;
-    acc.s[P_KL_NO] += o.kl_new_old * inv_nl;
-    acc.s[P_ABS_LR] += o.abs_lrno * inv_nl;
-    acc.s[P_RATIO] += o.ratio_stat * inv_nl;
-    acc.s[P_RATIO_SUM] += o.ratio_stat;
-    acc.s[P_RATIO_SQ] += ratio_sq;
-    acc.s[P_RATIO_REF_NEW] += o.exp_lrrn * inv_nl;
-    acc.s[P_RATIO_REF_OLD] += o.exp_ref_old * inv_nl;
-    acc.s[P_CLAMP_RN] += o.clamp_rn * inv_nl;
-    acc.s[P_CLAMP_NO] += o.clamp_no * inv_nl;
-    acc.s[P_TW] += o.w * inv_nl;
-  } else {
+    const float mf = m ? 1.0f : 0.0f;
+    const float k = mf * inv_nl;
+    acc.loss += (double)(mf * o.contrib);
+    acc.s[P_REWARD] += reward * k;
+    acc.s[P_ENTROPY] += ent * k;
+    acc.s[P_OLD] += old_lp * k;
+    acc.s[P_NEW] += nlp * k;
+    acc.s[P_REF] += ref_lp * k;
+    acc.s[P_ADV] += adv * k;
+    acc.s[P_KL] += o.kl * k;
+    acc.s[P_KL_NO] += o.kl_new_old * k;
+    acc.s[P_ABS_LR] += o.abs_lrno * k;
+    acc.s[P_RATIO] += o.ratio_stat * k;
+    acc.s[P_RATIO_SUM] += o.ratio_stat * mf;
+    acc.s[P_RATIO_SQ] += ratio_sq * mf;
+    acc.s[P_RATIO_REF_NEW] += o.exp_lrrn * k;
+    acc.s[P_RATIO_REF_OLD] += o.exp_ref_old * k;
+    acc.s[P_CLAMP_RN] += o.clamp_rn * k;
+    acc.s[P_CLAMP_NO] += o.clamp_no * k;
+    acc.s[P_TW] += o.w * k;
+    acc.s[P_N_MASKED] += mf;
+  } else if (m) {
+    acc.loss += (double)o.contrib;
     acc.s[P_REWARD] += per_label(reward, inv_nl);
     acc.s[P_ENTROPY] += per_label(ent, inv_nl);
     acc.s[P_OLD] += per_label(old_lp, inv_nl);
@@ -206,19 +207,17 @@ __device__ __forceinline__ void token_step(const LossArgs& a, Acc& acc, bool val
     acc.s[P_CLAMP_RN] += per_label(o.clamp_rn, inv_nl);
     acc.s[P_CLAMP_NO] += per_label(o.clamp_no, inv_nl);
     acc.s[P_TW] += per_label(o.w, inv_nl);
+    acc.s[P_N_MASKED] += 1.0f;
   }
-  acc.s[P_N_MASKED] += 1.0f;
-  acc.s[P_BAD_NLP] += o.bad_nlp;
-  acc.s[P_BAD_LRRN] += o.bad_lrrn;
-  acc.s[P_BAD_KL] += o.bad_kl;
-  acc.mx[0] = fmaxf(acc.mx[0], reward);
-  acc.mn[0] = fminf(acc.mn[0], reward);
-  acc.mx[1] = fmaxf(acc.mx[1], adv);
-  acc.mn[1] = fminf(acc.mn[1], adv);
-  acc.mx[2] = fmaxf(acc.mx[2], o.kl);
-  acc.mn[2] = fminf(acc.mn[2], o.kl);
-  acc.mx[3] = fmaxf(acc.mx[3], o.w);
-  acc.mn[3] = fminf(acc.mn[3], o.w);
+  const float ninf = -INFINITY, pinf = INFINITY;
+  acc.mx[0] = fmaxf(acc.mx[0], m ? reward : ninf);
+  acc.mn[0] = fminf(acc.mn[0], m ? reward : pinf);
+  acc.mx[1] = fmaxf(acc.mx[1], m ? adv : ninf);
+  acc.mn[1] = fminf(acc.mn[1], m ? adv : pinf);
+  acc.mx[2] = fmaxf(acc.mx[2], m ? o.kl : ninf);
+  acc.mn[2] = fminf(acc.mn[2], m ? o.kl : pinf);
+  acc.mx[3] = fmaxf(acc.mx[3], m ? o.w : ninf);
+  acc.mn[3] = fminf(acc.mn[3], m ? o.w : pinf);
 }
 
 __device__ __forceinline__ void block_reduce_store(const Acc& acc, double* out) {
