@@ -255,67 +255,96 @@ __device__ __forceinline__ void make_token(const PackArgs& a, const SeqCtx& c, i
   }
 }
 
-template <bool VEC, bool NT>
+// TPL tokens per lane and iteration.  Store shapes matter more than anything else here (measured with
+// scripts/exp/store_patterns.hip on 33.5 M tokens): the int64 columns written as two 16-byte stores
+// at a 32-byte lane stride cost 442 us (plain) / 820 us (non-temporal) for the twelve columns, while
+// wave-contiguous stores - TPL = 2: one 16-byte store per int64 column, one 8-byte store per fp32
+// column - take 404 us with the non-temporal hint.
+template <bool VEC, bool NT, int TPL>
 __global__ __launch_bounds__(kBlock) void pack_collate_kernel(PackArgs a) {
-  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
-  const int64_t ngroups = (a.total + 3) >> 2;
-  for (int64_t gidx = tid; gidx < ngroups; gidx += nthreads) {
-    const int64_t t0 = gidx << 2;
-    int j = find_seq(a.pk_dst, a.m, t0);
-    SeqCtx c;
-    load_seq(a, j, c);
-    Tok tk[4];
-    const int cnt = (a.total - t0) < 4 ? (int)(a.total - t0) : 4;
+  // Each workgroup owns one contiguous run of token groups, so the sequence index only moves
+  // forward: ONE binary search (12 dependent L2 round trips) per workgroup instead of one per
+  // group, then every lane walks on from where its previous group ended - zero steps most of the
+  // time, a few when short sequences end inside the span.
+  const int64_t ngroups = (a.total + TPL - 1) / TPL;
+  const int64_t per_block = (ngroups + gridDim.x - 1) / gridDim.x;
+  const int64_t g_begin = (int64_t)blockIdx.x * per_block;
+  const int64_t g_end = (g_begin + per_block < ngroups) ? (g_begin + per_block) : ngroups;
+  if (g_begin >= g_end) return;
+  int j = find_seq(a.pk_dst, a.m, g_begin * TPL);
+  SeqCtx c;
+  int cj = -1;  // sequence whose scalars `c` holds
+  for (int64_t gidx = g_begin + threadIdx.x; gidx < g_end; gidx += kBlock) {
+    const int64_t t0 = gidx * TPL;
+    while (t0 >= a.pk_dst[j + 1]) ++j;  // t0 < total = pk_dst[m] bounds the walk
+    if (cj != j) {
+      load_seq(a, j, c);
+      cj = j;
+    }
+    Tok tk[TPL];
+    const int cnt = (a.total - t0) < TPL ? (int)(a.total - t0) : TPL;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < TPL; ++k) {
       if (k < cnt) {
         const int64_t t = t0 + k;
         while (t >= c.dst_e) {  // also skips zero-length sequences
           ++j;
           load_seq(a, j, c);
+          cj = j;
         }
         make_token(a, c, t, tk[k]);
       } else {
         tk[k] = tk[0];
       }
     }
-    if (VEC && cnt == 4) {
+    if (VEC && cnt == TPL) {
       using l2 = long __attribute__((ext_vector_type(2)));
       using f4 = float __attribute__((ext_vector_type(4)));
-      auto st2 = [&](int64_t* p, int64_t x0, int64_t x1, int64_t x2, int64_t x3) {
-        l2 a01 = {x0, x1}, a23 = {x2, x3};
+      using f2 = float __attribute__((ext_vector_type(2)));
+      auto put = [&](auto* p, auto v) {
         if constexpr (NT) {  // the batch is written once and read much later: keep it out of L2
-          __builtin_nontemporal_store(a01, reinterpret_cast<l2*>(p + t0));
-          __builtin_nontemporal_store(a23, reinterpret_cast<l2*>(p + t0 + 2));
+          __builtin_nontemporal_store(v, p);
         } else {
-          *reinterpret_cast<l2*>(p + t0) = a01;
-          *reinterpret_cast<l2*>(p + t0 + 2) = a23;
+          *p = v;
         }
       };
-      auto stf = [&](float* p, float x0, float x1, float x2, float x3) {
-        f4 v = {x0, x1, x2, x3};
-        if constexpr (NT) {
-          __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p + t0));
-        } else {
-          *reinterpret_cast<f4*>(p + t0) = v;
-        }
-      };
-      st2(a.o_ids, tk[0].id, tk[1].id, tk[2].id, tk[3].id);
-      st2(a.o_labels, tk[0].label, tk[1].label, tk[2].label, tk[3].label);
-      st2(a.o_mask, 1, 1, 1, 1);
-      st2(a.o_pos, tk[0].pos, tk[1].pos, tk[2].pos, tk[3].pos);
-      st2(a.o_seg, tk[0].seg, tk[1].seg, tk[2].seg, tk[3].seg);
-      stf(a.o_rewards, tk[0].reward, tk[1].reward, tk[2].reward, tk[3].reward);
-      stf(a.o_adv, tk[0].adv, tk[1].adv, tk[2].adv, tk[3].adv);
-      stf(a.o_ref, tk[0].ref, tk[1].ref, tk[2].ref, tk[3].ref);
-      stf(a.o_old, tk[0].old, tk[1].old, tk[2].old, tk[3].old);
-      stf(a.o_gt, tk[0].gt, tk[1].gt, tk[2].gt, tk[3].gt);
-      stf(a.o_nl, tk[0].nl, tk[1].nl, tk[2].nl, tk[3].nl);
-      stf(a.o_ovf, tk[0].ovf, tk[1].ovf, tk[2].ovf, tk[3].ovf);
+      if constexpr (TPL == 4) {
+        auto st2 = [&](int64_t* p, int64_t x0, int64_t x1, int64_t x2, int64_t x3) {
+          put(reinterpret_cast<l2*>(p + t0), l2{x0, x1});
+          put(reinterpret_cast<l2*>(p + t0 + 2), l2{x2, x3});
+        };
+        auto stf = [&](float* p, float x0, float x1, float x2, float x3) { put(reinterpret_cast<f4*>(p + t0), f4{x0, x1, x2, x3}); };
+        st2(a.o_ids, tk[0].id, tk[1].id, tk[2].id, tk[3].id);
+        st2(a.o_labels, tk[0].label, tk[1].label, tk[2].label, tk[3].label);
+        st2(a.o_mask, 1, 1, 1, 1);
+        st2(a.o_pos, tk[0].pos, tk[1].pos, tk[2].pos, tk[3].pos);
+        st2(a.o_seg, tk[0].seg, tk[1].seg, tk[2].seg, tk[3].seg);
+        stf(a.o_rewards, tk[0].reward, tk[1].reward, tk[2].reward, tk[3].reward);
+        stf(a.o_adv, tk[0].adv, tk[1].adv, tk[2].adv, tk[3].adv);
+        stf(a.o_ref, tk[0].ref, tk[1].ref, tk[2].ref, tk[3].ref);
+        stf(a.o_old, tk[0].old, tk[1].old, tk[2].old, tk[3].old);
+        stf(a.o_gt, tk[0].gt, tk[1].gt, tk[2].gt, tk[3].gt);
+        stf(a.o_nl, tk[0].nl, tk[1].nl, tk[2].nl, tk[3].nl);
+        stf(a.o_ovf, tk[0].ovf, tk[1].ovf, tk[2].ovf, tk[3].ovf);
+      } else {
+        auto st2 = [&](int64_t* p, int64_t x0, int64_t x1) { put(reinterpret_cast<l2*>(p + t0), l2{x0, x1}); };
+        auto stf = [&](float* p, float x0, float x1) { put(reinterpret_cast<f2*>(p + t0), f2{x0, x1}); };
+        st2(a.o_ids, tk[0].id, tk[1].id);
+        st2(a.o_labels, tk[0].label, tk[1].label);
+        st2(a.o_mask, 1, 1);
+        st2(a.o_pos, tk[0].pos, tk[1].pos);
+        st2(a.o_seg, tk[0].seg, tk[1].seg);
+        stf(a.o_rewards, tk[0].reward, tk[1].reward);
+        stf(a.o_adv, tk[0].adv, tk[1].adv);
+        stf(a.o_ref, tk[0].ref, tk[1].ref);
+        stf(a.o_old, tk[0].old, tk[1].old);
+        stf(a.o_gt, tk[0].gt, tk[1].gt);
+        stf(a.o_nl, tk[0].nl, tk[1].nl);
+        stf(a.o_ovf, tk[0].ovf, tk[1].ovf);
+      }
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < TPL; ++k) {
         if (k >= cnt) break;
         const int64_t t = t0 + k;
         a.o_ids[t] = tk[k].id;
@@ -492,16 +521,22 @@ extern "C" int prl_pack_collate(int32_t m, int64_t total_tokens, const int32_t* 
                    prl::aligned16(out_advantages) && prl::aligned16(out_ref_logprobs) &&
                    prl::aligned16(out_old_logprobs) && prl::aligned16(out_group_tokens) &&
                    prl::aligned16(out_num_labels) && prl::aligned16(out_overflow);
-  const int nb = blocks_for((total_tokens + 3) / 4);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const char* nt_env = getenv("PRL_PACK_NT");
   const bool nt = nt_env ? (atoi(nt_env) != 0) : kPackNtDefault;
-  if (vec && nt) {
-    hipLaunchKernelGGL((pack_collate_kernel<true, true>), dim3(nb), dim3(kBlock), 0, s, a);
+  const char* tpl_env = getenv("PRL_PACK_TPL");  // measurement override: 4 = four tokens per lane
+  const int tpl = (tpl_env && atoi(tpl_env) == 4) ? 4 : 2;
+  const int nb = blocks_for((total_tokens + tpl - 1) / tpl);
+  if (vec && nt && tpl == 2) {
+    hipLaunchKernelGGL((pack_collate_kernel<true, true, 2>), dim3(nb), dim3(kBlock), 0, s, a);
+  } else if (vec && tpl == 2) {
+    hipLaunchKernelGGL((pack_collate_kernel<true, false, 2>), dim3(nb), dim3(kBlock), 0, s, a);
+  } else if (vec && nt) {
+    hipLaunchKernelGGL((pack_collate_kernel<true, true, 4>), dim3(nb), dim3(kBlock), 0, s, a);
   } else if (vec) {
-    hipLaunchKernelGGL((pack_collate_kernel<true, false>), dim3(nb), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((pack_collate_kernel<true, false, 4>), dim3(nb), dim3(kBlock), 0, s, a);
   } else {
-    hipLaunchKernelGGL((pack_collate_kernel<false, false>), dim3(nb), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((pack_collate_kernel<false, false, 4>), dim3(nb), dim3(kBlock), 0, s, a);
   }
   PRL_LAUNCH_CHECK("pack_collate_kernel");
   return PRL_OK;

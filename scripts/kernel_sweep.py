@@ -60,6 +60,12 @@ def main():
     y = torch.empty_like(x)
     med, mn = timeit(lambda: y.copy_(x))
     report("torch copy 1 GiB (read+write)", 2 * (1 << 30), med, mn)
+    z = torch.empty(2 << 30, dtype=torch.uint8, device=dev).view(torch.float32)
+    med, mn = timeit(lambda: z.fill_(1.0))
+    report("torch fill 2 GiB (write only)", 2 << 30, med, mn)
+    med, mn = timeit(lambda: z.sum())
+    report("torch sum 2 GiB fp32 (read only)", 2 << 30, med, mn)
+    del z
 
     # ---- preprocess at step scale: 512 sequences x 8192 tokens (1/8 of the 4096-sequence step)
     rag_h, _ = make_ragged(64, attempts=8, seq_length=T, vocab=V, seed=5, dense=True)

@@ -13,8 +13,9 @@ rag = rag_h.to(dev)
 prep = populate_rl_data_ragged(rag, 2, RLConfig(divide_advantage_by_std=False))
 mbs = [[i] for i in range(rag.n_seqs)]
 ntok = rag.n_tokens
-for nt in ("0", "1", "0", "1"):
+for tpl, nt in (("4", "0"), ("4", "1"), ("2", "0"), ("2", "1"), ("4", "0"), ("2", "1")):
     os.environ["PRL_PACK_NT"] = nt
+    os.environ["PRL_PACK_TPL"] = tpl
     ts = []
     for it in range(6):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,4 +23,4 @@ for nt in ("0", "1", "0", "1"):
         a.record(); pk = pack_prepared(prep, mbs, 2); b.record(); torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
     t = float(np.median(ts[1:]))
-    print(f"pack {ntok} tokens NT={nt}: {t*1e3:.0f} us incl. host planning -> {ntok*84/t/1e6:.0f} GB/s ({100*ntok*84/t/1e6/8000:.1f}% of 8 TB/s)")
+    print(f"pack {ntok} tokens TPL={tpl} NT={nt}: {t*1e3:.0f} us incl. host planning -> {ntok*84/t/1e6:.0f} GB/s ({100*ntok*84/t/1e6/8000:.1f}% of 8 TB/s)")
