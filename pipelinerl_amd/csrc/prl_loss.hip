@@ -257,44 +257,66 @@ __device__ __forceinline__ void block_reduce_store(const Acc& acc, double* out) 
   }
 }
 
-// Four consecutive tokens of every input column (16-byte loads; 52 VGPRs without the GSPO columns).
-struct TokVec4 {
-  longlong2 lab01, lab23, pos01, pos23;
-  float4 nlp, ent, old, ref, adv, rew, gt, nl, ov, xg, xc;
+// TPL consecutive tokens of every input column, fetched with the widest aligned loads (TPL = 4:
+// 16 bytes per fp32 column, 2 x 16 bytes per int64 column; TPL = 2: 8 / 16 bytes).
+template <int TPL>
+struct TokVec {
+  int64_t lab[TPL], pos[TPL];
+  float nlp[TPL], ent[TPL], old[TPL], ref[TPL], adv[TPL], rew[TPL], gt[TPL], nl[TPL], ov[TPL], xg[TPL], xc[TPL];
 };
 
-template <bool GSPO>
-__device__ __forceinline__ void load_vec4(const LossArgs& a, bool count_pos, int64_t u0, TokVec4& v) {
-  v.lab01 = *reinterpret_cast<const longlong2*>(a.labels + u0);
-  v.lab23 = *reinterpret_cast<const longlong2*>(a.labels + u0 + 2);
-  v.pos01 = make_longlong2(1, 1);
-  v.pos23 = make_longlong2(1, 1);
-  if (count_pos) {
-    v.pos01 = *reinterpret_cast<const longlong2*>(a.position_ids + u0);
-    v.pos23 = *reinterpret_cast<const longlong2*>(a.position_ids + u0 + 2);
-  }
-  v.nlp = *reinterpret_cast<const float4*>(a.nlp + u0);
-  v.ent = *reinterpret_cast<const float4*>(a.ent + u0);
-  v.old = *reinterpret_cast<const float4*>(a.old_lp + u0);
-  v.ref = *reinterpret_cast<const float4*>(a.ref_lp + u0);
-  v.adv = *reinterpret_cast<const float4*>(a.adv + u0);
-  v.rew = *reinterpret_cast<const float4*>(a.reward + u0);
-  v.gt = *reinterpret_cast<const float4*>(a.group_tokens + u0);
-  v.nl = *reinterpret_cast<const float4*>(a.num_labels + u0);
-  v.ov = *reinterpret_cast<const float4*>(a.overflow + u0);
-  if constexpr (GSPO) {
-    v.xg = *reinterpret_cast<const float4*>(a.ext_g + u0);
-    v.xc = *reinterpret_cast<const float4*>(a.ext_clamp + u0);
+template <int TPL>
+__device__ __forceinline__ void load_f(const float* p, float (&o)[TPL]) {
+  if constexpr (TPL == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
   } else {
-    v.xg = make_float4(0.f, 0.f, 0.f, 0.f);
-    v.xc = v.xg;
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    o[0] = t.x; o[1] = t.y;
   }
 }
 
-// VEC = 4: all base pointers 16-byte aligned; the n % 4 tail is handled by block 0's
-// first lanes with scalar accesses.  VEC = 1: fully scalar fallback for odd views.
+template <int TPL>
+__device__ __forceinline__ void load_i(const int64_t* p, int64_t (&o)[TPL]) {
+#pragma unroll
+  for (int k = 0; k < TPL; k += 2) {
+    const longlong2 t = *reinterpret_cast<const longlong2*>(p + k);
+    o[k] = t.x;
+    o[k + 1] = t.y;
+  }
+}
+
+template <int TPL, bool GSPO>
+__device__ __forceinline__ void load_vec(const LossArgs& a, bool count_pos, int64_t u0, TokVec<TPL>& v) {
+  load_i<TPL>(a.labels + u0, v.lab);
+  if (count_pos) {
+    load_i<TPL>(a.position_ids + u0, v.pos);
+  } else {
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) v.pos[k] = 1;
+  }
+  load_f<TPL>(a.nlp + u0, v.nlp);
+  load_f<TPL>(a.ent + u0, v.ent);
+  load_f<TPL>(a.old_lp + u0, v.old);
+  load_f<TPL>(a.ref_lp + u0, v.ref);
+  load_f<TPL>(a.adv + u0, v.adv);
+  load_f<TPL>(a.reward + u0, v.rew);
+  load_f<TPL>(a.group_tokens + u0, v.gt);
+  load_f<TPL>(a.num_labels + u0, v.nl);
+  load_f<TPL>(a.overflow + u0, v.ov);
+  if constexpr (GSPO) {
+    load_f<TPL>(a.ext_g + u0, v.xg);
+    load_f<TPL>(a.ext_clamp + u0, v.xc);
+  } else {
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) v.xg[k] = v.xc[k] = 0.0f;
+  }
+}
+
+// VEC = 4 / 2: all base pointers 16-byte aligned; the n % VEC tail is handled by the first lanes
+// with scalar accesses.  VEC = 1: fully scalar fallback for odd views.
 //
-// The per-token math is ~290 VALU instructions, and the accumulators plus one group of inputs
+// The per-token math is ~250 VALU instructions, and the accumulators plus one group of inputs
 // already take ~140 VGPRs (3 waves per SIMD), so the loads of the NEXT group are issued before
 // the current group is evaluated: the SQ counters of the unpipelined loop showed the waves
 // parked on s_waitcnt for 47 % of their cycles with the VALU 32 % busy.
@@ -308,51 +330,41 @@ __global__ __launch_bounds__(kBlock) void grpo_loss_partial_kernel(LossArgs a) {
   const bool flat = count_pos && a.cfg.flat_micro_batches;
   const bool gspo = GSPO;
 
-  if constexpr (VEC == 4) {
-    const int64_t n4 = a.n >> 2;
-    TokVec4 cur, nxt;
+  if constexpr (VEC > 1) {
+    const int64_t nv = a.n / VEC;
+    TokVec<VEC> cur, nxt;
     int64_t i = tid;
-    if (i < n4) load_vec4<GSPO>(a, count_pos, i << 2, cur);
-    for (; i < n4; i += nthreads) {
-      const int64_t u0 = i << 2;
+    if (i < nv) load_vec<VEC, GSPO>(a, count_pos, i * VEC, cur);
+    for (; i < nv; i += nthreads) {
+      const int64_t u0 = i * VEC;
       const int64_t inext = i + nthreads;
-      if (inext < n4) load_vec4<GSPO>(a, count_pos, inext << 2, nxt);
-
-      const int64_t lab[4] = {cur.lab01.x, cur.lab01.y, cur.lab23.x, cur.lab23.y};
-      const int64_t pos[4] = {cur.pos01.x, cur.pos01.y, cur.pos23.x, cur.pos23.y};
-      const float f_nlp[4] = {cur.nlp.x, cur.nlp.y, cur.nlp.z, cur.nlp.w};
-      const float f_ent[4] = {cur.ent.x, cur.ent.y, cur.ent.z, cur.ent.w};
-      const float f_old[4] = {cur.old.x, cur.old.y, cur.old.z, cur.old.w};
-      const float f_ref[4] = {cur.ref.x, cur.ref.y, cur.ref.z, cur.ref.w};
-      const float f_adv[4] = {cur.adv.x, cur.adv.y, cur.adv.z, cur.adv.w};
-      const float f_rew[4] = {cur.rew.x, cur.rew.y, cur.rew.z, cur.rew.w};
-      const float f_gt[4] = {cur.gt.x, cur.gt.y, cur.gt.z, cur.gt.w};
-      const float f_nl[4] = {cur.nl.x, cur.nl.y, cur.nl.z, cur.nl.w};
-      const float f_ov[4] = {cur.ov.x, cur.ov.y, cur.ov.z, cur.ov.w};
-      const float f_xg[4] = {cur.xg.x, cur.xg.y, cur.xg.z, cur.xg.w};
-      const float f_xc[4] = {cur.xc.x, cur.xc.y, cur.xc.z, cur.xc.w};
+      if (inext < nv) load_vec<VEC, GSPO>(a, count_pos, inext * VEC, nxt);
       // column of the first element of the group (cols may be any value >= 1)
       int64_t col = a.packed ? u0 : (u0 % a.cols);
-      float g[4], gh[4];
+      float g[VEC], gh[VEC];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool valid_pos = (col != 0) && !(flat && pos[k] == 0);
-        const bool seq_start = count_pos && (pos[k] == 0 || (u0 + k) == 0);
-        token_step<FAST>(a, acc, valid_pos, lab[k], seq_start, f_nlp[k], f_ent[k], f_old[k],
-                   f_ref[k], f_adv[k], f_rew[k], f_gt[k], f_nl[k], f_ov[k], f_xg[k], f_xc[k], g[k], gh[k]);
+      for (int k = 0; k < VEC; ++k) {
+        const bool valid_pos = (col != 0) && !(flat && cur.pos[k] == 0);
+        const bool seq_start = count_pos && (cur.pos[k] == 0 || (u0 + k) == 0);
+        token_step<FAST>(a, acc, valid_pos, cur.lab[k], seq_start, cur.nlp[k], cur.ent[k], cur.old[k], cur.ref[k], cur.adv[k],
+                         cur.rew[k], cur.gt[k], cur.nl[k], cur.ov[k], cur.xg[k], cur.xc[k], g[k], gh[k]);
         ++col;
         if (!a.packed && col == a.cols) col = 0;
       }
-      if (a.g_nlp) *reinterpret_cast<float4*>(a.g_nlp + u0) = make_float4(g[0], g[1], g[2], g[3]);
-      if (a.g_ent)
-        *reinterpret_cast<float4*>(a.g_ent + u0) = make_float4(gh[0], gh[1], gh[2], gh[3]);
+      if constexpr (VEC == 4) {
+        if (a.g_nlp) *reinterpret_cast<float4*>(a.g_nlp + u0) = make_float4(g[0], g[1], g[2], g[3]);
+        if (a.g_ent) *reinterpret_cast<float4*>(a.g_ent + u0) = make_float4(gh[0], gh[1], gh[2], gh[3]);
+      } else {
+        if (a.g_nlp) *reinterpret_cast<float2*>(a.g_nlp + u0) = make_float2(g[0], g[1]);
+        if (a.g_ent) *reinterpret_cast<float2*>(a.g_ent + u0) = make_float2(gh[0], gh[1]);
+      }
       cur = nxt;
     }
   }
 
-  // scalar path: whole range for VEC == 1, the n % 4 tail for VEC == 4
+  // scalar path: whole range for VEC == 1, the n % VEC tail otherwise
   {
-    const int64_t begin = (VEC == 4) ? ((a.n >> 2) << 2) : 0;
+    const int64_t begin = (VEC > 1) ? ((a.n / VEC) * VEC) : 0;
     for (int64_t u = begin + tid; u < a.n; u += nthreads) {
       const int64_t col = a.packed ? u : (u % a.cols);
       const bool seq_start = count_pos && (a.position_ids[u] == 0 || u == 0);
@@ -458,6 +470,20 @@ bool fast_stats() {
     return !(e && e[0] == '0');
   }();
   return on;
+}
+
+// Tokens per lane and iteration.  Two make every load wave-contiguous (the int64 columns are 16
+// bytes per lane at a 16-byte stride instead of two loads at a 32-byte stride) and fit 3 waves per
+// SIMD: 7 % faster for the statistics-only launch of a whole step (347 vs 375 us); with the
+// gradient written as well four tokens per lane (16-byte stores) stay ahead (390 vs 399 us).
+// PRL_LOSS_TPL=2|4 overrides (A/B measurements).
+int tokens_per_lane(bool writes_gradient) {
+  static const int forced = [] {
+    const char* e = getenv("PRL_LOSS_TPL");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 2 || forced == 4) return forced;
+  return writes_gradient ? 4 : 2;
 }
 
 int grid_for(int64_t n, int vec) {
@@ -566,6 +592,9 @@ extern "C" int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, i
     if (is_gspo) {
       nblocks = resident_grid<grpo_loss_partial_kernel<4, true, true>>(grid_for(a.n, 4));
       hipLaunchKernelGGL((grpo_loss_partial_kernel<4, true, true>), dim3(nblocks), dim3(kBlock), 0, s, a);
+    } else if (fast_stats() && tokens_per_lane(a.g_nlp != nullptr || a.g_ent != nullptr) == 2) {
+      nblocks = resident_grid<grpo_loss_partial_kernel<2, true, false>>(grid_for(a.n, 2));
+      hipLaunchKernelGGL((grpo_loss_partial_kernel<2, true, false>), dim3(nblocks), dim3(kBlock), 0, s, a);
     } else if (fast_stats()) {
       nblocks = resident_grid<grpo_loss_partial_kernel<4, true, false>>(grid_for(a.n, 4));
       hipLaunchKernelGGL((grpo_loss_partial_kernel<4, true, false>), dim3(nblocks), dim3(kBlock), 0, s, a);
