@@ -367,7 +367,13 @@ def main():
     pmc = ROOT / "profiles" / "pmc_traffic.json"
     if pmc.exists() and (seq_length, vocab) == (8192, 152064):  # the PMC passes were taken at this shape
         try:
-            traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+            table = json.loads(pmc.read_text())
+            traffic = table.get(dom, {}).get("hbm_bytes_per_launch")
+            # per-token PMC figures of the two step-scale kernels, scaled to this launch
+            if "grpo_loss_step" in kernels and "hbm_bytes_per_token" in table.get("grpo_loss_step", {}):
+                kernels["grpo_loss_step"]["traffic"] = table["grpo_loss_step"]["hbm_bytes_per_token"] * tokens_per_rank
+            if "preprocess_K5_K6" in kernels and "write_kb" in table.get("pack_collate", {}):
+                kernels["preprocess_K5_K6"]["pack_write_traffic"] = table["pack_collate"]["write_kb"] * 1024 / table["pack_collate"]["tokens"] * tokens_per_rank
         except Exception:
             traffic = None
     roofline = {
