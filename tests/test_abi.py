@@ -60,3 +60,33 @@ def test_abi_version_and_error_string(libprl):
     assert b"null" in libprl.prl_last_error()
     need = ctypes.c_size_t(0)
     assert libprl.prl_grpo_loss_workspace_bytes(1, 8192, ctypes.byref(need)) == 0 and need.value > 0
+
+
+def test_missing_extension_fails_loudly(tmp_path):
+    """No CPU fallback: with the shared object absent every hot-path entry point raises ImportError
+    (checked in a fresh interpreter so the already-loaded library of this process does not matter)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import os, sys; sys.path.insert(0, %r); os.environ['PRL_LIB'] = %r\n"
+        "import torch\n"
+        "from pipelinerl_amd.finetune.rl import logprob_entropy\n"
+        "from pipelinerl_amd.weight_sync import WeightSyncGroup\n"
+        "from pipelinerl_amd.shared_memory_array import SharedMemoryQueue\n"
+        "fails = 0\n"
+        "for fn in (lambda: logprob_entropy(torch.zeros(1, 4, 8), torch.zeros(1, 4, dtype=torch.long), 1.0),\n"
+        "           lambda: WeightSyncGroup._new_uid(),\n"
+        "           lambda: SharedMemoryQueue(None, 2, 64)):\n"
+        "    try:\n"
+        "        fn()\n"
+        "    except ImportError as e:\n"
+        "        assert 'no CPU fallback' in str(e) or 'not found' in str(e), e\n"
+        "        fails += 1\n"
+        "print('IMPORT_ERRORS', fails)\n"
+    ) % (str(root), str(tmp_path / "absent" / "libprl.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "IMPORT_ERRORS 3" in out.stdout, out.stdout + out.stderr[-1000:]
