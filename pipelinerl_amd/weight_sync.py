@@ -242,6 +242,52 @@ def _deliver(buf: torch.Tensor, bucket: Sequence[tuple[ParamSpec, int]], load_we
     return len(bucket)
 
 
+class _TwoStreamPipe:
+    """Event plumbing shared by the bucketed sender and receiver on a GPU: the RCCL transfers run on
+    their own HIP stream, the flatten / unflatten copies on the caller's stream, and two staging
+    buffers alternate - so bucket k+1 is on the wire while bucket k is being copied.
+    `wire(k, fn)` enqueues a transfer, `local(k, fn)` the copy work of bucket k."""
+
+    def __init__(self, device: torch.device):
+        self.enabled = torch.device(device).type == "cuda"
+        if self.enabled:
+            self.comm = torch.cuda.Stream(device)
+            self.main = torch.cuda.current_stream(device)
+            self.wire_done: dict[int, torch.cuda.Event] = {}
+            self.local_done: dict[int, torch.cuda.Event] = {}
+            start = torch.cuda.Event()
+            start.record(self.main)
+            self.comm.wait_event(start)  # everything queued before the update stays ahead of it
+
+    def wire(self, k: int, fn: Callable[[], None], after_local: int | None) -> None:
+        if not self.enabled:
+            fn()
+            return
+        if after_local is not None and after_local in self.local_done:
+            self.comm.wait_event(self.local_done[after_local])
+        with torch.cuda.stream(self.comm):
+            fn()
+            ev = torch.cuda.Event()
+            ev.record(self.comm)
+        self.wire_done[k] = ev
+
+    def local(self, k: int, fn: Callable[[], Any], after_wire: int | None) -> Any:
+        if not self.enabled:
+            return fn()
+        if after_wire is not None and after_wire in self.wire_done:
+            self.main.wait_event(self.wire_done[after_wire])
+        out = fn()
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.local_done[k] = ev
+        return out
+
+    def finish(self) -> None:
+        """The caller's stream continues only after the last transfer."""
+        if self.enabled and self.wire_done:
+            self.main.wait_event(self.wire_done[max(self.wire_done)])
+
+
 class BucketedSender:
     """Trainer side: flatten named parameters into reusable device buckets and broadcast them."""
 
@@ -260,17 +306,20 @@ class BucketedSender:
             cap = max(bucket_nbytes(b) for b in plan)
             self._staging = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)]
         tensors = dict(params)
+        pipe = _TwoStreamPipe(self.group.device)
         for k, bucket in enumerate(plan):
             buf = self._staging[k % 2][: bucket_nbytes(bucket)]
-            gather_into_bucket(buf, bucket, tensors)
-            self.group.broadcast_bucket(buf, mode=self.mode)
+            # flatten k (needs staging[k % 2] back from transfer k - 2), then put it on the wire
+            pipe.local(k, lambda buf=buf, bucket=bucket: gather_into_bucket(buf, bucket, tensors), after_wire=k - 2)
+            pipe.wire(k, lambda buf=buf: self.group.broadcast_bucket(buf, mode=self.mode), after_local=k)
+        pipe.finish()
         return specs
 
 
 class BucketedReceiver:
     """Worker side: receive the buckets implied by `parameters_info` and hand (name, tensor) views
-    to `load_weights`, bucket by bucket (the callback of bucket k overlaps the transfer of k+1
-    because both are merely enqueued on the stream)."""
+    to `load_weights` (or scatter them into registered destinations), bucket by bucket; transfers
+    run on their own stream, so bucket k + 1 arrives while bucket k is being unflattened."""
 
     def __init__(self, group: WeightSyncGroup, bucket_bytes: int = DEFAULT_BUCKET_BYTES, mode: str = "scatter_allgather"):
         self.group = group
@@ -289,10 +338,14 @@ class BucketedReceiver:
             cap = max(bucket_nbytes(b) for b in plan)
             self._staging = [torch.empty(cap, dtype=torch.uint8, device=self.group.device) for _ in range(2)]
         n = 0
+        pipe = _TwoStreamPipe(self.group.device)
         for k, bucket in enumerate(plan):
             buf = self._staging[k % 2][: bucket_nbytes(bucket)]
-            self.group.broadcast_bucket(buf, mode=self.mode)
-            n += _deliver(buf, bucket, load_weights, destinations)
+            # receive k (staging[k % 2] is free once bucket k - 2 has been handed out), then unflatten it
+            # on the caller's stream while bucket k + 1 is already arriving on the transfer stream
+            pipe.wire(k, lambda buf=buf: self.group.broadcast_bucket(buf, mode=self.mode), after_local=k - 2)
+            n += pipe.local(k, lambda buf=buf, bucket=bucket: _deliver(buf, bucket, load_weights, destinations), after_wire=k)
+        pipe.finish()
         return n
 
 
