@@ -1,0 +1,116 @@
+"""An fp32 lm_head evaluated on the bf16 matrix cores (first step).
+
+The reference keeps the output projection in fp32 (pipelinerl/finetune/checkpoints.py:87-103, vLLM side
+vllm_quantization.py:240-278) while the hidden states arriving at it are bf16.  On MI355X an fp32 GEMM
+runs at ~150 TFLOP/s and a bf16 MFMA GEMM at ~1450 TFLOP/s, so the three lm_head GEMMs of a 7B micro-batch
+(8192 x 3584 x 152064) cost ~176 ms in fp32 next to 1.8 ms for this package's loss kernel.
+
+bf16 products are exact in fp32 (8 + 8 mantissa bits), so splitting the fp32 operand into a sum of bf16 terms
+and accumulating the partial GEMMs in fp32 reproduces the fp32 result to the accuracy of the split:
+
+    W = W_hi + W_lo (+ ...),  W_hi = bf16(W),  W_lo = bf16(W - W_hi)
+    x @ W^T  =  x @ W_hi^T + x @ W_lo^T                      (x is bf16, exact)
+
+Measured on one MI355X (profiles/r01x_split_bf16_lm_head_probe.txt): two terms are as close to the fp64
+product as the fp32 GEMM itself (1.7e-5 vs 2.1e-5 max abs error at |logits| <= 7.8) at 3.5x its speed.
+The GEMMs are plain hipBLASLt library calls (`torch.mm(..., out_dtype=float32)`); what this module adds is
+the operand splitting and the backward that keeps every GEMM on the bf16 cores.
+"""
+
+from __future__ import annotations
+
+import torch
+
+
+def split_bf16(t: torch.Tensor, terms: int = 2) -> list[torch.Tensor]:
+    """fp32 tensor -> `terms` bf16 tensors whose fp32 sum approximates it to ~2^(-8 terms) relative."""
+    parts, rest = [], t.float()
+    for k in range(terms):
+        p = rest.to(torch.bfloat16)
+        parts.append(p)
+        if k + 1 < terms:
+            rest = rest - p.float()
+    return parts
+
+
+_ADDMM_OUT_DTYPE: bool | None = None  # does torch.addmm(fp32, bf16, bf16, out_dtype=fp32) work on this build?
+
+
+def _mm_acc(a_parts, b_parts, pairs) -> torch.Tensor:
+    """sum over (i, j) in pairs of a_parts[i] @ b_parts[j], accumulated in fp32 - inside the GEMM
+    epilogue (beta = 1) where the library supports it, otherwise with a separate add pass."""
+    global _ADDMM_OUT_DTYPE
+    acc = None
+    for i, j in pairs:
+        if acc is None:
+            acc = torch.mm(a_parts[i], b_parts[j], out_dtype=torch.float32)
+            continue
+        if _ADDMM_OUT_DTYPE is not False:
+            try:
+                acc = torch.addmm(acc, a_parts[i], b_parts[j], out_dtype=torch.float32)
+                _ADDMM_OUT_DTYPE = True
+                continue
+            except (RuntimeError, TypeError):
+                if _ADDMM_OUT_DTYPE:  # it worked before: a real error
+                    raise
+                _ADDMM_OUT_DTYPE = False
+        acc.add_(torch.mm(a_parts[i], b_parts[j], out_dtype=torch.float32))
+    return acc
+
+
+class _SplitBf16Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, w_parts: tuple[torch.Tensor, ...]):  # type: ignore[override]
+        if x.dtype != torch.bfloat16:
+            raise TypeError("split_bf16_linear expects bf16 hidden states (they are exact bf16 operands)")
+        x2 = x.reshape(-1, x.shape[-1])
+        out = _mm_acc([x2], [p.t() for p in w_parts], [(0, j) for j in range(len(w_parts))])
+        ctx.save_for_backward(x2, *w_parts)
+        ctx.x_shape = x.shape
+        ctx.needs_w = weight.requires_grad
+        return out.reshape(*x.shape[:-1], w_parts[0].shape[0])
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):  # type: ignore[override]
+        x2, *w_parts = ctx.saved_tensors
+        g = grad_out.reshape(-1, grad_out.shape[-1])
+        g_parts = split_bf16(g, 2) if g.dtype == torch.float32 else [g.to(torch.bfloat16)]
+        n_g, n_w = len(g_parts), len(w_parts)
+        # d x = G W: keep the terms down to the second order of the splits (hi*hi, hi*lo, lo*hi)
+        pairs = [(i, j) for i in range(n_g) for j in range(n_w) if i + j < max(n_g, n_w)]
+        dx = _mm_acc(g_parts, list(w_parts), pairs).to(torch.bfloat16).reshape(ctx.x_shape)
+        dw = None
+        if ctx.needs_w:  # d W = G^T x, x exact
+            dw = _mm_acc([p.t() for p in g_parts], [x2], [(i, 0) for i in range(n_g)])
+        return dx, dw, None
+
+
+class SplitBf16LmHead(torch.nn.Module):
+    """Drop-in for an fp32 `nn.Linear(hidden, vocab, bias=False)` output head: `weight` stays an fp32
+    parameter (optimizer, checkpoints and the weight broadcast see fp32), the forward / backward GEMMs run
+    as bf16 MFMA GEMMs with fp32 accumulation.  The bf16 split of the weight is refreshed whenever the
+    parameter changes (in-place optimizer steps bump its version counter)."""
+
+    def __init__(self, weight: torch.Tensor, terms: int = 2):
+        super().__init__()
+        self.weight = weight if isinstance(weight, torch.nn.Parameter) else torch.nn.Parameter(weight.float())
+        self.terms = terms
+        self._parts: tuple[torch.Tensor, ...] | None = None
+        self._parts_version = -1
+
+    @classmethod
+    def from_linear(cls, linear: torch.nn.Linear, terms: int = 2) -> "SplitBf16LmHead":
+        if linear.bias is not None:
+            raise ValueError("lm_head with a bias is not supported")
+        return cls(linear.weight if linear.weight.dtype == torch.float32 else torch.nn.Parameter(linear.weight.float()), terms)
+
+    def _split(self) -> tuple[torch.Tensor, ...]:
+        v = self.weight._version
+        if self._parts is None or self._parts_version != v or self._parts[0].device != self.weight.device:
+            with torch.no_grad():
+                self._parts = tuple(split_bf16(self.weight.detach(), self.terms))
+            self._parts_version = v
+        return self._parts
+
+    def forward(self, hidden: torch.Tensor) -> torch.Tensor:
+        return _SplitBf16Linear.apply(hidden.to(torch.bfloat16) if hidden.dtype != torch.bfloat16 else hidden, self.weight, self._split())

@@ -1,0 +1,78 @@
+"""SplitBf16LmHead: an fp32 output head evaluated as bf16 MFMA GEMMs with fp32 accumulation must agree
+with the fp32 GEMM it replaces (reference numerics: checkpoints.py:87-103 keep the head in fp32)."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_split_bf16_head_matches_fp32_linear(cuda_device):
+    from pipelinerl_amd.lm_head import SplitBf16LmHead, split_bf16
+
+    torch.manual_seed(0)
+    T, H, V = 384, 256, 1536
+    x = torch.randn(2, T // 2, H, device=cuda_device).to(torch.bfloat16)
+    w = torch.randn(V, H, device=cuda_device) * 0.05
+    parts = split_bf16(w, 2)
+    assert (parts[0].float() + parts[1].float() - w).abs().max() <= 2.0 ** -15 * w.abs().max()
+
+    head = SplitBf16LmHead(torch.nn.Parameter(w.clone()))
+    xa = x.clone().requires_grad_(True)
+    logits = head(xa)
+    assert logits.dtype == torch.float32 and logits.shape == (2, T // 2, V)
+    g = torch.randn_like(logits)
+    logits.backward(g)
+
+    w64 = w.double().requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
+    ref = x64 @ w64.t()
+    ref.backward(g.double())
+    fp32 = x.float() @ w.t()
+    scale = ref.abs().max().item()
+    err_split = (logits.double() - ref).abs().max().item()
+    err_fp32 = (fp32.double() - ref).abs().max().item()
+    assert err_split <= 4e-6 * scale and err_split <= 4 * err_fp32 + 1e-7  # fp32-GEMM class accuracy
+    assert (head.weight.grad.double() - w64.grad).abs().max() <= 2e-4 * w64.grad.abs().max()
+    # d hidden is returned in bf16 (the dtype of the hidden states): bf16 rounding of the fp64 result
+    assert (xa.grad.double() - x64.grad).abs().max() <= 2.0 ** -7 * x64.grad.abs().max()
+
+    # the split follows in-place parameter updates
+    with torch.no_grad():
+        head.weight.add_(0.01)
+    again = head(x)
+    assert (again.double() - x.double() @ (w.double() + 0.01).t()).abs().max() <= 4e-6 * scale + 1e-5
+
+
+def test_split_head_feeds_the_loss_kernel(libprl, cuda_device):
+    """hidden -> SplitBf16LmHead -> rl_step's fused loss kernel -> gradients reach hidden and the head."""
+    import types
+
+    from pipelinerl_amd.finetune.rl import RLConfig, rl_step
+    from pipelinerl_amd.hotpath import HotPathStep, dense_micro_batches
+    from pipelinerl_amd.lm_head import SplitBf16LmHead
+    from pipelinerl_amd.synthetic import make_ragged
+
+    V, H = 640, 64
+    rag_h, _ = make_ragged(2, attempts=2, seq_length=32, vocab=V, seed=5, prompt_min=3, prompt_max=6)
+    rag = rag_h.to(cuda_device)
+    cfg = RLConfig(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0, batch_size=4, divide_advantage_by_std=False)
+    batches = HotPathStep(cfg, 2, 0, 10).preprocess(rag, dense_micro_batches(rag_h, 200))
+    torch.manual_seed(3)
+    emb = torch.nn.Embedding(V, H).to(cuda_device).to(torch.bfloat16)
+    w = torch.nn.Parameter(torch.randn(V, H, device=cuda_device) * 0.1)
+
+    def run(head_fn):
+        for p in (emb.weight, w):
+            p.grad = None
+        model = lambda **kw: types.SimpleNamespace(logits=head_fn(emb(kw["input_ids"])))  # noqa: E731
+        loss, stats = rl_step(model, batches[0], 0, 10, cfg)
+        loss.backward()
+        return loss.item(), emb.weight.grad.float().clone(), w.grad.clone()
+
+    head = SplitBf16LmHead(w)
+    l_split, ge_split, gw_split = run(head)
+    l_fp32, ge_fp32, gw_fp32 = run(lambda h: h.float() @ w.t())
+    assert abs(l_split - l_fp32) <= 1e-5 * max(1.0, abs(l_fp32))
+    assert (gw_split - gw_fp32).abs().max() <= 1e-3 * gw_fp32.abs().max() + 1e-9
+    assert (ge_split - ge_fp32).abs().max() <= 2.0 ** -6 * ge_fp32.abs().max() + 1e-9
