@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 3
+#define PRL_ABI_VERSION 4
 
 #define PRL_OK 0
 #define PRL_EINVAL (-22)   /* bad argument                                  */
@@ -396,6 +396,12 @@ struct prl_segment {
 };
 int prl_bucket_gather(void* bucket, int64_t bucket_bytes, const struct prl_segment* segments, int64_t n_segments, void* stream);
 int prl_bucket_scatter(const void* bucket, int64_t bucket_bytes, const struct prl_segment* segments, int64_t n_segments, void* stream);
+
+/* ---- fp32 -> two bf16 planes ------------------------------------------------------------
+ * hi[i] = bf16(src[i]), lo[i] = bf16(src[i] - float(hi[i])) (round to nearest even), one pass.
+ * Operand preparation for evaluating the reference's fp32 output head (checkpoints.py:87-103) as
+ * bf16 MFMA GEMMs with fp32 accumulation (pipelinerl_amd/lm_head.py).  Device pointers. */
+int prl_split_bf16(int64_t n, const float* src, uint16_t* hi, uint16_t* lo, void* stream);
 
 #ifdef __cplusplus
 }

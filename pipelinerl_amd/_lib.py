@@ -13,7 +13,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl.so"
 
-PRL_ABI_VERSION = 3
+PRL_ABI_VERSION = 4
 PRL_OK = 0
 PRL_EINVAL = -22
 PRL_ENOMEM = -12
@@ -148,6 +148,7 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_ipc_close": (c_int32, [c_void_p]),
     "prl_bucket_gather": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "prl_bucket_scatter": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "prl_split_bf16": (c_int32, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib: ctypes.CDLL | None = None

@@ -23,7 +23,16 @@ import torch
 
 
 def split_bf16(t: torch.Tensor, terms: int = 2) -> list[torch.Tensor]:
-    """fp32 tensor -> `terms` bf16 tensors whose fp32 sum approximates it to ~2^(-8 terms) relative."""
+    """fp32 tensor -> `terms` bf16 tensors whose fp32 sum approximates it to ~2^(-8 terms) relative.
+    Two terms of a contiguous fp32 device tensor come out of ONE pass of the `prl_split_bf16` kernel."""
+    if terms == 2 and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0:
+        from . import _lib
+
+        hi = torch.empty_like(t, dtype=torch.bfloat16)
+        lo = torch.empty_like(t, dtype=torch.bfloat16)
+        with torch.cuda.device(t.device):
+            _lib.check(_lib.load().prl_split_bf16(t.numel(), t.data_ptr(), hi.data_ptr(), lo.data_ptr(), _lib.current_stream_ptr(t.device)))
+        return [hi, lo]
     parts, rest = [], t.float()
     for k in range(terms):
         p = rest.to(torch.bfloat16)

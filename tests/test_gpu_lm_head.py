@@ -76,3 +76,22 @@ def test_split_head_feeds_the_loss_kernel(libprl, cuda_device):
     assert abs(l_split - l_fp32) <= 1e-5 * max(1.0, abs(l_fp32))
     assert (gw_split - gw_fp32).abs().max() <= 1e-3 * gw_fp32.abs().max() + 1e-9
     assert (ge_split - ge_fp32).abs().max() <= 2.0 ** -6 * ge_fp32.abs().max() + 1e-9
+
+
+@pytest.mark.parametrize("n", [4096, 4099, 1 << 22, 3])
+def test_split_bf16_kernel_matches_torch(libprl, cuda_device, n):
+    """prl_split_bf16 (one pass) == the three-pass torch formulation, bit for bit."""
+    from pipelinerl_amd.lm_head import split_bf16
+
+    torch.manual_seed(n)
+    t = torch.randn(n + 4, device=cuda_device)[:n] * torch.logspace(-3, 3, n, device=cuda_device)
+    t = t.contiguous()
+    if n >= 8:
+        t[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1.0e-30, 65504.0], device=cuda_device)
+    hi, lo = split_bf16(t, 2)
+    want_hi = t.to(torch.bfloat16)
+    want_lo = (t - want_hi.float()).to(torch.bfloat16)
+    assert torch.equal(hi.view(torch.int16), want_hi.view(torch.int16))
+    assert torch.equal(lo.view(torch.int16), want_lo.view(torch.int16))
+    finite = torch.isfinite(hi.float() + lo.float())
+    assert ((hi.float() + lo.float() - t).abs()[finite] <= 2.0 ** -15 * t.abs()[finite] + 1e-38).all()
