@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=2048)
     ap.add_argument("--fused", action="store_true")
     ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--split-head", action="store_true", help="fp32 lm_head evaluated as bf16 MFMA GEMMs (pipelinerl_amd.lm_head)")
     args = ap.parse_args()
 
     import transformers
@@ -45,7 +46,12 @@ def main():
     torch.manual_seed(0)
     model = transformers.Qwen2ForCausalLM(cfg_m).to(dev).to(torch.bfloat16)
     model.lm_head = model.lm_head.float()  # fp32 lm_head (reference checkpoints.py:87-103)
-    model.lm_head.register_forward_pre_hook(lambda m, a: (a[0].float(),))
+    if args.split_head:
+        from pipelinerl_amd.lm_head import SplitBf16LmHead
+
+        model.lm_head = SplitBf16LmHead.from_linear(model.lm_head)  # same fp32 parameter, bf16 MFMA GEMMs
+    else:
+        model.lm_head.register_forward_pre_hook(lambda m, a: (a[0].float(),))
     model.gradient_checkpointing_enable()
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-6, fused=True)
@@ -96,7 +102,8 @@ def main():
     loss_fwd_ms = sum(a.elapsed_time(b) for a, b in timers["pairs"]) / args.steps
     print(json.dumps({
         "what": "end-to-end learner step incl. model fwd/bwd + AdamW (stock PyTorch-ROCm) + HIP loss path",
-        "model": f"Qwen2 random init, {n_params / 1e6:.0f}M params, {args.layers} layers, bf16 + fp32 lm_head, grad checkpointing, sdpa",
+        "model": f"Qwen2 random init, {n_params / 1e6:.0f}M params, {args.layers} layers, bf16 + fp32 lm_head"
+                 f"{' on bf16 matrix cores (2-term split)' if args.split_head else ''}, grad checkpointing, sdpa",
         "global_batch": bs, "seq_len": L, "micro_batch": mb, "logits_mode": "fused" if args.fused else "two_pass",
         "samples_per_s": bs / dt, "s_per_step": dt, "tokens_per_s": bs * L / dt,
         "loss_forward_path_ms_per_step": loss_fwd_ms, "loss_forward_fraction": loss_fwd_ms / 1e3 / dt,
