@@ -28,8 +28,11 @@ def split_bf16(t: torch.Tensor, terms: int = 2) -> list[torch.Tensor]:
     if terms == 2 and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0:
         from . import _lib
 
-        hi = torch.empty_like(t, dtype=torch.bfloat16)
-        lo = torch.empty_like(t, dtype=torch.bfloat16)
+        if t.numel() % 4 == 0:  # hi plane, then lo plane, in one buffer (the lo plane stays 8-byte aligned)
+            planes = torch.empty((2,) + tuple(t.shape), dtype=torch.bfloat16, device=t.device)
+            hi, lo = planes[0], planes[1]
+        else:
+            hi, lo = torch.empty_like(t, dtype=torch.bfloat16), torch.empty_like(t, dtype=torch.bfloat16)
         with torch.cuda.device(t.device):
             _lib.check(_lib.load().prl_split_bf16(t.numel(), t.data_ptr(), hi.data_ptr(), lo.data_ptr(), _lib.current_stream_ptr(t.device)))
         return [hi, lo]
@@ -69,11 +72,16 @@ def _mm_acc(a_parts, b_parts, pairs) -> torch.Tensor:
 
 class _SplitBf16Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, w_parts: tuple[torch.Tensor, ...]):  # type: ignore[override]
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, w_parts: tuple[torch.Tensor, ...], w_cat: torch.Tensor | None):  # type: ignore[override]
         if x.dtype != torch.bfloat16:
             raise TypeError("split_bf16_linear expects bf16 hidden states (they are exact bf16 operands)")
         x2 = x.reshape(-1, x.shape[-1])
-        out = _mm_acc([x2], [p.t() for p in w_parts], [(0, j) for j in range(len(w_parts))])
+        if w_cat is not None:
+            # sum_k x @ W_k^T as ONE GEMM over the concatenated inner dimension: [x | x | ..] @ [W_0 | W_1 | ..]^T.
+            # The partial products meet in the MFMA accumulators instead of a 5 GB read-modify-write pass.
+            out = torch.mm(torch.cat([x2] * len(w_parts), dim=1), w_cat.t(), out_dtype=torch.float32)
+        else:
+            out = _mm_acc([x2], [p.t() for p in w_parts], [(0, j) for j in range(len(w_parts))])
         ctx.save_for_backward(x2, *w_parts)
         ctx.x_shape = x.shape
         ctx.needs_w = weight.requires_grad
@@ -90,8 +98,14 @@ class _SplitBf16Linear(torch.autograd.Function):
         dx = _mm_acc(g_parts, list(w_parts), pairs).to(torch.bfloat16).reshape(ctx.x_shape)
         dw = None
         if ctx.needs_w:  # d W = G^T x, x exact
-            dw = _mm_acc([p.t() for p in g_parts], [x2], [(i, 0) for i in range(n_g)])
-        return dx, dw, None
+            stacked = (n_g == 2 and g_parts[0].is_contiguous() and g_parts[1].is_contiguous()
+                       and g_parts[1].data_ptr() == g_parts[0].data_ptr() + g_parts[0].numel() * 2)
+            if stacked:  # the two planes are one [2T, V] buffer: G_hi^T x + G_lo^T x as ONE GEMM over 2T
+                g_cat = torch.as_strided(g_parts[0], (2 * g.shape[0], g.shape[1]), (g.shape[1], 1))
+                dw = torch.mm(g_cat.t(), torch.cat([x2, x2], dim=0), out_dtype=torch.float32)
+            else:
+                dw = _mm_acc([p.t() for p in g_parts], [x2], [(i, 0) for i in range(n_g)])
+        return dx, dw, None, None
 
 
 class SplitBf16LmHead(torch.nn.Module):
@@ -105,6 +119,7 @@ class SplitBf16LmHead(torch.nn.Module):
         self.weight = weight if isinstance(weight, torch.nn.Parameter) else torch.nn.Parameter(weight.float())
         self.terms = terms
         self._parts: tuple[torch.Tensor, ...] | None = None
+        self._cat: torch.Tensor | None = None
         self._parts_version = -1
 
     @classmethod
@@ -117,9 +132,15 @@ class SplitBf16LmHead(torch.nn.Module):
         v = self.weight._version
         if self._parts is None or self._parts_version != v or self._parts[0].device != self.weight.device:
             with torch.no_grad():
-                self._parts = tuple(split_bf16(self.weight.detach(), self.terms))
+                parts = split_bf16(self.weight.detach(), self.terms)
+                # [V, terms * H]: the terms side by side along the inner dimension (forward), and the
+                # same storage viewed per term (backward) - once per optimizer step
+                self._cat = torch.cat(parts, dim=1)
+                h = self.weight.shape[1]
+                self._parts = tuple(self._cat[:, k * h : (k + 1) * h] for k in range(self.terms))
             self._parts_version = v
         return self._parts
 
     def forward(self, hidden: torch.Tensor) -> torch.Tensor:
-        return _SplitBf16Linear.apply(hidden.to(torch.bfloat16) if hidden.dtype != torch.bfloat16 else hidden, self.weight, self._split())
+        parts = self._split()
+        return _SplitBf16Linear.apply(hidden.to(torch.bfloat16) if hidden.dtype != torch.bfloat16 else hidden, self.weight, parts, self._cat)
