@@ -72,7 +72,7 @@ def _mm_acc(a_parts, b_parts, pairs) -> torch.Tensor:
 
 class _SplitBf16Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, w_parts: tuple[torch.Tensor, ...], w_cat: torch.Tensor | None):  # type: ignore[override]
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, w_parts: tuple[torch.Tensor, ...], w_cat: torch.Tensor | None, dx_terms: int = 3):  # type: ignore[override]
         if x.dtype != torch.bfloat16:
             raise TypeError("split_bf16_linear expects bf16 hidden states (they are exact bf16 operands)")
         x2 = x.reshape(-1, x.shape[-1])
@@ -84,6 +84,7 @@ class _SplitBf16Linear(torch.autograd.Function):
             out = _mm_acc([x2], [p.t() for p in w_parts], [(0, j) for j in range(len(w_parts))])
         ctx.save_for_backward(x2, *w_parts)
         ctx.x_shape = x.shape
+        ctx.dx_terms = dx_terms
         ctx.needs_w = weight.requires_grad
         return out.reshape(*x.shape[:-1], w_parts[0].shape[0])
 
@@ -94,7 +95,7 @@ class _SplitBf16Linear(torch.autograd.Function):
         g_parts = split_bf16(g, 2) if g.dtype == torch.float32 else [g.to(torch.bfloat16)]
         n_g, n_w = len(g_parts), len(w_parts)
         # d x = G W: keep the terms down to the second order of the splits (hi*hi, hi*lo, lo*hi)
-        pairs = [(i, j) for i in range(n_g) for j in range(n_w) if i + j < max(n_g, n_w)]
+        pairs = [(i, j) for i in range(n_g) for j in range(n_w) if i + j < max(n_g, n_w)][: ctx.dx_terms]
         dx = _mm_acc(g_parts, list(w_parts), pairs).to(torch.bfloat16).reshape(ctx.x_shape)
         dw = None
         if ctx.needs_w:  # d W = G^T x, x exact
@@ -105,7 +106,7 @@ class _SplitBf16Linear(torch.autograd.Function):
                 dw = torch.mm(g_cat.t(), torch.cat([x2, x2], dim=0), out_dtype=torch.float32)
             else:
                 dw = _mm_acc([p.t() for p in g_parts], [x2], [(i, 0) for i in range(n_g)])
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 class SplitBf16LmHead(torch.nn.Module):
@@ -114,8 +115,12 @@ class SplitBf16LmHead(torch.nn.Module):
     as bf16 MFMA GEMMs with fp32 accumulation.  The bf16 split of the weight is refreshed whenever the
     parameter changes (in-place optimizer steps bump its version counter)."""
 
-    def __init__(self, weight: torch.Tensor, terms: int = 2):
+    def __init__(self, weight: torch.Tensor, terms: int = 2, hidden_grad_terms: int = 3):
+        """`hidden_grad_terms`: how many of the partial products G_hi W_hi, G_hi W_lo, G_lo W_hi enter d hidden.
+        3 reproduces the fp32 product before it is rounded to the bf16 hidden dtype; 1 keeps only the leading
+        term, whose error (2^-9 relative) is of the order of that rounding - 2 GEMMs cheaper."""
         super().__init__()
+        self.hidden_grad_terms = hidden_grad_terms
         self.weight = weight if isinstance(weight, torch.nn.Parameter) else torch.nn.Parameter(weight.float())
         self.terms = terms
         self._parts: tuple[torch.Tensor, ...] | None = None
@@ -123,10 +128,10 @@ class SplitBf16LmHead(torch.nn.Module):
         self._parts_version = -1
 
     @classmethod
-    def from_linear(cls, linear: torch.nn.Linear, terms: int = 2) -> "SplitBf16LmHead":
+    def from_linear(cls, linear: torch.nn.Linear, terms: int = 2, hidden_grad_terms: int = 3) -> "SplitBf16LmHead":
         if linear.bias is not None:
             raise ValueError("lm_head with a bias is not supported")
-        return cls(linear.weight if linear.weight.dtype == torch.float32 else torch.nn.Parameter(linear.weight.float()), terms)
+        return cls(linear.weight if linear.weight.dtype == torch.float32 else torch.nn.Parameter(linear.weight.float()), terms, hidden_grad_terms)
 
     def _split(self) -> tuple[torch.Tensor, ...]:
         v = self.weight._version
@@ -143,4 +148,4 @@ class SplitBf16LmHead(torch.nn.Module):
 
     def forward(self, hidden: torch.Tensor) -> torch.Tensor:
         parts = self._split()
-        return _SplitBf16Linear.apply(hidden.to(torch.bfloat16) if hidden.dtype != torch.bfloat16 else hidden, self.weight, parts, self._cat)
+        return _SplitBf16Linear.apply(hidden.to(torch.bfloat16) if hidden.dtype != torch.bfloat16 else hidden, self.weight, parts, self._cat, self.hidden_grad_terms)

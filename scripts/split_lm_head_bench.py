@@ -40,7 +40,8 @@ def fwd_bwd(head):
 
 head = SplitBf16LmHead(w)
 fp32 = lambda h: torch.nn.functional.linear(h.float(), w)  # noqa: E731
-for name, fn in (("fp32 linear", fp32), ("split-bf16 head", head)):
+head1 = SplitBf16LmHead(w, hidden_grad_terms=1)
+for name, fn in (("fp32 linear", fp32), ("split-bf16 head", head), ("split, 1-term dX", head1)):
     f = timeit(lambda: fn(x.detach()))
     fb = timeit(lambda: fwd_bwd(fn))
     print(f"{name:18s}: forward {f:7.2f} ms   forward + backward (dX, dW) {fb:7.2f} ms")
