@@ -98,7 +98,7 @@ class _SplitBf16Linear(torch.autograd.Function):
         pairs = [(i, j) for i in range(n_g) for j in range(n_w) if i + j < max(n_g, n_w)][: ctx.dx_terms]
         dx = _mm_acc(g_parts, list(w_parts), pairs).to(torch.bfloat16).reshape(ctx.x_shape)
         dw = None
-        if ctx.needs_w:  # d W = G^T x, x exact
+        if ctx.needs_w:  # d W = G^T x, x exact (returned in fp32; autograd casts it to a bf16 parameter's dtype)
             stacked = (n_g == 2 and g_parts[0].is_contiguous() and g_parts[1].is_contiguous()
                        and g_parts[1].data_ptr() == g_parts[0].data_ptr() + g_parts[0].numel() * 2)
             if stacked:  # the two planes are one [2T, V] buffer: G_hi^T x + G_lo^T x as ONE GEMM over 2T
@@ -149,3 +149,45 @@ class SplitBf16LmHead(torch.nn.Module):
     def forward(self, hidden: torch.Tensor) -> torch.Tensor:
         parts = self._split()
         return _SplitBf16Linear.apply(hidden.to(torch.bfloat16) if hidden.dtype != torch.bfloat16 else hidden, self.weight, parts, self._cat, self.hidden_grad_terms)
+
+
+def apply_fp32_lm_head(model: torch.nn.Module, layer_prefix: str = "lm_head", hidden_grad_terms: int = 3) -> torch.nn.Module:
+    """Drop-in for the reference's `apply_fp32_lm_head(model, layer_prefix)` (finetune/checkpoints.py:44-103):
+    the output projection computes in fp32 precision whatever the dtype of its inputs - here on the bf16
+    matrix cores.  As in the reference the module and its parameter stay where they are (a tied weight keeps
+    its storage and dtype); only `forward` is replaced.
+
+      * fp32 weight (untied head upcast by the trainer): 2-term bf16 split, refreshed when the weight changes;
+      * bf16 weight (tied to the embedding): the weight is already an exact bf16 operand, ONE GEMM;
+      * a bias is added in fp32.
+    """
+    head = model
+    for part in layer_prefix.split("."):
+        head = getattr(head, part)
+    if not isinstance(head, torch.nn.Linear):
+        raise TypeError(f"{layer_prefix} is {type(head).__name__}, expected nn.Linear")
+    state = {"version": -1, "parts": None, "cat": None, "device": None}
+
+    def operands():
+        w = head.weight
+        if state["version"] != w._version or state["device"] != w.device:
+            with torch.no_grad():
+                if w.dtype == torch.bfloat16:
+                    state["parts"], state["cat"] = (w.detach(),), None
+                else:
+                    parts = split_bf16(w.detach().float(), 2)
+                    cat = torch.cat(parts, dim=1)
+                    hdim = w.shape[1]
+                    state["parts"], state["cat"] = tuple(cat[:, k * hdim : (k + 1) * hdim] for k in range(2)), cat
+            state["version"], state["device"] = w._version, w.device
+        return state["parts"], state["cat"]
+
+    def fp32_forward(x: torch.Tensor) -> torch.Tensor:
+        parts, cat = operands()
+        y = _SplitBf16Linear.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), head.weight, parts, cat, hidden_grad_terms)
+        if head.bias is not None:
+            y = y + head.bias.float()
+        return y
+
+    head.forward = fp32_forward
+    return model

@@ -95,3 +95,41 @@ def test_split_bf16_kernel_matches_torch(libprl, cuda_device, n):
     assert torch.equal(lo.view(torch.int16), want_lo.view(torch.int16))
     finite = torch.isfinite(hi.float() + lo.float())
     assert ((hi.float() + lo.float() - t).abs()[finite] <= 2.0 ** -15 * t.abs()[finite] + 1e-38).all()
+
+
+@pytest.mark.parametrize("tied", [False, True])
+def test_apply_fp32_lm_head_drop_in(cuda_device, tied):
+    """`apply_fp32_lm_head(model)` (reference checkpoints.py:44-103): fp32-precision logits from the
+    model's own lm_head module - fp32 weight (2-term split) or a bf16 weight tied to the embedding (exact)."""
+    from pipelinerl_amd.lm_head import apply_fp32_lm_head
+
+    class Tiny(torch.nn.Module):
+        def __init__(self, V=768, H=128):
+            super().__init__()
+            self.embed = torch.nn.Embedding(V, H)
+            self.lm_head = torch.nn.Linear(H, V, bias=False)
+
+        def forward(self, ids):
+            return self.lm_head(self.embed(ids))
+
+    torch.manual_seed(4)
+    m = Tiny().to(cuda_device).to(torch.bfloat16)
+    if tied:
+        m.lm_head.weight = m.embed.weight
+    else:
+        m.lm_head = m.lm_head.float()
+    apply_fp32_lm_head(m)
+    ids = torch.randint(0, 768, (2, 96), device=cuda_device)
+    logits = m(ids)
+    assert logits.dtype == torch.float32
+    h = m.embed(ids)
+    want = h.double() @ m.lm_head.weight.double().t()
+    assert (logits.double() - want).abs().max() <= 4e-6 * want.abs().max()
+    g = torch.randn_like(logits)
+    logits.backward(g)
+    w = m.lm_head.weight
+    assert w.grad is not None and w.grad.dtype == w.dtype
+    if not tied:
+        want_dw = g.reshape(-1, 768).double().t() @ h.reshape(-1, 128).double()
+        assert (w.grad.double() - want_dw).abs().max() <= 2e-4 * want_dw.abs().max()
+    assert m.lm_head.weight.data_ptr() == (m.embed.weight.data_ptr() if tied else m.lm_head.weight.data_ptr())
