@@ -84,7 +84,12 @@ def _worker(rank: int, world: int, port: int, out_q) -> None:
 def test_gspo_sequence_parallel_matches_reference(libprl, cuda_device):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, 29733, q), daemon=True) for r in range(2)]
+    import socket
+
+    with socket.socket() as sock:  # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q), daemon=True) for r in range(2)]
     for p in procs:
         p.start()
     try:
