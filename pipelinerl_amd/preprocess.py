@@ -228,12 +228,17 @@ class PreprocessorLoop:
     Back-pressure as in the reference (:587-592): publishing pauses while
     published - trainer_state.samples_processed exceeds max_ready_samples_per_lead * num_trainers."""
 
-    def __init__(self, cfg: PreprocessorConfig, device, trainer_state=None):
+    def __init__(self, cfg: PreprocessorConfig, device, trainer_state=None, ref_model=None):
+        """`ref_model`: a frozen reference policy on the preprocessor's GPU.  When given, every real
+        micro-batch gets its `ref_logprobs` from a no-grad forward of that model (K1 on its logits)
+        before it is published - the device-side replacement of the reference's HTTP round trip to a
+        second inference server (preprocess.py:86-104, llm.py:606-648)."""
         from .streams import SingleStreamSpec, StreamRangeSpec
 
         self.cfg = cfg
         self.device = device
         self.trainer_state = trainer_state
+        self.ref_model = ref_model
         self.sched = MicroBatchScheduler(cfg.num_trainers, cfg.train_batch_size, cfg.gradient_accumulation_passes,
                                          cfg.seq_length, seq_parallel=cfg.seq_parallel, length_of=lambda s: s.length)
         self.in_spec = SingleStreamSpec(exp_path=cfg.exp_path, topic=cfg.input_topic)
@@ -292,6 +297,10 @@ class PreprocessorLoop:
             else:
                 batch = packed[k]
                 k += 1
+                if self.ref_model is not None:
+                    from .finetune.rl import annotate_ref_logprobs
+
+                    annotate_ref_logprobs(self.ref_model, batch, self.cfg.rl.temperature)
             slices = batch.make_slices(self.cfg.seq_parallel) if self.cfg.seq_parallel > 1 else [batch]
             for off, piece in enumerate(slices):
                 writer.write(piece, partition=mb.trainer_id + off)

@@ -266,3 +266,48 @@ def test_native_step_with_reference_model_on_the_learner(libprl, cuda_device):
         assert torch.allclose(ga, pb.grad, rtol=1e-4, atol=1e-7)
     for k in ("loss", "kl", "ref_logprobs", "ratio_ref_new"):
         assert abs(stats_a[k] - sum(agg[k])) <= 1e-4 * max(1.0, abs(sum(agg[k]))), k
+
+
+def test_preprocessor_fills_ref_logprobs_from_a_model_on_its_gpu(libprl, cuda_device, tmp_path):
+    """PreprocessorLoop(ref_model=...): the published batches carry log p_ref of every labelled token
+    (what the reference fetches over HTTP, preprocess.py:86-104), equal to a torch log_softmax."""
+    from pipelinerl_amd import streams
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.preprocess import PreprocessorConfig, PreprocessorLoop
+    from pipelinerl_amd.synthetic import make_entries
+
+    streams.reset_streams_backend()
+    streams.set_streams_backend("files")
+    try:
+        attempts, V = 2, 64
+        raw = make_entries(4, attempts=attempts, seq_length=40, vocab=V, seed=33, prompt_min=3, prompt_max=8)
+        rl = RLConfig(policy_loss="ppo", kl_coef=0.1, final_kl_coef=0.1, divide_advantage_by_std=False)
+        cfg = PreprocessorConfig(exp_path=tmp_path, num_trainers=1, train_batch_size=1, gradient_accumulation_passes=8,
+                                 seq_length=80, attempts=attempts, rl=rl, eos_token_id=2, chunk_n_groups=2)
+        torch.manual_seed(5)
+        ref_model = TinyLM(V).to(cuda_device).eval()
+        with streams.write_to_streams(streams.SingleStreamSpec(exp_path=tmp_path, topic="actor")) as w:
+            for g in range(4):
+                w.write(raw[g * attempts:(g + 1) * attempts])
+        n = PreprocessorLoop(cfg, cuda_device, ref_model=ref_model).run(max_published_samples=8, idle_timeout=2.0)
+        assert n == 8
+        seen = 0
+        with streams.read_stream(streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data", partition=0)) as r:
+            for rec in r.read():
+                b = PipelineBatchEncoding(**rec).to_device(cuda_device)
+                if b.sentinel:
+                    continue
+                with torch.no_grad():
+                    lp = torch.log_softmax(ref_model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits.float(), -1)
+                want = torch.zeros_like(b.ref_logprobs)
+                want[:, 1:] = lp[:, :-1].gather(-1, b.input_ids[:, 1:, None])[..., 0]
+                want = torch.where(b.labels != -100, want, torch.zeros_like(want))
+                assert torch.allclose(b.ref_logprobs, want, rtol=1e-5, atol=1e-5)
+                assert not torch.equal(b.ref_logprobs, b.old_logprobs)
+                seen += int(b.seq_boundaries.shape[0]) - 1
+                if seen >= 8:
+                    break
+        assert seen == 8
+    finally:
+        streams.reset_streams_backend()
