@@ -63,7 +63,8 @@ class RLConfig(BaseModel):
     filter_zero_advantage_groups: bool = Field(default=False, description="drop all-zero-advantage groups")
     value_loss_coef: float = Field(default=0.0, description="value-head loss weight (value head unsupported)")
     # --- MI355X extensions (absent from the reference; defaults keep its behaviour) ---
-    fused_logits_grad: bool = Field(default=False, description="single-pass logits kernel: gradient computed in forward")
+    fused_logits_grad: bool = Field(default=True, description="single-pass logits kernel (gradient computed in the forward launch) "
+                                    "whenever the logits require a gradient; False = K1 forward, K2+K3, K1 backward as separate launches")
     inplace_logits_grad: bool = Field(default=False, description="write d loss/d logits over the logits buffer")
 
 
@@ -451,7 +452,8 @@ def rl_step(
     _lib.require_device(logits)
 
     loss, stats_dev = _GrpoLossFn.apply(
-        logits, batch, cfg, config.temperature, bool(config.fused_logits_grad) and config.policy_loss != "gspo",
+        logits, batch, cfg, config.temperature,
+        bool(config.fused_logits_grad) and config.policy_loss != "gspo" and logits.requires_grad and torch.is_grad_enabled(),
         bool(config.inplace_logits_grad), seq_parallel_group if config.policy_loss == "gspo" else None,
     )
     stats = stats_dev.cpu().tolist()  # the single device->host sync of the step
