@@ -186,21 +186,28 @@ def cpu_baseline(seq_length: int, vocab: int) -> dict:
     }
 
 
-def weight_sync_probe(rank: int, world: int, dev: torch.device) -> dict | None:
-    """Trainer -> actor weight broadcast (rank 0 -> all others) of a Qwen2.5-7B sized bf16 flat
-    bucket set over RCCL: plain broadcast vs scatter + all-gather.  Extra field, never `value`."""
+def weight_sync_probe(rank: int, world: int, dev: torch.device, out: dict) -> dict:
+    """Trainer -> actor weight update (rank 0 -> all others) over RCCL, Qwen2.5-7B sized (bf16):
+      (1) the wire alone: 15 x 1 GiB buckets, plain broadcast vs scatter + all-gather;
+      (2) the whole update as the trainer runs it: flatten 339 parameters into buckets (gather kernel),
+          move them (two-stream pipeline), scatter them into the receivers' own weight tensors, verified.
+    Results are written into `out` as they arrive (a watchdog may print it if a later stage hangs).
+    Extra field, never `value`."""
     import torch.distributed as dist
 
     total_bytes = int(os.environ.get("PRL_BENCH_WSYNC_BYTES", 15_231_233_024))  # 7.6B params bf16
     bucket_bytes = 1 << 30
+    grp = None
     try:
         from pipelinerl_amd.weight_sync import WeightSyncGroup
 
+        out["stage"] = "init"
         grp = WeightSyncGroup.from_torch_distributed(rank, world, dev)
         bucket = torch.empty(bucket_bytes, dtype=torch.uint8, device=dev)
         n_buckets = (total_bytes + bucket_bytes - 1) // bucket_bytes
-        out = {"bytes": n_buckets * bucket_bytes, "n_receivers": world - 1, "bucket_bytes": bucket_bytes}
+        out.update({"bytes": n_buckets * bucket_bytes, "n_receivers": world - 1, "bucket_bytes": bucket_bytes})
         for mode in ("broadcast", "scatter_allgather"):
+            out["stage"] = f"wire:{mode}"
             for it in range(2):  # first pass warms the RCCL channels
                 dist.barrier()
                 torch.cuda.synchronize()
@@ -214,10 +221,58 @@ def weight_sync_probe(rank: int, world: int, dev: torch.device) -> dict | None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             out[f"{mode}_ms"] = 1e3 * t.item()
             out[f"{mode}_GBps"] = out["bytes"] / t.item() / 1e9
-        grp.close()
-        return out
+        del bucket
     except Exception as e:  # the probe must never take the benchmark line down
-        return {"error": f"{type(e).__name__}: {e}"}
+        out["error"] = f"{type(e).__name__}: {e}"
+        return out
+    try:
+        from pipelinerl_amd.weight_sync import BucketedReceiver, BucketedSender, ParamSpec
+        from pipelinerl_amd.weight_sync_probe import qwen25_shapes
+
+        out["stage"] = "full_update"
+        shapes = qwen25_shapes("7b")
+        gen = torch.Generator(device=dev).manual_seed(77)  # same values on every rank: receivers can verify
+        probe_name = "model.norm.weight"
+        if rank == 0:
+            params = [(n, torch.empty(s, dtype=torch.bfloat16, device=dev).normal_(generator=gen)) for n, s in shapes]
+            sender = BucketedSender(grp, bucket_bytes)
+        else:
+            expect = None
+            dest = {}
+            for n, s in shapes:
+                t_ = torch.empty(s, dtype=torch.bfloat16, device=dev).normal_(generator=gen)
+                if n == probe_name:
+                    expect = t_.clone()
+                dest[n] = t_.zero_()
+            info = [ParamSpec(n, tuple(s), torch.bfloat16) for n, s in shapes]
+            receiver = BucketedReceiver(grp, bucket_bytes)
+        for it in range(2):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if rank == 0:
+                sender.send(params)
+            else:
+                receiver.receive(info, None, destinations=dest)
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt = time.perf_counter() - t0
+        ok = torch.tensor([1 if rank == 0 or torch.equal(dest[probe_name], expect) else 0], device=dev)
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        out["full_update_ms"] = 1e3 * t.item()
+        out["full_update_tensors"] = len(shapes)
+        out["full_update_verified"] = bool(ok.item())
+        out["stage"] = "done"
+    except Exception as e:  # noqa: BLE001 - keep the wire numbers
+        out["full_update_error"] = f"{type(e).__name__}: {e}"
+    finally:
+        try:
+            grp.close()
+        except Exception:  # noqa: BLE001
+            pass
+    return out
 
 
 def main():
@@ -428,18 +483,20 @@ def main():
             wsync = colocated_probe("7b" if args.workload.startswith("7b") else "0p5b", iters=5, rehome=True, ready_timeout=240.0)
         except Exception as e:  # noqa: BLE001 - the probe must never take the benchmark line down
             wsync = {"error": f"{type(e).__name__}: {e}"}
-    if world > 1 and args.backend == "nccl" and not args.no_weight_sync and os.environ.get("PRL_BENCH_WSYNC", "1") != "0":
+    force = os.environ.get("PRL_BENCH_FORCE_WSYNC") == "1"  # dry runs: exercise the probe's error handling under gloo
+    if world > 1 and (args.backend == "nccl" or force) and not args.no_weight_sync and os.environ.get("PRL_BENCH_WSYNC", "1") != "0":
         import threading
 
         done = threading.Event()
+        wsync = {}
 
         def watchdog():
-            if not done.wait(float(os.environ.get("PRL_BENCH_WSYNC_TIMEOUT", 180))):
-                emit({"error": "weight-sync probe timed out"})
+            if not done.wait(float(os.environ.get("PRL_BENCH_WSYNC_TIMEOUT", 240))):
+                emit({**wsync, "error": f"weight-sync probe timed out in stage {wsync.get('stage')}"})
                 os._exit(0)
 
         threading.Thread(target=watchdog, daemon=True).start()
-        wsync = weight_sync_probe(rank, world, dev)
+        weight_sync_probe(rank, world, dev, wsync)
         done.set()
     emit(wsync)
     if world > 1:
