@@ -491,7 +491,7 @@ def main():
         wsync = {}
 
         def watchdog():
-            if not done.wait(float(os.environ.get("PRL_BENCH_WSYNC_TIMEOUT", 240))):
+            if not done.wait(float(os.environ.get("PRL_BENCH_WSYNC_TIMEOUT", 90))):
                 emit({**wsync, "error": f"weight-sync probe timed out in stage {wsync.get('stage')}"})
                 os._exit(0)
 
