@@ -27,7 +27,8 @@ def main():
     ap.add_argument("--batch-size", type=int, default=512)
     ap.add_argument("--seq-len", type=int, default=2048)
     ap.add_argument("--fused", action="store_true")
-    ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--model", default="0p5b", choices=["0p5b", "7b"], help="Qwen2.5 shape (random init)")
     ap.add_argument("--split-head", action="store_true", help="fp32 lm_head evaluated as bf16 MFMA GEMMs (pipelinerl_amd.lm_head)")
     args = ap.parse_args()
 
@@ -39,12 +40,19 @@ def main():
     from pipelinerl_amd.synthetic import make_ragged
 
     dev = torch.device("cuda", 0)
-    V = 151936
-    cfg_m = transformers.Qwen2Config(vocab_size=V, hidden_size=896, intermediate_size=4864, num_hidden_layers=args.layers,
-                                     num_attention_heads=14, num_key_value_heads=2, max_position_embeddings=32768,
+    shape = {"0p5b": dict(V=151936, hidden=896, inter=4864, layers=24, heads=14, kv=2),
+             "7b": dict(V=152064, hidden=3584, inter=18944, layers=28, heads=28, kv=4)}[args.model]
+    V = shape["V"]
+    args.layers = args.layers or shape["layers"]
+    cfg_m = transformers.Qwen2Config(vocab_size=V, hidden_size=shape["hidden"], intermediate_size=shape["inter"], num_hidden_layers=args.layers,
+                                     num_attention_heads=shape["heads"], num_key_value_heads=shape["kv"], max_position_embeddings=32768,
                                      tie_word_embeddings=False, attn_implementation="sdpa")
     torch.manual_seed(0)
-    model = transformers.Qwen2ForCausalLM(cfg_m).to(dev).to(torch.bfloat16)
+    with torch.device(dev):  # build directly in HBM (a 7B random init on the host takes minutes)
+        torch.set_default_dtype(torch.bfloat16)
+        model = transformers.Qwen2ForCausalLM(cfg_m)
+        torch.set_default_dtype(torch.float32)
+    model = model.to(torch.bfloat16)
     model.lm_head = model.lm_head.float()  # fp32 lm_head (reference checkpoints.py:87-103)
     if args.split_head:
         from pipelinerl_amd.lm_head import SplitBf16LmHead
@@ -102,7 +110,7 @@ def main():
     loss_fwd_ms = sum(a.elapsed_time(b) for a, b in timers["pairs"]) / args.steps
     print(json.dumps({
         "what": "end-to-end learner step incl. model fwd/bwd + AdamW (stock PyTorch-ROCm) + HIP loss path",
-        "model": f"Qwen2 random init, {n_params / 1e6:.0f}M params, {args.layers} layers, bf16 + fp32 lm_head"
+        "model": f"Qwen2.5-{args.model} shape, random init, {n_params / 1e6:.0f}M params, {args.layers} layers, bf16 + fp32 lm_head"
                  f"{' on bf16 matrix cores (2-term split)' if args.split_head else ''}, grad checkpointing, sdpa",
         "global_batch": bs, "seq_len": L, "micro_batch": mb, "logits_mode": "fused" if args.fused else "two_pass",
         "samples_per_s": bs / dt, "s_per_step": dt, "tokens_per_s": bs * L / dt,
