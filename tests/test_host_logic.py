@@ -259,3 +259,19 @@ def test_rlconfig_accepts_the_reference_keys_with_the_reference_defaults():
     got = json.loads(json.dumps(field_table(RLConfig)))
     assert {k: got[k] for k in want} == want
     assert set(got) - set(want) == {"fused_logits_grad", "inplace_logits_grad"}  # MI355X extensions
+
+
+def test_split_bf16_host_formulation():
+    """lm_head.split_bf16 on host tensors (the torch formulation the HIP kernel is checked against):
+    each extra bf16 term removes 8 more bits of the residual."""
+    import torch
+
+    from pipelinerl_amd.lm_head import split_bf16
+
+    torch.manual_seed(0)
+    w = torch.randn(64, 33) * torch.logspace(-2, 2, 33)
+    for terms, bits in ((1, 8), (2, 16), (3, 24)):
+        parts = split_bf16(w, terms)
+        assert len(parts) == terms and all(p.dtype == torch.bfloat16 for p in parts)
+        rebuilt = sum(p.double() for p in parts)
+        assert ((rebuilt - w.double()).abs() <= 2.0 ** -(bits - 1) * w.double().abs() + 1e-30).all()
