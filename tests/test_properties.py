@@ -103,3 +103,42 @@ def test_bucket_plan_invariants(params, bucket_bytes):
             end = off + sp.nbytes
         assert bucket_nbytes(b) >= end
         assert len(b) == 1 or bucket_nbytes(b) <= bucket_bytes  # only a single oversized tensor may exceed the budget
+
+
+@settings(max_examples=50, deadline=None)
+@given(st.lists(st.tuples(st.integers(1, 12), st.integers(0, 20), st.integers(0, 3), st.booleans(), st.sampled_from([None, "stop", "length", " Length ", "weird"])),
+                min_size=1, max_size=25), st.booleans(), st.integers(0, 2**31 - 1))
+def test_rollouts_round_trip_through_both_wire_formats(seqs, with_ref, seed):
+    """RaggedRollouts -> binary record (shm backend) -> RaggedRollouts, and -> actor-stream dicts (JSONL
+    mirror / files backend) -> RaggedRollouts: every column identical, for ragged shapes incl. empty completions."""
+    import json
+
+    from pipelinerl_amd import batch_codec
+    from pipelinerl_amd.ragged import RaggedRollouts
+
+    rng = np.random.default_rng(seed)
+    entries = []
+    for i, (p, c, g, fin, reason) in enumerate(seqs):
+        ids = rng.integers(2, 1000, size=p + c).tolist()
+        e = {"input_ids": ids, "labels": [-100] * p + ids[p:], "logprobs": (-rng.random(c)).astype(np.float32).tolist(),
+             "ref_logprobs": (-rng.random(c)).astype(np.float32).tolist() if with_ref else [],
+             "reward": float(np.float32(rng.normal())), "group_id": f"g{g}", "finished": fin,
+             "metadata": {"model_version": int(rng.integers(0, 1000)), "rollout_index": i % 4, "step_index": int(rng.integers(0, 3))}}
+        if reason is not None:
+            e["finish_reason"] = reason
+        entries.append(e)
+    rag = RaggedRollouts.from_entries(entries)
+    cols = ("tokens", "labels", "logprobs", "seq_off", "lp_off", "reward", "group_index", "step_index", "rollout_index", "model_version",
+            "finished", "finish_code")
+
+    def same(a, b):
+        for name in cols:
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+        assert (a.ref_logprobs is None) == (b.ref_logprobs is None)
+        if a.ref_logprobs is not None:
+            assert torch.equal(a.ref_logprobs, b.ref_logprobs)
+        assert [a.group_ids[i] for i in a.host_group_index] == [b.group_ids[i] for i in b.host_group_index]
+
+    same(batch_codec.decode(batch_codec.encode_rollouts(rag)), rag)
+    # the JSONL form survives a text round trip as well (fp32 values print exactly as python floats)
+    same(RaggedRollouts.from_entries(json.loads(json.dumps(rag.to_entries()))), rag)
