@@ -15,14 +15,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session")
-def libprl():
-    """libprl.so, built on demand (hipcc cross-compiles without a GPU)."""
-    from pipelinerl_amd import _lib
-    from pipelinerl_amd.build import LIB_PATH, build
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """A fresh checkout has no libprl.so (it is git-ignored): build it once per session before any
+    test touches the package (hipcc cross-compiles for gfx950 without a GPU; a no-op when up to date)."""
+    from pipelinerl_amd.build import build
 
-    if not LIB_PATH.exists():
-        build()
+    build()
+
+
+@pytest.fixture(scope="session")
+def libprl(_built_library):
+    """The loaded libprl.so (ctypes handle with prototypes set)."""
+    from pipelinerl_amd import _lib
+
     return _lib.load()
 
 
