@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 4
+#define PRL_ABI_VERSION 5
 
 #define PRL_OK 0
 #define PRL_EINVAL (-22)   /* bad argument                                  */
@@ -130,6 +130,11 @@ typedef struct prl_loss_config {
   float kl_coef;               /* linear_decay_coef(...) for this step           (:293)    */
   float entropy_coef;          /* linear_decay_coef(...) for this step           (:292)    */
   float clamp_log_ratio_ref_new; /* :280-286                                               */
+  float upstream_scale;        /* prl_fused_logits_loss only: the d(objective)/d(loss) factor the
+                                  caller will back-propagate (accelerate's 1/accumulation, a loss
+                                  scaler), folded into d logits at no cost; 0 means 1.  The kernel
+                                  runs before autograd knows the factor, so the host states what
+                                  it expects and prl_scale_unless repairs a wrong guess ON DEVICE */
 } prl_loss_config;
 
 /* stats vector (double[PRL_NUM_STATS], device).  Sums follow App. A of SURVEY.md:
@@ -213,6 +218,22 @@ int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, int64_t cols
                           const float* group_tokens, const float* overflow,
                           float* new_logprobs, float* entropy, float* lse2,
                           void* grad_logits, prl_stream_t stream);
+
+/* Name of the kernel the last prl_fused_logits_loss call of this thread launched (the dispatch
+ * picks a row-resident or a two-sweep kernel from vocab size, dtype and alignment); test and
+ * profiling aid. */
+const char* prl_last_fused_kernel(void);
+
+/*
+ * In-place `data *= *upstream / expected` over n elements of dtype f32/bf16 - unless the device
+ * scalar *upstream already equals `expected`, in which case every workgroup returns after one
+ * 4-byte load.  Backward of the fused path: the gradient was produced in the forward launch with
+ * the expected upstream factor folded in (prl_loss_config.upstream_scale); this call makes it
+ * right for any other factor without a host synchronisation (the reference multiplies through
+ * autograd, finetune_loop.py:784-790).
+ */
+int prl_scale_unless(void* data, int64_t n, int32_t dtype, const float* upstream,
+                     float expected, prl_stream_t stream);
 
 /*
  * GSPO helper (rl/utils.py:106-208): per-segment masked sums of a and b plus token

@@ -13,7 +13,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl.so"
 
-PRL_ABI_VERSION = 4
+PRL_ABI_VERSION = 5
 PRL_OK = 0
 PRL_EINVAL = -22
 PRL_ENOMEM = -12
@@ -90,6 +90,7 @@ class PrlLossConfig(ctypes.Structure):
         ("kl_coef", c_float),
         ("entropy_coef", c_float),
         ("clamp_log_ratio_ref_new", c_float),
+        ("upstream_scale", c_float),
     ]
 
 
@@ -117,6 +118,8 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_grpo_loss_workspace_bytes": (c_int32, [c_int64, c_int64, POINTER(c_size_t)]),
     "prl_grpo_loss_fwd_bwd": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64] + [_P] * 13 + [_P, _P, _P, _P, _P, c_size_t, _P]),
     "prl_fused_logits_loss": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64, c_int64, _P, c_int32, c_int64, c_float] + [_P] * 8 + [_P, _P, _P, _P, _P]),
+    "prl_last_fused_kernel": (c_char_p, []),
+    "prl_scale_unless": (c_int32, [_P, c_int64, c_int32, _P, c_float, _P]),
     "prl_segment_sums": (c_int32, [c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prl_seq_scan": (c_int32, [c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),
     "prl_group_advantages": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),

@@ -368,6 +368,7 @@ struct FusedArgs {
   float* nlp;
   float* ent;
   float* lse2;
+  float up;  // expected upstream factor d objective / d loss (prl_loss_config.upstream_scale)
 };
 
 template <class T, int BLOCK, int UNROLL, bool REVERSE, bool NT>
@@ -414,6 +415,8 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_kernel(
     PrlTokenIn x{nlp,      H,           a.old_lp[u],       a.ref_lp[u], a.adv[u],
                  a.reward[u], a.group_tokens[u], 1.0f /*num_labels unused*/, a.overflow[u]};
     prl_token_grad(a.cfg, x, 1, &g, &gH);
+    g *= a.up;
+    gH *= a.up;
   }
   if (g == 0.0f && gH == 0.0f) {
     row_write_zero<T, BLOCK>(out, geo.vocab, geo.vec_ok);
@@ -559,6 +562,8 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_keep_kernel(
     PrlTokenIn x{nlp,      H,           a.old_lp[u],       a.ref_lp[u], a.adv[u],
                  a.reward[u], a.group_tokens[u], 1.0f, a.overflow[u]};
     prl_token_grad(a.cfg, x, 1, &g, &gH);
+    g *= a.up;
+    gH *= a.up;
   }
   if (g == 0.0f && gH == 0.0f) {
     row_write_zero<T, BLOCK>(out, geo.vocab, true);
@@ -598,6 +603,32 @@ constexpr int kBlock = 256;
 constexpr int kUnrollFwd = 8;
 constexpr int kUnrollBwd = 4;
 constexpr int kDefaultFusedVariant = 21;  // measured fastest on MI355X (profiles/r01_kernel_sweep.txt)
+
+thread_local const char* g_last_fused = "";
+
+// data[i] *= *upstream / expected, skipped entirely (one scalar load per workgroup) when the
+// device scalar already has the expected value.
+template <class T>
+__global__ __launch_bounds__(256) void scale_unless_kernel(typename T::scalar* data, int64_t n,
+                                                           const float* __restrict__ upstream, float expected) {
+  const float up = *upstream;
+  if (up == expected) return;
+  const float f = up / expected;
+  using vec = typename T::vec;
+  constexpr int NV = T::NV;
+  const int64_t nvec = (reinterpret_cast<uintptr_t>(data) & 15u) == 0 ? n / NV : 0;
+  vec* dv = reinterpret_cast<vec*>(data);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nvec; j += stride) {
+    float x[NV];
+    T::unpack(dv[j], x);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) x[i] *= f;
+    dv[j] = T::pack(x);
+  }
+  for (int64_t j = nvec * NV + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
+    data[j] = T::from_float(T::to_float(data[j]) * f);
+}
 
 int check_geom(int64_t rows, int64_t cols, int64_t vocab, const void* logits, int32_t dtype,
                int64_t stride, RowGeom* geo) {
@@ -673,6 +704,26 @@ extern "C" int prl_logprob_entropy_bwd(int64_t rows, int64_t cols, int64_t vocab
   return PRL_OK;
 }
 
+extern "C" const char* prl_last_fused_kernel(void) { return g_last_fused; }
+
+extern "C" int prl_scale_unless(void* data, int64_t n, int32_t dtype, const float* upstream, float expected,
+                                prl_stream_t stream) {
+  PRL_CHECK_ARG(data != nullptr && upstream != nullptr, "null pointer");
+  PRL_CHECK_ARG(n >= 0, "negative element count");
+  PRL_CHECK_ARG(dtype == PRL_DTYPE_F32 || dtype == PRL_DTYPE_BF16, "unsupported dtype %d", dtype);
+  PRL_CHECK_ARG(expected != 0.0f && expected == expected, "expected factor must be a non-zero number");
+  if (n == 0) return PRL_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(2048), block(256);
+  if (dtype == PRL_DTYPE_F32) {
+    hipLaunchKernelGGL((scale_unless_kernel<F32>), grid, block, 0, s, static_cast<float*>(data), n, upstream, expected);
+  } else {
+    hipLaunchKernelGGL((scale_unless_kernel<BF16>), grid, block, 0, s, static_cast<uint16_t*>(data), n, upstream, expected);
+  }
+  PRL_LAUNCH_CHECK("scale_unless_kernel");
+  return PRL_OK;
+}
+
 extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, int64_t cols,
                                      int64_t vocab, const void* logits, int32_t logits_dtype,
                                      int64_t logits_row_stride, float temperature,
@@ -693,7 +744,8 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
   PRL_CHECK_ARG(temperature > 0.0f, "temperature must be > 0");
   geo.vec_ok = geo.vec_ok && prl::aligned16(grad_logits);
   FusedArgs a{*cfg,      input_ids, labels,       old_logprobs, ref_logprobs, advantages,
-              rewards,   group_tokens, overflow,  new_logprobs, entropy,      lse2};
+              rewards,   group_tokens, overflow,  new_logprobs, entropy,      lse2,
+              cfg->upstream_scale == 0.0f ? 1.0f : cfg->upstream_scale};
   const float k2 = kLog2e / temperature;
   const float inv_temp = 1.0f / temperature;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -716,6 +768,7 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
 #define PRL_FUSED_LAUNCH(TT, ST, BLK, UNR, REV, NTS, LDSB)                                            \
   do {                                                                                              \
     auto kfn = fused_logits_loss_kernel<TT, BLK, UNR, REV, NTS>;                                    \
+    g_last_fused = "fused_logits_loss_kernel<" #TT "," #BLK "," #UNR "," #REV "," #NTS ">";        \
     const size_t lds_bytes = (LDSB) > 0 ? (size_t)(LDSB) : sizeof(Osm) * (BLK / kWave);             \
     static bool attr_set = false; /* one process drives one GPU: set the LDS opt-in once */         \
     if (lds_bytes > 48 * 1024 && !attr_set) {                                                       \
@@ -734,6 +787,7 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
       break;                                                                                        \
     }                                                                                               \
     auto kfn = fused_logits_loss_keep_kernel<TT, BLK, UNR, KR, KL, NTH>;                                 \
+    g_last_fused = "fused_logits_loss_keep_kernel<" #TT "," #BLK "," #UNR "," #KR "," #KL "," #NTH ">";  \
     size_t lds_bytes = 256 + (size_t)(KL) * BLK * 16;                                               \
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024; /* keep ONE workgroup per CU */               \
     static bool attr_set = false;                                                                   \

@@ -9,7 +9,7 @@ loss runs in the hand-written HIP kernels of libprl.so:
            <-------------------- K1 backward: d loss / d logits ----------------------
 
 There is one device->host copy per micro-batch (the 32-double stats vector; the reference
-does ~31 `.item()` syncs) and no CPU fallback: CPU tensors raise.
+does ~31 `.item()` syncs; backward never touches the host) and no CPU fallback: CPU tensors raise.
 """
 
 from __future__ import annotations
@@ -66,6 +66,9 @@ class RLConfig(BaseModel):
     fused_logits_grad: bool = Field(default=True, description="single-pass logits kernel (gradient computed in the forward launch) "
                                     "whenever the logits require a gradient; False = K1 forward, K2+K3, K1 backward as separate launches")
     inplace_logits_grad: bool = Field(default=False, description="write d loss/d logits over the logits buffer")
+    expected_loss_scale: float = Field(default=1.0, description="factor the caller applies to the returned loss before backward "
+                                       "(1/gradient_accumulation under accelerate, a loss scaler): the fused kernel folds it into d logits "
+                                       "in the forward launch; any other factor is repaired on device in backward, without a host sync")
 
 
 def make_rl_data_callback(args: Any, current_dir: Any, rl_config: "RLConfig | None", model: Any):
@@ -316,32 +319,44 @@ class _GrpoLossFn(torch.autograd.Function):
     """logits -> (loss, stats) with a hand-written backward to the logits."""
 
     @staticmethod
-    def forward(ctx, logits, batch, cfg, temperature, fused, inplace, sp_group=None):  # type: ignore[override]
+    def forward(ctx, logits, batch, cfg, temperature, fused, inplace, sp_group=None, expected_scale=1.0):  # type: ignore[override]
         lib = _lib.load()
         B, L, V = logits.shape
         dev = logits.device
         ids = batch.input_ids if batch.input_ids.is_contiguous() else batch.input_ids.contiguous()
         if fused:
             lg = logits if logits.is_contiguous() else logits.contiguous()
-            grad = lg if inplace else torch.empty_like(lg)
             nlp = torch.empty((B, L), dtype=torch.float32, device=dev)
             ent = torch.empty_like(nlp)
-            lse2 = torch.empty_like(nlp)
-            cont = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
-            with torch.cuda.device(dev):
-                _lib.check(
-                    lib.prl_fused_logits_loss(
-                        ctypes.byref(cfg), B, L, V, _lib.ptr(lg), _logits_dtype_code(lg), V, float(temperature),
-                        _lib.ptr(ids), _lib.ptr(cont(batch.labels)), _lib.ptr(cont(batch.old_logprobs)),
-                        _lib.ptr(cont(batch.ref_logprobs)), _lib.ptr(cont(batch.advantages)),
-                        _lib.ptr(cont(batch.rewards)), _lib.ptr(cont(batch.group_tokens)),
-                        _lib.ptr(cont(batch.overflow)), _lib.ptr(nlp), _lib.ptr(ent), _lib.ptr(lse2),
-                        _lib.ptr(grad), _lib.current_stream_ptr(dev),
+            if batch.sentinel:
+                # a sentinel batch has no labelled token (finetune/utils.py:17-78): loss 0, gradient 0.
+                # Nothing of the [T, V] logits needs to be read; backward hands out zeros.
+                nlp.zero_()
+                ent.zero_()
+                grad = None
+            else:
+                grad = lg if inplace else torch.empty_like(lg)
+                lse2 = torch.empty_like(nlp)
+                kcfg = type(cfg).from_buffer_copy(cfg)
+                kcfg.upstream_scale = float(expected_scale)
+                cont = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
+                with torch.cuda.device(dev):
+                    _lib.check(
+                        lib.prl_fused_logits_loss(
+                            ctypes.byref(kcfg), B, L, V, _lib.ptr(lg), _logits_dtype_code(lg), V, float(temperature),
+                            _lib.ptr(ids), _lib.ptr(cont(batch.labels)), _lib.ptr(cont(batch.old_logprobs)),
+                            _lib.ptr(cont(batch.ref_logprobs)), _lib.ptr(cont(batch.advantages)),
+                            _lib.ptr(cont(batch.rewards)), _lib.ptr(cont(batch.group_tokens)),
+                            _lib.ptr(cont(batch.overflow)), _lib.ptr(nlp), _lib.ptr(ent), _lib.ptr(lse2),
+                            _lib.ptr(grad), _lib.current_stream_ptr(dev),
+                        )
                     )
-                )
             loss, stats, _, _ = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=False)
             ctx.fused = True
             ctx.grad_logits = grad
+            ctx.zero_like = lg if grad is None else None
+            ctx.inplace = inplace
+            ctx.expected_scale = float(expected_scale)
         else:
             nlp, ent, lse2, lg = logprob_entropy(logits, ids, temperature)
             if cfg.policy_loss == _lib.PRL_POLICY_GSPO:
@@ -365,10 +380,18 @@ class _GrpoLossFn(torch.autograd.Function):
         if ctx.fused:
             grad = ctx.grad_logits
             ctx.grad_logits = None
-            scale = float(grad_loss.item())
-            if scale != 1.0:
-                grad.mul_(scale)
-            return grad, None, None, None, None, None, None
+            if grad is None:  # sentinel batch
+                lg = ctx.zero_like
+                ctx.zero_like = None
+                grad = lg.zero_() if ctx.inplace else torch.zeros_like(lg)
+                return grad, None, None, None, None, None, None, None
+            # d logits already carries `expected_scale`; any other upstream factor is applied by a
+            # kernel that returns after one scalar load when the guess was right (no host sync).
+            up = grad_loss.to(torch.float32).contiguous()
+            with torch.cuda.device(grad.device):
+                _lib.check(_lib.load().prl_scale_unless(_lib.ptr(grad), grad.numel(), _logits_dtype_code(grad), _lib.ptr(up),
+                                                        ctx.expected_scale, _lib.current_stream_ptr(grad.device)))
+            return grad, None, None, None, None, None, None, None
         lib = _lib.load()
         lg, ids, lse2, ent, g_nlp, g_ent = ctx.saved_tensors
         B, L, V = lg.shape
@@ -383,7 +406,7 @@ class _GrpoLossFn(torch.autograd.Function):
                     _lib.ptr(up), _lib.ptr(grad), _lib.current_stream_ptr(dev),
                 )
             )
-        return grad, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None
 
 
 _STAT_KEYS_IN_ORDER = [
@@ -455,6 +478,7 @@ def rl_step(
         logits, batch, cfg, config.temperature,
         bool(config.fused_logits_grad) and config.policy_loss != "gspo" and logits.requires_grad and torch.is_grad_enabled(),
         bool(config.inplace_logits_grad), seq_parallel_group if config.policy_loss == "gspo" else None,
+        float(config.expected_loss_scale) or 1.0,
     )
     stats = stats_dev.cpu().tolist()  # the single device->host sync of the step
     check_finite(stats)

@@ -109,11 +109,20 @@ class _SplitBf16Linear(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
+def _weight_key(w: torch.Tensor) -> tuple:
+    """What the cached split is valid for: in-place autograd-visible updates bump `_version`;
+    `p.data = other` (ColocatedSender.rehome, FSDP unshard) changes `data_ptr`; `.to(device)` the
+    device.  Writes through `p.data.copy_()` change none of them - see `invalidate()`."""
+    return (w._version, w.data_ptr(), w.device, tuple(w.shape))
+
+
 class SplitBf16LmHead(torch.nn.Module):
     """Drop-in for an fp32 `nn.Linear(hidden, vocab, bias=False)` output head: `weight` stays an fp32
     parameter (optimizer, checkpoints and the weight broadcast see fp32), the forward / backward GEMMs run
     as bf16 MFMA GEMMs with fp32 accumulation.  The bf16 split of the weight is refreshed whenever the
-    parameter changes (in-place optimizer steps bump its version counter)."""
+    parameter changes: in-place optimizer steps bump its version counter, a re-homed storage changes
+    its address; writers that go through `.data.copy_()` must call `invalidate()` (or use
+    `attach_optimizer`)."""
 
     def __init__(self, weight: torch.Tensor, terms: int = 2, hidden_grad_terms: int = 3):
         """`hidden_grad_terms`: how many of the partial products G_hi W_hi, G_hi W_lo, G_lo W_hi enter d hidden.
@@ -125,7 +134,7 @@ class SplitBf16LmHead(torch.nn.Module):
         self.terms = terms
         self._parts: tuple[torch.Tensor, ...] | None = None
         self._cat: torch.Tensor | None = None
-        self._parts_version = -1
+        self._parts_key = None
 
     @classmethod
     def from_linear(cls, linear: torch.nn.Linear, terms: int = 2, hidden_grad_terms: int = 3) -> "SplitBf16LmHead":
@@ -133,9 +142,19 @@ class SplitBf16LmHead(torch.nn.Module):
             raise ValueError("lm_head with a bias is not supported")
         return cls(linear.weight if linear.weight.dtype == torch.float32 else torch.nn.Parameter(linear.weight.float()), terms, hidden_grad_terms)
 
+    def invalidate(self) -> None:
+        """Drop the cached bf16 split.  REQUIRED after the weight was changed through a path that
+        neither bumps the parameter's version counter nor moves its storage: `p.data.copy_()` (ZeRO /
+        DeepSpeed, many checkpoint loaders), FSDP reshard into the same storage."""
+        self._parts_key = None
+
+    def attach_optimizer(self, optimizer: torch.optim.Optimizer) -> None:
+        """Re-split after every `optimizer.step()` whatever the optimizer does to the storage."""
+        optimizer.register_step_post_hook(lambda *_: self.invalidate())
+
     def _split(self) -> tuple[torch.Tensor, ...]:
-        v = self.weight._version
-        if self._parts is None or self._parts_version != v or self._parts[0].device != self.weight.device:
+        key = _weight_key(self.weight)
+        if self._parts is None or self._parts_key != key:
             with torch.no_grad():
                 parts = split_bf16(self.weight.detach(), self.terms)
                 # [V, terms * H]: the terms side by side along the inner dimension (forward), and the
@@ -143,7 +162,7 @@ class SplitBf16LmHead(torch.nn.Module):
                 self._cat = torch.cat(parts, dim=1)
                 h = self.weight.shape[1]
                 self._parts = tuple(self._cat[:, k * h : (k + 1) * h] for k in range(self.terms))
-            self._parts_version = v
+            self._parts_key = key
         return self._parts
 
     def forward(self, hidden: torch.Tensor) -> torch.Tensor:
@@ -166,11 +185,12 @@ def apply_fp32_lm_head(model: torch.nn.Module, layer_prefix: str = "lm_head", hi
         head = getattr(head, part)
     if not isinstance(head, torch.nn.Linear):
         raise TypeError(f"{layer_prefix} is {type(head).__name__}, expected nn.Linear")
-    state = {"version": -1, "parts": None, "cat": None, "device": None}
+    state = {"key": None, "parts": None, "cat": None}
 
     def operands():
         w = head.weight
-        if state["version"] != w._version or state["device"] != w.device:
+        key = _weight_key(w)
+        if state["key"] != key:
             with torch.no_grad():
                 if w.dtype == torch.bfloat16:
                     state["parts"], state["cat"] = (w.detach(),), None
@@ -179,7 +199,7 @@ def apply_fp32_lm_head(model: torch.nn.Module, layer_prefix: str = "lm_head", hi
                     cat = torch.cat(parts, dim=1)
                     hdim = w.shape[1]
                     state["parts"], state["cat"] = tuple(cat[:, k * hdim : (k + 1) * hdim] for k in range(2)), cat
-            state["version"], state["device"] = w._version, w.device
+            state["key"] = key
         return state["parts"], state["cat"]
 
     def fp32_forward(x: torch.Tensor) -> torch.Tensor:
@@ -190,4 +210,6 @@ def apply_fp32_lm_head(model: torch.nn.Module, layer_prefix: str = "lm_head", hi
         return y
 
     head.forward = fp32_forward
+    # same contract as SplitBf16LmHead.invalidate(): call after `.data.copy_()`-style updates
+    head.invalidate_split = lambda: state.update(key=None)
     return model

@@ -58,10 +58,22 @@ class WorkerExtension:
                 logger.warning(f"Unexpected dtype for {info.name}: {info.dtype}")
 
         def load(views):
-            loaded = list(self._load_weights(views))
-            if len(loaded) != len(views):
-                missing = [n for n, _ in views]
-                raise ValueError(f"model {missing} not found in model state dict")
+            # vLLM's `load_weights` returns the ENGINE's parameter names: q/k/v_proj collapse into one
+            # `qkv_proj`, gate/up_proj into `gate_up_proj`, so counts cannot be compared for a batch.
+            # The reference passes one tensor per call and requires exactly one loaded name
+            # (vllm1.py:120-124); for a bucket the same rule is applied tensor by tensor, which keeps
+            # its unknown-parameter error exact.  Engines that can vouch for a whole batch implement
+            # `_load_weights_batch` and return the trainer-side names they did not recognise.
+            batch = getattr(self, "_load_weights_batch", None)
+            if batch is not None and len(views) > 1:
+                unknown = list(batch(views))
+                if unknown:
+                    raise ValueError(f"model {unknown} not found in model state dict")
+                return
+            for name, tensor in views:
+                loaded = self._load_weights([(name, tensor)])
+                if len(list(loaded)) != 1:
+                    raise ValueError(f"model {name} not found in model state dict")
 
         if request.transport == "ipc":
             from .weight_sync import ColocatedReceiver
@@ -116,3 +128,8 @@ class StandaloneWeightReceiver(WorkerExtension):
             p.data.copy_(tensor.to(p.dtype), non_blocking=True)
             loaded.append(name)
         return loaded
+
+    def _load_weights_batch(self, weights):
+        """One pass over a whole bucket; returns the names this module does not have."""
+        done = set(self._load_weights(weights))
+        return [n for n, _ in weights if n not in done]
