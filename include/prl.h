@@ -31,6 +31,9 @@
  *   prl_pack_collate              pipelinerl/finetune/data.py:215-283
  *                                 (+ rl/__init__.py:573-594 field expansion)
  *   prl_pad_collate               pipelinerl/finetune/data.py:163-212
+ *   prl_lm_head_*                 pipelinerl/finetune/rl/__init__.py:204-233 (model forward's output
+ *                                 head + K1) with the numerics of
+ *                                 pipelinerl/finetune/checkpoints.py:87-103 (fp32 head)
  *   prl_ring_*                    pipelinerl/shared_memory_array.py:9-196,
  *                                 pipelinerl/streams.py:249-346
  *   prl_wsync_* / prl_ipc_* /
@@ -423,6 +426,65 @@ int prl_bucket_scatter(const void* bucket, int64_t bucket_bytes, const struct pr
  * Operand preparation for evaluating the reference's fp32 output head (checkpoints.py:87-103) as
  * bf16 MFMA GEMMs with fp32 accumulation (pipelinerl_amd/lm_head.py).  Device pointers. */
 int prl_split_bf16(int64_t n, const float* src, uint16_t* hi, uint16_t* lo, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Fused output head: hidden states -> new_logprobs / entropy, logits never   */
+/* written (reference rl/__init__.py:204-233 after the model's */
+/* lm_head, whose fp32 numerics checkpoints.py:87-103 enforces)                */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Operand preparation, once per optimizer step: weight [vocab, hidden] (f32 or bf16) ->
+ *   w_hi, w_lo   [vocab, hidden] bf16 planes, weight = hi + lo to ~2^-17 relative
+ *                (a bf16 weight is its own hi plane: pass w_lo = NULL and use the weight as w_hi)
+ *   wt_hi, wt_lo [hidden, vocab] the same planes transposed (backward only; nullable)
+ * Any output may be NULL.
+ */
+int prl_lm_head_prepare(int64_t vocab, int64_t hidden, const void* weight,
+                        int32_t weight_dtype, uint16_t* w_hi, uint16_t* w_lo,
+                        uint16_t* wt_hi, uint16_t* wt_lo, prl_stream_t stream);
+
+/* Scratch sizes: forward (partial soft-max states per vocabulary split) and backward (the
+ * d-logits planes of ONE chunk of `chunk_rows` logits rows, both layouts, + the transposed
+ * hidden chunk).  Either output pointer may be NULL. */
+int prl_lm_head_workspace_bytes(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
+                                int64_t chunk_rows, size_t* fwd_bytes, size_t* bwd_bytes);
+
+/*
+ * Forward.  hidden_bf16: [rows*cols, hidden] bf16 (the model's last hidden states), input_ids
+ * int64 [rows, cols].  With logits[q, v] = sum_k hidden[q, k] * (w_hi + w_lo)[v, k] (fp32
+ * accumulation on the bf16 matrix cores) the outputs are those of prl_logprob_entropy_fwd:
+ * token-aligned float32 [rows, cols] new_logprobs / entropy / lse2, column 0 := 0.
+ * hidden must be a multiple of 64.  No [rows*cols, vocab] buffer exists at any point.
+ */
+int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
+                            const uint16_t* hidden_bf16, const uint16_t* w_hi,
+                            const uint16_t* w_lo, const int64_t* input_ids,
+                            float temperature, float* new_logprobs, float* entropy,
+                            float* lse2, void* workspace, size_t workspace_bytes,
+                            prl_stream_t stream);
+
+/*
+ * Backward of the above for token-aligned upstream gradients grad_new_logprobs /
+ * grad_entropy (nullable) and a device scalar `upstream` (nullable => 1), exactly the
+ * d logits of prl_logprob_entropy_bwd pushed through the head:
+ *   grad_hidden [rows*cols, hidden] (bf16 or f32, overwritten; nullable)
+ *                 = d logits (w_hi + w_lo)
+ *   grad_weight [vocab, hidden] f32 (ACCUMULATED: +=; nullable) = d logits^T hidden
+ * Works chunk by chunk over `chunk_rows` logits rows: the logits of a chunk are recomputed,
+ * its d logits live as bf16 (hi, lo) planes in the workspace only.  vocab and hidden must be
+ * multiples of 64.
+ */
+int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
+                            const uint16_t* hidden_bf16, const uint16_t* w_hi,
+                            const uint16_t* w_lo, const uint16_t* wt_hi,
+                            const uint16_t* wt_lo, const int64_t* input_ids,
+                            float temperature, const float* lse2, const float* entropy,
+                            const float* grad_new_logprobs, const float* grad_entropy,
+                            const float* upstream, void* grad_hidden,
+                            int32_t grad_hidden_dtype, float* grad_weight,
+                            int64_t chunk_rows, void* workspace, size_t workspace_bytes,
+                            prl_stream_t stream);
 
 #ifdef __cplusplus
 }

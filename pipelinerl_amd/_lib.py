@@ -152,6 +152,11 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_bucket_gather": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "prl_bucket_scatter": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "prl_split_bf16": (c_int32, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "prl_lm_head_prepare": (c_int32, [c_int64, c_int64, _P, c_int32, _P, _P, _P, _P, _P]),
+    "prl_lm_head_workspace_bytes": (c_int32, [c_int64, c_int64, c_int64, c_int64, c_int64, POINTER(c_size_t), POINTER(c_size_t)]),
+    "prl_lm_head_logprob_fwd": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
+    "prl_lm_head_logprob_bwd": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P,
+                                          c_int32, _P, c_int64, _P, c_size_t, _P]),
 }
 
 _lib: ctypes.CDLL | None = None

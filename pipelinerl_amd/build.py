@@ -38,6 +38,7 @@ SOURCES = [
     "prl_logprob.hip",
     "prl_pack.hip",
     "prl_copy.hip",
+    "prl_lmhead.hip",
 ]
 
 

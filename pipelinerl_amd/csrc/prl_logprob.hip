@@ -18,15 +18,14 @@
 #include <cstdlib>
 
 #include "prl_common.h"
+#include "prl_osm.h"
 #include "prl_token_math.h"
 
 namespace {
 
 using prl::kWave;
+using namespace prl::osm;
 
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kLn2 = 0.6931471805599453f;
-constexpr float kNegBig = -3.0e38f;  // finite "minus infinity" (keeps 0 * x well defined)
 
 // ---- dtype adapters: a 16-byte vector of NV logits --------------------------------
 struct F32 {
@@ -81,51 +80,6 @@ struct BF16 {
     return x;
   }
 };
-
-// ---- online softmax state ----------------------------------------------------------
-struct Osm {
-  float M, S, W;
-};
-
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-__device__ __forceinline__ void osm_init(Osm& s) {
-  s.M = kNegBig;
-  s.S = 0.0f;
-  s.W = 0.0f;
-}
-
-// fold N values (already scaled to base-2 units) into the state
-template <int N>
-__device__ __forceinline__ void osm_push(Osm& s, const float (&y)[N]) {
-  float mx = y[0];
-#pragma unroll
-  for (int i = 1; i < N; ++i) mx = fmaxf(mx, y[i]);
-  if (mx > s.M) {
-    const float dm = s.M - mx;
-    const float sc = fast_exp2(dm);
-    s.W = sc * __builtin_fmaf(dm, s.S, s.W);
-    s.S = sc * s.S;
-    s.M = mx;
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const float d = y[i] - s.M;
-    const float e = fast_exp2(d);
-    s.S += e;
-    s.W = __builtin_fmaf(d, e, s.W);
-  }
-}
-
-__device__ __forceinline__ Osm osm_merge(const Osm& a, const Osm& b) {
-  Osm r;
-  r.M = fmaxf(a.M, b.M);
-  const float da = a.M - r.M, db = b.M - r.M;
-  const float ea = fast_exp2(da), eb = fast_exp2(db);
-  r.S = ea * a.S + eb * b.S;
-  r.W = ea * __builtin_fmaf(da, a.S, a.W) + eb * __builtin_fmaf(db, b.S, b.W);
-  return r;
-}
 
 template <int BLOCK>
 __device__ __forceinline__ Osm osm_block_reduce(Osm s, Osm* lds /* [BLOCK/64] */) {

@@ -1,0 +1,230 @@
+"""Fused output head: hidden states -> new_logprobs / entropy -> GRPO loss, with the
+[T, V] logits never materialised, forward or backward.
+
+The reference runs `model(**inputs).logits` - an fp32 `lm_head` (finetune/checkpoints.py:87-103)
+producing a [1, T, V] fp32 tensor, 4.98 GB per Qwen2.5-7B micro-batch - and then rl_step's K1
+(rl/__init__.py:204-233).  Here `rl_step_fused_head` asks the model for its LAST HIDDEN STATES and
+hands them, with the head's weight, to the MFMA kernels of csrc/prl_lmhead.hip:
+
+    hidden [T, H] bf16, W [V, H] (fp32 split into two bf16 planes, or bf16 as is)
+      --prl_lm_head_logprob_fwd-->  new_logprobs, entropy, lse2        (online softmax in the GEMM epilogue)
+      --K2+K3-->                    loss, 32 stats, d loss / d new_logprobs, d loss / d entropy
+      --prl_lm_head_logprob_bwd-->  d hidden, d W  (logits recomputed per row chunk, d logits live as bf16
+                                    planes of ONE chunk only)
+
+Memory: no logits (4.98 GB) and no d logits (4.98 GB) per micro-batch; the backward workspace is
+`chunk_rows / T` of that.  Numerics: bf16 x bf16 products are exact in fp32 and accumulate in fp32; the
+two-plane split reproduces the fp32 head to ~2^-17 relative.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Any
+
+import torch
+
+from . import _lib
+from .finetune.rl import RLConfig, check_finite, grpo_loss_from_logprobs, make_loss_config, stats_to_dict
+from .finetune.types import PipelineBatchEncoding
+from ._lib import STAT_INDEX
+
+
+def _weight_key(w: torch.Tensor) -> tuple:
+    return (w._version, w.data_ptr(), w.device, tuple(w.shape), w.dtype)
+
+
+class FusedLmHead:
+    """Prepared operands of one output-head weight [V, H]: bf16 planes (hi, lo) and their transposes.
+    Refreshed when the weight changes (version counter / storage address); writers that go through
+    `.data.copy_()` must call `invalidate()` - same contract as lm_head.SplitBf16LmHead."""
+
+    def __init__(self, weight: torch.Tensor, backward: bool = True, chunk_rows: int = 2048):
+        if weight.dim() != 2:
+            raise ValueError("lm_head weight must be [vocab, hidden]")
+        if weight.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f"lm_head weight must be float32 or bfloat16, got {weight.dtype}")
+        self.weight = weight
+        self.backward = backward
+        self.chunk_rows = int(chunk_rows)
+        self._key = None
+        self.w_hi = self.w_lo = self.wt_hi = self.wt_lo = None
+        self._ws: dict[Any, torch.Tensor] = {}
+
+    @property
+    def vocab(self) -> int:
+        return self.weight.shape[0]
+
+    @property
+    def hidden(self) -> int:
+        return self.weight.shape[1]
+
+    def invalidate(self) -> None:
+        self._key = None
+
+    def attach_optimizer(self, optimizer: torch.optim.Optimizer) -> None:
+        optimizer.register_step_post_hook(lambda *_: self.invalidate())
+
+    def refresh(self) -> None:
+        w = self.weight
+        key = _weight_key(w)
+        if key == self._key:
+            return
+        _lib.require_device(w)
+        lib = _lib.load()
+        V, H = w.shape
+        dev = w.device
+        src = w.detach()
+        if not src.is_contiguous():
+            src = src.contiguous()
+        plane = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dev)  # noqa: E731
+        if w.dtype == torch.bfloat16:  # a bf16 weight (tied embedding) is its own exact plane
+            self.w_hi, self.w_lo = src, None
+            self.wt_hi, self.wt_lo = (plane(H, V) if self.backward else None), None
+            outs = (None, None, self.wt_hi, None)
+        else:
+            self.w_hi, self.w_lo = plane(V, H), plane(V, H)
+            self.wt_hi, self.wt_lo = (plane(H, V), plane(H, V)) if self.backward else (None, None)
+            outs = (self.w_hi, self.w_lo, self.wt_hi, self.wt_lo)
+        if any(o is not None for o in outs):
+            with torch.cuda.device(dev):
+                _lib.check(lib.prl_lm_head_prepare(V, H, src.data_ptr(), 0 if w.dtype == torch.float32 else 1,
+                                                   *[_lib.ptr(o) for o in outs], _lib.current_stream_ptr(dev)))
+        self._key = key
+
+    def _workspace(self, kind: str, rows: int, cols: int, dev: torch.device, chunk_rows: int) -> torch.Tensor:
+        fwd, bwd = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _lib.check(_lib.load().prl_lm_head_workspace_bytes(rows, cols, self.hidden, self.vocab, chunk_rows, ctypes.byref(fwd), ctypes.byref(bwd)))
+        need = fwd.value if kind == "fwd" else bwd.value
+        key = (kind, dev, _lib.current_stream_ptr(dev))
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._ws[key] = ws
+        return ws
+
+    # -- forward ------------------------------------------------------------------------------------
+    def logprob_entropy(self, hidden: torch.Tensor, input_ids: torch.Tensor, temperature: float):
+        """hidden [B, L, H] -> token-aligned (new_logprobs, entropy, lse2), each fp32 [B, L]; no graph."""
+        lib = _lib.load()
+        _lib.require_device(hidden, input_ids)
+        self.refresh()
+        B, L, H = hidden.shape
+        if H != self.hidden:
+            raise ValueError(f"hidden size {H} != weight's {self.hidden}")
+        h = hidden.detach()
+        if h.dtype != torch.bfloat16:
+            h = h.to(torch.bfloat16)
+        if not h.is_contiguous():
+            h = h.contiguous()
+        ids = input_ids if input_ids.is_contiguous() else input_ids.contiguous()
+        dev = h.device
+        nlp = torch.empty((B, L), dtype=torch.float32, device=dev)
+        ent = torch.empty_like(nlp)
+        lse2 = torch.empty_like(nlp)
+        ws = self._workspace("fwd", B, L, dev, self.chunk_rows)
+        with torch.cuda.device(dev):
+            _lib.check(lib.prl_lm_head_logprob_fwd(B, L, H, self.vocab, h.data_ptr(), self.w_hi.data_ptr(), _lib.ptr(self.w_lo),
+                                                   ids.data_ptr(), float(temperature), nlp.data_ptr(), ent.data_ptr(), lse2.data_ptr(),
+                                                   ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev)))
+        return nlp, ent, lse2, h
+
+    # -- backward -----------------------------------------------------------------------------------
+    def backward_from_token_grads(self, h: torch.Tensor, input_ids: torch.Tensor, temperature: float, lse2: torch.Tensor,
+                                  ent: torch.Tensor, g_nlp: torch.Tensor, g_ent: torch.Tensor | None, upstream: torch.Tensor | None,
+                                  want_hidden: bool = True, grad_weight: torch.Tensor | None = None,
+                                  grad_hidden_dtype: torch.dtype = torch.bfloat16, chunk_rows: int | None = None):
+        """d hidden (returned) and d W (ACCUMULATED into `grad_weight`, fp32 [V, H]) from the token-aligned
+        gradients of new_logprobs / entropy."""
+        if not self.backward:
+            raise RuntimeError("this FusedLmHead was built with backward=False")
+        lib = _lib.load()
+        self.refresh()
+        B, L, H = h.shape
+        dev = h.device
+        chunk = int(chunk_rows or self.chunk_rows)
+        gh = torch.empty((B, L, H), dtype=grad_hidden_dtype, device=dev) if want_hidden else None
+        if grad_weight is not None and (grad_weight.dtype != torch.float32 or not grad_weight.is_contiguous() or tuple(grad_weight.shape) != (self.vocab, H)):
+            raise ValueError("grad_weight must be a contiguous float32 [vocab, hidden] tensor")
+        ws = self._workspace("bwd", B, L, dev, chunk)
+        ids = input_ids if input_ids.is_contiguous() else input_ids.contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(lib.prl_lm_head_logprob_bwd(
+                B, L, H, self.vocab, h.data_ptr(), self.w_hi.data_ptr(), _lib.ptr(self.w_lo), self.wt_hi.data_ptr(), _lib.ptr(self.wt_lo),
+                ids.data_ptr(), float(temperature), lse2.data_ptr(), ent.data_ptr(), g_nlp.data_ptr(), _lib.ptr(g_ent), _lib.ptr(upstream),
+                _lib.ptr(gh), 0 if grad_hidden_dtype == torch.float32 else 1, _lib.ptr(grad_weight), chunk, ws.data_ptr(), ws.numel(),
+                _lib.current_stream_ptr(dev)))
+        return gh
+
+
+class _FusedHeadLossFn(torch.autograd.Function):
+    """(hidden, weight) -> (loss, stats): K1 inside the head GEMM, K2+K3, hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, head: FusedLmHead, batch, cfg, temperature, chunk_rows):  # type: ignore[override]
+        nlp, ent, lse2, h = head.logprob_entropy(hidden, batch.input_ids, temperature)
+        need_grad = hidden.requires_grad or weight.requires_grad
+        loss, stats, g_nlp, g_ent = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=need_grad)
+        if need_grad:
+            ctx.save_for_backward(h, batch.input_ids, lse2, ent, g_nlp, g_ent if g_ent is not None else torch.empty(0, device=h.device))
+        ctx.has_g_ent = g_ent is not None
+        ctx.head, ctx.temperature, ctx.chunk_rows = head, float(temperature), chunk_rows
+        ctx.hidden_dtype, ctx.weight_dtype = hidden.dtype, weight.dtype
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_stats):  # type: ignore[override]
+        h, ids, lse2, ent, g_nlp, g_ent = ctx.saved_tensors
+        head: FusedLmHead = ctx.head
+        want_h, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gw = torch.zeros((head.vocab, head.hidden), dtype=torch.float32, device=h.device) if want_w else None
+        up = grad_loss.to(torch.float32).contiguous()
+        gh = head.backward_from_token_grads(h, ids, ctx.temperature, lse2, ent, g_nlp, g_ent if ctx.has_g_ent else None, up,
+                                            want_hidden=want_h, grad_weight=gw,
+                                            grad_hidden_dtype=torch.float32 if ctx.hidden_dtype == torch.float32 else torch.bfloat16,
+                                            chunk_rows=ctx.chunk_rows)
+        if gh is not None and gh.dtype != ctx.hidden_dtype:
+            gh = gh.to(ctx.hidden_dtype)
+        if gw is not None and gw.dtype != ctx.weight_dtype:
+            gw = gw.to(ctx.weight_dtype)
+        return gh, gw, None, None, None, None, None
+
+
+def fused_head_loss(hidden: torch.Tensor, weight: torch.Tensor, head: FusedLmHead, batch: PipelineBatchEncoding,
+                    config: RLConfig, current_step: int, max_step: int, chunk_rows: int | None = None):
+    """Loss + stats from last hidden states and the head weight; same return contract as `rl_step`."""
+    if config.policy_loss == "gspo":
+        raise NotImplementedError("the fused head covers ppo / reinforce; gspo goes through rl_step")
+    cfg, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
+    loss, stats_dev = _FusedHeadLossFn.apply(hidden, weight, head, batch, cfg, config.temperature, chunk_rows)
+    stats = stats_dev.cpu().tolist()
+    check_finite(stats)
+    input_size = batch.input_ids.numel()
+    if int(stats[STAT_INDEX["num_output_tokens_sum"]]) == 0:
+        return loss, {"input_size": float(input_size)}
+    return loss, stats_to_dict(stats, kl_coef, ent_coef, input_size)
+
+
+_heads: dict[int, FusedLmHead] = {}
+
+
+def rl_step_fused_head(model: Any, batch: PipelineBatchEncoding, current_step: int, max_step: int, config: RLConfig,
+                       seq_parallel_group=None, chunk_rows: int = 2048):
+    """`rl_step` (reference rl/__init__.py:136-143, same signature and return value) for a causal LM
+    that exposes its body and head separately, as Hugging Face models do (`model.model`,
+    `model.lm_head`): the body runs as usual, the head never produces logits."""
+    body = getattr(model, "model", None)
+    lm_head = getattr(model, "lm_head", None)
+    if body is None or lm_head is None or getattr(lm_head, "bias", None) is not None:
+        raise TypeError("rl_step_fused_head needs model.model (body) and a bias-free model.lm_head")
+    inputs = {"input_ids": batch.input_ids, "attention_mask": batch.attention_mask}
+    if batch.is_packed:
+        inputs["position_ids"] = batch.position_ids
+    out = body(**inputs)
+    hidden = out[0] if isinstance(out, (tuple, list)) else getattr(out, "last_hidden_state", out)
+    w = lm_head.weight
+    head = _heads.get(id(w))
+    if head is None or head.weight is not w:
+        head = _heads[id(w)] = FusedLmHead(w, backward=True, chunk_rows=chunk_rows)
+    return fused_head_loss(hidden, w, head, batch, config, current_step, max_step, chunk_rows)

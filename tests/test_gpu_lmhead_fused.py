@@ -1,0 +1,229 @@
+"""Fused output head (csrc/prl_lmhead.hip, pipelinerl_amd/fused_head.py): the logits are never
+written, so parity is established against the oracle FED WITH the fp64 product hidden @ W^T:
+
+    logits64 = hidden.double() @ W.double().T   (torch, on the GPU, fp64)
+    oracle.rl_loss.rl_step(logits64 -> fp32)    -> loss, statistics, d loss / d logits
+    d hidden = d logits @ W,  d W = d logits^T @ hidden   (fp64)
+
+at the BASELINE head shapes (H = 3584, V = 152 064: Qwen2.5-7B, fp32 weight split into two bf16
+planes; H = 896, V = 151 936: Qwen2.5-0.5B with its tied bf16 weight), plus small ragged shapes for
+the tile edges, both staging paths (LDS DMA and register staging) and chunked backward.
+Tolerance: 1e-4 relative (north_star), on loss, d hidden and d W."""
+
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rl_loss as orl
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+FP_TOL = 1e-4
+
+CFG = dict(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.05, final_kl_coef=0.05, entropy_bonus=0.01,
+           final_entropy_bonus=0.01, temperature=0.7, batch_size=8, clamp_log_ratio_ref_new_value=5, divide_advantage_by_std=False)
+
+
+def _problem(T, H, V, dev, weight_dtype=torch.float32, seed=0, hidden_scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    hidden = (torch.randn(1, T, H, generator=g) * hidden_scale).to(torch.bfloat16).to(dev)
+    W = (torch.randn(V, H, generator=g) * (2.0 / H ** 0.5)).to(weight_dtype).to(dev)
+    rng = np.random.default_rng(seed + 1)
+    ids = rng.integers(0, V, size=(1, T), dtype=np.int64)
+    labels = ids.copy()
+    labels[0, : max(2, T // 10)] = -100
+    labels[0, rng.random(T) < 0.1] = -100
+    half = T // 2
+    pos = np.concatenate([np.arange(half), np.arange(T - half)])[None].astype(np.int64)
+    labels[0, half] = -100
+    f32 = lambda a: np.asarray(a, dtype=np.float32)[None]  # noqa: E731
+    logits64 = hidden[0].double() @ W.double().t()
+    lp = torch.log_softmax(logits64 / CFG["temperature"], -1)
+    nlp = np.concatenate([[0.0], lp[torch.arange(T - 1), torch.from_numpy(ids[0, 1:]).to(dev)].cpu().numpy()])
+    old = nlp + rng.normal(0, 0.05, T)
+    batch = {
+        "input_ids": ids, "labels": labels, "position_ids": pos, "attention_mask": np.ones_like(ids),
+        "old_logprobs": f32(old), "ref_logprobs": f32(old + rng.normal(0, 0.05, T)), "advantages": f32(rng.normal(0, 1, T)),
+        "rewards": f32(rng.integers(0, 2, T)), "group_tokens": f32(np.full(T, 31.0)),
+        "num_labels": f32(np.full(T, float((labels != -100).sum()))), "overflow": f32(np.zeros(T)),
+    }
+    return hidden, W, batch, logits64
+
+
+def _oracle(hidden, W, batch, logits64):
+    want = orl.rl_step(logits64.float().cpu().numpy()[None], batch, CFG, 2, 10, True)
+    dl = torch.from_numpy(want["grad_logits"][0]).to(hidden.device).double()
+    want["d_hidden"] = (dl @ W.double()).cpu().numpy()
+    want["d_weight"] = (dl.t() @ hidden[0].double()).cpu().numpy()
+    return want
+
+
+def _run(hidden, W, batch, chunk_rows=None, grad_scale=1.0):
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.fused_head import FusedLmHead, fused_head_loss
+
+    dev = hidden.device
+    pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(dev)
+    h = hidden.clone().requires_grad_(True)
+    w = W.clone().requires_grad_(True)
+    head = FusedLmHead(w, chunk_rows=chunk_rows or 2048)
+    loss, stats = fused_head_loss(h, w, head, pb, RLConfig(**CFG), 2, 10, chunk_rows=chunk_rows)
+    (loss * grad_scale).backward()
+    torch.cuda.synchronize()
+    return loss, stats, h.grad, w.grad, head
+
+
+def _compare(loss, stats, gh, gw, want, scale=1.0):
+    assert abs(loss.item() - float(want["loss"])) <= FP_TOL * abs(float(want["loss"]))
+    for k, v in want["stats"].items():
+        assert abs(float(stats[k]) - float(v)) <= FP_TOL * max(abs(float(v)), 1.0), k
+    assert rel_err(gw.float().cpu().numpy(), want["d_weight"] * scale) <= FP_TOL
+    # d hidden is delivered in the hidden states' dtype (bf16): compare before that rounding where possible
+    tol_h = FP_TOL if gh.dtype == torch.float32 else 4e-3
+    assert rel_err(gh[0].float().cpu().numpy(), want["d_hidden"] * scale) <= tol_h
+
+
+@pytest.mark.parametrize("staging", ["1", "0"], ids=["lds_dma", "register_staging"])
+@pytest.mark.parametrize("T,H,V", [(130, 64, 192), (257, 128, 320), (64, 192, 4160)])
+def test_small_ragged_shapes(libprl, cuda_device, monkeypatch, staging, T, H, V):
+    """Tile edges everywhere: rows not a multiple of 128, a half-masked last vocabulary tile, one K step."""
+    monkeypatch.setenv("PRL_LMHEAD_STAGING", staging)
+    hidden, W, batch, logits64 = _problem(T, H, V, cuda_device, seed=T)
+    want = _oracle(hidden, W, batch, logits64)
+    loss, stats, gh, gw, _ = _run(hidden, W, batch)
+    _compare(loss, stats, gh, gw, want)
+
+
+def test_forward_values_and_split_count_independence(libprl, cuda_device, monkeypatch):
+    """new_logprobs / entropy against fp64 directly, for every vocabulary-split count (the partial
+    online-softmax states merge to the same answer), with a spiky row that forces running-max rescales."""
+    from pipelinerl_amd.fused_head import FusedLmHead
+
+    T, H, V = 200, 256, 8192
+    hidden, W, batch, logits64 = _problem(T, H, V, cuda_device, seed=5)
+    W = W.clone()
+    W[4000] = hidden[0, 17].float() * 0.5  # token 17's logit for id 4000 towers over the rest (~ |h|^2 / 2)
+    logits64 = hidden[0].double() @ W.double().t()
+    ids = torch.from_numpy(batch["input_ids"]).to(cuda_device)
+    z = logits64 / 0.9
+    lp = torch.log_softmax(z, -1)
+    w_nlp = lp[torch.arange(T - 1), ids[0, 1:]]
+    w_ent = -(lp.exp() * lp).sum(-1)
+    head = FusedLmHead(W, backward=False)
+    for ns in ("1", "2", "7", "64"):
+        monkeypatch.setenv("PRL_LMHEAD_NSPLIT", ns)
+        nlp, ent, lse2, _ = head.logprob_entropy(hidden, ids, 0.9)
+        assert nlp[0, 0].item() == 0 and ent[0, 0].item() == 0
+        assert torch.allclose(nlp[0, 1:].double(), w_nlp, rtol=FP_TOL, atol=2e-5), ns
+        assert torch.allclose(ent[0, 1:].double(), w_ent[:-1], rtol=FP_TOL, atol=2e-5), ns
+
+
+@pytest.mark.parametrize("staging", ["1", "0"], ids=["lds_dma", "register_staging"])
+def test_qwen7b_head_shape_vs_oracle(libprl, cuda_device, monkeypatch, staging):
+    """H = 3584, V = 152 064, fp32 weight (two bf16 planes): loss, statistics, d hidden, d W."""
+    monkeypatch.setenv("PRL_LMHEAD_STAGING", staging)
+    hidden, W, batch, logits64 = _problem(160, 3584, 152064, cuda_device, seed=3)
+    want = _oracle(hidden, W, batch, logits64)
+    loss, stats, gh, gw, head = _run(hidden, W, batch)
+    _compare(loss, stats, gh, gw, want)
+    # fp32 d hidden straight from the C ABI: the 1e-4 bar without the bf16 rounding of the autograd path
+    from pipelinerl_amd.finetune.rl import RLConfig, grpo_loss_from_logprobs, make_loss_config
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+
+    pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(cuda_device)
+    nlp, ent, lse2, h = head.logprob_entropy(hidden, pb.input_ids, CFG["temperature"])
+    c_cfg, _, _ = make_loss_config(RLConfig(**CFG), 2, 10)
+    _, _, g_nlp, g_ent = grpo_loss_from_logprobs(c_cfg, pb, nlp, ent)
+    gh32 = head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, grad_hidden_dtype=torch.float32)
+    assert rel_err(gh32[0].cpu().numpy(), want["d_hidden"]) <= FP_TOL
+
+
+def test_qwen0p5b_tied_bf16_head_vs_oracle(libprl, cuda_device):
+    """H = 896, V = 151 936, bf16 weight (tied embedding): a single exact plane."""
+    hidden, W, batch, logits64 = _problem(150, 896, 151936, cuda_device, weight_dtype=torch.bfloat16, seed=9)
+    want = _oracle(hidden, W, batch, logits64)
+    loss, stats, gh, gw, head = _run(hidden, W, batch)
+    assert head.w_lo is None
+    assert abs(loss.item() - float(want["loss"])) <= FP_TOL * abs(float(want["loss"]))
+    assert rel_err(gh[0].float().cpu().numpy(), want["d_hidden"]) <= 4e-3
+    assert rel_err(gw.float().cpu().numpy(), want["d_weight"]) <= 4e-3  # delivered in the weight's dtype (bf16)
+
+
+def test_chunked_backward_and_upstream_scale(libprl, cuda_device):
+    """Row chunks that do not divide the batch (and are not multiples of 128) give the same gradients;
+    an upstream factor on the loss scales both."""
+    hidden, W, batch, logits64 = _problem(300, 128, 1024, cuda_device, seed=21)
+    want = _oracle(hidden, W, batch, logits64)
+    for chunk, scale in ((None, 1.0), (128, 1.0), (100, 0.25), (299, 3.0)):
+        loss, stats, gh, gw, _ = _run(hidden, W, batch, chunk_rows=chunk, grad_scale=scale)
+        _compare(loss, stats, gh, gw, want, scale)
+
+
+def test_rl_step_fused_head_on_a_huggingface_style_model(libprl, cuda_device):
+    """`rl_step_fused_head` == `rl_step` on a model with `.model` (body) and `.lm_head`: same loss,
+    same parameter gradients, without the [T, V] logits."""
+    import copy
+    import types
+
+    from pipelinerl_amd.finetune.rl import RLConfig, rl_step
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.fused_head import rl_step_fused_head
+
+    V, H, T = 1024, 128, 96
+
+    class Body(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb = torch.nn.Embedding(V, H)
+            self.lin = torch.nn.Linear(H, H)
+
+        def forward(self, input_ids=None, **kw):
+            return (torch.tanh(self.lin(self.emb(input_ids))).to(torch.bfloat16),)
+
+    class LM(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = Body()
+            self.lm_head = torch.nn.Linear(H, V, bias=False)
+
+        def forward(self, **kw):
+            h = self.model(**kw)[0]
+            return types.SimpleNamespace(logits=h.float() @ self.lm_head.weight.t())
+
+    torch.manual_seed(0)
+    a = LM().to(cuda_device)
+    b = copy.deepcopy(a)
+    _, _, batch, _ = _problem(T, H, V, cuda_device, seed=2)
+    pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(cuda_device)
+    cfg = RLConfig(**CFG)
+    la, sa = rl_step(a, pb, 2, 10, cfg)
+    la.backward()
+    lb, sb = rl_step_fused_head(b, pb, 2, 10, cfg)
+    lb.backward()
+    assert abs(la.item() - lb.item()) <= FP_TOL * abs(la.item())
+    assert list(sa) == list(sb)
+    for k in sa:
+        assert abs(sa[k] - sb[k]) <= FP_TOL * max(abs(sa[k]), 1.0), k
+    for (n, pa), (_, pbb) in zip(a.named_parameters(), b.named_parameters()):
+        # the body's gradients pass through a bf16 d hidden in both models
+        assert rel_err(pbb.grad.cpu().numpy(), pa.grad.cpu().numpy()) <= 2e-2, n
+    assert rel_err(b.lm_head.weight.grad.cpu().numpy(), a.lm_head.weight.grad.cpu().numpy()) <= 1e-3
+
+
+def test_workspace_too_small_and_bad_shapes_are_refused(libprl, cuda_device):
+    from pipelinerl_amd import _lib
+
+    t = torch.zeros(1 << 20, dtype=torch.uint8, device=cuda_device)
+    P = t.data_ptr()
+    s = _lib.current_stream_ptr(cuda_device)
+    assert libprl.prl_lm_head_logprob_fwd(1, 128, 100, 1024, P, P, None, P, 1.0, P, P, P, P, 1 << 20, s) == _lib.PRL_EINVAL  # hidden % 64
+    assert libprl.prl_lm_head_logprob_fwd(1, 4096, 64, 1024, P, P, None, P, 1.0, P, P, P, P, 1024, s) == _lib.PRL_ENOMEM
+    assert libprl.prl_lm_head_logprob_bwd(1, 128, 64, 1000, P, P, None, P, None, P, 1.0, P, P, P, None, None, P, 1, None, 128, P, 1 << 20, s) == _lib.PRL_EINVAL  # vocab % 64
+    fwd, bwd = ctypes.c_size_t(), ctypes.c_size_t()
+    _lib.check(libprl.prl_lm_head_workspace_bytes(1, 8192, 3584, 152064, 2048, ctypes.byref(fwd), ctypes.byref(bwd)))
+    assert fwd.value < 2 << 20 and 2.4e9 < bwd.value < 2.6e9  # 4 bf16 planes of 2048 x 152064 + the transposed hidden chunk
