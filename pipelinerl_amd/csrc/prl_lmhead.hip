@@ -10,25 +10,33 @@
 //
 //   * fp32 accuracy on bf16 MFMA: the hidden states are bf16 already; the fp32 weight is split once
 //     per optimizer step into two bf16 planes W = W_hi + W_lo (prl_lm_head_prepare).  bf16 x bf16
-//     products are exact in fp32 and accumulate in fp32, so  h W_hi^T + h W_lo^T  reproduces the
+//     products are exact in fp32 and accumulate in fp32, so  W_hi h^T + W_lo h^T  reproduces the
 //     fp32 product to ~2^-17 relative - the planes are simply further K-steps of ONE accumulator.
-//   * forward: each workgroup owns 128 token rows and a range of vocabulary tiles; per 128 x 128 tile
-//     the accumulators go straight into per-lane online-softmax states (M, S, W of prl_osm.h) - the
-//     logits never leave the registers.  Partial states per (row, vocabulary split) are merged by a
-//     small second kernel that also writes the token-aligned new_logprobs / entropy / lse2.
+//   * operand roles: the WEIGHT rows (vocabulary) are the M side of the MFMA and the tokens the N
+//     side, so in the accumulator layout of v_mfma_f32_32x32x16 (column = lane & 31, rows spread over
+//     the 16 registers) a lane owns ONE token per 32 x 32 tile and its registers run along the
+//     vocabulary - the soft-max reduction is register-local, and a lane carries two online-softmax
+//     states (M, S, W of prl_osm.h) instead of one per accumulator row.
+//   * forward: each workgroup owns 128 tokens and a range of vocabulary tiles; the logits never leave
+//     the registers.  Partial states per (token, vocabulary split) are merged by a small second kernel
+//     that also writes the token-aligned new_logprobs / entropy / lse2.
 //   * backward: per chunk of rows the logits tile is recomputed by the same main loop, turned into
 //     d logits with the saved lse2 / entropy and the per-token loss gradients, split into bf16
 //     (hi, lo) planes and written in both layouts to a workspace sized for the chunk only; two more
 //     passes of the same NT GEMM core produce  d hidden = d logits W  and  d W += d logits^T hidden.
 //
-// GEMM core: C[M, N] = sum_terms A_t[M, Kc] B_t[N, Kc]^T, both operands contraction-contiguous bf16,
-// 128 x 128 x 64 tiles, 256 threads = 4 waves (2 x 2) of 64 x 64, mfma_f32_16x16x32_bf16, operands
-// brought HBM -> LDS by global_load_lds (16 B per lane, no VGPR round trip) into a double buffer,
-// 16-byte chunks XOR-swizzled on the SOURCE address so that the fragment ds_read_b128 are bank
-// conflict free, one barrier per K-step with the next tile's loads in flight during the MFMAs.
+// GEMM core: C[M, N] = sum_terms A_t[M, Kc] B_t[N, Kc]^T, both operands contraction-contiguous bf16.
+//   tile     BM x 128 x 64 with BM = 256 (512 threads, 8 waves as 4 x 2) or 128 (256 threads, 2 x 2);
+//            every wave computes 64 x 64 as 2 x 2 tiles of v_mfma_f32_32x32x16_bf16
+//   staging  HBM/L2 -> LDS by global_load_lds (16 B per lane, no VGPR round trip), 16-byte chunks
+//            XOR-swizzled on the SOURCE address so the fragment ds_read_b128 are bank-conflict free
+//   pipeline BM = 256: ring of 3 LDS stages (144 KB), two tiles of loads in flight; the wait for a tile
+//            is a COUNTED s_waitcnt vmcnt(N) and the barrier a raw s_barrier, so the younger tile's
+//            loads stay in flight across it (a `__syncthreads()` would drain them)
 // MFMA-bound by design; roofline = dense bf16 MFMA peak (2.5 PFLOP/s).
 
 #include <cstdlib>
+#include <cstring>
 
 #include "prl_common.h"
 #include "prl_lmhead_layout.h"
@@ -40,11 +48,32 @@ using namespace prl::osm;
 using namespace prl::lmhead;
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // double buffered: 64 KB -> two workgroups per CU
 constexpr int MAX_TERMS = 3;
+
+// Workgroup shape: BM x BN tile, (BM / 64) x 2 waves of 64 x (BN / 2), STAGES LDS buffers of (BM + BN) rows
+// x 128 bytes.  The staging traffic, not the matrix pipe, bounds these kernels: the LDS DMA sustains about
+// 24 bytes per clock and CU out of L2 (measured, profiles/r02c), and a K-step moves (BM + BN) * 128 bytes
+// for 2 * BM * BN * 64 flop - 87 flop/byte at 256 x 128 (measured 1.0 PFLOP/s), 131 at 256 x 256.
+template <int BM_, int BN_, int STAGES_>
+struct Cfg {
+  static constexpr int BM = BM_;
+  static constexpr int BN = BN_;
+  static constexpr int NT = BM_ * 2;  // 64 threads per 32 rows: 8 waves for 256 rows, 4 for 128
+  static constexpr int STAGES = STAGES_;
+  static constexpr int NJ = BN_ / 64;      // 32-column MFMA tiles per wave (2 x NJ tiles of 32 x 32)
+  static constexpr int WCOLS = BN_ / 2;    // columns per wave
+  static constexpr int QA = BM_ * 8 / NT;  // 16-byte chunks per thread and stage, A tile
+  static constexpr int QB = BN_ * 8 / NT;  //                                       B tile
+  static constexpr int LOADS = QA + QB;
+  static constexpr int A_BYTES = BM_ * ROW_BYTES;
+  static constexpr int STAGE_BYTES = (BM_ + BN_) * ROW_BYTES;
+  static constexpr int LDS_BYTES = STAGES_ * STAGE_BYTES;
+};
+using CfgWide = Cfg<256, 256, 2>;   // 128 KB LDS, one workgroup of 8 waves per CU, 64 x 128 per wave
+using CfgBig = Cfg<256, 128, 3>;    // 144 KB LDS, one workgroup of 8 waves per CU, two tiles of loads in flight
+using CfgSmall = Cfg<128, 128, 2>;  // 64 KB LDS, two workgroups of 4 waves per CU
 
 struct Terms {
   const uint16_t* a[MAX_TERMS];
@@ -78,34 +107,50 @@ __device__ __forceinline__ uint16_t to_bf16(float x) {
   return (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2)) & 0xffffu);
 }
 
+// Wait until at most N of this wave's LDS-DMA loads are outstanding (they complete in order, so the
+// older tile has landed), retire this wave's own LDS reads, then the workgroup barrier.  One asm
+// statement with a memory clobber: the compiler can neither drain the younger loads with a vmcnt(0)
+// (what `__syncthreads()` does while an LDS DMA is in flight) nor move LDS traffic across the barrier.
+template <int N>
+__device__ __forceinline__ void wait_tile_then_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 // -----------------------------------------------------------------------------------------------
-// main loop: acc[i][j] (16x16 tiles of this wave's 64 x 64) += sum over terms and K
+// main loop: acc[i][j] (32 x 32 tiles of this wave's 64 x 64) += sum over terms and K
 // -----------------------------------------------------------------------------------------------
-template <bool GLDS>
-__device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[4][4], const Terms& t, const Geom& g, int m0, int n0,
+template <class C>
+__device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Terms& t, const Geom& g, int m0, int n0,
                                               char* lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  // ---- staging (layout: prl_lmhead_layout.h): this thread fetches chunks q * 256 + tid, q = 0..3,
+  // ---- staging (layout: prl_lmhead_layout.h): this thread fetches chunks q * NT + tid of each tile,
   // i.e. rows stage_row(tid, q), all from source column stage_kcol(tid)
   const int kcol = stage_kcol(tid);
-  int64_t offA[4], offB[4];
+  int64_t offA[C::QA], offB[C::QB];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    int ra = m0 + stage_row(tid, q);
+  for (int q = 0; q < C::QA; ++q) {
+    int ra = m0 + stage_row(tid, q, C::NT);
     ra = ra < g.M ? ra : g.M - 1;  // rows past the edge re-read the last row; their results are discarded
-    int rb = n0 + stage_row(tid, q);
-    rb = rb < g.N ? rb : g.N - 1;
     offA[q] = (int64_t)ra * g.lda + kcol;
+  }
+#pragma unroll
+  for (int q = 0; q < C::QB; ++q) {
+    int rb = n0 + stage_row(tid, q, C::NT);
+    rb = rb < g.N ? rb : g.N - 1;
     offB[q] = (int64_t)rb * g.ldb + kcol;
   }
-  // ---- fragment reads: byte offsets of tile row-block i = 0 for the two 32-deep sub-steps; row-block i
-  // adds i * 16 rows * 128 bytes (the swizzle term depends on (row >> 1) & 7 only, unchanged by + 16 i)
-  const int rdA0 = frag_lds_byte(lane, wm, 0, 0), rdA1 = frag_lds_byte(lane, wm, 0, 1);
-  const int rdB0 = TILE_BYTES + frag_lds_byte(lane, wn, 0, 0), rdB1 = TILE_BYTES + frag_lds_byte(lane, wn, 0, 1);
+  // ---- fragment reads: byte offsets of MFMA tile i = 0 for the four 16-deep sub-steps; tile i = 1 adds
+  // 32 rows * 128 bytes (the swizzle term depends on (row >> 1) & 7 only, unchanged by + 32)
+  int rdA[4], rdB[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    rdA[ks] = frag_lds_byte(lane, wm * 64, 0, ks);
+    rdB[ks] = C::A_BYTES + frag_lds_byte(lane, wn * C::WCOLS, 0, ks);
+  }
 
   const int ksteps = g.Kc / BK;
   const int total = t.n * ksteps;
@@ -122,214 +167,204 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[4][4], const Terms& t
       sB = st_term == 1 ? t.b[1] : t.b[2];
     }
   };
-
-  auto compute = [&](int buf) {
-    const char* base = lds + buf * STAGE_BYTES;
+  // One 16-byte-per-lane LDS-DMA piece `idx` (0 .. LOADS-1: first the A tile's, then the B tile's) of the
+  // tile the staging cursor points at, into stage buffer `buf`.
+  auto stage_piece = [&](int buf, int idx) {
+    const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
+    if (idx < C::QA) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sA + offA[idx] + st_k),
+                                       (__attribute__((address_space(3))) void*)(lds + dst + idx * C::NT * 16), 16, 0, 0);
+    } else {
+      const int q = idx - C::QA;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sB + offB[q] + st_k),
+                                       (__attribute__((address_space(3))) void*)(lds + dst + C::A_BYTES + q * C::NT * 16), 16, 0, 0);
+    }
+  };
+  auto stage = [&](int buf) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ra = ks ? rdA1 : rdA0, rb = ks ? rdB1 : rdB0;
-      bf16x8 af[4], bfr[4];
+    for (int idx = 0; idx < C::LOADS; ++idx) stage_piece(buf, idx);
+  };
+  // MFMAs of one staged tile.  With `sbuf >= 0` the LDS-DMA pieces of the NEXT tile to stage are issued in
+  // between the MFMA groups instead of in one burst after the barrier: a piece costs ~60-180 issue cycles,
+  // and all waves of the workgroup leave the barrier together - a burst would idle the matrix pipe of
+  // every SIMD at once (measured on the same build: 17.7 ms interleaved vs 19.8 ms burst for the 7B forward).
+  auto compute = [&](int buf, int sbuf) {
+    const char* base = lds + buf * C::STAGE_BYTES;
+    constexpr int PER = (C::LOADS + 2) / 3;  // pieces after each of the first three MFMA groups
+    bf16x8 af[2][2], bfr[2][C::NJ];  // [ping-pong][tile]: the reads of sub-step ks + 1 are issued before the MFMAs of ks
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + ra + i * 2048);
+    for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(base + rdA[0] + i * 32 * ROW_BYTES);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(base + rb + j * 2048);
+    for (int j = 0; j < C::NJ; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(base + rdB[0] + j * 32 * ROW_BYTES);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks < 3) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) af[nxt][i] = *reinterpret_cast<const bf16x8*>(base + rdA[ks + 1] + i * 32 * ROW_BYTES);
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) bfr[nxt][j] = *reinterpret_cast<const bf16x8*>(base + rdB[ks + 1] + j * 32 * ROW_BYTES);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+      if (sbuf >= 0 && ks < 3) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+          if (ks * PER + k < C::LOADS) stage_piece(sbuf, ks * PER + k);
+      }
     }
   };
 
-  __syncthreads();  // whoever used the LDS before (previous tile, an epilogue) is done with it
-  if constexpr (GLDS) {
-    auto stage = [&](int buf) {
-      const unsigned dst = buf * STAGE_BYTES + stage_lds_byte(wave * 64, 0);  // + q * 4096 + lane * 16 (hardware)
+  constexpr int D = C::STAGES - 1;  // tiles of loads in flight ahead of the one being computed
+  __syncthreads();                  // whoever used the LDS before (previous tile, an epilogue) is done with it
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sA + offA[q] + st_k),
-                                         (__attribute__((address_space(3))) void*)(lds + dst + q * 4096), 16, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sB + offB[q] + st_k),
-                                         (__attribute__((address_space(3))) void*)(lds + dst + TILE_BYTES + q * 4096), 16, 0, 0);
-    };
-    stage(0);
+  for (int p = 0; p < D; ++p)
+    if (p < total) {
+      stage(p);
+      advance();
+    }
+  int cur = 0, nxt = D % C::STAGES;
+  int s = 0;
+  // steady state: tile s has landed once only the D - 1 younger stages remain outstanding; every wave has
+  // finished computing tile s - 1 when it passes the barrier, so that tile's buffer (where tile s + D goes)
+  // is free - its loads ride between the MFMAs of tile s
+  for (; s + D < total; ++s) {
+    wait_tile_then_barrier<(D - 1) * C::LOADS>();
+    compute(cur, nxt);
     advance();
-    for (int s = 0; s + 1 < total; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile s has landed
-      __syncthreads();                                    // ... everybody's has; buffer (s+1)&1 is free again
-      stage((s + 1) & 1);                                 // in flight during the MFMAs below
-      advance();
-      compute(s & 1);
+    cur = cur + 1 == C::STAGES ? 0 : cur + 1;
+    nxt = nxt + 1 == C::STAGES ? 0 : nxt + 1;
+  }
+  // drain: the last D tiles, nothing left to stage
+  for (; s < total; ++s) {
+    if (s + D - 1 < total) {
+      wait_tile_then_barrier<(D - 1) * C::LOADS>();
+    } else {
+      wait_tile_then_barrier<0>();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    compute((total - 1) & 1);
-  } else {
-    // register staging (fallback / A-B reference for the DMA path): same LDS image
-    struct Regs {
-      uint4 a0, a1, a2, a3, b0, b1, b2, b3;
-    };
-    auto gload = [&]() -> Regs {
-      Regs r;
-      r.a0 = *reinterpret_cast<const uint4*>(sA + offA[0] + st_k);
-      r.a1 = *reinterpret_cast<const uint4*>(sA + offA[1] + st_k);
-      r.a2 = *reinterpret_cast<const uint4*>(sA + offA[2] + st_k);
-      r.a3 = *reinterpret_cast<const uint4*>(sA + offA[3] + st_k);
-      r.b0 = *reinterpret_cast<const uint4*>(sB + offB[0] + st_k);
-      r.b1 = *reinterpret_cast<const uint4*>(sB + offB[1] + st_k);
-      r.b2 = *reinterpret_cast<const uint4*>(sB + offB[2] + st_k);
-      r.b3 = *reinterpret_cast<const uint4*>(sB + offB[3] + st_k);
-      return r;
-    };
-    auto lstore = [&](int buf, const Regs& r) {
-      char* base = lds + buf * STAGE_BYTES + stage_lds_byte(tid, 0);
-      *reinterpret_cast<uint4*>(base) = r.a0;
-      *reinterpret_cast<uint4*>(base + 4096) = r.a1;
-      *reinterpret_cast<uint4*>(base + 8192) = r.a2;
-      *reinterpret_cast<uint4*>(base + 12288) = r.a3;
-      *reinterpret_cast<uint4*>(base + TILE_BYTES) = r.b0;
-      *reinterpret_cast<uint4*>(base + TILE_BYTES + 4096) = r.b1;
-      *reinterpret_cast<uint4*>(base + TILE_BYTES + 8192) = r.b2;
-      *reinterpret_cast<uint4*>(base + TILE_BYTES + 12288) = r.b3;
-    };
-    {
-      const Regs r = gload();
-      advance();
-      lstore(0, r);
-    }
-    for (int s = 0; s + 1 < total; ++s) {
-      __syncthreads();
-      const Regs r = gload();
-      advance();
-      compute(s & 1);
-      lstore((s + 1) & 1, r);
-    }
-    __syncthreads();
-    compute((total - 1) & 1);
+    compute(cur, -1);
+    cur = cur + 1 == C::STAGES ? 0 : cur + 1;
   }
 }
 
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[4][4]) {
+template <int NJ>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NJ]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-}
-
-// C/D layout of mfma_f32_16x16x32: element `reg` of acc[i][j] is row 4 * (lane >> 4) + reg, column lane & 15
-// of the 16 x 16 tile (i, j)  (prl_lmhead_layout.h: acc_row / acc_col).
-struct LaneMap {
-  int row0;  // acc_row(lane, wm, 0, 0)   (+ i * 16 + reg)
-  int col0;  // acc_col(lane, wn, 0)      (+ j * 16)
-};
-__device__ __forceinline__ LaneMap lane_map() {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  return LaneMap{acc_row(lane, wave >> 1, 0, 0), acc_col(lane, wave & 1, 0)};
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 }
 
 // -----------------------------------------------------------------------------------------------
-// forward
+// forward.  A = weight planes (M = vocabulary), B = hidden (N = logits rows / tokens)
 // -----------------------------------------------------------------------------------------------
 struct FwdArgs {
-  Terms terms;          // a = hidden [n, hidden] (same pointer for every term), b = weight planes [vocab, hidden]
-  Geom geo;             // M = n logits rows, N = vocab, Kc = hidden
+  Terms terms;
+  Geom geo;             // M = vocab, N = n logits rows, Kc = hidden
   int64_t cols;         // batch columns: logits row q predicts token q + 1 unless q % cols == cols - 1
   const int64_t* ids;   // [n]
   float k2;             // log2(e) / temperature
-  int mt, nt, nsplit;
-  float* part;          // [nsplit][mt * BM][4]  (M, S, W, -)
-  float* ysel;          // [mt * BM] selected logit (base-2 units), written by whichever split owns the column
+  int vt, tt, nsplit;   // vocabulary tiles (of BM), token tiles (of BN), vocabulary splits
+  int64_t padded;       // tt * BN
+  float* part;          // [nsplit][padded][4]  (M, S, W, -)
+  float* ysel;          // [padded] selected logit (base-2 units), written by whichever split owns the row
 };
 
-template <bool GLDS>
-__global__ __launch_bounds__(NTHREADS, 2) void lmhead_fwd_kernel(FwdArgs a) {
+template <class C>
+__global__ __launch_bounds__(C::NT, 2) void lmhead_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  int tm, split;
-  tile_coords(blockIdx.x, a.mt, a.nsplit, tm, split);
-  const int m0 = tm * BM;
-  const int nt0 = (int)((int64_t)a.nt * split / a.nsplit), nt1 = (int)((int64_t)a.nt * (split + 1) / a.nsplit);
-  const LaneMap lm = lane_map();
+  int tok_tile, split;
+  tile_coords(blockIdx.x, a.tt, a.nsplit, tok_tile, split);
+  constexpr int BN = C::BN, NJ = C::NJ;
+  const int n0 = tok_tile * BN;
+  const int vt0 = (int)((int64_t)a.vt * split / a.nsplit), vt1 = (int)((int64_t)a.vt * (split + 1) / a.nsplit);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
+  const int V = a.geo.M;
 
-  Osm st[4][4];
-  int tgt[4][4];  // target column of each of this lane's 16 rows, -1: none
+  Osm st[NJ];
+  int tgt[NJ];  // target vocabulary row of this lane's tokens, -1: none
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      osm_init(st[i][r]);
-      const int64_t q = m0 + lm.row0 + i * 16 + r;
-      int id = -1;
-      if (q < a.geo.M && (q % a.cols) != a.cols - 1) {
-        const int64_t v = a.ids[q + 1];
-        if (v >= 0 && v < a.geo.N) id = (int)v;
-      }
-      tgt[i][r] = id;
+  for (int j = 0; j < NJ; ++j) {
+    osm_init(st[j]);
+    const int64_t q = n0 + acc_col(lane, wcol0, j);
+    int id = -1;
+    if (q < a.geo.N && (q % a.cols) != a.cols - 1) {
+      const int64_t v = a.ids[q + 1];
+      if (v >= 0 && v < V) id = (int)v;
     }
-
-  f32x4 acc[4][4];
-  for (int tn = nt0; tn < nt1; ++tn) {
-    const int n0 = tn * BN;
-    zero_acc(acc);
-    gemm_mainloop<GLDS>(acc, a.terms, a.geo, m0, n0, lds);
-    const int cbase = n0 + lm.col0;
-    const bool full = n0 + BN <= a.geo.N;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float y[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = acc[i][j][r] * a.k2;
-        const int d = tgt[i][r] - cbase;  // this lane holds columns cbase + 16 j
-        if (d >= 0 && d < 64 && (d & 15) == 0) {
-          const int64_t q = m0 + lm.row0 + i * 16 + r;
-          a.ysel[q] = d == 0 ? y[0] : d == 16 ? y[1] : d == 32 ? y[2] : y[3];
-        }
-        if (full) {
-          osm_push<4>(st[i][r], y);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (cbase + j * 16 < a.geo.N) {
-              float one[1] = {y[j]};
-              osm_push<1>(st[i][r], one);
-            }
-        }
-      }
+    tgt[j] = id;
   }
 
-  // merge the 16 lanes that share a row, then the two waves that share it (wn = 0, 1)
+  f32x16 acc[2][NJ];
+  for (int tv = vt0; tv < vt1; ++tv) {
+    const int m0 = tv * C::BM;
+    zero_acc<NJ>(acc);
+    gemm_mainloop<C>(acc, a.terms, a.geo, m0, n0, lds);
+    const int vbase = m0 + acc_row(lane, wrow0, 0, 0);  // vocabulary row of acc[0][j][0]; + 32 i + (reg & 3) + 8 (reg >> 2)
+    const bool full = m0 + C::BM <= V;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < NJ; ++j) {
+      float y[32];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      Osm s = st[i][r];
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        Osm o2;
-        o2.M = __shfl_xor(s.M, o, 64);
-        o2.S = __shfl_xor(s.S, o, 64);
-        o2.W = __shfl_xor(s.W, o, 64);
-        s = osm_merge(s, o2);
+        for (int r = 0; r < 16; ++r) y[i * 16 + r] = acc[i][j][r] * a.k2;
+      const int d = tgt[j] - vbase;
+      if (d >= 0 && d < 64 && (d & 7) < 4) {  // the target row is one of this lane's 32
+        float sel = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (d == i * 32 + (r & 3) + 8 * (r >> 2)) sel = y[i * 16 + r];
+        a.ysel[n0 + acc_col(lane, wcol0, j)] = sel;
       }
-      st[i][r] = s;
+      if (full) {
+        osm_push<32>(st[j], y);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (vbase + i * 32 + (r & 3) + 8 * (r >> 2) < V) {
+              float one[1] = {y[i * 16 + r]};
+              osm_push<1>(st[j], one);
+            }
+      }
     }
+  }
+
+  // the two half-waves (lane, lane ^ 32) hold the same tokens; then the waves wm = 0 .. WM-1 that share them
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    Osm o;
+    o.M = __shfl_xor(st[j].M, 32, 64);
+    o.S = __shfl_xor(st[j].S, 32, 64);
+    o.W = __shfl_xor(st[j].W, 32, 64);
+    st[j] = osm_merge(st[j], o);
+  }
   __syncthreads();  // the last tile's LDS reads are done: reuse the buffer for the cross-wave hand-off
-  float4* red = reinterpret_cast<float4*>(lds);  // [2][BM]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((lane & 15) == 0) {
+  constexpr int WM = C::BM / 64;
+  float4* red = reinterpret_cast<float4*>(lds);  // [WM][BN]
+  if (lane < 32) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        red[(wave & 1) * BM + lm.row0 + i * 16 + r] = float4{st[i][r].M, st[i][r].S, st[i][r].W, 0.0f};
+    for (int j = 0; j < NJ; ++j) red[(wave >> 1) * BN + acc_col(lane, wcol0, j)] = float4{st[j].M, st[j].S, st[j].W, 0.0f};
   }
   __syncthreads();
-  if (tid < BM) {
-    const float4 x = red[tid], y = red[BM + tid];
-    const Osm m = osm_merge(Osm{x.x, x.y, x.z}, Osm{y.x, y.y, y.z});
-    reinterpret_cast<float4*>(a.part)[((int64_t)split * a.mt * BM) + m0 + tid] = float4{m.M, m.S, m.W, 0.0f};
+  if (tid < BN) {
+    float4 x = red[tid];
+    Osm m{x.x, x.y, x.z};
+#pragma unroll
+    for (int w = 1; w < WM; ++w) {
+      x = red[w * BN + tid];
+      m = osm_merge(m, Osm{x.x, x.y, x.z});
+    }
+    reinterpret_cast<float4*>(a.part)[(int64_t)split * a.padded + n0 + tid] = float4{m.M, m.S, m.W, 0.0f};
   }
 }
 
@@ -367,9 +402,8 @@ __global__ __launch_bounds__(256) void lmhead_fwd_finish_kernel(int64_t n, int64
 // -----------------------------------------------------------------------------------------------
 struct DlArgs {
   Terms terms;
-  Geom geo;             // M = rows of this chunk, N = vocab, Kc = hidden
+  Geom geo;             // M = vocab, N = rows of this chunk, Kc = hidden
   int64_t row_base;     // first logits row of the chunk (global index q)
-  int64_t n_total;      // total logits rows
   int64_t cols;
   const int64_t* ids;
   const float* lse2;    // token-aligned [n_total]
@@ -378,73 +412,78 @@ struct DlArgs {
   const float* g_ent;   // nullable
   const float* upstream;  // nullable device scalar
   float k2, inv_temp;
-  int mt, nt;
-  int chunk_pad;        // rows of the chunk buffers (multiple of BM)
+  int vt, tt;
+  int chunk_pad;        // rows of the chunk buffers (multiple of 128)
   uint16_t* dl_hi;      // [chunk_pad, vocab]
   uint16_t* dl_lo;
   uint16_t* dlT_hi;     // [vocab, chunk_pad]
   uint16_t* dlT_lo;
 };
 
-template <bool GLDS>
-__global__ __launch_bounds__(NTHREADS, 2) void lmhead_dlogits_kernel(DlArgs a) {
+template <class C>
+__global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  int tm, tn;
-  tile_coords(blockIdx.x, a.mt, a.nt, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const LaneMap lm = lane_map();
-  f32x4 acc[4][4];
-  zero_acc(acc);
-  gemm_mainloop<GLDS>(acc, a.terms, a.geo, m0, n0, lds);
+  int tv, tk;
+  tile_coords(blockIdx.x, a.vt, a.tt, tv, tk);
+  constexpr int NJ = C::NJ;
+  const int m0 = tv * C::BM, n0 = tk * C::BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
+  f32x16 acc[2][NJ];
+  zero_acc<NJ>(acc);
+  gemm_mainloop<C>(acc, a.terms, a.geo, m0, n0, lds);
 
   const float up = a.upstream ? *a.upstream : 1.0f;
-  const int64_t V = a.geo.N;
+  const int64_t V = a.geo.M;
+  const int vbase = m0 + acc_row(lane, wrow0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < NJ; ++j) {
+    const int lrow = n0 + acc_col(lane, wcol0, j);  // row inside the chunk buffers
+    if (lrow >= a.chunk_pad) continue;               // a 256-row tile may overhang a chunk padded to 128
+    const int64_t q = a.row_base + lrow;
+    float g = 0.0f, gH = 0.0f, l2 = 0.0f, H = 0.0f;
+    int id = -1;
+    if (lrow < a.geo.N && (q % a.cols) != a.cols - 1) {
+      const int64_t u = q + 1;
+      g = a.g_nlp[u] * up;
+      gH = a.g_ent ? a.g_ent[u] * up : 0.0f;
+      l2 = a.lse2[u];
+      H = a.ent[u];
+      const int64_t v = a.ids[u];
+      if (v >= 0 && v < V) id = (int)v;
+    }
+    const float gi = g * a.inv_temp, ngi = -g * a.inv_temp, nhi = -gH * a.inv_temp;
+    const bool live = (g != 0.0f) || (gH != 0.0f);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int lrow = m0 + lm.row0 + i * 16 + r;  // row inside the chunk buffers
-      const int64_t q = a.row_base + lrow;
-      float g = 0.0f, gH = 0.0f, l2 = 0.0f, H = 0.0f;
-      int id = -1;
-      if (lrow < a.geo.M && (q % a.cols) != a.cols - 1) {
-        const int64_t u = q + 1;
-        g = a.g_nlp[u] * up;
-        gH = a.g_ent ? a.g_ent[u] * up : 0.0f;
-        l2 = a.lse2[u];
-        H = a.ent[u];
-        const int64_t v = a.ids[u];
-        if (v >= 0 && v < V) id = (int)v;
-      }
-      const float gi = g * a.inv_temp, ngi = -g * a.inv_temp, nhi = -gH * a.inv_temp;
-      const bool live = (g != 0.0f) || (gH != 0.0f);
-      uint16_t hi[4], lo[4];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = n0 + lm.col0 + j * 16;
-        float v = 0.0f;
-        if (live) {
-          const float d2 = __builtin_fmaf(acc[i][j][r], a.k2, -l2);  // log2 p
-          const float p = fast_exp2(d2);
-          v = ngi * p;
-          if (gH != 0.0f) v = __builtin_fmaf(nhi * p, __builtin_fmaf(d2, kLn2, H), v);
-          if (col == id) v += gi;
+      for (int rg = 0; rg < 4; ++rg) {  // four consecutive vocabulary rows: registers 4 rg .. 4 rg + 3
+        const int v0 = vbase + i * 32 + 8 * rg;
+        uint16_t hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float val = 0.0f;
+          if (live) {
+            const float d2 = __builtin_fmaf(acc[i][j][rg * 4 + e], a.k2, -l2);  // log2 p
+            const float p = fast_exp2(d2);
+            val = ngi * p;
+            if (gH != 0.0f) val = __builtin_fmaf(nhi * p, __builtin_fmaf(d2, kLn2, H), val);
+            if (v0 + e == id) val += gi;
+          }
+          split2(val, hi[e], lo[e]);
         }
-        split2(v, hi[j], lo[j]);
-      }
-      if (lrow < a.chunk_pad) {
+        if (v0 + 3 < V) {  // V is a multiple of 4: a group of four is inside or outside as a whole
+          const int64_t o = (int64_t)lrow * V + v0;  // 8-byte aligned: V % 4 == 0, v0 % 4 == 0
+          *reinterpret_cast<uint2*>(a.dl_hi + o) = uint2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
+          *reinterpret_cast<uint2*>(a.dl_lo + o) = uint2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int col = n0 + lm.col0 + j * 16;
-          if (col < V) {
-            a.dl_hi[(int64_t)lrow * V + col] = hi[j];
-            a.dl_lo[(int64_t)lrow * V + col] = lo[j];
-            a.dlT_hi[(int64_t)col * a.chunk_pad + lrow] = hi[j];
-            a.dlT_lo[(int64_t)col * a.chunk_pad + lrow] = lo[j];
+          for (int e = 0; e < 4; ++e) {
+            a.dlT_hi[(int64_t)(v0 + e) * a.chunk_pad + lrow] = hi[e];
+            a.dlT_lo[(int64_t)(v0 + e) * a.chunk_pad + lrow] = lo[e];
           }
         }
       }
-    }
+  }
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -460,25 +499,27 @@ struct GemmArgs {
   int accumulate;   // fp32 only: out += acc
 };
 
-template <bool GLDS>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs a) {
+template <class C>
+__global__ __launch_bounds__(C::NT, 2) void gemm_nt_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int tm, tn;
   tile_coords(blockIdx.x, a.mt, a.nt, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const LaneMap lm = lane_map();
-  f32x4 acc[4][4];
-  zero_acc(acc);
-  gemm_mainloop<GLDS>(acc, a.terms, a.geo, m0, n0, lds);
+  constexpr int NJ = C::NJ;
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
+  f32x16 acc[2][NJ];
+  zero_acc<NJ>(acc);
+  gemm_mainloop<C>(acc, a.terms, a.geo, m0, n0, lds);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + lm.row0 + i * 16 + r;
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + acc_row(lane, wrow0, i, r);
       if (row >= a.geo.M) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = n0 + lm.col0 + j * 16;
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + acc_col(lane, wcol0, j);  // 32 consecutive lanes -> 32 consecutive columns
         if (col >= a.geo.N) continue;
         const int64_t o = (int64_t)row * a.ldc + col;
         if (a.out_bf16) {
@@ -531,43 +572,59 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(int64_t R, int64_t
   }
 }
 
-// PRL_LMHEAD_STAGING=0 selects register staging instead of the LDS DMA (read per call, so one
-// process can A/B the two).
-int g_use_glds() {
-  const char* e = getenv("PRL_LMHEAD_STAGING");
-  return (e && atoi(e) == 0) ? 0 : 1;
+// Workgroup shape per launch.  PRL_LMHEAD_TILE = 128 | 256 | 256x256 forces one (read per call, so one
+// process can A/B them); default: the largest tile whose grid still fills the 256 CUs.
+enum Shape { kSmall = 0, kBig = 1, kWide = 2 };
+Shape pick_shape(int64_t m_rows, int64_t n_cols) {
+  if (const char* e = getenv("PRL_LMHEAD_TILE")) {
+    if (!strcmp(e, "128")) return kSmall;
+    if (!strcmp(e, "256")) return kBig;
+    if (!strcmp(e, "256x256")) return kWide;
+  }
+  const int64_t m256 = (m_rows + 255) / 256;
+  if (m256 * ((n_cols + 255) / 256) >= 200) return kWide;
+  if (m256 * ((n_cols + 127) / 128) >= 200) return kBig;
+  return kSmall;
 }
+int shape_bm(Shape s) { return s == kSmall ? 128 : 256; }
+int shape_bn(Shape s) { return s == kWide ? 256 : 128; }
 
 template <class K, class A>
-int launch_tiles(K kfn, int blocks, const A& args, hipStream_t s, const char* name) {
+int launch_tiles(K kfn, int threads, int lds_bytes, int blocks, const A& args, hipStream_t s, const char* name) {
   static thread_local const void* configured[8] = {nullptr};
   const void* key = reinterpret_cast<const void*>(kfn);
   bool seen = false;
   for (auto c : configured) seen = seen || c == key;
   if (!seen) {
-    PRL_HIP_CHECK(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    PRL_HIP_CHECK(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     for (auto& c : configured)
       if (c == nullptr) {
         c = key;
         break;
       }
   }
-  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(NTHREADS), LDS_BYTES, s, args);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3((unsigned)threads), (size_t)lds_bytes, s, args);
   PRL_LAUNCH_CHECK(name);
   return PRL_OK;
 }
 
-int fwd_nsplit(int mt, int nt) {
-  if (const char* e = getenv("PRL_LMHEAD_NSPLIT")) {
-    const int v = atoi(e);
-    if (v >= 1) return v < nt ? v : nt;
-  }
-  int ns = (512 + mt - 1) / mt;  // two workgroups per CU resident, all 256 CUs busy
-  if (ns < 1) ns = 1;
-  return ns < nt ? ns : nt;
-}
+#define PRL_LAUNCH_CFG(shape, KERNEL, blocks, args, s, name)                                                            \
+  ((shape) == kWide  ? launch_tiles(KERNEL<CfgWide>, CfgWide::NT, CfgWide::LDS_BYTES, blocks, args, s, name)            \
+   : (shape) == kBig ? launch_tiles(KERNEL<CfgBig>, CfgBig::NT, CfgBig::LDS_BYTES, blocks, args, s, name)               \
+                     : launch_tiles(KERNEL<CfgSmall>, CfgSmall::NT, CfgSmall::LDS_BYTES, blocks, args, s, name))
 
 int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// vocabulary splits of the forward: enough workgroups to fill 256 CUs (x 2 for the small shape)
+int fwd_nsplit(int token_tiles, int vocab_tiles, bool one_per_cu) {
+  if (const char* e = getenv("PRL_LMHEAD_NSPLIT")) {
+    const int v = atoi(e);
+    if (v >= 1) return v < vocab_tiles ? v : vocab_tiles;
+  }
+  int ns = ceil_div(one_per_cu ? 256 : 512, token_tiles);
+  if (ns < 1) ns = 1;
+  return ns < vocab_tiles ? ns : vocab_tiles;
+}
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -578,7 +635,7 @@ struct BwdLayout {
 
 BwdLayout bwd_layout(int64_t hidden, int64_t vocab, int64_t chunk_rows) {
   BwdLayout L;
-  L.chunk_pad = ceil_div(chunk_rows, BM) * BM;
+  L.chunk_pad = ceil_div(chunk_rows, 128) * 128;
   size_t o = 0;
   L.hT = o;
   o += align256((size_t)hidden * L.chunk_pad * 2);
@@ -619,8 +676,15 @@ extern "C" int prl_lm_head_workspace_bytes(int64_t rows, int64_t cols, int64_t h
                                            size_t* fwd_bytes, size_t* bwd_bytes) {
   PRL_CHECK_ARG(rows >= 1 && cols >= 1 && hidden >= 1 && vocab >= 1, "bad sizes");
   const int64_t n = rows * cols;
-  const int mt = ceil_div(n, BM), nt = ceil_div(vocab, BN);
-  if (fwd_bytes) *fwd_bytes = align256((size_t)fwd_nsplit(mt, nt) * mt * BM * 16) + align256((size_t)mt * BM * 4);
+  // tokens padded to 256; the split count depends on the workgroup shape chosen at launch: size for the largest
+  const int64_t padded = (int64_t)ceil_div(n, 256) * 256;
+  int ns = 1;
+  for (int sh = 0; sh < 3; ++sh) {
+    const Shape shp = (Shape)sh;
+    const int k = fwd_nsplit(ceil_div(n, shape_bn(shp)), ceil_div(vocab, shape_bm(shp)), shp != kSmall);
+    ns = k > ns ? k : ns;
+  }
+  if (fwd_bytes) *fwd_bytes = align256((size_t)ns * padded * 16) + align256((size_t)padded * 4);
   if (bwd_bytes) {
     PRL_CHECK_ARG(chunk_rows >= 1, "chunk_rows must be >= 1");
     *bwd_bytes = bwd_layout(hidden, vocab, chunk_rows < n ? chunk_rows : n).total;
@@ -634,8 +698,8 @@ extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidde
                                        void* workspace, size_t workspace_bytes, prl_stream_t stream) {
   PRL_CHECK_ARG(rows >= 1 && cols >= 1, "rows and cols must be >= 1");
   PRL_CHECK_ARG(hidden >= BK && hidden % BK == 0, "hidden size %lld must be a multiple of %d", (long long)hidden, BK);
-  PRL_CHECK_ARG(vocab >= 1 && vocab < ((int64_t)1 << 31), "vocab out of range");
-  PRL_CHECK_ARG(rows * cols < ((int64_t)1 << 31) - BM, "too many rows");
+  PRL_CHECK_ARG(vocab >= 1 && vocab < ((int64_t)1 << 31) - 256, "vocab out of range");
+  PRL_CHECK_ARG(rows * cols < ((int64_t)1 << 31) - 256, "too many rows");
   PRL_CHECK_ARG(hidden_bf16 && w_hi && input_ids && new_logprobs && entropy && lse2 && workspace, "null pointer");
   PRL_CHECK_ARG(prl::aligned16(hidden_bf16) && prl::aligned16(w_hi) && (!w_lo || prl::aligned16(w_lo)), "operands must be 16-byte aligned");
   PRL_CHECK_ARG(temperature > 0.0f, "temperature must be > 0");
@@ -643,28 +707,27 @@ extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidde
   FwdArgs a;
   a.terms.n = w_lo ? 2 : 1;
   for (int k = 0; k < MAX_TERMS; ++k) {
-    a.terms.a[k] = hidden_bf16;
-    a.terms.b[k] = (k == 1 && w_lo) ? w_lo : w_hi;
+    a.terms.a[k] = (k == 1 && w_lo) ? w_lo : w_hi;
+    a.terms.b[k] = hidden_bf16;
   }
-  a.geo = Geom{(int)n, (int)vocab, (int)hidden, hidden, hidden};
+  a.geo = Geom{(int)vocab, (int)n, (int)hidden, hidden, hidden};
   a.cols = cols;
   a.ids = input_ids;
   a.k2 = kLog2e / temperature;
-  a.mt = ceil_div(n, BM);
-  a.nt = ceil_div(vocab, BN);
-  a.nsplit = fwd_nsplit(a.mt, a.nt);
-  const size_t part_bytes = align256((size_t)a.nsplit * a.mt * BM * 16);
-  const size_t need = part_bytes + align256((size_t)a.mt * BM * 4);
+  const Shape shape = pick_shape(vocab, n);
+  a.tt = ceil_div(n, shape_bn(shape));
+  a.vt = ceil_div(vocab, shape_bm(shape));
+  a.nsplit = fwd_nsplit(a.tt, a.vt, shape != kSmall);
+  a.padded = (int64_t)a.tt * shape_bn(shape);
+  const size_t part_bytes = align256((size_t)a.nsplit * a.padded * 16);
+  const size_t need = part_bytes + align256((size_t)a.padded * 4);
   if (workspace_bytes < need) return prl::set_error(PRL_ENOMEM, "lm_head forward workspace: %zu bytes given, %zu needed", workspace_bytes, need);
   a.part = static_cast<float*>(workspace);
   a.ysel = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_bytes);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int blocks = a.mt * a.nsplit;
-  int rc = g_use_glds() ? launch_tiles(lmhead_fwd_kernel<true>, blocks, a, s, "lmhead_fwd_kernel")
-                        : launch_tiles(lmhead_fwd_kernel<false>, blocks, a, s, "lmhead_fwd_kernel");
-  if (rc) return rc;
+  if (int rc = PRL_LAUNCH_CFG(shape, lmhead_fwd_kernel, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel")) return rc;
   hipLaunchKernelGGL(lmhead_fwd_finish_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, n, cols, (int)vocab, a.nsplit,
-                     (int64_t)a.mt * BM, a.part, a.ysel, input_ids, new_logprobs, entropy, lse2);
+                     a.padded, a.part, a.ysel, input_ids, new_logprobs, entropy, lse2);
   PRL_LAUNCH_CHECK("lmhead_fwd_finish_kernel");
   return PRL_OK;
 }
@@ -678,9 +741,9 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
                                        size_t workspace_bytes, prl_stream_t stream) {
   PRL_CHECK_ARG(rows >= 1 && cols >= 1, "rows and cols must be >= 1");
   PRL_CHECK_ARG(hidden >= BK && hidden % BK == 0, "hidden size %lld must be a multiple of %d", (long long)hidden, BK);
-  PRL_CHECK_ARG(vocab >= BK && vocab % BK == 0 && vocab < ((int64_t)1 << 31),
+  PRL_CHECK_ARG(vocab >= BK && vocab % BK == 0 && vocab < ((int64_t)1 << 31) - 256,
                 "the fused backward contracts over the vocabulary: vocab %lld must be a multiple of %d", (long long)vocab, BK);
-  PRL_CHECK_ARG(rows * cols < ((int64_t)1 << 31) - BM, "too many rows");
+  PRL_CHECK_ARG(rows * cols < ((int64_t)1 << 31) - 256, "too many rows");
   PRL_CHECK_ARG(hidden_bf16 && w_hi && wt_hi && input_ids && lse2 && entropy && grad_new_logprobs && workspace, "null pointer");
   PRL_CHECK_ARG((w_lo == nullptr) == (wt_lo == nullptr), "w_lo and wt_lo go together");
   PRL_CHECK_ARG(grad_hidden || grad_weight, "nothing to compute");
@@ -698,42 +761,38 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
   uint16_t* dlT_hi = reinterpret_cast<uint16_t*>(ws + L.dlT_hi);
   uint16_t* dlT_lo = reinterpret_cast<uint16_t*>(ws + L.dlT_lo);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool glds = g_use_glds() != 0;
-  const int nt = ceil_div(vocab, BN);
-  const int kt = ceil_div(hidden, BN);
 
   for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
     const int64_t m = (n - r0) < chunk_rows ? (n - r0) : chunk_rows;
-    const int mt = ceil_div(m, BM);
     // ---- 1. d logits planes of this chunk (recompute the logits tile by tile)
-    DlArgs d;
-    d.terms.n = w_lo ? 2 : 1;
-    for (int k = 0; k < MAX_TERMS; ++k) {
-      d.terms.a[k] = hidden_bf16 + r0 * hidden;
-      d.terms.b[k] = (k == 1 && w_lo) ? w_lo : w_hi;
+    {
+      DlArgs d;
+      d.terms.n = w_lo ? 2 : 1;
+      for (int k = 0; k < MAX_TERMS; ++k) {
+        d.terms.a[k] = (k == 1 && w_lo) ? w_lo : w_hi;
+        d.terms.b[k] = hidden_bf16 + r0 * hidden;
+      }
+      d.geo = Geom{(int)vocab, (int)m, (int)hidden, hidden, hidden};
+      d.row_base = r0;
+      d.cols = cols;
+      d.ids = input_ids;
+      d.lse2 = lse2;
+      d.ent = entropy;
+      d.g_nlp = grad_new_logprobs;
+      d.g_ent = grad_entropy;
+      d.upstream = upstream;
+      d.k2 = kLog2e / temperature;
+      d.inv_temp = 1.0f / temperature;
+      d.chunk_pad = L.chunk_pad;
+      d.dl_hi = dl_hi;
+      d.dl_lo = dl_lo;
+      d.dlT_hi = dlT_hi;
+      d.dlT_lo = dlT_lo;
+      const Shape shape = pick_shape(vocab, L.chunk_pad);
+      d.vt = ceil_div(vocab, shape_bm(shape));
+      d.tt = ceil_div(L.chunk_pad, shape_bn(shape));  // token tiles of the chunk buffers (pad rows are written as zeros)
+      if (int rc = PRL_LAUNCH_CFG(shape, lmhead_dlogits_kernel, d.vt * d.tt, d, s, "lmhead_dlogits_kernel")) return rc;
     }
-    d.geo = Geom{(int)m, (int)vocab, (int)hidden, hidden, hidden};
-    d.row_base = r0;
-    d.n_total = n;
-    d.cols = cols;
-    d.ids = input_ids;
-    d.lse2 = lse2;
-    d.ent = entropy;
-    d.g_nlp = grad_new_logprobs;
-    d.g_ent = grad_entropy;
-    d.upstream = upstream;
-    d.k2 = kLog2e / temperature;
-    d.inv_temp = 1.0f / temperature;
-    d.mt = L.chunk_pad / BM;  // pad rows of the chunk buffers are written too (zeros)
-    d.nt = nt;
-    d.chunk_pad = L.chunk_pad;
-    d.dl_hi = dl_hi;
-    d.dl_lo = dl_lo;
-    d.dlT_hi = dlT_hi;
-    d.dlT_lo = dlT_lo;
-    int rc = glds ? launch_tiles(lmhead_dlogits_kernel<true>, d.mt * d.nt, d, s, "lmhead_dlogits_kernel")
-                  : launch_tiles(lmhead_dlogits_kernel<false>, d.mt * d.nt, d, s, "lmhead_dlogits_kernel");
-    if (rc) return rc;
     // ---- 2. d hidden[chunk] = dl W  (contraction over the vocabulary; hi x hi + lo x hi + hi x lo)
     if (grad_hidden) {
       GemmArgs g;
@@ -745,15 +804,14 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       g.terms.a[2] = dl_hi;
       g.terms.b[2] = wt_lo ? wt_lo : wt_hi;
       g.geo = Geom{(int)m, (int)hidden, (int)vocab, vocab, vocab};
-      g.mt = mt;
-      g.nt = kt;
+      const Shape shape = pick_shape(m, hidden);
+      g.mt = ceil_div(m, shape_bm(shape));
+      g.nt = ceil_div(hidden, shape_bn(shape));
       g.ldc = hidden;
       g.out_bf16 = grad_hidden_dtype == PRL_DTYPE_BF16;
       g.accumulate = 0;
       g.out = static_cast<char*>(grad_hidden) + (size_t)r0 * hidden * (g.out_bf16 ? 2 : 4);
-      rc = glds ? launch_tiles(gemm_nt_kernel<true>, g.mt * g.nt, g, s, "gemm_nt_kernel(d hidden)")
-                : launch_tiles(gemm_nt_kernel<false>, g.mt * g.nt, g, s, "gemm_nt_kernel(d hidden)");
-      if (rc) return rc;
+      if (int rc = PRL_LAUNCH_CFG(shape, gemm_nt_kernel, g.mt * g.nt, g, s, "gemm_nt_kernel(d hidden)")) return rc;
     }
     // ---- 3. d W += dl^T h  (contraction over the chunk's rows; hidden is exact in bf16)
     if (grad_weight) {
@@ -768,15 +826,14 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       g.terms.a[2] = dlT_lo;
       g.terms.b[0] = g.terms.b[1] = g.terms.b[2] = hT;
       g.geo = Geom{(int)vocab, (int)hidden, L.chunk_pad, L.chunk_pad, L.chunk_pad};
-      g.mt = nt;
-      g.nt = kt;
+      const Shape shape = pick_shape(vocab, hidden);
+      g.mt = ceil_div(vocab, shape_bm(shape));
+      g.nt = ceil_div(hidden, shape_bn(shape));
       g.ldc = hidden;
       g.out_bf16 = 0;
       g.accumulate = 1;
       g.out = grad_weight;
-      rc = glds ? launch_tiles(gemm_nt_kernel<true>, g.mt * g.nt, g, s, "gemm_nt_kernel(d weight)")
-                : launch_tiles(gemm_nt_kernel<false>, g.mt * g.nt, g, s, "gemm_nt_kernel(d weight)");
-      if (rc) return rc;
+      if (int rc = PRL_LAUNCH_CFG(shape, gemm_nt_kernel, g.mt * g.nt, g, s, "gemm_nt_kernel(d weight)")) return rc;
     }
   }
   return PRL_OK;

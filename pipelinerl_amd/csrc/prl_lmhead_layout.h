@@ -1,6 +1,10 @@
 // Index arithmetic of the MFMA GEMM core in prl_lmhead.hip, kept in one header so that the device
 // kernels and the host-compiled unit-test harness (tests/harness/lmhead_layout_host.cpp) use the SAME
 // functions: tile raster, LDS image of a staged operand tile, fragment reads, accumulator layout.
+//
+// Tile: BM x BN x 64 (rows x columns x contraction, bf16).  The waves of a workgroup form a
+// (waves / 2) x 2 grid; a wave computes 64 rows x (BN / 2) columns as 2 x (BN / 64) MFMA tiles of
+// 32 x 32 (v_mfma_f32_32x32x16_bf16, the full-rate bf16 shape: 32 cycles per 32 768 flop).
 #pragma once
 
 #include <stdint.h>
@@ -14,14 +18,13 @@
 namespace prl {
 namespace lmhead {
 
-constexpr int BM = 128, BN = 128, BK = 64;  // tile: rows x columns x contraction (bf16 elements)
-constexpr int NTHREADS = 256;               // 4 waves as 2 (rows) x 2 (columns), 64 x 64 each
-constexpr int TILE_BYTES = BM * BK * 2;     // one operand tile in LDS: 128 rows x 128 bytes
+constexpr int BK = 64;
+constexpr int ROW_BYTES = BK * 2;  // one tile row in LDS: 128 bytes = 8 chunks of 16
 
 // Block id -> tile coordinates.  The hardware deals consecutive block ids round-robin over the 8
 // XCDs (each with its own L2): give every XCD a contiguous range of the tile list, and walk that
-// list in groups of 8 row tiles x all column tiles, row-fastest, so that the ~64 workgroups an XCD
-// runs at a time cover ~8 x 8 tiles and share each A / B panel 8 ways in its L2.
+// list in groups of 8 row tiles x all column tiles, row-fastest, so that the workgroups an XCD runs
+// at a time cover a compact patch of tiles and share each A / B panel in its L2.
 PRL_LHD void tile_coords(int bid, int mt, int nt, int& tm, int& tn) {
   const int total = mt * nt;
   const int q = total >> 3, r = total & 7;
@@ -37,29 +40,31 @@ PRL_LHD void tile_coords(int bid, int mt, int nt, int& tm, int& tn) {
   tn = in / gsz;
 }
 
-// ---- staging.  An operand tile is 1024 chunks of 16 bytes; thread `tid` moves chunks q * 256 + tid,
-// q = 0..3.  global_load_lds writes lane-linearly (wave base + lane * 16), so chunk c sits at LDS byte
-// c * 16 = row (c >> 3), slot (c & 7); the XOR swizzle is applied to the SOURCE: the slot holds the
-// logical k-chunk  slot ^ ((row >> 1) & 7).
-PRL_LHD int stage_row(int tid, int q) { return q * 32 + (tid >> 3); }
-// ((q * 32 + (tid >> 3)) >> 1) & 7 == (tid >> 4) & 7 for every q: one source column per thread
+// ---- staging.  An operand tile of R rows is R * 8 chunks of 16 bytes; thread `tid` of an NT-thread
+// workgroup moves chunks q * NT + tid.  global_load_lds writes lane-linearly (wave base + lane * 16), so
+// chunk c sits at LDS byte c * 16 = row (c >> 3), slot (c & 7); the XOR swizzle is applied to the SOURCE:
+// the slot holds the logical k-chunk  slot ^ ((row >> 1) & 7).
+PRL_LHD int stage_row(int tid, int q, int nt) { return q * (nt >> 3) + (tid >> 3); }
+// ((q * NT / 8 + (tid >> 3)) >> 1) & 7 == (tid >> 4) & 7 for NT in {256, 512}: one source column per thread
 PRL_LHD int stage_kcol(int tid) { return ((tid & 7) ^ ((tid >> 4) & 7)) * 8; }  // elements
-PRL_LHD int stage_lds_byte(int tid, int q) { return (q * 256 + tid) * 16; }
+PRL_LHD int stage_lds_byte(int tid, int q, int nt) { return (q * nt + tid) * 16; }
 
-// ---- fragment reads for mfma_f32_16x16x32_bf16: lane l supplies row (l & 15) and the 8 contraction
-// elements 8 * (l >> 4) .. + 7 of a 32-deep sub-step `ks` (0, 1) of the 64-deep tile.
+// ---- fragment reads for mfma_f32_32x32x16_bf16: lane l supplies row (l & 31) and the 8 contraction
+// elements 8 * (l >> 5) .. + 7 of a 16-deep sub-step `ks` (0..3) of the 64-deep tile.
 // Row r, logical chunk kc is at byte r * 128 + ((kc ^ ((r >> 1) & 7)) << 4); within a 16-lane group
 // (16 consecutive rows, one kc) these are 16 distinct 16-byte slots of the 256-byte bank row.
-PRL_LHD int frag_row(int lane, int w, int i) { return w * 64 + i * 16 + (lane & 15); }  // w: wave row / column
-PRL_LHD int frag_kchunk(int lane, int ks) { return ks * 4 + (lane >> 4); }
-PRL_LHD int frag_lds_byte(int lane, int w, int i, int ks) {
-  const int r = frag_row(lane, w, i);
-  return r * 128 + ((frag_kchunk(lane, ks) ^ ((r >> 1) & 7)) << 4);
+PRL_LHD int frag_row(int lane, int wave_row0, int i) { return wave_row0 + i * 32 + (lane & 31); }  // wave_row0: first tile row of the wave
+PRL_LHD int frag_kchunk(int lane, int ks) { return ks * 2 + (lane >> 5); }
+PRL_LHD int frag_lds_byte(int lane, int wave_row0, int i, int ks) {
+  const int r = frag_row(lane, wave_row0, i);
+  return r * ROW_BYTES + ((frag_kchunk(lane, ks) ^ ((r >> 1) & 7)) << 4);
 }
 
-// ---- accumulators: element `reg` of the 16 x 16 tile (i, j) of wave (wm, wn)
-PRL_LHD int acc_row(int lane, int wm, int i, int reg) { return wm * 64 + i * 16 + 4 * (lane >> 4) + reg; }
-PRL_LHD int acc_col(int lane, int wn, int j) { return wn * 64 + j * 16 + (lane & 15); }
+// ---- accumulators: element `reg` (0..15) of the 32 x 32 tile (i, j) of the wave whose sub-tile starts
+// at (wave_row0, wave_col0) = (64 * (wave >> 1), (BN / 2) * (wave & 1))
+PRL_LHD int acc_row_in_tile(int lane, int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+PRL_LHD int acc_row(int lane, int wave_row0, int i, int reg) { return wave_row0 + i * 32 + acc_row_in_tile(lane, reg); }
+PRL_LHD int acc_col(int lane, int wave_col0, int j) { return wave_col0 + j * 32 + (lane & 31); }
 
 }  // namespace lmhead
 }  // namespace prl

@@ -1,0 +1,36 @@
+#!/bin/bash
+# PMC passes over the fused-head forward kernel (separate runs, kernel-trace only)
+set -u
+OUT=gpurun_out/r02c
+mkdir -p $OUT
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ_[A-Z_0-9]+|TCC_[A-Z_0-9]+|TCP_[A-Z_0-9]+|GRBM_[A-Z_]+|FETCH_SIZE|WRITE_SIZE|MfmaUtil|VALUBusy|LDSBankConflict)\b" | sort -u > $OUT/counters_available.txt
+wc -l $OUT/counters_available.txt
+grep -E "MFMA|LDS_BANK|WAIT_INST|WAIT_ANY|ACTIVE_INST_ANY|WAVE_CYCLES|BUSY_CYCLES|TCC_HIT|TCC_MISS|TCC_REQ|TCP_TCC|GUI_ACTIVE|LDS_IDX|LDS_DATA|INSTS_VALU\b|TCC_EA0_RDREQ\b|TCP_PENDING|TCP_TA_TCP_STATE_READ|TCC_TAG_STALL|TCC_BUSY" $OUT/counters_available.txt | tr '\n' ' '
+echo
+run() { # name counters...
+  local name=$1; shift
+  (cd /tmp && timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/$OUT/pmc_$name -o pmc -- python $R/scripts/lmhead_fwd_only.py 2 > $R/$OUT/pmc_$name.log 2>&1; echo "pmc $name exit $?")
+  f=$(find $OUT/pmc_$name -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python - "$f" <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    k = r.get("Kernel_Name", "")
+    if "lmhead_fwd_kernel" in k:
+        agg["lmhead_fwd_kernel"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in agg.items():
+    print(k, {c: sum(v) / len(v) for c, v in d.items()}, "dispatches", {c: len(v) for c, v in d.items()})
+PY
+}
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS
+run sq2 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES GRBM_GUI_ACTIVE
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE
+run fetch FETCH_SIZE
+run tcp TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum
+echo "== plain timing, tile 256 vs 128"
+python scripts/lmhead_fwd_only.py 5; PRL_LMHEAD_TILE=128 python scripts/lmhead_fwd_only.py 5
+find $OUT -name "*kernel_trace.csv" -size +1M -delete; find $OUT -name "*.db" -delete
+echo "== done"

@@ -79,31 +79,31 @@ head.refresh()
 torch.cuda.synchronize()
 prep_ms, _ = timeit(lambda: (head.invalidate(), head.__setattr__("_key", None), head.refresh()), iters=2)
 emit(what="prepare (split + transpose, once per optimizer step)", ms=round(prep_ms, 3))
-for staging in ("1", "0"):
-    os.environ["PRL_LMHEAD_STAGING"] = staging
-    for ns in (None, "4", "16"):
+for tile in ("256x256", "256", "128"):
+    os.environ["PRL_LMHEAD_TILE"] = tile
+    for ns in (None, "8", "16"):
         if ns is None:
             os.environ.pop("PRL_LMHEAD_NSPLIT", None)
         else:
             os.environ["PRL_LMHEAD_NSPLIT"] = ns
         med, best = timeit(lambda: head.logprob_entropy(hidden, ids, 1.0))
-        emit(what="fused forward", staging="lds_dma" if staging == "1" else "registers", nsplit=ns or "default", ms=round(med, 3),
+        emit(what="fused forward", tile=tile, nsplit=ns or "default", ms=round(med, 3),
              best_ms=round(best, 3), mfma_tflops=round(planes * gemm / med / 1e9, 1), fp32_equiv_tflops=round(gemm / med / 1e9, 1))
 os.environ.pop("PRL_LMHEAD_NSPLIT", None)
-os.environ["PRL_LMHEAD_STAGING"] = "1"
+os.environ.pop("PRL_LMHEAD_TILE", None)
 
 if not args.skip_bwd:
     nlp, ent, lse2, h = head.logprob_entropy(hidden, ids, 1.0)
     _, _, g_nlp, _ = grpo_loss_from_logprobs(cfg, batch, nlp, ent)
     gw = torch.zeros(V, H, device=dev)
-    for staging in ("1", "0"):
-        os.environ["PRL_LMHEAD_STAGING"] = staging
+    for tile in ("256x256", "256", "default"):
+        os.environ["PRL_LMHEAD_TILE"] = tile
         med, best = timeit(lambda: head.backward_from_token_grads(h, ids, 1.0, lse2, ent, g_nlp, None, None, grad_weight=gw), iters=max(2, args.iters // 2))
         # recompute (planes) + d hidden (planes + 1 products) + d W (2 products)
         terms = planes + (planes + 1) + 2
-        emit(what="fused backward (d hidden + d W)", staging="lds_dma" if staging == "1" else "registers", chunk_rows=args.chunk_rows,
+        emit(what="fused backward (d hidden + d W)", tile=tile, chunk_rows=args.chunk_rows,
              ms=round(med, 3), best_ms=round(best, 3), mfma_tflops=round(terms * gemm / med / 1e9, 1), fp32_equiv_tflops=round(3 * gemm / med / 1e9, 1))
-    os.environ["PRL_LMHEAD_STAGING"] = "1"
+    os.environ.pop("PRL_LMHEAD_TILE", None)
     med, _ = timeit(lambda: head.backward_from_token_grads(h, ids, 1.0, lse2, ent, g_nlp, None, None, want_hidden=True, grad_weight=None), iters=2)
     emit(what="fused backward, d hidden only", ms=round(med, 3))
     del gw

@@ -7,7 +7,7 @@ written, so parity is established against the oracle FED WITH the fp64 product h
 
 at the BASELINE head shapes (H = 3584, V = 152 064: Qwen2.5-7B, fp32 weight split into two bf16
 planes; H = 896, V = 151 936: Qwen2.5-0.5B with its tied bf16 weight), plus small ragged shapes for
-the tile edges, both staging paths (LDS DMA and register staging) and chunked backward.
+the tile edges, all three workgroup shapes (256 x 256, 256 x 128 with the 3-stage ring, 128 x 128) and chunked backward.
 Tolerance: 1e-4 relative (north_star), on loss, d hidden and d W."""
 
 import ctypes
@@ -88,11 +88,12 @@ def _compare(loss, stats, gh, gw, want, scale=1.0):
     assert rel_err(gh[0].float().cpu().numpy(), want["d_hidden"] * scale) <= tol_h
 
 
-@pytest.mark.parametrize("staging", ["1", "0"], ids=["lds_dma", "register_staging"])
-@pytest.mark.parametrize("T,H,V", [(130, 64, 192), (257, 128, 320), (64, 192, 4160)])
-def test_small_ragged_shapes(libprl, cuda_device, monkeypatch, staging, T, H, V):
-    """Tile edges everywhere: rows not a multiple of 128, a half-masked last vocabulary tile, one K step."""
-    monkeypatch.setenv("PRL_LMHEAD_STAGING", staging)
+@pytest.mark.parametrize("tile", ["256x256", "256", "128"], ids=["tile256x256", "tile256x128_ring3", "tile128x128"])
+@pytest.mark.parametrize("T,H,V", [(130, 64, 192), (257, 128, 320), (64, 192, 4160), (300, 64, 1088)])
+def test_small_ragged_shapes(libprl, cuda_device, monkeypatch, tile, T, H, V):
+    """Tile edges everywhere: rows not a multiple of 128, a partly masked last vocabulary tile, one K step
+    (fewer tiles than pipeline stages), both workgroup shapes."""
+    monkeypatch.setenv("PRL_LMHEAD_TILE", tile)
     hidden, W, batch, logits64 = _problem(T, H, V, cuda_device, seed=T)
     want = _oracle(hidden, W, batch, logits64)
     loss, stats, gh, gw, _ = _run(hidden, W, batch)
@@ -115,18 +116,22 @@ def test_forward_values_and_split_count_independence(libprl, cuda_device, monkey
     w_nlp = lp[torch.arange(T - 1), ids[0, 1:]]
     w_ent = -(lp.exp() * lp).sum(-1)
     head = FusedLmHead(W, backward=False)
-    for ns in ("1", "2", "7", "64"):
+    for tile, ns in (("256x256", "1"), ("256x256", "3"), ("256x256", "64"), ("256", "1"), ("256", "2"), ("256", "7"), ("256", "64"), ("128", "1"), ("128", "5"), ("128", "64")):
         monkeypatch.setenv("PRL_LMHEAD_NSPLIT", ns)
+        monkeypatch.setenv("PRL_LMHEAD_TILE", tile)
         nlp, ent, lse2, _ = head.logprob_entropy(hidden, ids, 0.9)
         assert nlp[0, 0].item() == 0 and ent[0, 0].item() == 0
         assert torch.allclose(nlp[0, 1:].double(), w_nlp, rtol=FP_TOL, atol=2e-5), ns
         assert torch.allclose(ent[0, 1:].double(), w_ent[:-1], rtol=FP_TOL, atol=2e-5), ns
 
 
-@pytest.mark.parametrize("staging", ["1", "0"], ids=["lds_dma", "register_staging"])
-def test_qwen7b_head_shape_vs_oracle(libprl, cuda_device, monkeypatch, staging):
+@pytest.mark.parametrize("tile", ["256x256", "256", "128", None], ids=["tile256x256", "tile256x128_ring3", "tile128x128", "default_dispatch"])
+def test_qwen7b_head_shape_vs_oracle(libprl, cuda_device, monkeypatch, tile):
     """H = 3584, V = 152 064, fp32 weight (two bf16 planes): loss, statistics, d hidden, d W."""
-    monkeypatch.setenv("PRL_LMHEAD_STAGING", staging)
+    if tile is None:
+        monkeypatch.delenv("PRL_LMHEAD_TILE", raising=False)
+    else:
+        monkeypatch.setenv("PRL_LMHEAD_TILE", tile)
     hidden, W, batch, logits64 = _problem(160, 3584, 152064, cuda_device, seed=3)
     want = _oracle(hidden, W, batch, logits64)
     loss, stats, gh, gw, head = _run(hidden, W, batch)
@@ -154,9 +159,14 @@ def test_qwen0p5b_tied_bf16_head_vs_oracle(libprl, cuda_device):
     assert rel_err(gw.float().cpu().numpy(), want["d_weight"]) <= 4e-3  # delivered in the weight's dtype (bf16)
 
 
-def test_chunked_backward_and_upstream_scale(libprl, cuda_device):
+@pytest.mark.parametrize("tile", ["256x256", None], ids=["tile256x256", "default_dispatch"])
+def test_chunked_backward_and_upstream_scale(libprl, cuda_device, monkeypatch, tile):
     """Row chunks that do not divide the batch (and are not multiples of 128) give the same gradients;
     an upstream factor on the loss scales both."""
+    if tile:
+        monkeypatch.setenv("PRL_LMHEAD_TILE", tile)
+    else:
+        monkeypatch.delenv("PRL_LMHEAD_TILE", raising=False)
     hidden, W, batch, logits64 = _problem(300, 128, 1024, cuda_device, seed=21)
     want = _oracle(hidden, W, batch, logits64)
     for chunk, scale in ((None, 1.0), (128, 1.0), (100, 0.25), (299, 3.0)):
