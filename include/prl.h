@@ -464,6 +464,9 @@ int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidden, int64_t 
                             float* lse2, void* workspace, size_t workspace_bytes,
                             prl_stream_t stream);
 
+#define PRL_LM_HEAD_DH_LEADING_TERM 1 /* flags: d hidden from the leading bf16 product only (d logits_hi x W_hi):
+                                         2^-9 relative error, the size of a bf16 rounding - meant for bf16 grad_hidden */
+
 /*
  * Backward of the above for token-aligned upstream gradients grad_new_logprobs /
  * grad_entropy (nullable) and a device scalar `upstream` (nullable => 1), exactly the
@@ -483,8 +486,8 @@ int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidden, int64_t 
                             const float* grad_new_logprobs, const float* grad_entropy,
                             const float* upstream, void* grad_hidden,
                             int32_t grad_hidden_dtype, float* grad_weight,
-                            int64_t chunk_rows, void* workspace, size_t workspace_bytes,
-                            prl_stream_t stream);
+                            int64_t chunk_rows, int32_t flags, void* workspace,
+                            size_t workspace_bytes, prl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,7 @@ PRL_FINISH_STOP = 2
 PRL_NUM_STATS = 32
 PRL_WSYNC_UID_BYTES = 128
 PRL_IPC_HANDLE_BYTES = 64
+PRL_LM_HEAD_DH_LEADING_TERM = 1
 
 # index of every public statistic in the device stats vector (enum in include/prl.h)
 STAT_INDEX = {
@@ -156,7 +157,7 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_lm_head_workspace_bytes": (c_int32, [c_int64, c_int64, c_int64, c_int64, c_int64, POINTER(c_size_t), POINTER(c_size_t)]),
     "prl_lm_head_logprob_fwd": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
     "prl_lm_head_logprob_bwd": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P,
-                                          c_int32, _P, c_int64, _P, c_size_t, _P]),
+                                          c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
 }
 
 _lib: ctypes.CDLL | None = None

@@ -119,7 +119,16 @@ __device__ __forceinline__ void wait_tile_then_barrier() {
 // -----------------------------------------------------------------------------------------------
 // main loop: acc[i][j] (32 x 32 tiles of this wave's 64 x 64) += sum over terms and K
 // -----------------------------------------------------------------------------------------------
-template <class C>
+// EXP (experiment bits; 0 = the shipped schedule; only 16 / 32 / 48 are instantiated, for the 256 x 256 forward,
+// selected with PRL_LMHEAD_EXP - the timing ablations behind profiles/r02h_lmhead_fwd_ablation.txt):
+//   1  all LDS-DMA pieces right after the first MFMA group instead of spread over three   } measured: +-1 %
+//   2  s_setprio(1) around every MFMA group                                                } -5 %
+//   4  LDS-DMA loads with the sc0 cache-policy bit                                         } 0
+//   8  pieces spread over the first two MFMA groups                                        } (profiles/r02f_*)
+//  16  ablation: no LDS-DMA loads at all (wrong results; MFMA + LDS-read + barrier time only)
+//  32  ablation: no MFMAs (wrong results; staging + LDS-read + barrier time only)
+//  64  ablation: no fragment reads from LDS inside the loop (wrong results)
+template <class C, int EXP = 0>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Terms& t, const Geom& g, int m0, int n0,
                                               char* lds) {
   const int tid = threadIdx.x;
@@ -171,13 +180,15 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
   // tile the staging cursor points at, into stage buffer `buf`.
   auto stage_piece = [&](int buf, int idx) {
     const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
+    constexpr int AUX = (EXP & 4) ? 1 : 0;
+    if constexpr ((EXP & 16) != 0) return;
     if (idx < C::QA) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sA + offA[idx] + st_k),
-                                       (__attribute__((address_space(3))) void*)(lds + dst + idx * C::NT * 16), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lds + dst + idx * C::NT * 16), 16, 0, AUX);
     } else {
       const int q = idx - C::QA;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sB + offB[q] + st_k),
-                                       (__attribute__((address_space(3))) void*)(lds + dst + C::A_BYTES + q * C::NT * 16), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lds + dst + C::A_BYTES + q * C::NT * 16), 16, 0, AUX);
     }
   };
   auto stage = [&](int buf) {
@@ -190,7 +201,8 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
   // every SIMD at once (measured on the same build: 17.7 ms interleaved vs 19.8 ms burst for the 7B forward).
   auto compute = [&](int buf, int sbuf) {
     const char* base = lds + buf * C::STAGE_BYTES;
-    constexpr int PER = (C::LOADS + 2) / 3;  // pieces after each of the first three MFMA groups
+    constexpr int GROUPS = (EXP & 1) ? 1 : (EXP & 8) ? 2 : 3;
+    constexpr int PER = (C::LOADS + GROUPS - 1) / GROUPS;  // pieces after each of the first GROUPS MFMA groups
     bf16x8 af[2][2], bfr[2][C::NJ];  // [ping-pong][tile]: the reads of sub-step ks + 1 are issued before the MFMAs of ks
 #pragma unroll
     for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(base + rdA[0] + i * 32 * ROW_BYTES);
@@ -200,16 +212,32 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
     for (int ks = 0; ks < 4; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
       if (ks < 3) {
+        if constexpr ((EXP & 64) != 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[nxt][i] = *reinterpret_cast<const bf16x8*>(base + rdA[ks + 1] + i * 32 * ROW_BYTES);
+          for (int i = 0; i < 2; ++i) af[nxt][i] = af[cur][i];
 #pragma unroll
-        for (int j = 0; j < C::NJ; ++j) bfr[nxt][j] = *reinterpret_cast<const bf16x8*>(base + rdB[ks + 1] + j * 32 * ROW_BYTES);
+          for (int j = 0; j < C::NJ; ++j) bfr[nxt][j] = bfr[cur][j];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) af[nxt][i] = *reinterpret_cast<const bf16x8*>(base + rdA[ks + 1] + i * 32 * ROW_BYTES);
+#pragma unroll
+          for (int j = 0; j < C::NJ; ++j) bfr[nxt][j] = *reinterpret_cast<const bf16x8*>(base + rdB[ks + 1] + j * 32 * ROW_BYTES);
+        }
       }
+      if constexpr ((EXP & 2) != 0) __builtin_amdgcn_s_setprio(1);
+      if constexpr ((EXP & 32) != 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(af[cur][i]));
 #pragma unroll
-        for (int j = 0; j < C::NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
-      if (sbuf >= 0 && ks < 3) {
+        for (int j = 0; j < C::NJ; ++j) asm volatile("" ::"v"(bfr[cur][j]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < C::NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+      }
+      if constexpr ((EXP & 2) != 0) __builtin_amdgcn_s_setprio(0);
+      if (sbuf >= 0 && ks < GROUPS) {
 #pragma unroll
         for (int k = 0; k < PER; ++k)
           if (ks * PER + k < C::LOADS) stage_piece(sbuf, ks * PER + k);
@@ -274,7 +302,7 @@ struct FwdArgs {
   float* ysel;          // [padded] selected logit (base-2 units), written by whichever split owns the row
 };
 
-template <class C>
+template <class C, int EXP = 0>
 __global__ __launch_bounds__(C::NT, 2) void lmhead_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int tok_tile, split;
@@ -304,7 +332,7 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_fwd_kernel(FwdArgs a) {
   for (int tv = vt0; tv < vt1; ++tv) {
     const int m0 = tv * C::BM;
     zero_acc<NJ>(acc);
-    gemm_mainloop<C>(acc, a.terms, a.geo, m0, n0, lds);
+    gemm_mainloop<C, EXP>(acc, a.terms, a.geo, m0, n0, lds);
     const int vbase = m0 + acc_row(lane, wrow0, 0, 0);  // vocabulary row of acc[0][j][0]; + 32 i + (reg & 3) + 8 (reg >> 2)
     const bool full = m0 + C::BM <= V;
 #pragma unroll
@@ -725,7 +753,25 @@ extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidde
   a.part = static_cast<float*>(workspace);
   a.ysel = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_bytes);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (int rc = PRL_LAUNCH_CFG(shape, lmhead_fwd_kernel, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel")) return rc;
+  int exp_bits = 0;
+  if (const char* e = getenv("PRL_LMHEAD_EXP")) exp_bits = atoi(e);
+  if (shape == kWide && exp_bits) {  // schedule experiments, 256 x 256 forward only
+    int rc = PRL_EINVAL;
+#define PRL_EXP_CASE(E)                                                                                                  \
+  case E:                                                                                                                \
+    rc = launch_tiles(lmhead_fwd_kernel<CfgWide, E>, CfgWide::NT, CfgWide::LDS_BYTES, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel"); \
+    break;
+    switch (exp_bits) {
+      PRL_EXP_CASE(16)
+      PRL_EXP_CASE(32)
+      PRL_EXP_CASE(48)
+      default: return prl::set_error(PRL_EINVAL, "PRL_LMHEAD_EXP=%d is not built", exp_bits);
+    }
+#undef PRL_EXP_CASE
+    if (rc) return rc;
+  } else if (int rc = PRL_LAUNCH_CFG(shape, lmhead_fwd_kernel, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel")) {
+    return rc;
+  }
   hipLaunchKernelGGL(lmhead_fwd_finish_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, n, cols, (int)vocab, a.nsplit,
                      a.padded, a.part, a.ysel, input_ids, new_logprobs, entropy, lse2);
   PRL_LAUNCH_CHECK("lmhead_fwd_finish_kernel");
@@ -737,8 +783,8 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
                                        const uint16_t* wt_lo, const int64_t* input_ids, float temperature,
                                        const float* lse2, const float* entropy, const float* grad_new_logprobs,
                                        const float* grad_entropy, const float* upstream, void* grad_hidden,
-                                       int32_t grad_hidden_dtype, float* grad_weight, int64_t chunk_rows, void* workspace,
-                                       size_t workspace_bytes, prl_stream_t stream) {
+                                       int32_t grad_hidden_dtype, float* grad_weight, int64_t chunk_rows, int32_t flags,
+                                       void* workspace, size_t workspace_bytes, prl_stream_t stream) {
   PRL_CHECK_ARG(rows >= 1 && cols >= 1, "rows and cols must be >= 1");
   PRL_CHECK_ARG(hidden >= BK && hidden % BK == 0, "hidden size %lld must be a multiple of %d", (long long)hidden, BK);
   PRL_CHECK_ARG(vocab >= BK && vocab % BK == 0 && vocab < ((int64_t)1 << 31) - 256,
@@ -796,7 +842,9 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
     // ---- 2. d hidden[chunk] = dl W  (contraction over the vocabulary; hi x hi + lo x hi + hi x lo)
     if (grad_hidden) {
       GemmArgs g;
-      g.terms.n = w_lo ? 3 : 2;
+      // PRL_LM_HEAD_DH_LEADING_TERM: only d logits_hi x W_hi.  The two dropped products are 2^-9 relative
+      // corrections - the size of the rounding d hidden receives anyway when it is delivered in bf16.
+      g.terms.n = (flags & PRL_LM_HEAD_DH_LEADING_TERM) ? 1 : (w_lo ? 3 : 2);
       g.terms.a[0] = dl_hi;
       g.terms.b[0] = wt_hi;
       g.terms.a[1] = dl_lo;

@@ -39,7 +39,10 @@ class FusedLmHead:
     Refreshed when the weight changes (version counter / storage address); writers that go through
     `.data.copy_()` must call `invalidate()` - same contract as lm_head.SplitBf16LmHead."""
 
-    def __init__(self, weight: torch.Tensor, backward: bool = True, chunk_rows: int = 2048):
+    def __init__(self, weight: torch.Tensor, backward: bool = True, chunk_rows: int = 4096, hidden_grad_terms: int = 3):
+        """`chunk_rows`: logits rows whose d logits planes live in the workspace at a time (4 x chunk x V x 2 bytes).
+        `hidden_grad_terms`: 3 = d hidden from every bf16 product (fp32-GEMM accuracy before the final rounding),
+        1 = leading product only (2^-9 relative, the size of the bf16 rounding of d hidden; two GEMM passes less)."""
         if weight.dim() != 2:
             raise ValueError("lm_head weight must be [vocab, hidden]")
         if weight.dtype not in (torch.float32, torch.bfloat16):
@@ -47,6 +50,7 @@ class FusedLmHead:
         self.weight = weight
         self.backward = backward
         self.chunk_rows = int(chunk_rows)
+        self.hidden_grad_terms = int(hidden_grad_terms)
         self._key = None
         self.w_hi = self.w_lo = self.wt_hi = self.wt_lo = None
         self._ws: dict[Any, torch.Tensor] = {}
@@ -152,7 +156,8 @@ class FusedLmHead:
             _lib.check(lib.prl_lm_head_logprob_bwd(
                 B, L, H, self.vocab, h.data_ptr(), self.w_hi.data_ptr(), _lib.ptr(self.w_lo), self.wt_hi.data_ptr(), _lib.ptr(self.wt_lo),
                 ids.data_ptr(), float(temperature), lse2.data_ptr(), ent.data_ptr(), g_nlp.data_ptr(), _lib.ptr(g_ent), _lib.ptr(upstream),
-                _lib.ptr(gh), 0 if grad_hidden_dtype == torch.float32 else 1, _lib.ptr(grad_weight), chunk, ws.data_ptr(), ws.numel(),
+                _lib.ptr(gh), 0 if grad_hidden_dtype == torch.float32 else 1, _lib.ptr(grad_weight), chunk,
+                _lib.PRL_LM_HEAD_DH_LEADING_TERM if self.hidden_grad_terms == 1 else 0, ws.data_ptr(), ws.numel(),
                 _lib.current_stream_ptr(dev)))
         return gh
 
@@ -210,7 +215,7 @@ _heads: dict[int, FusedLmHead] = {}
 
 
 def rl_step_fused_head(model: Any, batch: PipelineBatchEncoding, current_step: int, max_step: int, config: RLConfig,
-                       seq_parallel_group=None, chunk_rows: int = 2048):
+                       seq_parallel_group=None, chunk_rows: int = 4096):
     """`rl_step` (reference rl/__init__.py:136-143, same signature and return value) for a causal LM
     that exposes its body and head separately, as Hugging Face models do (`model.model`,
     `model.lm_head`): the body runs as usual, the head never produces logits."""

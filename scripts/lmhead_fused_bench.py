@@ -24,7 +24,7 @@ ap.add_argument("--tokens", type=int, default=8192)
 ap.add_argument("--hidden", type=int, default=3584)
 ap.add_argument("--vocab", type=int, default=152064)
 ap.add_argument("--iters", type=int, default=5)
-ap.add_argument("--chunk-rows", type=int, default=2048)
+ap.add_argument("--chunk-rows", type=int, default=4096)
 ap.add_argument("--skip-library", action="store_true")
 ap.add_argument("--skip-bwd", action="store_true")
 ap.add_argument("--bf16-weight", action="store_true")
@@ -106,6 +106,11 @@ if not args.skip_bwd:
     os.environ.pop("PRL_LMHEAD_TILE", None)
     med, _ = timeit(lambda: head.backward_from_token_grads(h, ids, 1.0, lse2, ent, g_nlp, None, None, want_hidden=True, grad_weight=None), iters=2)
     emit(what="fused backward, d hidden only", ms=round(med, 3))
+    head.hidden_grad_terms = 1
+    gw = torch.zeros(V, H, device=dev)
+    med, best = timeit(lambda: head.backward_from_token_grads(h, ids, 1.0, lse2, ent, g_nlp, None, None, grad_weight=gw), iters=2)
+    emit(what="fused backward, leading-term d hidden (hidden_grad_terms=1)", ms=round(med, 3), best_ms=round(best, 3))
+    head.hidden_grad_terms = 3
     del gw
 
 if not args.skip_library and not args.bf16_weight:

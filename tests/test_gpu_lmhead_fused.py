@@ -71,7 +71,7 @@ def _run(hidden, W, batch, chunk_rows=None, grad_scale=1.0):
     pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(dev)
     h = hidden.clone().requires_grad_(True)
     w = W.clone().requires_grad_(True)
-    head = FusedLmHead(w, chunk_rows=chunk_rows or 2048)
+    head = FusedLmHead(w, chunk_rows=chunk_rows or 4096)
     loss, stats = fused_head_loss(h, w, head, pb, RLConfig(**CFG), 2, 10, chunk_rows=chunk_rows)
     (loss * grad_scale).backward()
     torch.cuda.synchronize()
@@ -174,6 +174,24 @@ def test_chunked_backward_and_upstream_scale(libprl, cuda_device, monkeypatch, t
         _compare(loss, stats, gh, gw, want, scale)
 
 
+def test_leading_term_hidden_gradient(libprl, cuda_device):
+    """hidden_grad_terms = 1: d hidden from d logits_hi x W_hi only - within the bf16 rounding of the full result."""
+    from pipelinerl_amd.finetune.rl import RLConfig, grpo_loss_from_logprobs, make_loss_config
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.fused_head import FusedLmHead
+
+    hidden, W, batch, logits64 = _problem(200, 256, 2048, cuda_device, seed=13)
+    want = _oracle(hidden, W, batch, logits64)
+    pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(cuda_device)
+    head = FusedLmHead(W, hidden_grad_terms=1)
+    nlp, ent, lse2, h = head.logprob_entropy(hidden, pb.input_ids, CFG["temperature"])
+    c_cfg, _, _ = make_loss_config(RLConfig(**CFG), 2, 10)
+    _, _, g_nlp, g_ent = grpo_loss_from_logprobs(c_cfg, pb, nlp, ent)
+    gh = head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, grad_hidden_dtype=torch.float32)
+    err = rel_err(gh[0].cpu().numpy(), want["d_hidden"])
+    assert 1e-5 < err <= 6e-3, err  # 2^-9 relative per product, not the 1e-4 of the three-term default
+
+
 def test_rl_step_fused_head_on_a_huggingface_style_model(libprl, cuda_device):
     """`rl_step_fused_head` == `rl_step` on a model with `.model` (body) and `.lm_head`: same loss,
     same parameter gradients, without the [T, V] logits."""
@@ -233,7 +251,7 @@ def test_workspace_too_small_and_bad_shapes_are_refused(libprl, cuda_device):
     s = _lib.current_stream_ptr(cuda_device)
     assert libprl.prl_lm_head_logprob_fwd(1, 128, 100, 1024, P, P, None, P, 1.0, P, P, P, P, 1 << 20, s) == _lib.PRL_EINVAL  # hidden % 64
     assert libprl.prl_lm_head_logprob_fwd(1, 4096, 64, 1024, P, P, None, P, 1.0, P, P, P, P, 1024, s) == _lib.PRL_ENOMEM
-    assert libprl.prl_lm_head_logprob_bwd(1, 128, 64, 1000, P, P, None, P, None, P, 1.0, P, P, P, None, None, P, 1, None, 128, P, 1 << 20, s) == _lib.PRL_EINVAL  # vocab % 64
+    assert libprl.prl_lm_head_logprob_bwd(1, 128, 64, 1000, P, P, None, P, None, P, 1.0, P, P, P, None, None, P, 1, None, 128, 0, P, 1 << 20, s) == _lib.PRL_EINVAL  # vocab % 64
     fwd, bwd = ctypes.c_size_t(), ctypes.c_size_t()
     _lib.check(libprl.prl_lm_head_workspace_bytes(1, 8192, 3584, 152064, 2048, ctypes.byref(fwd), ctypes.byref(bwd)))
     assert fwd.value < 2 << 20 and 2.4e9 < bwd.value < 2.6e9  # 4 bf16 planes of 2048 x 152064 + the transposed hidden chunk
