@@ -34,8 +34,8 @@
  *   prl_lm_head_*                 pipelinerl/finetune/rl/__init__.py:204-233 (model forward's output
  *                                 head + K1) with the numerics of
  *                                 pipelinerl/finetune/checkpoints.py:87-103 (fp32 head)
- *   prl_ring_*                    pipelinerl/shared_memory_array.py:9-196,
- *                                 pipelinerl/streams.py:249-346
+ *   prl_ring_*                    pipelinerl/shared_memory_array.py:9-196
+ *   prl_log_*                     pipelinerl/streams.py:120-192, 249-346
  *   prl_wsync_* / prl_ipc_* /
  *   prl_bucket_*                  pipelinerl/finetune_loop.py:205-292,
  *                                 pipelinerl/vllm1.py:62-134,
@@ -372,6 +372,37 @@ int prl_ring_max_record_bytes(prl_ring* r, uint64_t* nbytes);
 int prl_ring_close(prl_ring* r);           /* detach (creator also unlinks) */
 int prl_ring_detach(prl_ring* r);          /* detach only: the segment stays for late readers */
 int prl_ring_unlink(const char* name);
+
+/* ------------------------------------------------------------------------- */
+/* Transport: shared-memory record LOG (host side, no GPU)                    */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Append-only log with per-reader cursors - the semantics of the reference's stream backends
+ * (Redis XREAD from id 0, pipelinerl/streams.py:120-192; a JSONL file tailed from offset 0,
+ * :281-346): every reader sees every record from the first one, any number of readers, the
+ * writer never waits for a reader, a writer that is closed and reopened appends to the same
+ * stream (finetune_loop.py:244), readers block without polling.  Segmented POSIX shared memory:
+ * /<name> (control block) + /<name>.<k> (segments, grown on demand).
+ */
+typedef struct prl_log prl_log;
+
+#define PRL_LOG_CREATE 1    /* create the log if it does not exist (attach otherwise)            */
+#define PRL_LOG_TRUNCATE 2  /* remove an existing log of that name first (mode "w")              */
+#define PRL_LOG_READER 4    /* register a read cursor (lets a trimming writer see this reader)   */
+#define PRL_LOG_TRIM 8      /* at creation: unlink segments every registered reader has left     */
+
+/* PRL_EAGAIN: the log is being created by another process right now (retry); PRL_EFAULT: absent. */
+int prl_log_open(const char* name, uint64_t segment_bytes, int32_t flags, prl_log** out);
+int prl_log_append(prl_log* l, const void* data, uint64_t nbytes);
+/* Next record of this handle's cursor (starts at the first retained record): *ptr points INTO
+ * the mapping, valid until the next read / close.  timeout_ms < 0 blocks, 0 returns PRL_EAGAIN
+ * at the tail, > 0 PRL_ETIMEDOUT. */
+int prl_log_read(prl_log* l, const void** ptr, uint64_t* nbytes, int64_t timeout_ms);
+int prl_log_stats(prl_log* l, uint64_t* n_records, uint64_t* n_bytes,
+                  uint64_t* first_segment, uint64_t* n_segments);
+int prl_log_close(prl_log* l);
+int prl_log_unlink(const char* name); /* remove the control block and every segment */
 
 /* ------------------------------------------------------------------------- */
 /* Weight sync: trainer -> inference workers over RCCL / xGMI                */

@@ -35,6 +35,7 @@ PRL_NUM_STATS = 32
 PRL_WSYNC_UID_BYTES = 128
 PRL_IPC_HANDLE_BYTES = 64
 PRL_LM_HEAD_DH_LEADING_TERM = 1
+PRL_LOG_CREATE, PRL_LOG_TRUNCATE, PRL_LOG_READER, PRL_LOG_TRIM = 1, 2, 4, 8
 
 # index of every public statistic in the device stats vector (enum in include/prl.h)
 STAT_INDEX = {
@@ -140,6 +141,12 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_ring_close": (c_int32, [c_void_p]),
     "prl_ring_detach": (c_int32, [c_void_p]),
     "prl_ring_unlink": (c_int32, [c_char_p]),
+    "prl_log_open": (c_int32, [c_char_p, c_uint64, c_int32, POINTER(c_void_p)]),
+    "prl_log_append": (c_int32, [c_void_p, c_void_p, c_uint64]),
+    "prl_log_read": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_uint64), c_int64]),
+    "prl_log_stats": (c_int32, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
+    "prl_log_close": (c_int32, [c_void_p]),
+    "prl_log_unlink": (c_int32, [c_char_p]),
     "prl_wsync_unique_id": (c_int32, [POINTER(c_uint8)]),
     "prl_wsync_init": (c_int32, [POINTER(c_uint8), c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     "prl_wsync_bcast_bucket": (c_int32, [c_void_p, c_void_p, c_uint64, c_int32, c_void_p]),

@@ -32,6 +32,7 @@ HIP_FLAGS = [f"--offload-arch={ARCH}", "-x", "hip"]
 SOURCES = [
     "prl_api.cpp",
     "prl_ring.cpp",
+    "prl_log.cpp",
     "prl_wsync.cpp",
     "prl_ipc.cpp",
     "prl_loss.hip",

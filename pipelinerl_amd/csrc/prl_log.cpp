@@ -54,7 +54,7 @@ struct alignas(64) LogCtl {
   uint64_t segment_bytes;  // default payload capacity of a segment
   uint32_t flags;          // PRL_LOG_TRIM
   uint32_t _pad;
-  alignas(64) std::atomic<uint32_t> lock;       // 0 free, else pid of the writer holding it
+  alignas(64) std::atomic<uint32_t> lock;       // 0 free, else thread id of the writer holding it
   alignas(64) std::atomic<uint32_t> commits;    // futex word: bumped per committed record
   alignas(64) std::atomic<uint64_t> n_segments;  // segments created so far (indices 0 .. n-1)
   std::atomic<uint64_t> first_segment;           // oldest segment still linked
@@ -184,14 +184,21 @@ int create_segment(const std::string& base, uint64_t k, uint64_t capacity, Mappi
   return PRL_OK;
 }
 
+// The lock word holds the kernel thread id of the owner (unique system-wide, unlike a pid it tells two
+// writers of one process apart).  A holder that died is detected through /proc/<tid>.
+bool thread_alive(uint32_t tid) {
+  char path[48];
+  snprintf(path, sizeof path, "/proc/%u", tid);
+  return access(path, F_OK) == 0;
+}
+
 void lock_ctl(LogCtl* c) {
-  const uint32_t me = (uint32_t)getpid();
+  const uint32_t me = (uint32_t)syscall(SYS_gettid);
   for (int spins = 0;; ++spins) {
     uint32_t cur = 0;
     if (c->lock.compare_exchange_strong(cur, me, std::memory_order_acquire)) return;
-    if (cur == me) return;  // re-entry after a failed append in this process
     if (spins > 64) {
-      if (kill((pid_t)cur, 0) != 0 && errno == ESRCH) {  // the holder died: take the lock over
+      if (spins % 256 == 65 && !thread_alive(cur)) {  // the holder died: take the lock over
         if (c->lock.compare_exchange_strong(cur, me, std::memory_order_acquire)) return;
         continue;
       }

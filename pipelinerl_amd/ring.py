@@ -1,10 +1,12 @@
-"""Python handle of the shared-memory record ring (C ABI `prl_ring_*`, csrc/prl_ring.cpp)."""
+"""Python handles of the shared-memory record ring (C ABI `prl_ring_*`, csrc/prl_ring.cpp) and of the
+shared-memory record log (`prl_log_*`, csrc/prl_log.cpp)."""
 
 from __future__ import annotations
 
 import ctypes
 import os
 import queue
+import time
 import uuid
 
 from . import _lib
@@ -90,6 +92,69 @@ class Ring:
     @staticmethod
     def unlink_name(name: str) -> None:
         _lib.load().prl_ring_unlink(name.encode())
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Log:
+    """Append-only record log with per-reader cursors (csrc/prl_log.cpp): every reader handle sees
+    every record from the first retained one, a writer never waits for readers and may be closed and
+    reopened, readers park on a futex.  One handle is either used for `append` or for `read`."""
+
+    def __init__(self, name: str, create: bool = False, truncate: bool = False, reader: bool = False, trim: bool = False,
+                 segment_bytes: int = 64 << 20, wait: float | None = None):
+        """`wait`: seconds to keep retrying while the log does not exist yet (None = forever for readers,
+        no retry for writers that create)."""
+        lib = _lib.load()
+        self.name = name
+        flags = (_lib.PRL_LOG_CREATE if create else 0) | (_lib.PRL_LOG_TRUNCATE if truncate else 0) \
+            | (_lib.PRL_LOG_READER if reader else 0) | (_lib.PRL_LOG_TRIM if trim else 0)
+        h = ctypes.c_void_p()
+        deadline = None if wait is None else time.time() + wait
+        while True:
+            rc = lib.prl_log_open(name.encode(), segment_bytes, flags, ctypes.byref(h))
+            if rc == _lib.PRL_OK:
+                break
+            # EAGAIN: another process is creating it right now; EFAULT: not there yet (readers wait)
+            if rc == _lib.PRL_EAGAIN or (rc == _lib.PRL_EFAULT and not create):
+                if deadline is not None and time.time() > deadline:
+                    _lib.check(rc)
+                flags &= ~_lib.PRL_LOG_TRUNCATE  # never truncate twice
+                time.sleep(0.002)
+                continue
+            _lib.check(rc)
+        self._h = h
+
+    def append(self, data: bytes | bytearray | memoryview) -> None:
+        buf = data if isinstance(data, bytes) else (ctypes.c_char * len(data)).from_buffer_copy(data)
+        _lib.check(_lib.load().prl_log_append(self._h, buf, len(data)))
+
+    def read(self, block: bool = True, timeout: float | None = None) -> bytes:
+        """Next record of this handle's cursor (a copy).  Raises `queue.Empty` at the tail when not blocking."""
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        rc = _lib.load().prl_log_read(self._h, ctypes.byref(p), ctypes.byref(n), Ring._timeout_ms(block, timeout))
+        if rc in (_lib.PRL_EAGAIN, _lib.PRL_ETIMEDOUT):
+            raise queue.Empty()
+        _lib.check(rc)
+        return ctypes.string_at(p.value, n.value)
+
+    def stats(self) -> dict[str, int]:
+        v = [ctypes.c_uint64() for _ in range(4)]
+        _lib.check(_lib.load().prl_log_stats(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(zip(("records", "bytes", "first_segment", "segments"), (x.value for x in v)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h:
+            _lib.load().prl_log_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    @staticmethod
+    def unlink_name(name: str) -> None:
+        _lib.load().prl_log_unlink(name.encode())
 
     def __del__(self):
         try:

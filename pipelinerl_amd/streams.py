@@ -10,15 +10,22 @@ Backends
          encoder instead of orjson, so files are parse-compatible, not byte-identical) (`debug.streams_from`): `<exp>/streams/<topic>/<instance>/<partition>/0.jsonl`,
          one JSON object per line, tensors as nested lists, flush per record (:238-278).  The
          reader tails the file and never sees EOF (:281-346).
-  shm    MI355X-native transport for the hot `training_data` hop: one `prl_ring` per
-         (topic, instance, partition); a `PipelineBatchEncoding` travels as a binary SoA record
-         (header + raw int64 / fp32 buffers, see `batch_codec`) instead of ~114 bytes of JSON text
-         per token, and blocked readers park on a futex instead of polling every 100 ms.
-         Non-batch records (trainer messages, stats dicts) travel as JSON bytes.  With
+  shm    MI355X-native transport: one `prl_log` (csrc/prl_log.cpp) per (topic, instance, partition) - an
+         append-only record LOG in POSIX shared memory with the reference backends' semantics: every
+         reader sees every record from the first one, any number of readers per topic (`TrainerState`
+         follows the trainer topic in the actor, the preprocessor and the launcher at once,
+         state.py:36-48), the writer never waits for a reader, a writer that is closed and reopened
+         appends to the same stream (finetune_loop.py:244), mode "w" starts it over.  A
+         `PipelineBatchEncoding` travels as a binary SoA record (header + raw int64 / fp32 buffers, see
+         `batch_codec`) instead of ~114 bytes of JSON text per token, and readers park on a futex
+         instead of polling every 100 ms.  The bulk topics (`trim_topics`, default `training_data` and
+         `actor`) drop segments every registered reader has consumed; everything else is retained
+         like a file.  Non-batch records (trainer messages, stats dicts) travel as JSON bytes.  With
          `mirror_jsonl=True` (or a list of topics) every record is also appended to the files-backend
          location, so the run can be replayed with `backend: files` (`debug.streams_from`).
-  redis  accepted for config compatibility and served by `shm` (the image has no redis server or
-         client; single-node semantics are the same: ordered topics, blocking readers).
+  redis  the reference's wire format (XADD {index, data = pickle}, XREAD from id 0, streams.py:120-192),
+         implemented against the `redis` client package.  This image ships neither that package nor a
+         server: selecting it without them raises ImportError - it is never silently replaced.
 """
 
 from __future__ import annotations
@@ -55,12 +62,12 @@ def set_streams_backend(backend: Literal["files", "shm", "redis"], **kwargs: Any
     if _backend is not None:
         raise ValueError("Backend already set. Cannot change it.")
     if backend == "redis":
-        # conf/streams/redis.yaml of the reference: a single-node run gets the same semantics
-        # (ordered topics, blocking readers) from the shared-memory rings, so the option keeps
-        # working; host/port are ignored.  Rings are bounded: a full ring back-pressures the writer.
-        logger.warning("streams backend 'redis' is served by the shared-memory ring backend ('shm') in pipelinerl_amd")
-        backend, kwargs = "shm", {"n_slots": kwargs.get("n_slots", 1024), "slot_bytes": kwargs.get("slot_bytes", 16 << 20)}
-    if backend not in ("files", "shm"):
+        try:
+            import redis  # noqa: F401
+        except ImportError as e:
+            raise ImportError("streams backend 'redis' needs the `redis` client package (and a server); it is not installed here. "
+                              "Use backend 'shm' (same log semantics in shared memory, one node) or 'files'.") from e
+    if backend not in ("files", "shm", "redis"):
         raise ValueError(f"Invalid backend: {backend}. Only 'redis', 'files' and 'shm' are supported.")
     _backend, _backend_options = backend, dict(kwargs)
 
@@ -69,6 +76,13 @@ def reset_streams_backend() -> None:
     """Testing hook: forget the configured backend."""
     global _backend, _backend_options
     _backend, _backend_options = None, {}
+
+
+def unlink_shm_stream(stream: "SingleStreamSpec") -> None:
+    """Remove the shared-memory log of a stream (cleanup of runs started with `keep=True`)."""
+    from .ring import Log
+
+    Log.unlink_name(ring_name(stream))
 
 
 def raise_if_backend_not_set() -> None:
@@ -250,15 +264,40 @@ def ring_name(stream: SingleStreamSpec) -> str:
     return "prl_" + hashlib.sha1(key.encode()).hexdigest()[:24]
 
 
+DEFAULT_TRIM_TOPICS = ("training_data", "actor")
+
+
+def _shm_options(topic: str) -> tuple[int, bool]:
+    seg = int(_backend_options.get("segment_bytes", 64 << 20))
+    trim_topics = _backend_options.get("trim_topics", DEFAULT_TRIM_TOPICS)
+    return seg, topic in tuple(trim_topics)
+
+
+_created_logs: set[str] = set()
+
+
+def _unlink_at_exit(name: str) -> None:
+    """A log outlives its writers (a reader may attach after the producer finished, like a file on
+    disk); the process that first opened it for writing removes it when it exits."""
+    import atexit
+
+    from .ring import Log
+
+    if name not in _created_logs:
+        _created_logs.add(name)
+        atexit.register(Log.unlink_name, name)
+
+
 class ShmStreamWriter(StreamWriter):
-    """Creates the ring (the writer of a (topic, partition) is unique, reference :451) and appends
-    binary records.  `mode` is accepted for interface parity; a ring always starts empty."""
+    """Appends binary records to the stream's shared-memory log: attach if it exists (mode "a" after a
+    previous writer - the reference reopens the trainer topic for every weight update), create it
+    otherwise; mode "w" starts an empty log (FileStreamWriter("w") truncates the file)."""
 
     def __init__(self, stream: SingleStreamSpec, mode: Literal["w", "a"] = "a"):
+        if mode not in ("w", "a"):
+            raise ValueError(f"Invalid mode: {mode}. Only 'w' and 'a' are supported.")
         self.stream = stream
         self.mode = mode
-        self.n_slots = int(_backend_options.get("n_slots", 64))
-        self.slot_bytes = int(_backend_options.get("slot_bytes", 16 << 20))
         # `mirror_jsonl`: True or a list of topics - every record also goes to the files-backend
         # location as one JSON line, so a run can be replayed later with `backend: files`
         # (`debug.streams_from`); rollouts are mirrored as the actor's list-of-dicts record.
@@ -266,21 +305,19 @@ class ShmStreamWriter(StreamWriter):
         self._mirror = FileStreamWriter(stream, mode) if (mirror is True or (isinstance(mirror, (list, tuple, set)) and stream.topic in mirror)) else None
 
     def __enter__(self):
-        from .ring import Ring
-
-        import atexit
+        from .ring import Log
 
         name = ring_name(self.stream)
-        self._ring = Ring(name, n_slots=self.n_slots, slot_bytes=self.slot_bytes, create=True)
-        # Streams outlive their writer (a reader may attach after the producer finished, like a
-        # file on disk): the segment is only unlinked when the creating process exits.
-        atexit.register(Ring.unlink_name, name)
+        seg, trim = _shm_options(self.stream.topic)
+        self._log = Log(name, create=True, truncate=self.mode == "w", trim=trim, segment_bytes=seg)
+        if not _backend_options.get("keep", False):
+            _unlink_at_exit(name)
         if self._mirror is not None:
             self._mirror.__enter__()
         return self
 
     def __exit__(self, exc_type, exc_value, traceback):
-        self._ring.close(unlink=False)
+        self._log.close()
         if self._mirror is not None:
             self._mirror.__exit__(exc_type, exc_value, traceback)
 
@@ -293,36 +330,122 @@ class ShmStreamWriter(StreamWriter):
             payload = batch_codec.encode_rollouts(data)
         else:
             payload = batch_codec.encode_json(_dumps(data))
-        self._ring.put_bytes(payload)
+        self._log.append(payload)
         if self._mirror is not None:
             self._mirror.write(data.to_entries() if isinstance(data, RaggedRollouts) else data)
 
 
 class ShmStreamReader(StreamReader):
+    """Own cursor over the stream's log, starting at its first record; waits for the log to appear."""
+
     def __init__(self, stream: SingleStreamSpec):
         self.stream = stream
 
     def __enter__(self):
         from . import _lib
-        from .ring import Ring
+        from .ring import Log
 
         warned = 0.0
         while True:
             try:
-                self._ring = Ring(ring_name(self.stream), create=False)
+                self._log = Log(ring_name(self.stream), reader=True, wait=_RECHECK_DELAY)
                 return self
             except _lib.PrlError:
                 if time.time() - warned > _RECHECK_DELAY:
                     logger.warning(f"Waiting for {self.stream} to be created")
                     warned = time.time()
-                time.sleep(0.01)
 
     def __exit__(self, exc_type, exc_value, traceback):
-        self._ring.close()
+        self._log.close()
 
     def read(self):
         while True:
-            yield batch_codec.decode(self._ring.get_bytes())
+            yield batch_codec.decode(self._log.read())
+
+
+# ---------------------------------------------------------------------------------------------
+# redis backend (reference streams.py:106-232; needs the `redis` package + a server)
+# ---------------------------------------------------------------------------------------------
+
+
+def _connect_to_redis():
+    import redis
+
+    host, port = _backend_options.get("host", "localhost"), int(_backend_options.get("port", 6379))
+    while True:
+        try:
+            client = redis.Redis(host=host, port=port)
+            client.ping()
+            return client
+        except (redis.exceptions.TimeoutError, redis.ConnectionError) as e:
+            logger.warning(f"Waiting for Redis server ({type(e)}). Retrying in 5 seconds.")
+            time.sleep(5)
+
+
+class RedisStreamWriter(StreamWriter):
+    """XADD {index, data = pickle(record)} with the running index the reference keeps (:121-160)."""
+
+    def __init__(self, stream: SingleStreamSpec, mode: Literal["w", "a"] = "a"):
+        self.stream = stream
+        self._stream_name = str(stream)
+        self._redis = _connect_to_redis()
+        last = self._redis.xrevrange(self._stream_name, count=1)
+        if mode == "a":
+            self._index = int(last[0][1][b"index"].decode()) + 1 if last else 0
+        elif mode == "w":
+            if last:
+                raise ValueError(f"Stream {self.stream} already exists. Cannot overwrite it.")
+            self._index = 0
+        else:
+            raise ValueError(f"Invalid mode: {mode}. Only 'w' and 'a' are supported.")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        self._redis.close()
+
+    def write(self, data, partition: int | None = None):
+        import pickle
+
+        if partition is not None:
+            raise ValueError()
+        if isinstance(data, BaseModel):
+            data = data.model_dump()
+        self._redis.xadd(self._stream_name, {"index": self._index, "data": pickle.dumps(data)}, maxlen=1000000, approximate=True)
+        self._index += 1
+
+
+class RedisStreamReader(StreamReader):
+    """XREAD from id 0, one entry at a time, checking the writer's running index (:163-192)."""
+
+    def __init__(self, stream: SingleStreamSpec):
+        self.stream = stream
+        self._stream_name = str(stream)
+        self._redis = _connect_to_redis()
+        self._last_id: Any = 0
+        self._index = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        self._redis.close()
+
+    def read(self):
+        import pickle
+
+        block = int(_REREAD_DELAY * 1000)
+        while True:
+            response = self._redis.xread({self._stream_name: self._last_id}, count=1, block=block)
+            if response:
+                _, result = response[0]
+                entry_id, entry = result[0]
+                if int(entry[b"index"].decode("utf-8")) != self._index:
+                    raise ValueError(f"Index mismatch: expected {self._index}, got {entry[b'index']}")
+                self._last_id = entry_id
+                self._index += 1
+                yield pickle.loads(entry[b"data"])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -365,7 +488,7 @@ def read_stream(stream: SingleStreamSpec) -> StreamReader:
     raise_if_backend_not_set()
     if not isinstance(stream, SingleStreamSpec):
         raise ValueError(f"Invalid stream spec: {stream}")
-    return FileStreamReader(stream) if _backend == "files" else ShmStreamReader(stream)
+    return {"files": FileStreamReader, "shm": ShmStreamReader, "redis": RedisStreamReader}[_backend](stream)
 
 
 def write_to_streams(streams: StreamSpec, mode: Literal["w", "a"] = "a") -> StreamWriter:
@@ -373,7 +496,7 @@ def write_to_streams(streams: StreamSpec, mode: Literal["w", "a"] = "a") -> Stre
     raise_if_backend_not_set()
     if not isinstance(streams, (SingleStreamSpec, StreamRangeSpec)):
         raise ValueError(f"Invalid stream spec: {streams}")
-    writer_cls = FileStreamWriter if _backend == "files" else ShmStreamWriter
+    writer_cls = {"files": FileStreamWriter, "shm": ShmStreamWriter, "redis": RedisStreamWriter}[_backend]
     if isinstance(streams, SingleStreamSpec):
         return writer_cls(streams, mode)
     return PartitionedStreamWriter(streams, mode, writer_cls)

@@ -36,7 +36,7 @@ def test_replay_actor_stream_through_preprocessor_and_learner(libprl, cuda_devic
     from pipelinerl_amd.synthetic import make_entries
 
     streams.reset_streams_backend()
-    streams.set_streams_backend(backend, **({"n_slots": 64, "slot_bytes": 1 << 20} if backend == "shm" else {}))
+    streams.set_streams_backend(backend, **({"segment_bytes": 1 << 20} if backend == "shm" else {}))
     try:
         attempts, V = 4, 64
         raw = make_entries(6, attempts=attempts, seq_length=48, vocab=V, seed=21, prompt_min=3, prompt_max=8)
@@ -59,7 +59,6 @@ def test_replay_actor_stream_through_preprocessor_and_learner(libprl, cuda_devic
                 raise e
 
         def _preprocessor():
-            # the ring of the shm backend must exist before the reader attaches: writer first
             with streams.write_to_streams(actor_spec) as w:
                 for g in range(6):
                     group = raw[g * attempts:(g + 1) * attempts]
@@ -111,10 +110,10 @@ def test_replay_actor_stream_through_preprocessor_and_learner(libprl, cuda_devic
         step.finish()
         t.join(timeout=20)
         assert published["n"] == 16
-        if backend == "files":
-            st = TrainerState(tmp_path)
-            st.start_listening()
-            assert st.wait_for_training_done(timeout=10) and st.samples_processed == 16
+        # both transports are logs: a follower that starts after the trainer finished still sees every message
+        st = TrainerState(tmp_path)
+        st.start_listening()
+        assert st.wait_for_training_done(timeout=10) and st.samples_processed == 16
     finally:
         streams.reset_streams_backend()
 

@@ -1,0 +1,262 @@
+"""Log semantics of the shm streams backend (csrc/prl_log.cpp) - what the reference's Redis and files
+backends give every consumer (streams.py:120-192, 281-346): every reader sees every record from the
+first one, several readers per topic, a writer is never blocked by a reader (present or absent), a
+writer that is closed and reopened appends to the same stream, mode "w" starts over.  The trainer topic
+depends on all of it: `TrainerState` follows it in the actor, the preprocessor and the launcher at once
+(state.py:36-48) and `WeightUpdateManager` reopens it for every update (finetune_loop.py:244)."""
+
+import json
+import multiprocessing as mp
+import queue
+import threading
+import time
+
+import pytest
+
+from helpers import GOLDEN
+
+
+@pytest.fixture()
+def streams(tmp_path):
+    from pipelinerl_amd import streams as s
+
+    s.reset_streams_backend()
+    s.set_streams_backend("shm", segment_bytes=1 << 16)
+    yield s
+    s.reset_streams_backend()
+
+
+def _take(reader_cm, n, timeout=10.0):
+    """First n records of a fresh reader (its own cursor), with a watchdog."""
+    out, err = [], []
+
+    def run():
+        try:
+            with reader_cm as r:
+                for rec in r.read():
+                    out.append(rec)
+                    if len(out) == n:
+                        return
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(timeout)
+    assert not err, err
+    assert not t.is_alive(), f"reader got {len(out)} of {n} records"
+    return out
+
+
+def test_every_reader_sees_every_record_from_the_first(streams, tmp_path):
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="weight_update_request")
+    with streams.write_to_streams(spec) as w:
+        for i in range(50):
+            w.write({"kind": "samples_processed", "samples_processed": i})
+        # two readers opened while the writer lives, each from record 0
+        a = _take(streams.read_stream(spec), 50)
+        b = _take(streams.read_stream(spec), 50)
+        assert [r["samples_processed"] for r in a] == list(range(50)) == [r["samples_processed"] for r in b]
+        w.write({"kind": "training_done"})
+    # a late reader, after the writer closed: still everything
+    c = _take(streams.read_stream(spec), 51)
+    assert c[-1] == {"kind": "training_done"} and c[:50] == a
+
+
+def test_reopened_writer_appends_and_mode_w_starts_over(streams, tmp_path):
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="t")
+    seen = []
+    ready = threading.Event()
+
+    def follower():
+        with streams.read_stream(spec) as r:
+            for rec in r.read():
+                seen.append(rec)
+                ready.set()
+                if len(seen) == 4:
+                    return
+
+    t = threading.Thread(target=follower, daemon=True)
+    t.start()
+    with streams.write_to_streams(spec) as w:
+        w.write({"i": 0})
+    assert ready.wait(5)
+    for i in (1, 2):  # a new writer per message, like send_weight_update
+        with streams.write_to_streams(spec, "a") as w:
+            w.write({"i": i})
+    with streams.write_to_streams(spec) as w:
+        w.write({"i": 3})
+    t.join(5)
+    assert seen == [{"i": k} for k in range(4)]  # the follower opened before the reopen still gets everything
+    with streams.write_to_streams(spec, "w") as w:
+        w.write({"i": "fresh"})
+    assert _take(streams.read_stream(spec), 1) == [{"i": "fresh"}]
+
+
+def test_writer_is_never_blocked_by_readers(streams, tmp_path):
+    """No reader at all, then a reader that stopped consuming: 5 MB through 64 KB segments without waiting."""
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="stats")
+    payload = "x" * 1000
+    t0 = time.time()
+    with streams.write_to_streams(spec) as w:
+        for i in range(2500):
+            w.write({"i": i, "p": payload})
+        stalled = streams.read_stream(spec)
+        stalled.__enter__()
+        first = next(iter(stalled.read()))
+        for i in range(2500, 5000):
+            w.write({"i": i, "p": payload})
+        stalled.__exit__(None, None, None)
+    assert time.time() - t0 < 20 and first["i"] == 0
+    got = _take(streams.read_stream(spec), 5000, timeout=30)
+    assert [r["i"] for r in got] == list(range(5000))
+    from pipelinerl_amd.ring import Log
+
+    st = Log(streams.ring_name(spec)).stats()
+    assert st["records"] == 5000 and st["segments"] > 50 and st["first_segment"] == 0  # an untrimmed topic keeps everything
+
+
+def test_bulk_topics_trim_what_every_registered_reader_consumed(streams, tmp_path):
+    from pipelinerl_amd.ring import Log
+
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data", partition=3)
+    payload = "y" * 4000
+    with streams.write_to_streams(spec) as w:
+        for i in range(100):  # no reader yet: nothing may be dropped, a first reader must find record 0
+            w.write({"i": i, "p": payload})
+        log = Log(streams.ring_name(spec))
+        assert log.stats()["first_segment"] == 0
+        reader = streams.read_stream(spec)
+        reader.__enter__()
+        it = iter(reader.read())
+        assert [next(it)["i"] for _ in range(100)] == list(range(100))
+        for i in range(100, 200):  # the reader sits near the tail: consumed segments go away as new ones open
+            w.write({"i": i, "p": payload})
+        st = log.stats()
+        assert st["first_segment"] > 0 and st["segments"] - st["first_segment"] < st["segments"]
+        assert [next(it)["i"] for _ in range(100)] == list(range(100, 200))
+        reader.__exit__(None, None, None)
+        log.close()
+
+
+def test_oversize_record_gets_its_own_segment(streams, tmp_path):
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="big")
+    big = {"blob": "z" * (300 << 10)}  # 300 KB > 64 KB segments
+    with streams.write_to_streams(spec) as w:
+        w.write({"i": 0})
+        w.write(big)
+        w.write({"i": 2})
+    got = _take(streams.read_stream(spec), 3)
+    assert got[0] == {"i": 0} and got[1] == big and got[2] == {"i": 2}
+
+
+def test_three_trainer_state_followers_reach_the_reference_state(tmp_path):
+    """Three `TrainerState` objects (actor, preprocessor, launcher) follow the trainer topic on the shm
+    backend while the trainer publishes through a persistent writer AND per-update writers; each ends in
+    the state the reference's own TrainerState reached on the same messages."""
+    from pipelinerl_amd import streams
+    from pipelinerl_amd.finetune_loop import TRAINER_TOPIC, parse_trainer_message
+    from pipelinerl_amd.state import TrainerState
+
+    g = json.loads((GOLDEN / "trainer_messages.json").read_text())
+    lines = next(iter(g["files"].values())).splitlines()  # the file the reference's own writer produced
+    messages = [json.loads(l) for l in lines]
+    want = g["state_trace"][-1]  # the reference TrainerState after the last message
+    streams.reset_streams_backend()
+    streams.set_streams_backend("shm")
+    try:
+        spec = streams.SingleStreamSpec(exp_path=tmp_path, topic=TRAINER_TOPIC)
+        followers = [TrainerState(tmp_path) for _ in range(3)]
+        with streams.write_to_streams(spec) as persistent:
+            persistent.write(parse_trainer_message(messages[0]))
+            for f in followers[:2]:
+                f.start_listening()
+            for m in messages[1:]:
+                msg = parse_trainer_message(m)
+                if msg.kind == "weight_update_success":  # the reference opens a new writer for this one
+                    with streams.write_to_streams(spec) as w:
+                        w.write(msg)
+                else:
+                    persistent.write(msg)
+            followers[2].start_listening()  # a late follower
+            deadline = time.time() + 10
+            while time.time() < deadline and not all(f.training_done for f in followers):
+                time.sleep(0.01)
+        for f in followers:
+            assert f.training_done == want["training_done"]
+            assert f.propagated_weight_version == want["propagated_weight_version"]
+            assert f.samples_processed == want["samples_processed"]
+    finally:
+        streams.reset_streams_backend()
+
+
+def _child_reader(exp_path, topic, n, out_q):
+    from pipelinerl_amd import streams
+
+    streams.set_streams_backend("shm", segment_bytes=1 << 16)
+    spec = streams.SingleStreamSpec(exp_path=exp_path, topic=topic)
+    got = []
+    with streams.read_stream(spec) as r:
+        for rec in r.read():
+            got.append(rec["i"])
+            if len(got) == n:
+                break
+    out_q.put(got)
+
+
+def _child_writer(exp_path, topic, lo, hi):
+    from pipelinerl_amd import streams
+
+    streams.set_streams_backend("shm", segment_bytes=1 << 16, keep=True)
+    spec = streams.SingleStreamSpec(exp_path=exp_path, topic=topic)
+    with streams.write_to_streams(spec) as w:
+        for i in range(lo, hi):
+            w.write({"i": i, "pad": "p" * 200})
+
+
+def test_fan_out_across_processes_with_a_second_writer_process(streams, tmp_path):
+    """Two reader PROCESSES and one reader thread follow a topic written first by this process and then
+    by a separate writer process (spawn): all three see the same complete sequence."""
+    ctx = mp.get_context("spawn")
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="fan")
+    n = 600
+    q = ctx.Queue()
+    with streams.write_to_streams(spec) as w:
+        w.write({"i": 0, "pad": ""})
+        readers = [ctx.Process(target=_child_reader, args=(tmp_path, "fan", n, q)) for _ in range(2)]
+        for p in readers:
+            p.start()
+        for i in range(1, 300):
+            w.write({"i": i, "pad": "p" * 200})
+    wp = ctx.Process(target=_child_writer, args=(tmp_path, "fan", 300, n))
+    wp.start()
+    wp.join(30)
+    local = _take(streams.read_stream(spec), n, timeout=30)
+    results = [q.get(timeout=30) for _ in readers]
+    for p in readers:
+        p.join(10)
+    assert [r["i"] for r in local] == list(range(n))
+    assert results[0] == list(range(n)) and results[1] == list(range(n))
+
+
+def test_reader_timeout_and_nonblocking(tmp_path):
+    from pipelinerl_amd.ring import Log
+
+    name = f"prl_test_{time.time_ns()}"
+    w = Log(name, create=True, segment_bytes=4096)
+    try:
+        r = Log(name, reader=True)
+        with pytest.raises(queue.Empty):
+            r.read(block=False)
+        t0 = time.time()
+        with pytest.raises(queue.Empty):
+            r.read(timeout=0.2)
+        assert 0.15 < time.time() - t0 < 2
+        w.append(b"abc")
+        assert r.read(block=False) == b"abc"
+        w.append(b"")
+        assert r.read() == b""
+        r.close()
+    finally:
+        w.close()
+        Log.unlink_name(name)

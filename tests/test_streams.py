@@ -50,8 +50,13 @@ def test_backend_must_be_set_once(streams, tmp_path):
     with pytest.raises(ValueError):
         streams.set_streams_backend("files")
     streams.reset_streams_backend()
-    streams.set_streams_backend("redis", host="localhost", port=6379)  # config compatibility: served by shm
-    assert streams._backend == "shm" and streams._backend_options["n_slots"] == 1024
+    # `redis` is the reference's own wire format and needs the redis client: without it the choice fails
+    # loudly instead of being served by another transport
+    try:
+        import redis  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            streams.set_streams_backend("redis", host="localhost", port=6379)
     streams.reset_streams_backend()
     with pytest.raises(ValueError):
         streams.set_streams_backend("carrier-pigeon")
@@ -127,7 +132,7 @@ def test_partitioned_writer(streams, tmp_path):
 
 
 def test_shm_backend_roundtrip(streams, tmp_path, libprl):
-    streams.set_streams_backend("shm", n_slots=4, slot_bytes=1 << 16)
+    streams.set_streams_backend("shm", segment_bytes=1 << 16)
     batch, want = _batch()
     spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data", partition=1)
     with streams.write_to_streams(spec) as w:
@@ -267,7 +272,7 @@ def test_shm_backend_jsonl_mirror_allows_replay(streams, tmp_path):
 
     rag, _ = make_ragged(2, attempts=3, seq_length=40, vocab=60, seed=4, prompt_min=3, prompt_max=8, with_ref=True)
     batch, want_batch = _batch()
-    streams.set_streams_backend("shm", n_slots=8, slot_bytes=1 << 20, mirror_jsonl=["actor", "training_data"])
+    streams.set_streams_backend("shm", segment_bytes=1 << 20, mirror_jsonl=["actor", "training_data"])
     a = streams.SingleStreamSpec(exp_path=tmp_path, topic="actor")
     t = streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data")
     s = streams.SingleStreamSpec(exp_path=tmp_path, topic="stats")
