@@ -28,6 +28,7 @@
  *   prl_segment_sums              pipelinerl/finetune/rl/utils.py:106-208
  *   prl_seq_scan / prl_group_advantages
  *                                 pipelinerl/finetune/rl/__init__.py:453-570
+ *   prl_patch_oov                 pipelinerl/preprocess.py:107-141
  *   prl_pack_collate              pipelinerl/finetune/data.py:215-283
  *                                 (+ rl/__init__.py:573-594 field expansion)
  *   prl_pad_collate               pipelinerl/finetune/data.py:163-212
@@ -265,6 +266,15 @@ int prl_seq_scan(int32_t n_seqs, const int32_t* tokens, const int32_t* labels,
                  const int64_t* seq_off, const uint8_t* finish_code,
                  const uint8_t* finished, int32_t eos_token_id, float* num_labels,
                  float* overflow, prl_stream_t stream);
+
+/*
+ * Out-of-vocabulary patch (preprocess.py:107-141 `replace_oov_tokens_with_the`): every token id
+ * outside [0, table_size) or with valid[id] == 0 becomes `the_token_id`, in place, on the ragged
+ * int32 token buffer; labels are untouched like in the reference.  *patched (device u64, nullable,
+ * zeroed by the caller) receives the number of replaced tokens.
+ */
+int prl_patch_oov(int64_t n_tokens, int32_t* tokens, const uint8_t* valid, int32_t table_size,
+                  int32_t the_token_id, uint64_t* patched, prl_stream_t stream);
 
 /*
  * Leave-one-out advantages per (group_id, step_index) key and mean rollout tokens

@@ -124,6 +124,7 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_scale_unless": (c_int32, [_P, c_int64, c_int32, _P, c_float, _P]),
     "prl_segment_sums": (c_int32, [c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prl_seq_scan": (c_int32, [c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),
+    "prl_patch_oov": (c_int32, [c_int64, _P, _P, c_int32, c_int32, _P, _P]),
     "prl_group_advantages": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
     "prl_pack_collate": (c_int32, [c_int32, c_int64] + [_P] * 14 + [c_int32, c_int32] + [_P] * 12 + [_P]),
     "prl_pad_collate": (c_int32, [c_int32, c_int64, c_int32] + [_P] * 12 + [c_int32] + [_P] * 10 + [_P]),

@@ -445,7 +445,39 @@ int blocks_for(int64_t items) {
   return (int)b;
 }
 
+// tokens[i] := the_id wherever tokens[i] is outside [0, table_size) or valid[tokens[i]] == 0
+// (reference preprocess.py:107-141, `replace_oov_tokens_with_the`: only input_ids change, labels keep
+// what the actor sent).  One 4-byte read + one conditional 4-byte write per token; *patched counts them.
+__global__ __launch_bounds__(kBlock) void patch_oov_kernel(int64_t n, int32_t* __restrict__ tokens,
+                                                           const uint8_t* __restrict__ valid, int32_t table_size,
+                                                           int32_t the_id, unsigned long long* __restrict__ patched) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long mine = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int32_t t = tokens[i];
+    const bool ok = t >= 0 && t < table_size && valid[t] != 0;
+    if (!ok) {
+      tokens[i] = the_id;
+      ++mine;
+    }
+  }
+  if (patched && mine) atomicAdd(patched, mine);
+}
+
 }  // namespace
+
+extern "C" int prl_patch_oov(int64_t n_tokens, int32_t* tokens, const uint8_t* valid, int32_t table_size,
+                             int32_t the_token_id, uint64_t* patched, prl_stream_t stream) {
+  PRL_CHECK_ARG(n_tokens >= 0 && table_size >= 0, "negative size");
+  if (n_tokens == 0) return PRL_OK;
+  PRL_CHECK_ARG(tokens && (valid || table_size == 0), "null pointer");
+  const int64_t want = (n_tokens + kBlock - 1) / kBlock;
+  const int nb = (int)(want < kMaxBlocks ? want : kMaxBlocks);
+  hipLaunchKernelGGL(patch_oov_kernel, dim3(nb), dim3(kBlock), 0, static_cast<hipStream_t>(stream), n_tokens, tokens, valid,
+                     table_size, the_token_id, reinterpret_cast<unsigned long long*>(patched));
+  PRL_LAUNCH_CHECK("patch_oov_kernel");
+  return PRL_OK;
+}
 
 extern "C" int prl_seq_scan(int32_t n_seqs, const int32_t* tokens, const int32_t* labels,
                             const int64_t* seq_off, const uint8_t* finish_code,

@@ -291,12 +291,17 @@ class LearnerStep:
         max_lag: int | None = None,
         rl_step_fn: Callable = _rl_step,
         process_group: Any = None,
+        seq_parallel_group: Any = None,
     ):
+        """`seq_parallel_group`: the ranks that hold the slices of one packed sequence (`seq_parallel` > 1);
+        forwarded to `rl_step` like the reference does (finetune_loop.py:768-775) - GSPO needs it to add the
+        per-segment sums over the slices."""
         import torch.distributed as dist
 
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
         self.rl_step_fn = rl_step_fn
         self.group = process_group
+        self.seq_parallel_group = seq_parallel_group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.distributed else 1
         self.rank = dist.get_rank(process_group) if self.distributed else 0
@@ -381,7 +386,11 @@ class LearnerStep:
         do_optimizer_step = self.total_samples == self.target_samples
 
         with self._sync_context(do_optimizer_step):
-            loss, stats = self.rl_step_fn(self.model, batch, m.completed_steps, self.max_train_steps, self.rl_config)
+            if self.seq_parallel_group is not None:
+                loss, stats = self.rl_step_fn(self.model, batch, m.completed_steps, self.max_train_steps, self.rl_config,
+                                              seq_parallel_group=self.seq_parallel_group)
+            else:
+                loss, stats = self.rl_step_fn(self.model, batch, m.completed_steps, self.max_train_steps, self.rl_config)
             if is_sentinel:
                 loss = loss * 0.0  # keeps every rank's forward/backward count equal, adds nothing
             else:

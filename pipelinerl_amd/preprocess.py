@@ -85,7 +85,7 @@ class MicroBatchScheduler:
         self._length_of = length_of
 
     def push(self, samples: Iterable[Any]) -> None:
-        self.queue.extend(samples)
+        self.queue.extend(samples)  # `queue` may be replaced by a bounded ring (PreprocessorLoop)
 
     def _advance(self) -> None:
         self.trainer_id = (self.trainer_id + self.seq_parallel) % self.num_trainers
@@ -191,10 +191,210 @@ def concat_prepared(parts: Sequence[PreparedRollouts]) -> PreparedRollouts:
     )
 
 
+# ---------------------------------------------------------------------------------------------
+# the lossy / elastic half of the loop (reference preprocess.py:190-282, 565-585, 664-694)
+# ---------------------------------------------------------------------------------------------
+
+
+class ChunkLoader:
+    """Reader thread of the preprocessor (`run_dataset_loader`, reference :190-228): takes
+    `chunk_n_groups` groups at a time from the input stream, checks the group sizes, and hands the chunk
+    to a BOUNDED queue.  When the queue is full and `pop_old_data` is on, the OLDEST waiting chunk is
+    dropped to make room (the learner should train on fresh rollouts rather than stall the actor);
+    otherwise the put blocks.  An error ends the thread after being forwarded through the queue.
+    A group is a list of TrainingText dicts (text record) or a `RaggedRollouts` (binary record)."""
+
+    def __init__(self, raw_chunk_queue, data_stream, check_group_size: int, chunk_n_groups: int, pop_old_data: bool,
+                 reader_factory=None):
+        self.queue = raw_chunk_queue
+        self.data_stream = data_stream
+        self.check_group_size = check_group_size
+        self.chunk_n_groups = chunk_n_groups
+        self.pop_old_data = pop_old_data
+        self.old_and_dropped = 0
+        self._reader_factory = reader_factory
+
+    @staticmethod
+    def group_sizes_ok(groups: list, group_size: int) -> bool:
+        for g in groups:
+            if isinstance(g, RaggedRollouts):
+                pairs = np.unique(np.stack([g.host_group_index, g.host_rollout_index]), axis=1)
+                if not (np.bincount(pairs[0]) == group_size).all():
+                    return False
+        texts = [e for g in groups if not isinstance(g, RaggedRollouts) for e in g]
+        return check_group_sizes(texts, group_size)
+
+    def run(self) -> None:
+        import queue as _q
+
+        from .streams import read_stream
+
+        last_notice = 0
+        with (self._reader_factory or read_stream)(self.data_stream) as reader:
+            while True:
+                try:
+                    groups = []
+                    for group in reader.read():
+                        groups.append(group)
+                        if len(groups) == self.chunk_n_groups:
+                            break
+                    if not self.group_sizes_ok(groups, self.check_group_size):
+                        raise ValueError("Invalid group sizes in data")
+                    try:
+                        self.queue.put_nowait(groups)
+                    except _q.Full:
+                        if self.pop_old_data:
+                            try:
+                                self.queue.get_nowait()
+                                self.old_and_dropped += 1
+                                if self.old_and_dropped // 100 != last_notice:
+                                    logger.info(f"So far removed {self.old_and_dropped} old elements from preprocessor queue")
+                                    last_notice = self.old_and_dropped // 100
+                            except _q.Empty:
+                                pass
+                        self.queue.put(groups)  # blocking; after a drop there is room in most cases
+                except Exception as e:  # noqa: BLE001 - forwarded to the main loop
+                    logger.error(f"Error in dataset loader: {e}")
+                    self.queue.put(e)
+                    break
+
+
+class SlidingWindowAggregator:
+    """Samples / tokens per second over the last `window_size` updates (reference :239-282)."""
+
+    def __init__(self, window_size: int, clock=time.time):
+        self.window_size = window_size
+        self.tokens_window: list[list[int]] = []
+        self.timestamps: list[float] = []
+        self._clock = clock
+
+    def has_enough_data(self) -> bool:
+        return len(self.tokens_window) == self.window_size
+
+    def update(self, token_counts: list[int]) -> None:
+        self.tokens_window.append(list(token_counts))
+        self.timestamps.append(self._clock())
+        if len(self.tokens_window) > self.window_size:
+            del self.tokens_window[0], self.timestamps[0]
+
+    def get_stats(self) -> dict[str, float]:
+        span = self.timestamps[-1] - self.timestamps[0] if self.timestamps else 0.0
+        if span < 1e-6:
+            return {"samples_per_second": 0, "tokens_per_second": 0}
+        return {"samples_per_second": sum(len(t) for t in self.tokens_window) / span,
+                "tokens_per_second": sum(sum(t) for t in self.tokens_window) / span}
+
+
+class ProcessedRing:
+    """The ring of preprocessed samples the scheduler draws from (`processed_entries_queue`, a
+    `deque(maxlen=ring_buffer_size)`, reference :455, :572-585).  `admit` moves samples from the arrival
+    buffer into the ring: with `pop_old_data` a full ring drops its OLDEST sample for every new one;
+    without, admission stops until the scheduler has made room.  After every admitted sample the
+    throughput window is updated with the lengths of everything in the ring and `max_model_version`
+    becomes the newest model version in it - exactly the reference's bookkeeping."""
+
+    def __init__(self, maxlen: int, pop_old_data: bool, stats: SlidingWindowAggregator | None = None,
+                 length_of=lambda s: s.length, version_of=lambda s: s.model_version):
+        self.entries: deque = deque(maxlen=maxlen)
+        self.pop_old_data = pop_old_data
+        self.popped = 0
+        self.max_model_version: int | None = None
+        self.stats = stats
+        self._length_of, self._version_of = length_of, version_of
+
+    def admit(self, buffer: deque) -> None:
+        q = self.entries
+        while buffer:
+            if len(q) == q.maxlen:
+                if not self.pop_old_data:
+                    break
+                self.popped += 1
+                if self.popped % 100 == 0:
+                    logger.warning(f"Popped {self.popped} old entries from processed entries queue")
+            q.append(buffer.popleft())  # a full deque(maxlen) drops from the left
+            if self.stats is not None:
+                self.stats.update([self._length_of(e) for e in q])
+            self.max_model_version = max((self._version_of(e) for e in q), default=0)
+
+
+def preprocessor_stats_record(published_samples: int, max_model_version: Any, raw_queue_chunks: int, output_queue_chunks: int,
+                              chunk_n_groups: int, attempts: int, num_filtered_out: int, total_filtered_out: int,
+                              aggregator: SlidingWindowAggregator | None) -> dict[str, Any]:
+    """One record of the `preprocessor_stats` stream, keys and arithmetic of reference :669-681."""
+    per_chunk = chunk_n_groups * attempts
+    stats = {
+        "preprocessor/published_samples": published_samples,
+        "preprocessor/published_model_version": max_model_version,
+        "preprocessor/queue/raw_samples": raw_queue_chunks * per_chunk,
+        "preprocessor/queue/raw": raw_queue_chunks,
+        "preprocessor/queue/output_samples": output_queue_chunks * per_chunk,
+        "preprocessor/queue/output": output_queue_chunks,
+        "preprocessor/filtered_out_samples": num_filtered_out,
+        "preprocessor/total_filtered_out_samples": total_filtered_out,
+    }
+    if aggregator is not None and aggregator.has_enough_data():
+        stats.update({"preprocessor/" + k: v for k, v in aggregator.get_stats().items()})
+    return stats
+
+
+def should_write_stats(published_samples: int, last_published_samples: int, debug_mode: Any, batch_done: bool, log_every_n_samples: int) -> bool:
+    """When the reference emits a stats record (:664-667)."""
+    return published_samples > last_published_samples and bool(
+        debug_mode or batch_done or (published_samples - last_published_samples > log_every_n_samples))
+
+
+def replace_oov_tokens_with_the(data: list[dict], tokenizer: Any) -> list[dict]:
+    """Host front end with the reference's contract (:107-141): token ids that are not in the
+    tokenizer's vocabulary become the id of "the" in `input_ids` (labels are left as they are)."""
+    vocab = tokenizer.get_vocab()
+    valid = np.zeros(max(vocab.values()) + 1, dtype=bool)
+    valid[list(vocab.values())] = True
+    the_id = vocab["the"]
+    patched = 0
+    for entry in data:
+        ids = np.asarray(entry["input_ids"], dtype=np.int64)
+        ok = (ids >= 0) & (ids < len(valid))
+        ok[ok] = valid[ids[ok]]
+        if not ok.all():
+            patched += 1
+            logger.warning(f"Patching entry with invalid token ids: {ids[~ok].tolist()}")
+            entry["input_ids"] = np.where(ok, ids, the_id).tolist()
+    if patched:
+        logger.warning(f"Patched {patched} entries with invalid token ids from {len(data)}")
+    return data
+
+
+class OovPatcher:
+    """Device form of the above for ragged rollouts: one pass of `prl_patch_oov` over the token buffer."""
+
+    def __init__(self, vocab_ids: Iterable[int], the_token_id: int, device):
+        ids = np.fromiter(vocab_ids, dtype=np.int64)
+        table = np.zeros(int(ids.max()) + 1 if len(ids) else 0, dtype=np.uint8)
+        table[ids] = 1
+        self.valid = torch.from_numpy(table).to(device)
+        self.the_token_id = int(the_token_id)
+        self.count = torch.zeros(1, dtype=torch.int64, device=device)
+
+    @classmethod
+    def from_tokenizer(cls, tokenizer: Any, device) -> "OovPatcher":
+        vocab = tokenizer.get_vocab()
+        return cls(vocab.values(), vocab["the"], device)
+
+    def apply(self, rollouts: RaggedRollouts) -> RaggedRollouts:
+        from . import _lib
+
+        t = rollouts.tokens
+        _lib.require_device(t)
+        with torch.cuda.device(t.device):
+            _lib.check(_lib.load().prl_patch_oov(t.numel(), t.data_ptr(), self.valid.data_ptr(), self.valid.numel(), self.the_token_id,
+                                                 self.count.data_ptr(), _lib.current_stream_ptr(t.device)))
+        return rollouts
+
+
 @dataclass
 class PreprocessorConfig:
-    """The keys of the reference config the preprocessor loop consumes (conf/base.yaml:25-44,
-    conf/finetune/base.yaml; SURVEY.md §5 "config")."""
+    """The keys of the reference config the preprocessor loop consumes (conf/base.yaml:25-44, 105,
+    conf/finetune/base.yaml; SURVEY.md §5 "config"), same defaults."""
 
     exp_path: Any
     num_trainers: int
@@ -205,10 +405,26 @@ class PreprocessorConfig:
     rl: RLConfig
     eos_token_id: int
     seq_parallel: int = 1
+    seq_packing: bool = True
+    padding_side: str = "right"
     chunk_n_groups: int = 2
+    raw_queue_size: int = 8
+    dataset_buffer_size: int = 0
+    ring_buffer_size: int = 128
     max_ready_samples_per_lead: int = 64
+    pop_old_data: bool = True
+    max_lag: int | None = None
+    debug_mode: Any = None
+    log_every_n_samples: int = 128
+    samples_target: int | None = None  # final_train_steps * train_batch_size * gradient_accumulation_passes (:431-432)
     input_topic: str = "actor"
     output_topic: str = "training_data"
+    stats_topic: str = "preprocessor_stats"
+
+    @property
+    def drops_old_data(self) -> bool:
+        """`pop_old_data = cfg.max_lag is None and cfg.pop_old_data and not cfg.debug.mode` (:408)."""
+        return self.max_lag is None and self.pop_old_data and not self.debug_mode
 
 
 @dataclass
@@ -216,19 +432,22 @@ class _Sample:
     chunk: int
     index: int
     length: int
+    model_version: int = 0
 
 
 class PreprocessorLoop:
-    """`run_preprocessing_loop` of the reference (preprocess.py:370-704) without worker processes:
-    the per-chunk work that needed N CPU workers is two kernel launches here.
+    """`run_preprocessing_loop` of the reference (preprocess.py:370-704) without worker processes: the
+    per-chunk work that needed N CPU workers is two kernel launches here.
 
-        actor stream -> chunks of `chunk_n_groups` groups -> K5 on device -> MicroBatchScheduler
-        -> ONE K6 launch per drain -> per-trainer `training_data` partitions (+ sentinels)
+        actor stream -> ChunkLoader (bounded queue, drop-oldest) -> K5 on device (+ OOV patch, zero-advantage
+        filter) -> arrival buffer -> ProcessedRing (drop-oldest) -> MicroBatchScheduler -> ONE K6 launch per
+        drain (packed, with sequence-parallel fillers) or K7 (unpacked) -> per-trainer `training_data`
+        partitions (+ sentinels), `preprocessor_stats` records
 
     Back-pressure as in the reference (:587-592): publishing pauses while
     published - trainer_state.samples_processed exceeds max_ready_samples_per_lead * num_trainers."""
 
-    def __init__(self, cfg: PreprocessorConfig, device, trainer_state=None, ref_model=None):
+    def __init__(self, cfg: PreprocessorConfig, device, trainer_state=None, ref_model=None, oov_patcher: OovPatcher | None = None):
         """`ref_model`: a frozen reference policy on the preprocessor's GPU.  When given, every real
         micro-batch gets its `ref_logprobs` from a no-grad forward of that model (K1 on its logits)
         before it is published - the device-side replacement of the reference's HTTP round trip to a
@@ -239,49 +458,64 @@ class PreprocessorLoop:
         self.device = device
         self.trainer_state = trainer_state
         self.ref_model = ref_model
+        self.oov_patcher = oov_patcher
+        published = 0
+        if trainer_state is not None and getattr(trainer_state, "samples_processed", None) is not None:
+            published = int(trainer_state.samples_processed)  # resume where the trainer is (:458)
         self.sched = MicroBatchScheduler(cfg.num_trainers, cfg.train_batch_size, cfg.gradient_accumulation_passes,
-                                         cfg.seq_length, seq_parallel=cfg.seq_parallel, length_of=lambda s: s.length)
+                                         cfg.seq_length, seq_parallel=cfg.seq_parallel, seq_packing=cfg.seq_packing,
+                                         published_samples=published, length_of=lambda s: s.length)
+        self.aggregator = SlidingWindowAggregator(window_size=max(10, 1000 // cfg.chunk_n_groups))
+        self.ring = ProcessedRing(cfg.ring_buffer_size, cfg.drops_old_data, self.aggregator)
+        self.sched.queue = self.ring.entries  # the scheduler consumes the head of the ring
+        self.buffer: deque = deque()
         self.in_spec = SingleStreamSpec(exp_path=cfg.exp_path, topic=cfg.input_topic)
         self.out_spec = StreamRangeSpec(exp_path=cfg.exp_path, topic=cfg.output_topic, partition_range=(0, max(cfg.num_trainers, 1)))
+        self.stats_spec = SingleStreamSpec(exp_path=cfg.exp_path, topic=cfg.stats_topic)
         self.chunks: dict[int, PreparedRollouts] = {}
         self._next_chunk = 0
         self.filtered_out = 0
-        self.max_model_version = 0
+        self.total_filtered_out = 0
+        self.last_published_samples = published
+        self.loader: ChunkLoader | None = None
+
+    @property
+    def max_model_version(self) -> int:
+        return self.ring.max_model_version or 0
 
     def _ingest(self, groups: list) -> None:
         """`groups`: stream records, each either a list of TrainingText dicts (the reference's text
         record) or a `RaggedRollouts` (binary record of the shm backend)."""
         if all(isinstance(g, RaggedRollouts) for g in groups):
             rag = concat_ragged(groups).to(self.device)
-            sizes = np.bincount(rag.host_group_index)
-            pairs = np.unique(np.stack([rag.host_group_index, rag.host_rollout_index]), axis=1)
-            if not (np.bincount(pairs[0], minlength=len(sizes)) == self.cfg.attempts).all():
-                raise ValueError("Group sizes are wrong")
-            prep = populate_rl_data_ragged(rag, self.cfg.eos_token_id, self.cfg.rl)
         else:
-            entries = [e for g in groups for e in g]
-            if not check_group_sizes(entries, self.cfg.attempts):
-                raise ValueError("Group sizes are wrong")
-            prep = preprocess_chunk(entries, self.cfg.eos_token_id, self.cfg.rl, self.device)
+            rag = RaggedRollouts.from_entries([e for g in groups for e in g]).to(self.device)
+        if self.oov_patcher is not None:
+            self.oov_patcher.apply(rag)
+        prep = populate_rl_data_ragged(rag, self.cfg.eos_token_id, self.cfg.rl)
         keep = np.ones(prep.rollouts.n_seqs, dtype=bool)
+        self.filtered_out = 0
         if self.cfg.rl.filter_zero_advantage_groups:
             keep = nonzero_advantage_mask(prep)
-            self.filtered_out += int((~keep).sum())
+            self.filtered_out = int((~keep).sum())
+            self.total_filtered_out += self.filtered_out
         cid = self._next_chunk
         self._next_chunk += 1
         self.chunks[cid] = prep
         lens = prep.rollouts.seq_lengths()
-        self.max_model_version = max(self.max_model_version, int(prep.rollouts.host_model_version.max()))
-        self.sched.push(_Sample(cid, i, int(lens[i])) for i in range(len(lens)) if keep[i])
+        versions = prep.rollouts.host_model_version
+        self.buffer.extend(_Sample(cid, i, int(lens[i]), int(versions[i])) for i in range(len(lens)) if keep[i])
 
     def _publish(self, writer) -> bool:
         """Drain the scheduler once and write what it emitted.  Returns batch_done."""
-        from .finetune.data import pack_prepared
+        from .finetune.data import pack_prepared, pad_prepared
         from .finetune.utils import create_sentinel_batch
 
+        sp = self.cfg.seq_parallel
         mbs, done = self.sched.drain()
         real = [mb for mb in mbs if not mb.sentinel]
-        packed = None
+        packed: Any = None
+        merged = base = None
         if real:
             used = sorted({s.chunk for mb in real for s in mb.samples})
             merged = concat_prepared([self.chunks[c] for c in used])
@@ -289,67 +523,86 @@ class PreprocessorLoop:
             for c in used:
                 base[c] = acc
                 acc += self.chunks[c].rollouts.n_seqs
-            packed = pack_prepared(merged, [[base[s.chunk] + s.index for s in mb.samples] for mb in real], self.cfg.eos_token_id)
+            if self.cfg.seq_packing:
+                # sequence-parallel filler: the packed length must divide by seq_parallel (data.py:222-230)
+                pads = [(-sum(s.length for s in mb.samples)) % sp for mb in real] if sp > 1 else None
+                packed = pack_prepared(merged, [[base[s.chunk] + s.index for s in mb.samples] for mb in real], self.cfg.eos_token_id,
+                                       sentinel_pad=pads)
         k = 0
         for mb in mbs:
             if mb.sentinel:
                 batch = create_sentinel_batch(None, tokenizer=type("T", (), {"eos_token_id": self.cfg.eos_token_id})(), model_version=self.max_model_version)
-            else:
+            elif self.cfg.seq_packing:
                 batch = packed[k]
                 k += 1
-                if self.ref_model is not None:
-                    from .finetune.rl import annotate_ref_logprobs
+            else:  # unpacked: fixed train_batch_size rows padded to a common length (reference `collate`, :639-648)
+                batch = pad_prepared(merged, [base[s.chunk] + s.index for s in mb.samples], padding_side=self.cfg.padding_side)
+            if not mb.sentinel and self.ref_model is not None:
+                from .finetune.rl import annotate_ref_logprobs
 
-                    annotate_ref_logprobs(self.ref_model, batch, self.cfg.rl.temperature)
-            slices = batch.make_slices(self.cfg.seq_parallel) if self.cfg.seq_parallel > 1 else [batch]
+                annotate_ref_logprobs(self.ref_model, batch, self.cfg.rl.temperature)
+            slices = batch.make_slices(sp) if sp > 1 else [batch]
             for off, piece in enumerate(slices):
                 writer.write(piece, partition=mb.trainer_id + off)
-        # chunks whose samples have all been scheduled can be dropped
-        alive = {s.chunk for s in self.sched.queue} | {s.chunk for s in self.sched._current}
+        # chunks whose samples have all been scheduled or dropped can go
+        alive = {s.chunk for s in self.ring.entries} | {s.chunk for s in self.sched._current} | {s.chunk for s in self.buffer}
         for c in [c for c in self.chunks if c not in alive]:
             del self.chunks[c]
         return done
 
+    def _maybe_write_stats(self, stats_writer, batch_done: bool, raw_queue_chunks: int) -> None:
+        pub = self.sched.published_samples
+        if not should_write_stats(pub, self.last_published_samples, self.cfg.debug_mode, batch_done, self.cfg.log_every_n_samples):
+            return
+        # there is no worker output queue here (K5 runs inline): its two gauges read 0
+        stats_writer.write(preprocessor_stats_record(pub, self.ring.max_model_version, raw_queue_chunks, 0, self.cfg.chunk_n_groups,
+                                                     self.cfg.attempts, self.filtered_out, self.total_filtered_out, self.aggregator))
+        self.last_published_samples = pub
+        self.filtered_out = 0
+
     def run(self, max_published_samples: int | None = None, idle_timeout: float = 5.0) -> int:
-        """Consume the actor stream until `max_published_samples` were published (or the stream stays
-        silent for `idle_timeout` seconds).  Returns the number of published samples."""
+        """Consume the actor stream until the trainer reports `samples_target` processed samples (the
+        reference's stop rule, :513-518), `max_published_samples` were published, or the stream stays
+        silent for `idle_timeout` seconds.  Returns the number of published samples."""
         import queue
         import threading
 
-        from .streams import read_stream, write_to_streams
+        from .streams import write_to_streams
 
-        groups_q: queue.Queue = queue.Queue()
-
-        def reader():
-            with read_stream(self.in_spec) as r:
-                for record in r.read():
-                    groups_q.put(record)
-
-        threading.Thread(target=reader, daemon=True).start()
-        pending: list[list[dict]] = []
+        cfg = self.cfg
+        raw_q: queue.Queue = queue.Queue(cfg.raw_queue_size)
+        self.loader = ChunkLoader(raw_q, self.in_spec, cfg.attempts, cfg.chunk_n_groups, cfg.drops_old_data)
+        threading.Thread(target=self.loader.run, name="preprocessor-loader", daemon=True).start()
         start = self.sched.published_samples
         last_data = time.time()
-        with write_to_streams(self.out_spec) as writer:
+        ts = self.trainer_state
+        with write_to_streams(self.out_spec) as writer, write_to_streams(self.stats_spec) as stats_writer:
             while max_published_samples is None or self.sched.published_samples - start < max_published_samples:
+                if cfg.samples_target is not None and ts is not None and ts.samples_processed is not None and ts.samples_processed >= cfg.samples_target:
+                    logger.info("Trainer signalled completion; stopping preprocessor loop")
+                    break
                 try:
-                    pending.append(groups_q.get(timeout=0.01))
+                    chunk = raw_q.get(timeout=0.01)
+                    if isinstance(chunk, Exception):
+                        raise chunk
+                    self._ingest(chunk)
                     last_data = time.time()
                 except queue.Empty:
-                    if time.time() - last_data > idle_timeout and not self.sched.queue:
+                    if time.time() - last_data > idle_timeout and not self.ring.entries and not self.buffer:
                         break
-                if len(pending) >= self.cfg.chunk_n_groups:
-                    self._ingest(pending)
-                    pending = []
-                ts = self.trainer_state
+                if len(self.buffer) < cfg.dataset_buffer_size:
+                    continue
+                self.ring.admit(self.buffer)
                 if ts is not None and ts.samples_processed is not None:
-                    limit = self.cfg.max_ready_samples_per_lead * self.cfg.num_trainers
-                    if self.sched.published_samples - ts.samples_processed > limit:
-                        continue
-                while self.sched.queue:
+                    if self.sched.published_samples - ts.samples_processed > cfg.max_ready_samples_per_lead * cfg.num_trainers:
+                        continue  # wait for the finetune loop to catch up
+                batch_done = False
+                while self.ring.entries and not batch_done:
                     before = self.sched.published_samples
-                    done = self._publish(writer)
-                    if self.sched.published_samples == before and not done:
+                    batch_done = self._publish(writer)
+                    if self.sched.published_samples == before and not batch_done:
                         break
                     if max_published_samples is not None and self.sched.published_samples - start >= max_published_samples:
                         break
+                self._maybe_write_stats(stats_writer, batch_done, raw_q.qsize())
         return self.sched.published_samples - start

@@ -310,3 +310,156 @@ def test_preprocessor_fills_ref_logprobs_from_a_model_on_its_gpu(libprl, cuda_de
         assert seen == 8
     finally:
         streams.reset_streams_backend()
+
+
+def _write_actor_groups(streams, tmp_path, raw, attempts, n_groups, binary):
+    from pipelinerl_amd.ragged import RaggedRollouts
+
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="actor")
+    with streams.write_to_streams(spec) as w:
+        for g in range(n_groups):
+            group = raw[g * attempts:(g + 1) * attempts]
+            w.write(RaggedRollouts.from_entries(group) if binary else group)
+
+
+def _collect(streams, tmp_path, topic, partition, n, timeout=20.0):
+    out = []
+
+    def run():
+        with streams.read_stream(streams.SingleStreamSpec(exp_path=tmp_path, topic=topic, partition=partition)) as r:
+            for rec in r.read():
+                out.append(rec)
+                if len(out) >= n:
+                    return
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(timeout)
+    return out
+
+
+def test_preprocessor_unpacked_mode_publishes_padded_batches(libprl, cuda_device, tmp_path):
+    """seq_packing = False: fixed train_batch_size rows per micro-batch through K7 (reference `collate`,
+    preprocess.py:639-648), equal to the oracle's collate of the same samples."""
+    from pipelinerl_amd import streams
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.preprocess import PreprocessorConfig, PreprocessorLoop
+    from pipelinerl_amd.synthetic import make_entries
+
+    streams.reset_streams_backend()
+    streams.set_streams_backend("shm")
+    try:
+        attempts = 4
+        raw = make_entries(4, attempts=attempts, seq_length=40, vocab=64, seed=5, prompt_min=3, prompt_max=8)
+        rl = RLConfig(divide_advantage_by_std=False)
+        cfg = PreprocessorConfig(exp_path=tmp_path, num_trainers=1, train_batch_size=4, gradient_accumulation_passes=2, seq_length=64,
+                                 attempts=attempts, rl=rl, eos_token_id=2, seq_packing=False, padding_side="left")
+        _write_actor_groups(streams, tmp_path, raw, attempts, 4, binary=True)
+        n = PreprocessorLoop(cfg, cuda_device).run(max_published_samples=16, idle_timeout=2.0)
+        assert n == 16
+        recs = _collect(streams, tmp_path, "training_data", 0, 4)
+        data = opre.preprocess_chunk(raw, 2, False)
+        for k, rec in enumerate(recs):
+            got = PipelineBatchEncoding(**rec)
+            want = opre.collate(data[k * 4:(k + 1) * 4], "left")
+            assert not got.is_packed and got.input_ids.shape == want["input_ids"].shape
+            for key in ("input_ids", "labels", "attention_mask", "rewards", "advantages", "old_logprobs", "group_tokens", "num_labels", "overflow"):
+                assert torch.equal(getattr(got, key).cpu(), torch.from_numpy(want[key])), key
+    finally:
+        streams.reset_streams_backend()
+
+
+def test_preprocessor_sequence_parallel_slices_and_counts(libprl, cuda_device, tmp_path):
+    """seq_parallel = 2: every packed micro-batch is padded with a filler sequence to an even length
+    (data.py:222-230), cut in two slices for trainers (lead, lead + 1), `padding` is carried, and the
+    trainer-side sequence count ignores the filler (finetune_loop.py:303-312)."""
+    from pipelinerl_amd import streams
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.finetune_loop import get_batch_sequence_count
+    from pipelinerl_amd.preprocess import PreprocessorConfig, PreprocessorLoop
+    from pipelinerl_amd.synthetic import make_entries
+
+    streams.reset_streams_backend()
+    streams.set_streams_backend("shm")
+    try:
+        attempts = 4
+        raw = make_entries(4, attempts=attempts, seq_length=31, vocab=64, seed=9, prompt_min=3, prompt_max=8)
+        cfg = PreprocessorConfig(exp_path=tmp_path, num_trainers=2, train_batch_size=1, gradient_accumulation_passes=8, seq_length=64,
+                                 attempts=attempts, rl=RLConfig(divide_advantage_by_std=False), eos_token_id=2, seq_parallel=2)
+        _write_actor_groups(streams, tmp_path, raw, attempts, 4, binary=False)
+        loop = PreprocessorLoop(cfg, cuda_device)
+        assert loop.run(max_published_samples=8, idle_timeout=2.0) >= 8
+        a = _collect(streams, tmp_path, "training_data", 0, 3)
+        b = _collect(streams, tmp_path, "training_data", 1, 3)
+        assert len(a) == len(b) == 3
+        total_seqs = 0
+        for ra, rb in zip(a, b):
+            sa, sb = PipelineBatchEncoding(**ra), PipelineBatchEncoding(**rb)
+            assert sa.input_ids.shape == sb.input_ids.shape and sa.padding == sb.padding
+            full = torch.cat([sa.input_ids, sb.input_ids], dim=1)
+            assert full.shape[1] % 2 == 0
+            if sa.padding:
+                assert (torch.cat([sa.labels, sb.labels], dim=1)[0, -sa.padding:] == -100).all()
+            starts = int((torch.cat([sa.position_ids, sb.position_ids], dim=1) == 0).sum())  # sequences incl. the filler
+            assert get_batch_sequence_count(sa) == get_batch_sequence_count(sb) == starts - (1 if sa.padding else 0)
+            total_seqs += get_batch_sequence_count(sa)
+        assert 3 <= total_seqs <= loop.sched.published_samples
+    finally:
+        streams.reset_streams_backend()
+
+
+def test_preprocessor_drops_old_samples_and_reports_stats(libprl, cuda_device, tmp_path):
+    """A ring of 6 samples fed with 24: with `pop_old_data` the oldest are dropped before they are
+    scheduled (reference :572-585), the newest survive, and `preprocessor_stats` records are written."""
+    from pipelinerl_amd import streams
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.preprocess import PreprocessorConfig, PreprocessorLoop
+    from pipelinerl_amd.state import TrainerState
+    from pipelinerl_amd.synthetic import make_entries
+
+    streams.reset_streams_backend()
+    streams.set_streams_backend("shm")
+    try:
+        attempts = 4
+        raw = make_entries(6, attempts=attempts, seq_length=40, vocab=64, seed=11, prompt_min=3, prompt_max=8)
+        cfg = PreprocessorConfig(exp_path=tmp_path, num_trainers=1, train_batch_size=1, gradient_accumulation_passes=4, seq_length=200,
+                                 attempts=attempts, rl=RLConfig(divide_advantage_by_std=False), eos_token_id=2, chunk_n_groups=6,
+                                 ring_buffer_size=6, log_every_n_samples=1)
+        _write_actor_groups(streams, tmp_path, raw, attempts, 6, binary=True)
+        loop = PreprocessorLoop(cfg, cuda_device)
+        n = loop.run(max_published_samples=4, idle_timeout=2.0)
+        assert loop.ring.popped == 24 - 6 and n == 4  # one chunk of 24 samples through a ring of 6
+        recs = _collect(streams, tmp_path, "training_data", 0, 1)
+        first = PipelineBatchEncoding(**recs[0])
+        # the first published sample is sample 18 of the chunk: the 18 older ones were dropped
+        want_ids = raw[18]["input_ids"]
+        assert first.input_ids[0, :len(want_ids)].tolist() == want_ids
+        stats = _collect(streams, tmp_path, "preprocessor_stats", 0, 1)
+        assert stats and stats[0]["preprocessor/published_samples"] >= 4 and "preprocessor/queue/raw" in stats[0]
+    finally:
+        streams.reset_streams_backend()
+
+
+def test_oov_patch_kernel_matches_the_reference(libprl, cuda_device):
+    import json
+
+    from helpers import GOLDEN
+    from pipelinerl_amd.preprocess import OovPatcher
+    from pipelinerl_amd.ragged import RaggedRollouts
+
+    g = json.loads((GOLDEN / "preprocess_loop.json").read_text())["oov"]
+    entries = [{"input_ids": e["input_ids"], "labels": e["labels"], "logprobs": e["logprobs"], "reward": 0.0, "group_id": "g", "finished": True,
+                "metadata": {"model_version": 0, "rollout_index": i, "step_index": 0}} for i, e in enumerate(g["data"])]
+    rag = RaggedRollouts.from_entries(entries).to(cuda_device)
+    patcher = OovPatcher(g["vocab_ids"], g["the_token_id"], cuda_device)
+    patcher.apply(rag)
+    toks = rag.tokens.cpu().tolist()
+    off = rag.host_seq_off
+    assert [toks[off[i]:off[i + 1]] for i in range(len(entries))] == g["patched_input_ids"]
+    labs = rag.labels.cpu().tolist()
+    assert [labs[off[i]:off[i + 1]] for i in range(len(entries))] == g["labels_after"]
+    n_bad = sum(a != b for e, p in zip(g["data"], g["patched_input_ids"]) for a, b in zip(e["input_ids"], p))
+    assert int(patcher.count.item()) == n_bad
