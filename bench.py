@@ -11,10 +11,13 @@ One "step" = one optimizer step's worth of the post-model hot path for the BASEL
     per micro-batch (8192 tokens, V = 152 064 fp32 logits resident in HBM):
         fused K1 + token gradient + K1 backward  (d loss / d logits written to a second buffer)
     K2+K3  ONE loss + 32-stat launch over all tokens of the step
-    one all-gather of the stats vector across ranks (N > 1)
+    N > 1: one all-gather of the stats vector across ranks AND the data-parallel gradient all-reduce of a
+    7B learner (15.2 GB of bf16 gradients in 1 GiB buckets over RCCL) - without it the sharded path has no
+    exchange step and a scaling figure says nothing about a DP learner
 
-The transformer forward/backward itself is outside the path (stock PyTorch-ROCm).
-Scaling is STRONG: the global batch of 4096 sequences is fixed and sharded across ranks.
+The transformer forward/backward itself is outside the path (stock PyTorch-ROCm); the line
+carries `e2e` (a model-in-the-loop step measured separately) so that `value` is not read as end-to-end
+learner throughput.  Scaling is STRONG: the global batch of 4096 sequences is fixed and sharded across ranks.
 Rank 0 prints ONE JSON line.
 """
 
@@ -34,6 +37,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, same guide (AMD's 5 PF figure includes 2:1 sparsity)
 
 WORKLOADS = {
     # name: (global batch, seq_length, vocab, attempts)
@@ -52,6 +56,11 @@ def parse_args():
     p.add_argument("--logits-mode", default=os.environ.get("PRL_BENCH_LOGITS_MODE", "fused"), choices=["fused", "two_pass"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-weight-sync", action="store_true")
+    p.add_argument("--no-fused-head", action="store_true", help="skip the MFMA fused-head measurement (roofline_mfma)")
+    p.add_argument("--no-grad-allreduce", action="store_true", help="N > 1: leave the gradient-sized all-reduce out of the step")
+    p.add_argument("--grad-bytes", type=int, default=int(os.environ.get("PRL_BENCH_GRAD_BYTES", 15_231_233_024)),
+                   help="N > 1: bytes of data-parallel gradients all-reduced per step (default: Qwen2.5-7B in bf16)")
+    p.add_argument("--e2e", action="store_true", help="N = 1: also run scripts/e2e_learner_bench.py (7B shape, fused head) live instead of quoting profiles/")
     p.add_argument("--cpu-baseline-threads", default=None,
                    help="comma-separated thread counts: time ONLY the cpu_baseline loss leg at each count and exit (no GPU work)")
     p.add_argument("--backend", default=os.environ.get("PRL_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
@@ -183,7 +192,87 @@ def cpu_baseline(seq_length: int, vocab: int) -> dict:
         "scalar_port": {"value": 1.0 / (t_pre + t_np_tok * seq_length), "cores": 1,
                         "sample": f"same path, single-thread numpy on {t_np} tokens ({t_np_tok * 1e6:.0f} us/token)"},
         "host": {"nproc": os.cpu_count(), "cgroup_cpu_quota": cores},
+        "reference_autograd": _committed_json("profiles/r02_reference_autograd_cpu.json",
+                                              note="the reference's own rl_step + autograd backward, measured ONCE in the build container "
+                                                   "(the GPU box has no /root/reference); a stated constant, not re-measured here"),
     }
+
+
+def _committed_json(rel: str, note: str) -> dict | None:
+    """A measurement committed under profiles/ by an earlier, separate run: quoted with its source."""
+    f = ROOT / rel
+    if not f.exists():
+        return None
+    try:
+        d = json.loads(f.read_text().splitlines()[0])
+    except Exception:  # noqa: BLE001
+        return None
+    d["source"] = rel
+    d["note"] = note
+    return d
+
+
+def fused_head_probe(dev: torch.device, seq_length: int, vocab: int, hidden: int) -> dict:
+    """The MFMA-bound part of the path: hidden states -> new_logprobs / entropy and back, logits
+    never written.  One micro-batch of `seq_length` tokens; HIP events on torch's current stream (where the
+    kernels are launched).  flops counted as executed bf16 MFMA work: every plane product of the 2-term split."""
+    from pipelinerl_amd.finetune.rl import RLConfig, grpo_loss_from_logprobs, make_loss_config
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.fused_head import FusedLmHead
+
+    T, H, V = seq_length, hidden, vocab
+    g = torch.Generator(device=dev).manual_seed(5)
+    h = torch.empty(1, T, H, device=dev).normal_(generator=g).to(torch.bfloat16)
+    W = torch.empty(V, H, device=dev).normal_(0.0, 0.02, generator=g)
+    ids = torch.randint(3, V, (1, T), device=dev, generator=g)
+    labels = ids.clone()
+    labels[:, : T // 16] = -100
+    old = -torch.empty(1, T, device=dev).normal_(generator=g).abs() * 0.7
+    z = torch.zeros(1, T, device=dev)
+    batch = PipelineBatchEncoding(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids), position_ids=torch.arange(T, device=dev)[None],
+                                  old_logprobs=old, ref_logprobs=old.clone(), advantages=torch.empty(1, T, device=dev).normal_(generator=g), rewards=z.clone(),
+                                  group_tokens=torch.full((1, T), 5000.0, device=dev), num_labels=torch.full((1, T), float(T - T // 16), device=dev),
+                                  overflow=z.clone(), model_version=0, is_packed=True)
+    cfg, _, _ = make_loss_config(RLConfig(policy_loss="ppo", epsilon_low=0.02, epsilon_high=0.02, kl_coef=0.0, final_kl_coef=0.0, batch_size=4096,
+                                          clamp_log_ratio_ref_new_value=5, divide_advantage_by_std=False), 0, 10)
+    head = FusedLmHead(W)
+    head.refresh()
+
+    def timed(fn, iters):
+        fn()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    fwd_ms = timed(lambda: head.logprob_entropy(h, ids, 1.0), 5)
+    nlp, ent, lse2, hb = head.logprob_entropy(h, ids, 1.0)
+    _, _, g_nlp, _ = grpo_loss_from_logprobs(cfg, batch, nlp, ent)
+    gw = torch.zeros(V, H, device=dev)
+    bwd_ms = timed(lambda: head.backward_from_token_grads(hb, ids, 1.0, lse2, ent, g_nlp, None, None, grad_weight=gw), 2)
+    gemm = 2.0 * T * V * H
+    fwd_tf = 2 * gemm / (fwd_ms * 1e-3) / 1e12
+    del gw, head, W
+    torch.cuda.empty_cache()
+    return {
+        "bound": "mfma", "kernel": "lmhead_fwd_kernel<256x256x64, 8 waves, v_mfma_f32_32x32x16_bf16>", "achieved": fwd_tf, "peak": MFMA_BF16_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": fwd_tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+        "flops_per_launch": 2 * gemm, "ms_per_launch": fwd_ms,
+        "config": {"tokens": T, "hidden": H, "vocab": V, "weight": "fp32 as two bf16 planes (fp32-GEMM accuracy)", "logits_materialised_bytes": 0},
+        "backward": {"ms": bwd_ms, "executed_tflops": 7 * gemm / (bwd_ms * 1e-3) / 1e12, "chunk_rows": head_chunk_rows(),
+                     "what": "recompute (2 products) + d hidden (3) + d W (2), d logits as bf16 planes of one row chunk"},
+        "fp32_equivalent_tflops": gemm / (fwd_ms * 1e-3) / 1e12,
+        "note": "second roofline object for the MFMA-bound fused output head (hidden -> log-prob/entropy, logits never in HBM); "
+                "`roofline` above stays the HBM-bound kernel that dominates `value`",
+    }
+
+
+def head_chunk_rows() -> int:
+    return 4096
 
 
 def weight_sync_probe(rank: int, world: int, dev: torch.device, out: dict) -> dict:
@@ -358,12 +447,19 @@ def main():
     torch.cuda.synchronize()
 
     timer = EventTimer()
+    grad_buckets = []
+    if world > 1 and not args.no_grad_allreduce and args.backend == "nccl":
+        left = args.grad_bytes
+        while left > 0:
+            n = min(left, 1 << 30)
+            grad_buckets.append(torch.zeros(n // 2, dtype=torch.bfloat16, device=dev))
+            left -= n
 
     def one_step(timed: bool):
         step = HotPathStep(cfg, eos_token_id=2, current_step=0, max_step=10)
         if timed:
-            with timer.time("preprocess_K5_K6"):
-                step.preprocess(rag, micro_batches)
+            with timer.time("preprocess_K5_K6"):  # incl. the host planning (numpy plan + three small uploads)
+                step.preprocess(rag, micro_batches, timer=timer)  # + event pairs around K5 and the K6 kernel alone
         else:
             step.preprocess(rag, micro_batches)
         for j in range(n_seq):
@@ -380,6 +476,14 @@ def main():
                 loss, stats = step.finish()
         else:
             loss, stats = step.finish()
+        if grad_buckets:  # the DP learner's exchange step: all-reduce of the gradients, bucket by bucket
+            ctx = timer.time("grad_allreduce") if timed else None
+            if ctx:
+                ctx.__enter__()
+            for gb in grad_buckets:
+                dist.all_reduce(gb)
+            if ctx:
+                ctx.__exit__(None, None, None)
         return loss, stats
 
     def barrier():
@@ -411,6 +515,8 @@ def main():
         "fused_logits_loss": seq_length * (2 * V4 + 56),          # logits read once + d logits written once
         "grpo_loss_step": tokens_per_rank * 52,                   # 56 B/token minus the unwritten 4 B gradient
         "preprocess_K5_K6": tokens_per_rank * (84 + 8),           # K6 16 B read + 68 B written; K5 scan 8 B read
+        "pack_collate_kernel": tokens_per_rank * 84,              # the K6 kernel alone
+        "group_advantages_K5": tokens_per_rank * 8,               # the K5 scan (+ O(S) group arithmetic)
     }
     for name, k in kernels.items():
         if name in algo:
@@ -419,11 +525,14 @@ def main():
             k["hbm_frac"] = k["GBps"] / HBM_PEAK_GBS
     dom = "fused_logits_loss" if "fused_logits_loss" in kernels else max(kernels, key=lambda n: kernels[n]["avg_us"] * kernels[n]["launches"])
     traffic = None
+    traffic_source = None
     pmc = ROOT / "profiles" / "pmc_traffic.json"
     if pmc.exists() and (seq_length, vocab) == (8192, 152064):  # the PMC passes were taken at this shape
         try:
             table = json.loads(pmc.read_text())
             traffic = table.get(dom, {}).get("hbm_bytes_per_launch")
+            traffic_source = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round 1, committed; "
+                              "NOT measured in this run)")
             # per-token PMC figures of the two step-scale kernels, scaled to this launch
             if "grpo_loss_step" in kernels and "hbm_bytes_per_token" in table.get("grpo_loss_step", {}):
                 kernels["grpo_loss_step"]["traffic"] = table["grpo_loss_step"]["hbm_bytes_per_token"] * tokens_per_rank
@@ -433,10 +542,44 @@ def main():
             traffic = None
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": kernels[dom]["hbm_frac"], "traffic": traffic,
+        "frac": kernels[dom]["hbm_frac"], "traffic": traffic, "traffic_source": traffic_source,
     }
+    if grad_buckets and "grad_allreduce" in kernels:
+        k = kernels["grad_allreduce"]
+        k["bytes"] = sum(b.numel() * 2 for b in grad_buckets)
+        k["busbw_GBps"] = 2 * (world - 1) / world * k["bytes"] / (k["avg_us"] * 1e-6) / 1e9
 
     cpu_base = None if (args.no_cpu_baseline or world != 1) else cpu_baseline(seq_length, vocab)
+
+    # ---- secondary objects (never part of `value`) ----
+    hidden = {152064: 3584, 151936: 896}.get(vocab, 256)
+    roofline_mfma = None
+    if world == 1 and not args.no_fused_head:
+        try:
+            del logits, grad_logits
+            torch.cuda.empty_cache()
+            roofline_mfma = fused_head_probe(dev, seq_length, vocab, hidden)
+        except Exception as e:  # noqa: BLE001 - must never take the benchmark line down
+            roofline_mfma = {"error": f"{type(e).__name__}: {e}"}
+        logits = grad_logits = None
+    e2e = None
+    if world == 1 and args.workload.startswith("7b"):
+        if args.e2e:
+            import subprocess
+
+            out = ROOT / "gpurun_out" / "bench_e2e_7b.json"
+            out.parent.mkdir(exist_ok=True)
+            r = subprocess.run([sys.executable, str(ROOT / "scripts" / "e2e_learner_bench.py"), "--model", "7b", "--batch-size", "16", "--seq-len", "8192",
+                                "--micro-batch", "1", "--fused", "--fused-head", "--steps", "1", "--warmup", "1", "--out", str(out)],
+                               capture_output=True, text=True, timeout=900)
+            e2e = json.loads(out.read_text()) if r.returncode == 0 and out.exists() else {"error": (r.stderr or r.stdout)[-400:]}
+            if "error" not in e2e:
+                e2e["source"] = "measured in this run (scripts/e2e_learner_bench.py)"
+        else:
+            e2e = _committed_json("profiles/r02_e2e_learner_7b_fused_head.json",
+                                  note="MODEL-IN-THE-LOOP step (random-init Qwen2.5-7B shape, stock PyTorch-ROCm forward/backward + AdamW on ONE MI355X, "
+                                       "bs 16 x 8192) measured separately with scripts/e2e_learner_bench.py and committed; `value` above is the post-model "
+                                       "hot path on resident logits, NOT learner throughput")
 
     label = {"7b_grpo_bs4096_seq8192": "7B GRPO bs=4096", "0p5b_grpo_bs512_seq2048": "0.5B GRPO bs=512 seq=2048"}.get(args.workload, args.workload)
 
@@ -459,9 +602,12 @@ def main():
             "config": {"workload": args.workload, "global_batch": bs, "seq_len": seq_length, "vocab": vocab,
                        "tokens_per_step": bs * seq_length, "parallelism": f"dp{world}", "logits_mode": args.logits_mode,
                        "policy_loss": "ppo", "kl_coef": 0.0, "old_logprob_sigma": sigma,
+                       "grad_allreduce_bytes_per_step": sum(b.numel() * 2 for b in grad_buckets) if grad_buckets else 0,
                        "h2d_ragged_input": {"bytes": h2d_bytes, "ms": 1e3 * t_h2d, "ms_pinned": 1e3 * t_h2d_pinned,
                                             "note": "one step's ragged rollouts, pageable vs page-locked host memory; not part of value"}},
             "roofline": roofline,
+            "roofline_mfma": roofline_mfma,
+            "e2e": e2e,
             "kernels": kernels,
             "cpu_baseline": cpu_base,
             "weight_sync": wsync,
@@ -475,7 +621,7 @@ def main():
     if world == 1 and not args.no_weight_sync and os.environ.get("PRL_BENCH_WSYNC", "1") != "0":
         # one GPU: the only trainer -> actor layout is colocated; hand the 7B / 0.5B parameter set to a
         # second process on this GPU over HIP IPC (request-to-ack of send_weight_update, median of 5)
-        del logits, grad_logits
+        logits = grad_logits = None
         torch.cuda.empty_cache()
         try:
             from pipelinerl_amd.weight_sync_probe import colocated_probe

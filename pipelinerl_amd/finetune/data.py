@@ -13,6 +13,8 @@ Two levels:
 
 from __future__ import annotations
 
+import contextlib
+
 import logging
 from typing import Any, Iterable, Sequence
 
@@ -132,6 +134,7 @@ def pack_prepared(
     eos_token_id: int,
     sentinel_pad: Sequence[int] | None = None,
     per_token_columns: int = 0,
+    timer: Any = None,
 ) -> PackedStep:
     """Pack `micro_batches[j]` (lists of sequence indices into `prep`) into packed batches with a
     single K6 launch.  `sentinel_pad[j]` > 0 appends that many filler tokens to micro-batch j
@@ -149,7 +152,9 @@ def pack_prepared(
     d_dst = torch.from_numpy(pk_dst).to(dev, non_blocking=True)
     d_seg = torch.from_numpy(pk_seg).to(dev, non_blocking=True)
     if m and total:
-        with torch.cuda.device(dev):
+        # `timer` (bench.py's EventTimer): HIP events around the kernel alone, so that the host planning
+        # above (O(#sequences) numpy + three small uploads) is not charged to the kernel's bandwidth
+        with torch.cuda.device(dev), (timer.time("pack_collate_kernel") if timer is not None else contextlib.nullcontext()):
             _lib.check(
                 lib.prl_pack_collate(
                     m, total, _lib.ptr(d_src), _lib.ptr(d_dst), _lib.ptr(d_seg), _lib.ptr(r.tokens),

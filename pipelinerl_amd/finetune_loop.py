@@ -169,6 +169,123 @@ def batch_generator(batch_queue: Queue, stop: threading.Event | None = None):
 
 
 # ---------------------------------------------------------------------------------------------
+# where the trainer's FULL parameters come from (reference :205-268)
+# ---------------------------------------------------------------------------------------------
+
+
+class ParameterSource:
+    """Full (unsharded) parameters of the trained model for a weight update.
+
+    `describe()` - names, FULL shapes and dtypes, computable on every rank without communication;
+    `fetch(specs)` - context manager giving {name: full tensor} for the listed parameters on the main rank.
+    For sharded trainers entering it is a COLLECTIVE: every trainer rank calls `fetch` with the same
+    lists in the same order (`WeightUpdateManager.send_weight_update` does that)."""
+
+    def describe(self) -> list[tuple[str, tuple[int, ...], torch.dtype]]:
+        raise NotImplementedError
+
+    def fetch(self, specs: list) -> Any:
+        raise NotImplementedError
+
+
+class PlainParameters(ParameterSource):
+    """DDP / single GPU: the unwrapped module's `named_parameters()` (reference :263-265)."""
+
+    def __init__(self, model: Any, named_parameters_fn: Callable | None = None):
+        self._fn = named_parameters_fn or (lambda: _unwrap(model).named_parameters())
+
+    def _params(self) -> dict[str, torch.Tensor]:
+        return {n: p.detach() for n, p in self._fn()}
+
+    def describe(self):
+        return [(n, tuple(p.shape), p.dtype) for n, p in self._params().items()]
+
+    @contextlib.contextmanager
+    def fetch(self, specs):
+        params = self._params()
+        yield {sp.name: params[sp.name] for sp in specs}
+
+
+class Zero3Parameters(ParameterSource):
+    """DeepSpeed ZeRO stage 3: every parameter is partitioned over the trainer ranks; its full shape is
+    `parameter.ds_shape` and `deepspeed.zero.GatheredParameters` materialises it (reference :209-238, one
+    parameter at a time).  Here a whole BUCKET of parameters is gathered at once: 15 collectives for
+    Qwen2.5-7B instead of 339.  `gathered` is injectable so the protocol can be exercised without
+    DeepSpeed (tests/test_distributed_cpu.py)."""
+
+    def __init__(self, engine: Any, gathered: Callable | None = None):
+        module = engine.module if hasattr(engine, "module") else engine
+        module = getattr(module, "pretrained_model", module)  # value-head wrapper: only the policy travels (:217-221)
+        self._named = dict(module.named_parameters())
+        if gathered is None:
+            import deepspeed  # noqa: PLC0415 - optional dependency
+
+            gathered = deepspeed.zero.GatheredParameters
+        self._gathered = gathered
+
+    def describe(self):
+        return [(n, tuple(getattr(p, "ds_shape", p.shape)), p.dtype) for n, p in self._named.items()]
+
+    @contextlib.contextmanager
+    def fetch(self, specs):
+        params = [self._named[sp.name] for sp in specs]
+        with self._gathered(params):
+            yield {sp.name: p.data for sp, p in zip(specs, params)}
+
+
+class FsdpParameters(ParameterSource):
+    """torch FSDP: the FULL_STATE_DICT gathered to rank 0 (reference :250-262).  A tied `lm_head.weight`
+    shows up in the state dict although it is not a parameter of its own; it is dropped like the
+    reference does (:258-262) so that the receiver does not load the embedding twice."""
+
+    def __init__(self, model: Any, state_dict_fn: Callable | None = None):
+        self.model = model
+        self._state_dict_fn = state_dict_fn
+        self._cache: dict[str, torch.Tensor] | None = None
+
+    def _full_state(self) -> dict[str, torch.Tensor]:
+        if self._state_dict_fn is not None:
+            sd = dict(self._state_dict_fn())
+        else:
+            from torch.distributed.fsdp import FullStateDictConfig, FullyShardedDataParallel as FSDP, StateDictType
+
+            with FSDP.state_dict_type(self.model, StateDictType.FULL_STATE_DICT, FullStateDictConfig(offload_to_cpu=False, rank0_only=True)):
+                sd = dict(self.model.state_dict())
+        if "lm_head.weight" in sd:
+            logger.info("Removing lm_head.weight from gathered parameters, because it's not a parameter.")
+            del sd["lm_head.weight"]
+        return sd
+
+    def gather(self) -> None:
+        """Collective: every trainer rank calls it once per update; rank 0 keeps the result until `release`."""
+        self._cache = self._full_state()
+
+    def release(self) -> None:
+        self._cache = None
+
+    def describe(self):
+        if self._cache is None:
+            self.gather()
+        return [(n, tuple(t.shape), t.dtype) for n, t in self._cache.items()]
+
+    @contextlib.contextmanager
+    def fetch(self, specs):
+        yield {sp.name: self._cache[sp.name] for sp in specs}
+
+
+def parameter_source_for(model: Any, named_parameters_fn: Callable | None = None) -> ParameterSource:
+    """The reference's dispatch (:209-212, :250): DeepSpeed engine at ZeRO stage 3, FSDP, or plain."""
+    if named_parameters_fn is not None:
+        return PlainParameters(model, named_parameters_fn)
+    stage = getattr(model, "zero_optimization_stage", None)
+    if callable(stage) and stage() == 3:
+        return Zero3Parameters(model)
+    if type(model).__name__ == "FullyShardedDataParallel":
+        return FsdpParameters(model)
+    return PlainParameters(model)
+
+
+# ---------------------------------------------------------------------------------------------
 # weight updates, send side (reference :174-292)
 # ---------------------------------------------------------------------------------------------
 
@@ -184,13 +301,14 @@ class WeightUpdateManager:
 
     def __init__(self, llm_urls: list[str], accelerated_model: Any, update_stream: SingleStreamSpec | None,
                  actor_update_group: Any, is_main_process: bool = True, named_parameters_fn: Callable | None = None,
-                 transport: str = "bucketed", bucket_bytes: int = 1 << 30, post: Callable | None = None):
+                 transport: str = "bucketed", bucket_bytes: int = 1 << 30, post: Callable | None = None,
+                 parameter_source: ParameterSource | None = None):
         self.llm_urls = llm_urls
         self.accelerated_model = accelerated_model
         self.update_stream = update_stream
         self.actor_update_group = actor_update_group
         self.is_main_process = is_main_process
-        self.named_parameters_fn = named_parameters_fn or (lambda: _unwrap(accelerated_model).named_parameters())
+        self.source = parameter_source or parameter_source_for(accelerated_model, named_parameters_fn)
         self.transport = transport
         self.bucket_bytes = bucket_bytes
         self.thread_pool = ThreadPoolExecutor(max_workers=max(1, len(llm_urls)))
@@ -213,31 +331,51 @@ class WeightUpdateManager:
             self._shutdown = True
 
     def send_weight_update(self, version: int) -> None:
-        """Blocking; every trainer rank calls it, rank 0 sends."""
-        if self.is_main_process:
-            from .weight_sync import BucketedSender
+        """Blocking; every trainer rank calls it (gathering sharded parameters is a collective among
+        them), rank 0 sends."""
+        from .weight_sync import BucketedSender, ParamSpec, bucket_nbytes, plan_buckets
 
-            params = [(n, p.detach()) for n, p in self.named_parameters_fn()]
-            info = [ParameterInfo(name=n, shape=list(p.shape), dtype=str(p.dtype)) for n, p in params]
+        src = self.source
+        if isinstance(src, FsdpParameters):
+            src.gather()  # collective: FULL_STATE_DICT to rank 0
+        described = src.describe()
+        specs = [ParamSpec(n, tuple(shape), dt) for n, shape, dt in described]
+        futures = []
+        if self.is_main_process:
+            info = [ParameterInfo(name=sp.name, shape=list(sp.shape), dtype=str(sp.dtype)) for sp in specs]
             message = WeightUpdateRequest(version=version, parameters_info=info, transport=self.transport, bucket_bytes=self.bucket_bytes)
             if self.transport == "ipc":
                 # colocated: fill the exported buckets first, the request then carries their handles
                 from .weight_sync import ColocatedSender
 
-                if self._sender is None:
-                    self._sender = ColocatedSender(params[0][1].device, self.bucket_bytes)
-                desc = self._sender.publish(params)
+                with src.fetch(specs) as tensors:
+                    params = [(sp.name, tensors[sp.name]) for sp in specs]
+                    if self._sender is None:
+                        self._sender = ColocatedSender(params[0][1].device, self.bucket_bytes)
+                    desc = self._sender.publish(params)
                 message.ipc_handles, message.ipc_nbytes = desc["ipc_handles"], desc["ipc_nbytes"]
             futures = self.request_weight_updates(message)
-            if self.transport == "ipc":
-                pass  # the POST returns when the worker has copied the buckets
-            elif self.transport == "bucketed":
+        if self.transport == "ipc":
+            pass  # the POST returns when the worker has copied the buckets
+        elif self.transport == "bucketed":
+            if self.is_main_process:
                 if self._sender is None:
                     self._sender = BucketedSender(self.actor_update_group, self.bucket_bytes)
-                self._sender.send(params)
-            else:  # the reference's one-broadcast-per-parameter protocol
-                for _, p in params:
-                    self.actor_update_group.broadcast(p.data, src=0)
+                self._sender.send_streamed(specs, src.fetch)
+            elif not isinstance(src, PlainParameters):
+                # the other trainer ranks take part in the same gathers, bucket by bucket
+                for bucket in plan_buckets(specs, self.bucket_bytes):
+                    with src.fetch([sp for sp, _ in bucket]):
+                        pass
+        else:  # the reference's one-broadcast-per-parameter protocol (:230-238, :276-282)
+            for sp in specs:
+                if self.is_main_process or not isinstance(src, PlainParameters):
+                    with src.fetch([sp]) as tensors:
+                        if self.is_main_process:
+                            self.actor_update_group.broadcast(tensors[sp.name].data, src=0)
+        if isinstance(src, FsdpParameters):
+            src.release()
+        if self.is_main_process:
             for f in futures:
                 f.result()
             if self.update_stream is not None:
@@ -473,35 +611,102 @@ class NativeLearnerStep:
 
     No host synchronisation happens inside the step; `step()` returns device tensors and only
     `stats_dict()` copies 256 bytes to the host.  Numerically identical to running the drop-in
-    `rl_step` per micro-batch and summing (tests/test_gpu_pipeline.py)."""
+    `rl_step` per micro-batch and summing (tests/test_gpu_pipeline.py).
+
+    The `step()` contract of the reference loop (finetune_loop.py:647-957) is kept at STEP granularity:
+
+      * sample accounting (:627-646, :698-713): every rank passes its share of the step; ONE all-gather
+        of (micro-batches, samples) per step checks that the shares add up to `samples_per_step` and
+        tells every rank the largest micro-batch count - ranks with fewer run sentinel micro-batches
+        (zero loss, full forward/backward) so that sharded trainers, whose every forward/backward is
+        a collective, stay in lock-step (:599-607, :784-786).  The reference does this with an
+        all_gather per MICRO-batch (:709);
+      * `SamplesProcessed` is published once per step (:805-808 publishes per micro-batch);
+      * `maybe_send_weights()` applies the weight_update_interval rule after the optimizer step (:936-949);
+      * resume: pass the `TrainingMetrics` restored from a checkpoint - samples, completed steps and the
+        last broadcast version continue from there (:618-626)."""
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, rl_config: RLConfig, eos_token_id: int,
                  samples_per_step: int, max_train_steps: int, lr_scheduler: Any = None,
                  gradient_clipping_threshold: float | None = None, process_group: Any = None,
-                 ref_model: torch.nn.Module | None = None):
+                 ref_model: torch.nn.Module | None = None, training_metrics: TrainingMetrics | None = None,
+                 weight_update_manager: WeightUpdateManager | None = None, weight_update_interval: int = 1,
+                 send_weight_updates: bool = True, trainer_stream: SingleStreamSpec | None = None,
+                 equalize_micro_batches: bool = True):
         """`ref_model`: a frozen reference policy on this GPU.  When given, the KL-to-reference term
         uses ITS log-probabilities, computed per micro-batch right before the policy forward (SURVEY
-        §8f-3: replaces the HTTP round trip to a second inference server for KL-enabled configs)."""
+        §8f-3: replaces the HTTP round trip to a second inference server for KL-enabled configs).
+        `samples_per_step`: the GLOBAL number of samples per optimizer step (the loss normaliser).
+        `equalize_micro_batches`: pad with sentinel micro-batches up to the largest count over the ranks
+        (needed by ZeRO / FSDP; plain DDP only needs every rank to run at least one)."""
+        import torch.distributed as dist
+
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
         self.ref_model = ref_model
         self.rl_config = rl_config.model_copy()
         self.rl_config.batch_size = samples_per_step
+        self.samples_per_step = samples_per_step
         self.eos_token_id = eos_token_id
         self.max_train_steps = max_train_steps
         self.gradient_clipping_threshold = gradient_clipping_threshold
         self.group = process_group
-        self.metrics = TrainingMetrics()
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self.rank = dist.get_rank(process_group) if self.distributed else 0
+        self.metrics = training_metrics or TrainingMetrics()
+        self.weight_update_manager = weight_update_manager
+        self.weight_update_interval = weight_update_interval
+        self.send_weight_updates = send_weight_updates
+        self.equalize = equalize_micro_batches
         self._last = None
+        self._writer_cm = self._writer = None
+        if trainer_stream is not None and self.rank == 0:
+            self._writer_cm = write_to_streams(trainer_stream)
+            self._writer = self._writer_cm.__enter__()
+
+    def publish(self, message: BaseModel) -> None:
+        if self._writer is not None:
+            self._writer.write(message)
+
+    def _share_counts(self, n_micro_batches: int, n_samples: int, device) -> tuple[int, int]:
+        """(largest micro-batch count over the ranks, total samples) - one all-gather of two integers."""
+        if not self.distributed or self.world == 1:
+            return n_micro_batches, n_samples
+        import torch.distributed as dist
+
+        gloo = dist.get_backend(self.group) == "gloo"
+        mine = torch.tensor([n_micro_batches, n_samples], dtype=torch.int64, device="cpu" if gloo else device)
+        everyone = torch.empty((self.world, 2), dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(everyone, mine.unsqueeze(0), group=self.group)
+        everyone = everyone.cpu()
+        return int(everyone[:, 0].max()), int(everyone[:, 1].sum())
+
+    def _sentinel_pass(self, device) -> None:
+        """One zero-loss forward/backward (finetune_loop.py:784-786) so this rank takes part in the collectives."""
+        from .finetune.utils import create_sentinel_batch
+
+        b = create_sentinel_batch(device, tokenizer=type("T", (), {"eos_token_id": self.eos_token_id})(), model_version=0)
+        logits = self.model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits
+        logits.backward(torch.zeros_like(logits))
 
     def step(self, rollouts, micro_batches) -> dict[str, Any]:
+        """`rollouts`: THIS rank's share of the step (ragged, on the device); `micro_batches`: its packing plan."""
         from .hotpath import HotPathStep
 
         hp = HotPathStep(self.rl_config, self.eos_token_id, self.metrics.completed_steps, self.max_train_steps, group=self.group)
         batches = hp.preprocess(rollouts, micro_batches)
         n = len(batches)
-        for j in range(n):
+        n_max, n_samples = self._share_counts(n, rollouts.n_seqs, rollouts.device)
+        assert n_samples == self.samples_per_step, f"the ranks' shares hold {n_samples} samples, a step takes {self.samples_per_step}"
+        n_passes = max(n_max, 1) if self.equalize else max(n, 1)
+        for j in range(n_passes):
+            last = j == n_passes - 1
+            ctx = self.model.no_sync() if (hasattr(self.model, "no_sync") and not last) else contextlib.nullcontext()
+            if j >= n:  # this rank ran out of data: keep the collectives of the others company
+                with ctx:
+                    self._sentinel_pass(rollouts.device)
+                continue
             b = batches[j]
-            ctx = self.model.no_sync() if (hasattr(self.model, "no_sync") and j < n - 1) else contextlib.nullcontext()
             if self.ref_model is not None:
                 with torch.no_grad():
                     ref_logits = self.ref_model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits
@@ -526,9 +731,30 @@ class NativeLearnerStep:
         m = self.metrics
         m.completed_steps += 1
         m.passes += n
-        m.samples += self.rl_config.batch_size
+        m.samples += self.samples_per_step
+        m.tokens += int(hp.offsets[-1]) * self.world
+        self.publish(SamplesProcessed(samples_processed=m.samples))
         self._last = hp
-        return {"loss": loss, "stats": stats, "micro_batches": n}
+        return {"loss": loss, "stats": stats, "micro_batches": n, "did_optimizer_step": True, "sentinel_passes": n_passes - n}
+
+    def maybe_send_weights(self) -> bool:
+        """After `step()`: broadcast when enough samples were trained since the last broadcast
+        (`weight_update_interval`, reference :936-949).  Model version == samples trained."""
+        m = self.metrics
+        if not self.send_weight_updates or self.weight_update_manager is None:
+            return False
+        if m.samples - m.last_broadcasted_version < self.weight_update_interval:
+            return False
+        self.weight_update_manager.send_weight_update(m.samples)
+        m.last_broadcasted_version = m.samples
+        return True
+
+    def finish(self) -> None:
+        """Signal `TrainingDone` and close the trainer stream."""
+        self.publish(TrainingDone())
+        if self._writer_cm is not None:
+            self._writer_cm.__exit__(None, None, None)
+            self._writer_cm = self._writer = None
 
     def stats_dict(self, stats: torch.Tensor) -> dict[str, float]:
         return self._last.stats_dict(stats)

@@ -65,10 +65,14 @@ class HotPathStep:
         self.offsets: list[int] = []
 
     # -- preprocess ---------------------------------------------------------------------------
-    def preprocess(self, rollouts: RaggedRollouts, micro_batches: Sequence[Sequence[int]]):
-        """K5 + one K6 launch.  The returned micro-batches are views into one flat step batch."""
-        prep: PreparedRollouts = populate_rl_data_ragged(rollouts, self.eos_token_id, self.config)
-        self.batches = pack_prepared(prep, micro_batches, self.eos_token_id)
+    def preprocess(self, rollouts: RaggedRollouts, micro_batches: Sequence[Sequence[int]], timer: Any = None):
+        """K5 + one K6 launch.  The returned micro-batches are views into one flat step batch.
+        `timer`: optional event timer (bench.py) for the two device parts alone."""
+        import contextlib
+
+        with (timer.time("group_advantages_K5") if timer is not None else contextlib.nullcontext()):
+            prep: PreparedRollouts = populate_rl_data_ragged(rollouts, self.eos_token_id, self.config)
+        self.batches = pack_prepared(prep, micro_batches, self.eos_token_id, timer=timer)
         self.offsets = [int(x) for x in self.batches.token_off]
         total = self.offsets[-1]
         dev = rollouts.device

@@ -85,6 +85,28 @@ class RaggedRollouts:
             kw[f.name] = v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) else v
         return RaggedRollouts(**kw)
 
+    def select(self, seq_range: range) -> "RaggedRollouts":
+        """A contiguous run of sequences [start, stop) as its own ragged set (views of the flat buffers,
+        offsets rebased) - how a data-parallel rank takes its share of a step's rollouts (whole groups)."""
+        a, b = seq_range.start, seq_range.stop
+        assert seq_range.step == 1 and 0 <= a <= b <= self.n_seqs
+        t0, t1 = int(self.host_seq_off[a]), int(self.host_seq_off[b])
+        l0, l1 = int(self.host_lp_off[a]), int(self.host_lp_off[b])
+        so = (self.host_seq_off[a:b + 1] - t0).astype(np.int64)
+        lo = (self.host_lp_off[a:b + 1] - l0).astype(np.int64)
+        dev = self.device
+        sl = slice(a, b)
+        return RaggedRollouts(
+            tokens=self.tokens[t0:t1], labels=self.labels[t0:t1], logprobs=self.logprobs[l0:l1],
+            ref_logprobs=None if self.ref_logprobs is None else self.ref_logprobs[l0:l1],
+            seq_off=torch.from_numpy(so).to(dev), lp_off=torch.from_numpy(lo).to(dev), reward=self.reward[sl],
+            group_index=self.group_index[sl], step_index=self.step_index[sl], rollout_index=self.rollout_index[sl],
+            model_version=self.model_version[sl], finished=self.finished[sl], finish_code=self.finish_code[sl],
+            group_ids=self.group_ids, host_seq_off=so, host_lp_off=lo, host_group_index=self.host_group_index[sl],
+            host_step_index=self.host_step_index[sl], host_rollout_index=self.host_rollout_index[sl],
+            host_model_version=self.host_model_version[sl],
+        )
+
     def pin_memory(self) -> "RaggedRollouts":
         """Page-locked host copy (one memcpy per column) so that `.to(device)` runs at PCIe rate
         instead of through the driver's pageable staging path."""

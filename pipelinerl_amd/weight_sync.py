@@ -316,6 +316,26 @@ class BucketedSender:
         return specs
 
 
+    def send_streamed(self, specs: Sequence[ParamSpec], fetch: Callable[[list[ParamSpec]], Any]) -> list[ParamSpec]:
+        """As `send`, for trainers whose parameters are SHARDED (ZeRO-3, FSDP): the full tensors of a bucket
+        exist only inside `with fetch(bucket_specs) as tensors:` (a collective gather among the trainer
+        ranks), they are flattened into the staging buffer there and released again - at no point is more
+        than one bucket of full parameters alive, where the reference gathers and sends parameter by
+        parameter (finetune_loop.py:230-238)."""
+        plan = plan_buckets(list(specs), self.bucket_bytes)
+        if len(self._staging) < 2:
+            cap = max(bucket_nbytes(b) for b in plan)
+            self._staging = [torch.empty(cap, dtype=torch.uint8, device=self.group.device) for _ in range(2)]
+        pipe = _TwoStreamPipe(self.group.device)
+        for k, bucket in enumerate(plan):
+            buf = self._staging[k % 2][: bucket_nbytes(bucket)]
+            with fetch([sp for sp, _ in bucket]) as tensors:
+                pipe.local(k, lambda buf=buf, bucket=bucket, tensors=tensors: gather_into_bucket(buf, bucket, tensors), after_wire=k - 2)
+            pipe.wire(k, lambda buf=buf: self.group.broadcast_bucket(buf, mode=self.mode), after_local=k)
+        pipe.finish()
+        return list(specs)
+
+
 class BucketedReceiver:
     """Worker side: receive the buckets implied by `parameters_info` and hand (name, tensor) views
     to `load_weights` (or scatter them into registered destinations), bucket by bucket; transfers

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--model", default="0p5b", choices=["0p5b", "7b"], help="Qwen2.5 shape (random init)")
     ap.add_argument("--split-head", action="store_true", help="fp32 lm_head evaluated as bf16 MFMA GEMMs (pipelinerl_amd.lm_head)")
+    ap.add_argument("--fused-head", action="store_true", help="fused head: hidden states -> loss without materialising the logits (pipelinerl_amd.fused_head)")
+    ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     args = ap.parse_args()
 
     import transformers
@@ -54,7 +56,9 @@ def main():
         torch.set_default_dtype(torch.float32)
     model = model.to(torch.bfloat16)
     model.lm_head = model.lm_head.float()  # fp32 lm_head (reference checkpoints.py:87-103)
-    if args.split_head:
+    if args.fused_head:
+        pass  # the fp32 nn.Linear stays as the parameter holder; its forward is never called
+    elif args.split_head:
         from pipelinerl_amd.lm_head import SplitBf16LmHead
 
         model.lm_head = SplitBf16LmHead.from_linear(model.lm_head)  # same fp32 parameter, bf16 MFMA GEMMs
@@ -83,7 +87,21 @@ def main():
             marks["a"].record()
             return out
 
-        loss, stats = rl_step(wrapped, batch, cur, mx, config)
+        if args.fused_head:
+            from pipelinerl_amd.fused_head import rl_step_fused_head
+
+            body = model_.model
+
+            def wrapped_body(**kw):
+                out = body(**kw)
+                marks["a"] = torch.cuda.Event(enable_timing=True)
+                marks["a"].record()
+                return out
+
+            shim = types.SimpleNamespace(model=wrapped_body, lm_head=model_.lm_head)
+            loss, stats = rl_step_fused_head(shim, batch, cur, mx, config)
+        else:
+            loss, stats = rl_step(wrapped, batch, cur, mx, config)
         b = torch.cuda.Event(enable_timing=True)
         b.record()
         timers.setdefault("pairs", []).append((marks["a"], b))
@@ -108,15 +126,20 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     loss_fwd_ms = sum(a.elapsed_time(b) for a, b in timers["pairs"]) / args.steps
-    print(json.dumps({
+    line = json.dumps({
         "what": "end-to-end learner step incl. model fwd/bwd + AdamW (stock PyTorch-ROCm) + HIP loss path",
+        "head": "fused (logits never written)" if args.fused_head else ("split-bf16 GEMMs" if args.split_head else "fp32 nn.Linear"),
+        "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9,
         "model": f"Qwen2.5-{args.model} shape, random init, {n_params / 1e6:.0f}M params, {args.layers} layers, bf16 + fp32 lm_head"
                  f"{' on bf16 matrix cores (2-term split)' if args.split_head else ''}, grad checkpointing, sdpa",
         "global_batch": bs, "seq_len": L, "micro_batch": mb, "logits_mode": "fused" if args.fused else "two_pass",
         "samples_per_s": bs / dt, "s_per_step": dt, "tokens_per_s": bs * L / dt,
         "loss_forward_path_ms_per_step": loss_fwd_ms, "loss_forward_fraction": loss_fwd_ms / 1e3 / dt,
         "loss": float(res["loss"]), "rl_metrics": {k: res["metrics"].get(k) for k in ("rl/loss", "rl/ess", "rl/num_output_tokens_sum")},
-    }))
+    })
+    print(line)
+    if args.out:
+        Path(args.out).write_text(line + "\n")
 
 
 if __name__ == "__main__":

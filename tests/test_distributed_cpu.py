@@ -294,3 +294,145 @@ def test_unique_id_rendezvous_over_tcpstore(libprl):
         t.join(timeout=60)
     uids = [out[r][0] for r in range(3)]
     assert len(uids[0]) == 128 and uids[0] == uids[1] == uids[2] and any(uids[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# sharded trainers on the send side (reference finetune_loop.py:209-268)
+# ---------------------------------------------------------------------------------------------
+
+
+class _ShardedParam:
+    """A ZeRO-3 style parameter: each trainer rank holds a flat slice, `ds_shape` is the full shape."""
+
+    def __init__(self, full: torch.Tensor, rank: int, n_trainers: int):
+        flat = full.reshape(-1)
+        per = (flat.numel() + n_trainers - 1) // n_trainers
+        self.ds_shape = tuple(full.shape)
+        self.dtype = full.dtype
+        self.shard = flat[rank * per:(rank + 1) * per].clone()
+        self.per, self.numel = per, flat.numel()
+        self.data = torch.empty(0, dtype=full.dtype)  # partitioned: no full tensor outside a gather
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+
+def _zero3_rank(rank, world, port, out_dir, transport):
+    """ranks 0, 1: trainers holding ZeRO-3 style shards; rank 2: the inference worker."""
+    import contextlib
+
+    import torch.distributed as dist
+
+    from pipelinerl_amd import streams
+    from pipelinerl_amd.finetune_loop import WeightUpdateManager, Zero3Parameters
+    from pipelinerl_amd.vllm_worker import StandaloneWeightReceiver
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    trainers = dist.new_group([0, 1])
+    update = dist.new_group([0, 2])  # rank 0 (trainer main) -> rank 2 (worker)
+    streams.set_streams_backend("files")
+    torch.manual_seed(0)
+    full_model = TinyLM(vocab=300, dim=33)
+    gathers = []
+
+    class UpdateGroup(GlooBucketGroup):
+        def broadcast_bucket(self, bucket, mode="scatter_allgather", src=0):
+            dist.broadcast(bucket, src=0 if src == 0 else 2, group=update)
+
+        def broadcast(self, tensor, src=0, stream=None):
+            dist.broadcast(tensor, src=0, group=update)
+
+    if rank < 2:
+        sharded = {n: _ShardedParam(p.detach(), rank, 2) for n, p in full_model.named_parameters()}
+
+        @contextlib.contextmanager
+        def gathered(params):  # stands in for deepspeed.zero.GatheredParameters: a collective among the trainers
+            gathers.append(len(params))
+            for p in params:
+                parts = [torch.zeros(p.per, dtype=p.dtype) for _ in range(2)]
+                mine = torch.zeros(p.per, dtype=p.dtype)
+                mine[: p.shard.numel()] = p.shard
+                dist.all_gather(parts, mine, group=trainers)
+                p.data = torch.cat(parts)[: p.numel].reshape(p.ds_shape)
+            try:
+                yield
+            finally:
+                for p in params:
+                    p.data = torch.empty(0, dtype=p.dtype)
+
+        engine = types.SimpleNamespace(module=types.SimpleNamespace(named_parameters=lambda: sharded.items()), zero_optimization_stage=lambda: 3)
+        source = Zero3Parameters(engine, gathered=gathered)
+        posted = []
+        mgr = WeightUpdateManager(["http://worker"], engine, None, UpdateGroup(torch.device("cpu")), is_main_process=(rank == 0),
+                                  transport=transport, bucket_bytes=1 << 16, post=lambda url, payload: posted.append(payload), parameter_source=source)
+        import pipelinerl_amd.finetune_loop as fl
+
+        fl._barrier = lambda: dist.barrier(group=trainers)  # the worker rank is not a trainer
+        if rank == 0:
+            # the HTTP request reaches the worker through the object channel of the update group
+            desc = [{"name": n, "shape": list(shape), "dtype": str(dt)} for n, shape, dt in source.describe()]
+            dist.broadcast_object_list([{"parameters_info": desc, "transport": transport, "bucket_bytes": 1 << 16, "version": 5}], src=0, group=update)
+        mgr.send_weight_update(5)
+        mgr.shutdown()
+        Path(out_dir, f"trainer{rank}.json").write_text(json.dumps({"gathers": gathers, "posted": len(posted),
+                                                                     "all_released": all(p.data.numel() == 0 for p in sharded.values())}))
+    else:
+        torch.manual_seed(1)
+        worker_model = TinyLM(vocab=300, dim=33)  # different values: must end up equal to the trainers' model
+        recv = StandaloneWeightReceiver(worker_model, torch.device("cpu"))
+        recv.model_update_group = UpdateGroup(torch.device("cpu"))
+        box = [None]
+        dist.broadcast_object_list(box, src=0, group=update)
+        recv.receive_weight_update({**box[0], "kind": "weight_update_request"})
+        same = all(torch.equal(a, b) for (_, a), (_, b) in zip(worker_model.named_parameters(), full_model.named_parameters()))
+        Path(out_dir, "worker.json").write_text(json.dumps({"same": bool(same)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport", ["bucketed", "per_tensor"])
+def test_zero3_style_sharded_trainers_send_full_weights(tmp_path, transport):
+    """Two trainer ranks hold flat shards of every parameter (ZeRO-3): the update gathers one BUCKET of
+    parameters at a time on both ranks (collective), rank 0 flattens and sends, everything is released
+    again; the worker ends up with the full weights."""
+    port = _free_port()
+    mp.spawn(_zero3_rank, args=(3, port, tmp_path, transport), nprocs=3, join=True)
+    assert json.loads((tmp_path / "worker.json").read_text())["same"]
+    t0 = json.loads((tmp_path / "trainer0.json").read_text())
+    t1 = json.loads((tmp_path / "trainer1.json").read_text())
+    assert t0["gathers"] == t1["gathers"] and t0["all_released"] and t1["all_released"]
+    n_params = len(list(TinyLM(vocab=300, dim=33).named_parameters()))
+    if transport == "bucketed":
+        assert sum(t0["gathers"]) == n_params and len(t0["gathers"]) < n_params  # several parameters per gather
+    else:
+        assert t0["gathers"] == [1] * n_params  # the reference's schedule: one gather + one broadcast per parameter
+    assert t0["posted"] == 1 and t1["posted"] == 0
+
+
+def test_fsdp_source_drops_the_tied_head_and_dispatch_picks_the_source():
+    from pipelinerl_amd.finetune_loop import FsdpParameters, PlainParameters, Zero3Parameters, parameter_source_for
+
+    emb = torch.randn(5, 3)
+    sd = {"model.embed_tokens.weight": emb, "model.norm.weight": torch.ones(3), "lm_head.weight": emb}
+    src = FsdpParameters(object(), state_dict_fn=lambda: sd)
+    assert [n for n, _, _ in src.describe()] == ["model.embed_tokens.weight", "model.norm.weight"]  # reference :258-262
+    from pipelinerl_amd.weight_sync import ParamSpec
+
+    with src.fetch([ParamSpec("model.norm.weight", (3,), torch.float32)]) as t:
+        assert torch.equal(t["model.norm.weight"], torch.ones(3))
+    src.release()
+    assert isinstance(parameter_source_for(TinyLM()), PlainParameters)
+    FullyShardedDataParallel = type("FullyShardedDataParallel", (), {})
+    assert isinstance(parameter_source_for(FullyShardedDataParallel()), FsdpParameters)
+    engine = types.SimpleNamespace(zero_optimization_stage=lambda: 3, module=TinyLM())
+    try:
+        import deepspeed  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            parameter_source_for(engine)
+    else:
+        assert isinstance(parameter_source_for(engine), Zero3Parameters)
+    assert isinstance(parameter_source_for(types.SimpleNamespace(zero_optimization_stage=lambda: 2, named_parameters=lambda: [])), PlainParameters)

@@ -31,7 +31,16 @@ def test_bench_json_contract(libprl, cuda_device):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
-    assert {"fused_logits_loss", "grpo_loss_step", "preprocess_K5_K6"} <= set(d["kernels"])
+    assert "traffic_source" in r  # the counter traffic is a committed figure, labelled as such
+    assert {"fused_logits_loss", "grpo_loss_step", "preprocess_K5_K6", "pack_collate_kernel", "group_advantages_K5"} <= set(d["kernels"])
+    k = d["kernels"]
+    assert k["pack_collate_kernel"]["avg_us"] <= k["preprocess_K5_K6"]["avg_us"]  # the kernel alone vs kernel + host planning
+    m = d["roofline_mfma"]  # the MFMA-bound fused head, a second roofline object
+    assert "error" not in m, m
+    assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and m["peak"] == 2500.0 and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-12
+    assert m["config"]["logits_materialised_bytes"] == 0 and m["backward"]["ms"] > 0
+    ra = c["reference_autograd"]
+    assert ra is None or (ra["source"].startswith("profiles/") and ra["us_per_token"] > 0)
     w = d["weight_sync"]  # N = 1: colocated hand-off over HIP IPC
     assert "error" not in w, w
     assert w["metric"] == "trainer_to_actor_weight_sync_ms" and w["median_ms"] > 0 and w["gbytes"] > 0.9

@@ -10,6 +10,7 @@ import types
 import pytest
 import torch
 
+from oracle import preprocess as opre
 from oracle import rl_loss as orl
 
 pytestmark = pytest.mark.gpu
