@@ -241,8 +241,10 @@ int prl_scale_unless(void* data, int64_t n, int32_t dtype, const float* upstream
 
 /*
  * GSPO helper (rl/utils.py:106-208): per-segment masked sums of a and b plus token
- * counts.  segment_ids int64 [1, cols]; mask = labels != -100; a, b token-aligned
- * float32.  Outputs float64 [n_segments] x3, zeroed by the call.
+ * counts.  segment_ids int64 [1, cols], NON-DECREASING from column 1 on (a packed batch, or a
+ * sequence-parallel slice of one); mask = labels != -100; a, b token-aligned float32.
+ * Outputs float64 [n_segments] x3, every entry written by the call, reduced in a fixed order
+ * (bitwise reproducible).  Unsorted or out-of-range ids yield NaN in all outputs.
  */
 int prl_segment_sums(int64_t cols, int32_t n_segments, const int64_t* segment_ids,
                      const int64_t* labels, const float* a, const float* b,

@@ -619,25 +619,84 @@ extern "C" int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, i
 
 // --------------------------------------------------------------------------------------
 // GSPO helper: per-segment masked sums (reference rl/utils.py:106-208, index_add_ x3).
-// One wave-level pre-reduction per run of equal segment ids would be faster, but GSPO is
-// not on any BASELINE config; a straightforward fp64 atomic scatter keeps it correct.
+// Segment ids of a packed batch (and of a sequence-parallel slice of one) are non-decreasing,
+// so a segment is one contiguous run: workgroup s finds its run by binary search and reduces it
+// in a FIXED order (per-thread strided fp64 partials -> wave shuffle tree -> waves in order).
+// Bitwise reproducible like the rest of the loss path - no atomics, no arrival order.  A row
+// whose ids are not sorted is detected by a second tiny launch and answered with NaN sums,
+// which the loss turns into the reference's non-finite assertion instead of a silent error.
 // --------------------------------------------------------------------------------------
 namespace {
 
 __global__ __launch_bounds__(kBlock) void segment_sums_kernel(int64_t cols, int32_t n_segments,
-                                                              const int64_t* seg,
-                                                              const int64_t* labels,
-                                                              const float* a, const float* b,
-                                                              double* a_sum, double* b_sum,
-                                                              double* count) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t u = 1 + (int64_t)blockIdx.x * kBlock + threadIdx.x; u < cols; u += stride) {
+                                                              const int64_t* __restrict__ seg,
+                                                              const int64_t* __restrict__ labels,
+                                                              const float* __restrict__ a, const float* __restrict__ b,
+                                                              double* a_sum, double* b_sum, double* count) {
+  __shared__ double red[3][kBlock / prl::kWave];
+  const int64_t s = blockIdx.x;
+  // first u in [1, cols) with seg[u] >= s, and first with seg[u] > s (column 0 carries no prediction)
+  auto bound = [&](int64_t key) {
+    int64_t lo = 1, hi = cols;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (seg[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const int64_t u0 = bound(s), u1 = bound(s + 1);
+  double c = 0.0, sa = 0.0, sb = 0.0;
+  for (int64_t u = u0 + threadIdx.x; u < u1; u += kBlock) {
     if (labels[u] == -100) continue;
-    const int64_t s = seg[u];
-    if (s < 0 || s >= n_segments) continue;
-    atomicAdd(&count[s], 1.0);
-    atomicAdd(&a_sum[s], (double)a[u]);
-    atomicAdd(&b_sum[s], (double)b[u]);
+    c += 1.0;
+    sa += (double)a[u];
+    sb += (double)b[u];
+  }
+  c = prl::wave_sum(c);
+  sa = prl::wave_sum(sa);
+  sb = prl::wave_sum(sb);
+  const int lane = threadIdx.x & (prl::kWave - 1), wid = threadIdx.x / prl::kWave;
+  if (lane == 0) {
+    red[0][wid] = c;
+    red[1][wid] = sa;
+    red[2][wid] = sb;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tc = 0.0, ta = 0.0, tb = 0.0;
+    for (int w = 0; w < kBlock / prl::kWave; ++w) {
+      tc += red[0][w];
+      ta += red[1][w];
+      tb += red[2][w];
+    }
+    count[s] = tc;
+    a_sum[s] = ta;
+    b_sum[s] = tb;
+  }
+}
+
+// NaN the results if the ids of [1, cols) are not non-decreasing or leave [0, n_segments)
+__global__ __launch_bounds__(kBlock) void segment_order_check_kernel(int64_t cols, int32_t n_segments,
+                                                                     const int64_t* __restrict__ seg,
+                                                                     const int64_t* __restrict__ labels,
+                                                                     double* a_sum, double* b_sum, double* count) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int64_t u = 1 + threadIdx.x; u < cols; u += kBlock) {
+    if (u + 1 < cols && seg[u] > seg[u + 1]) mine = 1;
+    if (labels[u] != -100 && (seg[u] < 0 || seg[u] >= n_segments)) mine = 1;
+  }
+  if (mine) atomicOr(&bad, 1);
+  __syncthreads();
+  if (bad) {
+    const double nan = __builtin_nan("");
+    for (int i = threadIdx.x; i < n_segments; i += kBlock) {
+      a_sum[i] = nan;
+      b_sum[i] = nan;
+      count[i] = nan;
+    }
   }
 }
 
@@ -650,16 +709,18 @@ extern "C" int prl_segment_sums(int64_t cols, int32_t n_segments, const int64_t*
   PRL_CHECK_ARG(cols >= 0 && n_segments >= 0, "negative shape");
   PRL_CHECK_ARG(segment_ids && labels && a && b && a_sum && b_sum && count, "null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (n_segments > 0) {
+  if (n_segments == 0) return PRL_OK;
+  if (cols <= 1) {
     PRL_HIP_CHECK(hipMemsetAsync(a_sum, 0, sizeof(double) * n_segments, s));
     PRL_HIP_CHECK(hipMemsetAsync(b_sum, 0, sizeof(double) * n_segments, s));
     PRL_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(double) * n_segments, s));
+    return PRL_OK;
   }
-  if (cols > 1 && n_segments > 0) {
-    const int nblocks = grid_for(cols, 1);
-    hipLaunchKernelGGL(segment_sums_kernel, dim3(nblocks), dim3(kBlock), 0, s, cols, n_segments,
-                       segment_ids, labels, a, b, a_sum, b_sum, count);
-    PRL_LAUNCH_CHECK("segment_sums_kernel");
-  }
+  hipLaunchKernelGGL(segment_sums_kernel, dim3(n_segments), dim3(kBlock), 0, s, cols, n_segments,
+                     segment_ids, labels, a, b, a_sum, b_sum, count);
+  PRL_LAUNCH_CHECK("segment_sums_kernel");
+  hipLaunchKernelGGL(segment_order_check_kernel, dim3(1), dim3(kBlock), 0, s, cols, n_segments, segment_ids,
+                     labels, a_sum, b_sum, count);
+  PRL_LAUNCH_CHECK("segment_order_check_kernel");
   return PRL_OK;
 }

@@ -581,3 +581,33 @@ def test_zero_advantage_group_mask(libprl, cuda_device, name):
         e["uid"] = i
     kept, dropped = filter_zero_advantage_groups(data)
     assert sorted(e["uid"] for e in kept) == np.flatnonzero(keep).tolist() and dropped == int((~keep).sum())
+
+
+def test_segment_sums_are_reproducible_and_checked(libprl, cuda_device):
+    """The GSPO per-segment sums: equal to an fp64 index_add (reference rl/utils.py:106-208), bitwise
+    identical from run to run (fixed reduction order, no atomics), NaN when the segment ids are not
+    the non-decreasing ids of a packed batch."""
+    from pipelinerl_amd.finetune.rl import segment_sums
+
+    torch.manual_seed(3)
+    T, S = 20000, 37
+    cuts = torch.sort(torch.randperm(T - 2)[: S - 1] + 1).values
+    seg = torch.zeros(T, dtype=torch.int64)
+    seg[cuts] = 1
+    seg = torch.cumsum(seg, 0)[None].to(cuda_device)
+    labels = torch.randint(0, 100, (1, T), device=cuda_device)
+    labels[torch.rand(1, T, device=cuda_device) < 0.3] = -100
+    a = torch.randn(1, T, device=cuda_device) * 1e3
+    b = torch.randn(1, T, device=cuda_device)
+    runs = [segment_sums(seg, labels, a, b, S) for _ in range(4)]
+    for r in runs[1:]:
+        for x, y in zip(runs[0], r):
+            assert torch.equal(x, y)
+    m = (labels[0, 1:] != -100)
+    idx = seg[0, 1:][m]
+    for got, src in zip(runs[0], (a[0, 1:][m].double(), b[0, 1:][m].double(), torch.ones(int(m.sum()), dtype=torch.float64, device=cuda_device))):
+        want = torch.zeros(S, dtype=torch.float64, device=cuda_device).index_add_(0, idx, src)
+        assert torch.allclose(got, want, rtol=1e-12, atol=1e-9)
+    bad = seg.clone()
+    bad[0, 500], bad[0, 501] = 5, 4
+    assert all(torch.isnan(x).all() for x in segment_sums(bad, labels, a, b, S))
