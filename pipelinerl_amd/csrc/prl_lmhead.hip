@@ -75,6 +75,20 @@ using CfgWide = Cfg<256, 256, 2>;   // 128 KB LDS, one workgroup of 8 waves per 
 using CfgBig = Cfg<256, 128, 3>;    // 144 KB LDS, one workgroup of 8 waves per CU, two tiles of loads in flight
 using CfgSmall = Cfg<128, 128, 2>;  // 64 KB LDS, two workgroups of 4 waves per CU
 
+// Dual-plane shape: C += (A1 + A2) B^T with the two A planes (W_hi / W_lo, or d logits hi / lo) sharing ONE
+// staged B tile.  256 x 256 tile, 32-deep stages of three 16 KB tiles (A1, A2, B) in a ring of 3: 48 KB per
+// 32 MFMAs per wave instead of 64 KB (the staging path is what bounds the 256 x 256 shape), two stages of loads
+// in flight instead of one, 8 instead of 12 fragment reads per 16 MFMAs.
+struct CfgDual {
+  static constexpr int BM = 256, BN = 256, NT = 512, STAGES = 3;
+  static constexpr int NJ = 4, WCOLS = 128;
+  static constexpr int Q = 2;                       // 16-byte chunks per thread, tile and stage
+  static constexpr int LOADS = 3 * Q;
+  static constexpr int TILE_BYTES = 256 * ROW_BYTES32;  // 16 KB
+  static constexpr int STAGE_BYTES = 3 * TILE_BYTES;    // 48 KB
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;  // 144 KB
+};
+
 struct Terms {
   const uint16_t* a[MAX_TERMS];
   const uint16_t* b[MAX_TERMS];
@@ -277,6 +291,116 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
   }
 }
 
+// -----------------------------------------------------------------------------------------------
+// dual-plane main loop: acc += (A1 + A2)[m0.., :] B[n0.., :]^T over Kc, 32-deep stages (see CfgDual)
+// -----------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
+                                                   const Geom& g, int m0, int n0, char* lds) {
+  using C = CfgDual;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kcol = stage_kcol32(tid);
+  int64_t offA[C::Q], offB[C::Q];
+#pragma unroll
+  for (int q = 0; q < C::Q; ++q) {
+    int ra = m0 + stage_row32(tid, q, C::NT);
+    ra = ra < g.M ? ra : g.M - 1;
+    int rb = n0 + stage_row32(tid, q, C::NT);
+    rb = rb < g.N ? rb : g.N - 1;
+    offA[q] = (int64_t)ra * g.lda + kcol;
+    offB[q] = (int64_t)rb * g.ldb + kcol;
+  }
+  int rdA[2], rdB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    rdA[ks] = frag_lds_byte32(lane, wm * 64, 0, ks);
+    rdB[ks] = 2 * C::TILE_BYTES + frag_lds_byte32(lane, wn * C::WCOLS, 0, ks);
+  }
+  const int total = g.Kc / BK32;
+  int st_k = 0;  // contraction offset of the NEXT tile to stage
+  auto stage_piece = [&](int buf, int idx) {  // idx 0..5: A1 q0 q1, A2 q0 q1, B q0 q1
+    const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
+    const int tile = idx / C::Q, q = idx % C::Q;
+    const uint16_t* src = tile == 0 ? A1 + offA[q] : tile == 1 ? A2 + offA[q] : B + offB[q];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + st_k),
+                                     (__attribute__((address_space(3))) void*)(lds + dst + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
+  };
+  auto compute = [&](int buf, int sbuf) {
+    const char* base = lds + buf * C::STAGE_BYTES;
+    bf16x8 a1[2][2], a2[2][2], bfr[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a1[0][i] = *reinterpret_cast<const bf16x8*>(base + rdA[0] + i * 32 * ROW_BYTES32);
+      a2[0][i] = *reinterpret_cast<const bf16x8*>(base + C::TILE_BYTES + rdA[0] + i * 32 * ROW_BYTES32);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(base + rdB[0] + j * 32 * ROW_BYTES32);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a1[1][i] = *reinterpret_cast<const bf16x8*>(base + rdA[1] + i * 32 * ROW_BYTES32);
+          a2[1][i] = *reinterpret_cast<const bf16x8*>(base + C::TILE_BYTES + rdA[1] + i * 32 * ROW_BYTES32);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[1][j] = *reinterpret_cast<const bf16x8*>(base + rdB[1] + j * 32 * ROW_BYTES32);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        }
+      if (sbuf >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) stage_piece(sbuf, ks * 3 + k);
+      }
+    }
+  };
+
+  constexpr int D = C::STAGES - 1;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < D; ++p)
+    if (p < total) {
+#pragma unroll
+      for (int idx = 0; idx < C::LOADS; ++idx) stage_piece(p, idx);
+      st_k += BK32;
+    }
+  int cur = 0, nxt = D % C::STAGES;
+  int s = 0;
+  for (; s + D < total; ++s) {
+    wait_tile_then_barrier<(D - 1) * C::LOADS>();
+    compute(cur, nxt);
+    st_k += BK32;
+    cur = cur + 1 == C::STAGES ? 0 : cur + 1;
+    nxt = nxt + 1 == C::STAGES ? 0 : nxt + 1;
+  }
+  for (; s < total; ++s) {
+    if (s + D - 1 < total) {
+      wait_tile_then_barrier<(D - 1) * C::LOADS>();
+    } else {
+      wait_tile_then_barrier<0>();
+    }
+    compute(cur, -1);
+    cur = cur + 1 == C::STAGES ? 0 : cur + 1;
+  }
+}
+
+// One call site for both cores: DUAL runs the dual-plane loop on (terms.a[0], terms.a[1], terms.b[0])
+template <class C, bool DUAL, int EXP = 0>
+__device__ __forceinline__ void run_mainloop(f32x16 (&acc)[2][C::NJ], const Terms& t, const Geom& g, int m0, int n0, char* lds) {
+  if constexpr (DUAL) {
+    gemm_mainloop_dual(acc, t.a[0], t.a[1], t.b[0], g, m0, n0, lds);
+  } else {
+    gemm_mainloop<C, EXP>(acc, t, g, m0, n0, lds);
+  }
+}
+
 template <int NJ>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NJ]) {
 #pragma unroll
@@ -302,7 +426,7 @@ struct FwdArgs {
   float* ysel;          // [padded] selected logit (base-2 units), written by whichever split owns the row
 };
 
-template <class C, int EXP = 0>
+template <class C, int EXP = 0, bool DUAL = false>
 __global__ __launch_bounds__(C::NT, 2) void lmhead_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int tok_tile, split;
@@ -332,7 +456,7 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_fwd_kernel(FwdArgs a) {
   for (int tv = vt0; tv < vt1; ++tv) {
     const int m0 = tv * C::BM;
     zero_acc<NJ>(acc);
-    gemm_mainloop<C, EXP>(acc, a.terms, a.geo, m0, n0, lds);
+    run_mainloop<C, DUAL, EXP>(acc, a.terms, a.geo, m0, n0, lds);
     const int vbase = m0 + acc_row(lane, wrow0, 0, 0);  // vocabulary row of acc[0][j][0]; + 32 i + (reg & 3) + 8 (reg >> 2)
     const bool full = m0 + C::BM <= V;
 #pragma unroll
@@ -448,7 +572,7 @@ struct DlArgs {
   uint16_t* dlT_lo;
 };
 
-template <class C>
+template <class C, bool DUAL = false>
 __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int tv, tk;
@@ -459,7 +583,7 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
   const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
   f32x16 acc[2][NJ];
   zero_acc<NJ>(acc);
-  gemm_mainloop<C>(acc, a.terms, a.geo, m0, n0, lds);
+  run_mainloop<C, DUAL>(acc, a.terms, a.geo, m0, n0, lds);
 
   const float up = a.upstream ? *a.upstream : 1.0f;
   const int64_t V = a.geo.M;
@@ -527,7 +651,7 @@ struct GemmArgs {
   int accumulate;   // fp32 only: out += acc
 };
 
-template <class C>
+template <class C, bool DUAL = false>
 __global__ __launch_bounds__(C::NT, 2) void gemm_nt_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int tm, tn;
@@ -538,7 +662,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_nt_kernel(GemmArgs a) {
   const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
   f32x16 acc[2][NJ];
   zero_acc<NJ>(acc);
-  gemm_mainloop<C>(acc, a.terms, a.geo, m0, n0, lds);
+  run_mainloop<C, DUAL>(acc, a.terms, a.geo, m0, n0, lds);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -614,6 +738,14 @@ Shape pick_shape(int64_t m_rows, int64_t n_cols) {
   if (m256 * ((n_cols + 127) / 128) >= 200) return kBig;
   return kSmall;
 }
+// The dual-plane core applies when a launch has exactly two terms that share their B operand (W_hi / W_lo
+// against the hidden states; d logits hi / lo against the transposed hidden states) and the 256 x 256 shape
+// was chosen.  PRL_LMHEAD_DUAL=0 keeps the generic core (A/B reference).
+bool use_dual(Shape shape, const Terms& t) {
+  if (shape != kWide || t.n != 2 || t.b[0] != t.b[1]) return false;
+  const char* e = getenv("PRL_LMHEAD_DUAL");
+  return !(e && atoi(e) == 0);
+}
 int shape_bm(Shape s) { return s == kSmall ? 128 : 256; }
 int shape_bn(Shape s) { return s == kWide ? 256 : 128; }
 
@@ -635,6 +767,9 @@ int launch_tiles(K kfn, int threads, int lds_bytes, int blocks, const A& args, h
   PRL_LAUNCH_CHECK(name);
   return PRL_OK;
 }
+
+#define PRL_LAUNCH_DUAL(KERNEL, blocks, args, s, name) \
+  launch_tiles(KERNEL, CfgDual::NT, CfgDual::LDS_BYTES, blocks, args, s, name)
 
 #define PRL_LAUNCH_CFG(shape, KERNEL, blocks, args, s, name)                                                            \
   ((shape) == kWide  ? launch_tiles(KERNEL<CfgWide>, CfgWide::NT, CfgWide::LDS_BYTES, blocks, args, s, name)            \
@@ -769,6 +904,8 @@ extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidde
     }
 #undef PRL_EXP_CASE
     if (rc) return rc;
+  } else if (use_dual(shape, a.terms)) {
+    if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 0, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual)")) return rc;
   } else if (int rc = PRL_LAUNCH_CFG(shape, lmhead_fwd_kernel, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel")) {
     return rc;
   }
@@ -837,7 +974,11 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       const Shape shape = pick_shape(vocab, L.chunk_pad);
       d.vt = ceil_div(vocab, shape_bm(shape));
       d.tt = ceil_div(L.chunk_pad, shape_bn(shape));  // token tiles of the chunk buffers (pad rows are written as zeros)
-      if (int rc = PRL_LAUNCH_CFG(shape, lmhead_dlogits_kernel, d.vt * d.tt, d, s, "lmhead_dlogits_kernel")) return rc;
+      if (use_dual(shape, d.terms)) {
+        if (int rc = PRL_LAUNCH_DUAL((lmhead_dlogits_kernel<CfgDual, true>), d.vt * d.tt, d, s, "lmhead_dlogits_kernel(dual)")) return rc;
+      } else if (int rc = PRL_LAUNCH_CFG(shape, lmhead_dlogits_kernel, d.vt * d.tt, d, s, "lmhead_dlogits_kernel")) {
+        return rc;
+      }
     }
     // ---- 2. d hidden[chunk] = dl W  (contraction over the vocabulary; hi x hi + lo x hi + hi x lo)
     if (grad_hidden) {
@@ -881,7 +1022,11 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       g.out_bf16 = 0;
       g.accumulate = 1;
       g.out = grad_weight;
-      if (int rc = PRL_LAUNCH_CFG(shape, gemm_nt_kernel, g.mt * g.nt, g, s, "gemm_nt_kernel(d weight)")) return rc;
+      if (use_dual(shape, g.terms)) {
+        if (int rc = PRL_LAUNCH_DUAL((gemm_nt_kernel<CfgDual, true>), g.mt * g.nt, g, s, "gemm_nt_kernel(d weight, dual)")) return rc;
+      } else if (int rc = PRL_LAUNCH_CFG(shape, gemm_nt_kernel, g.mt * g.nt, g, s, "gemm_nt_kernel(d weight)")) {
+        return rc;
+      }
     }
   }
   return PRL_OK;

@@ -60,6 +60,20 @@ PRL_LHD int frag_lds_byte(int lane, int wave_row0, int i, int ks) {
   return r * ROW_BYTES + ((frag_kchunk(lane, ks) ^ ((r >> 1) & 7)) << 4);
 }
 
+// ---- the 32-deep variant (dual-plane core: two A planes share one B tile per stage).  A tile row is
+// 64 bytes = 4 chunks, four rows fill a 256-byte bank row; chunk c = q * NT + tid is row (c >> 2),
+// slot (c & 3) and holds the logical k-chunk  slot ^ ((row >> 2) & 3).
+constexpr int BK32 = 32;
+constexpr int ROW_BYTES32 = BK32 * 2;
+PRL_LHD int stage_row32(int tid, int q, int nt) { return q * (nt >> 2) + (tid >> 2); }
+// ((q * NT / 4 + (tid >> 2)) >> 2) & 3 == (tid >> 4) & 3 for NT = 512
+PRL_LHD int stage_kcol32(int tid) { return ((tid & 3) ^ ((tid >> 4) & 3)) * 8; }  // elements
+// fragment of sub-step ks (0, 1): lane l supplies row (l & 31), k-chunk ks * 2 + (l >> 5)
+PRL_LHD int frag_lds_byte32(int lane, int wave_row0, int i, int ks) {
+  const int r = frag_row(lane, wave_row0, i);
+  return r * ROW_BYTES32 + (((ks * 2 + (lane >> 5)) ^ ((r >> 2) & 3)) << 4);
+}
+
 // ---- accumulators: element `reg` (0..15) of the 32 x 32 tile (i, j) of the wave whose sub-tile starts
 // at (wave_row0, wave_col0) = (64 * (wave >> 1), (BN / 2) * (wave & 1))
 PRL_LHD int acc_row_in_tile(int lane, int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }

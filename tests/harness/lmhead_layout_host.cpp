@@ -33,6 +33,20 @@ void lmh_fragment(const uint8_t* lds, int lane, int w, int i, int ks, uint16_t* 
 
 int lmh_frag_byte(int lane, int w, int i, int ks) { return frag_lds_byte(lane, w, i, ks); }
 
+// ---- the 32-deep layout of the dual-plane core
+void lmh_stage32(const uint16_t* src, uint8_t* lds_out, int rows, int nthreads) {  // src [rows][32]
+  const int nq = rows * 4 / nthreads;
+  for (int tid = 0; tid < nthreads; ++tid)
+    for (int q = 0; q < nq; ++q)
+      memcpy(lds_out + stage_lds_byte(tid, q, nthreads), src + stage_row32(tid, q, nthreads) * BK32 + stage_kcol32(tid), 16);
+}
+void lmh_fragment32(const uint8_t* lds, int lane, int row0, int i, int ks, uint16_t* out8, int* row, int* k0) {
+  memcpy(out8, lds + frag_lds_byte32(lane, row0, i, ks), 16);
+  *row = frag_row(lane, row0, i);
+  *k0 = ks * 16 + 8 * (lane >> 5);
+}
+int lmh_frag_byte32(int lane, int row0, int i, int ks) { return frag_lds_byte32(lane, row0, i, ks); }
+
 // Full emulation of C = A B^T for one (64 * wm_count) x bn x 64 tile through the staged images, the
 // fragment reads and the documented MFMA semantics D[m][n] += sum_k A[m][k] B[n][k] with
 // operand lane l: m (or n) = l & 31, k = 8 (l >> 5) + e;  D lane l, reg r: m = (r & 3) + 8 (r >> 2) + 4 (l >> 5), n = l & 31.

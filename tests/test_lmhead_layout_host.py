@@ -25,6 +25,10 @@ def lmh(tmp_path_factory):
     lib.lmh_fragment.argtypes = [U8, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, U16, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     lib.lmh_frag_byte.argtypes = [ctypes.c_int] * 4
     lib.lmh_frag_byte.restype = ctypes.c_int
+    lib.lmh_stage32.argtypes = [U16, U8, ctypes.c_int, ctypes.c_int]
+    lib.lmh_fragment32.argtypes = lib.lmh_fragment.argtypes
+    lib.lmh_frag_byte32.argtypes = [ctypes.c_int] * 4
+    lib.lmh_frag_byte32.restype = ctypes.c_int
     lib.lmh_emulate_tile.argtypes = [U16, U16, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int]
     return lib
 
@@ -103,3 +107,31 @@ def test_emulated_tile_product_is_not_transposed(lmh, wm_count, bn):
     lmh.lmh_emulate_tile(a.ctypes.data_as(U16), b.ctypes.data_as(U16), c.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), wm_count, bn)
     want = a.astype(np.float64) @ b.astype(np.float64).T
     assert np.array_equal(c, want)
+
+
+def test_32_deep_layout_of_the_dual_plane_core(lmh):
+    """256 rows x 32 contraction elements staged by 512 threads: every (row, k) reaches the lane the MFMA
+    operand layout assigns it to, and the fragment reads are bank-conflict free for the real lane groups."""
+    rows, nthreads = 256, 512
+    src = (np.arange(rows)[:, None] * 32 + np.arange(32)[None, :]).astype(np.uint16)
+    lds = np.zeros(rows * 64, dtype=np.uint8)
+    lmh.lmh_stage32(src.ctypes.data_as(U16), lds.ctypes.data_as(U8), rows, nthreads)
+    assert sorted(np.frombuffer(lds.tobytes(), dtype=np.uint16).tolist()) == sorted(src.reshape(-1).tolist())
+    out = (ctypes.c_uint16 * 8)()
+    row, k0 = ctypes.c_int(), ctypes.c_int()
+    covered = set()
+    for row0 in (0, 64, 128, 192):
+        for i in range(2):
+            for ks in range(2):
+                for lane in range(64):
+                    lmh.lmh_fragment32(lds.ctypes.data_as(U8), lane, row0, i, ks, out, ctypes.byref(row), ctypes.byref(k0))
+                    assert row.value == row0 + i * 32 + (lane & 31)
+                    assert list(out) == [row.value * 32 + k0.value + e for e in range(8)]
+                    covered.update((row.value, k0.value + e) for e in range(8))
+    assert len(covered) == rows * 32
+    for row0 in (0, 128):
+        for i in range(4):
+            for ks in range(2):
+                for group in B128_GROUPS:
+                    slots = {(lmh.lmh_frag_byte32(l, row0, i, ks) % 256) // 16 for l in group}
+                    assert len(slots) == 16
