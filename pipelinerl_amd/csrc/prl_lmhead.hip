@@ -142,6 +142,7 @@ __device__ __forceinline__ void wait_tile_then_barrier() {
 //  16  ablation: no LDS-DMA loads at all (wrong results; MFMA + LDS-read + barrier time only)
 //  32  ablation: no MFMAs (wrong results; staging + LDS-read + barrier time only)
 //  64  ablation: no fragment reads from LDS inside the loop (wrong results)
+// 256  A/B reference for the staggered schedule of the 8-wave shapes: interleaved DMA issue, all waves alike
 template <class C, int EXP = 0>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Terms& t, const Geom& g, int m0, int n0,
                                               char* lds) {
@@ -213,10 +214,23 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
   // between the MFMA groups instead of in one burst after the barrier: a piece costs ~60-180 issue cycles,
   // and all waves of the workgroup leave the barrier together - a burst would idle the matrix pipe of
   // every SIMD at once (measured on the same build: 17.7 ms interleaved vs 19.8 ms burst for the 7B forward).
+  // STAGGER (8-wave shapes): the two waves that share a SIMD (w and w + 4) do their non-matrix work at opposite
+  // ends of the step - waves 4-7 issue the next tile's DMA right after the barrier and then run their MFMA cluster,
+  // waves 0-3 run the cluster first and issue afterwards - so that between two barriers one wave of every SIMD is in
+  // its matrix cluster while its partner issues loads (dual-plane forward: 14.7 -> 13.8 ms).  4-wave shapes (one wave
+  // per SIMD and workgroup, two workgroups per CU) keep the interleaved issue.
+  // Measured on this (generic) core it does NOT pay: 256 x 128 forward 16.3 -> 16.7 ms, backward 61.0 -> 62.1 ms -
+  // with 64-deep stages the DMA burst of 8 pieces is long enough to delay the partner; kept behind EXP bit 512.
+  constexpr bool STAGGER = C::NT == 512 && (EXP & 512) != 0;
+  const bool dma_first = STAGGER && wave >= 4;
   auto compute = [&](int buf, int sbuf) {
     const char* base = lds + buf * C::STAGE_BYTES;
     constexpr int GROUPS = (EXP & 1) ? 1 : (EXP & 8) ? 2 : 3;
     constexpr int PER = (C::LOADS + GROUPS - 1) / GROUPS;  // pieces after each of the first GROUPS MFMA groups
+    if (STAGGER && sbuf >= 0 && dma_first) {
+#pragma unroll
+      for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
+    }
     bf16x8 af[2][2], bfr[2][C::NJ];  // [ping-pong][tile]: the reads of sub-step ks + 1 are issued before the MFMAs of ks
 #pragma unroll
     for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(base + rdA[0] + i * 32 * ROW_BYTES);
@@ -251,11 +265,15 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
           for (int j = 0; j < C::NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
       }
       if constexpr ((EXP & 2) != 0) __builtin_amdgcn_s_setprio(0);
-      if (sbuf >= 0 && ks < GROUPS) {
+      if (!STAGGER && sbuf >= 0 && ks < GROUPS) {
 #pragma unroll
         for (int k = 0; k < PER; ++k)
           if (ks * PER + k < C::LOADS) stage_piece(sbuf, ks * PER + k);
       }
+    }
+    if (STAGGER && sbuf >= 0 && !dma_first) {
+#pragma unroll
+      for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
     }
   };
 
@@ -294,6 +312,12 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
 // -----------------------------------------------------------------------------------------------
 // dual-plane main loop: acc += (A1 + A2)[m0.., :] B[n0.., :]^T over Kc, 32-deep stages (see CfgDual)
 // -----------------------------------------------------------------------------------------------
+// MODE 0: DMA pieces interleaved with the MFMA groups, all waves alike.
+// MODE 1: STAGGERED - the two waves that share a SIMD (w and w + 4) do their non-matrix work at opposite ends of
+//         the step: waves 4-7 issue the next tile's DMA right after the barrier, then run their MFMA cluster; waves
+//         0-3 run their MFMA cluster first and issue the DMA afterwards.  Between two barriers one wave of every
+//         SIMD is in its matrix cluster while its partner issues loads - the role split of the 8-phase GEMM schedule.
+template <int MODE = 0>
 __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
                                                    const Geom& g, int m0, int n0, char* lds) {
   using C = CfgDual;
@@ -327,8 +351,13 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + st_k),
                                      (__attribute__((address_space(3))) void*)(lds + dst + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
   };
+  const bool dma_first = MODE == 1 && wave >= 4;
   auto compute = [&](int buf, int sbuf) {
     const char* base = lds + buf * C::STAGE_BYTES;
+    if (MODE == 1 && sbuf >= 0 && dma_first) {
+#pragma unroll
+      for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
+    }
     bf16x8 a1[2][2], a2[2][2], bfr[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -348,17 +377,24 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
 #pragma unroll
         for (int j = 0; j < 4; ++j) bfr[1][j] = *reinterpret_cast<const bf16x8*>(base + rdB[1] + j * 32 * ROW_BYTES32);
       }
+      // plane by plane: the two MFMAs that accumulate into the same tile are 8 instructions apart, not
+      // back to back (a dependent MFMA waits for its predecessor's result)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-        }
-      if (sbuf >= 0) {
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+      if (MODE == 0 && sbuf >= 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) stage_piece(sbuf, ks * 3 + k);
       }
+    }
+    if (MODE == 1 && sbuf >= 0 && !dma_first) {
+#pragma unroll
+      for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
     }
   };
 
@@ -395,7 +431,7 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
 template <class C, bool DUAL, int EXP = 0>
 __device__ __forceinline__ void run_mainloop(f32x16 (&acc)[2][C::NJ], const Terms& t, const Geom& g, int m0, int n0, char* lds) {
   if constexpr (DUAL) {
-    gemm_mainloop_dual(acc, t.a[0], t.a[1], t.b[0], g, m0, n0, lds);
+    gemm_mainloop_dual<(EXP & 256) ? 0 : 1>(acc, t.a[0], t.a[1], t.b[0], g, m0, n0, lds);
   } else {
     gemm_mainloop<C, EXP>(acc, t, g, m0, n0, lds);
   }
@@ -890,7 +926,7 @@ extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidde
   hipStream_t s = static_cast<hipStream_t>(stream);
   int exp_bits = 0;
   if (const char* e = getenv("PRL_LMHEAD_EXP")) exp_bits = atoi(e);
-  if (shape == kWide && exp_bits) {  // schedule experiments, 256 x 256 forward only
+  if (shape == kWide && exp_bits && exp_bits != 256) {  // timing ablations, generic 256 x 256 forward only
     int rc = PRL_EINVAL;
 #define PRL_EXP_CASE(E)                                                                                                  \
   case E:                                                                                                                \
@@ -905,7 +941,11 @@ extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidde
 #undef PRL_EXP_CASE
     if (rc) return rc;
   } else if (use_dual(shape, a.terms)) {
-    if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 0, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual)")) return rc;
+    if (exp_bits == 256) {  // A/B reference: DMA pieces interleaved with the MFMA groups, all waves alike
+      if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 256, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual, interleaved)")) return rc;
+    } else if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 0, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual)")) {
+      return rc;
+    }
   } else if (int rc = PRL_LAUNCH_CFG(shape, lmhead_fwd_kernel, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel")) {
     return rc;
   }
