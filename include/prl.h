@@ -489,7 +489,8 @@ int prl_lm_head_prepare(int64_t vocab, int64_t hidden, const void* weight,
 
 /* Scratch sizes: forward (partial soft-max states per vocabulary split) and backward (the
  * d-logits planes of ONE chunk of `chunk_rows` logits rows, both layouts, + the transposed
- * hidden chunk).  Either output pointer may be NULL. */
+ * hidden chunk + 8 fp32 [chunk_rows, hidden] slices for the split-K d hidden product, whose
+ * slices are added in a fixed order: bitwise reproducible).  Either output pointer may be NULL. */
 int prl_lm_head_workspace_bytes(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
                                 int64_t chunk_rows, size_t* fwd_bytes, size_t* bwd_bytes);
 

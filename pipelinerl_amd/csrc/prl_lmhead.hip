@@ -317,6 +317,12 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
 //         the step: waves 4-7 issue the next tile's DMA right after the barrier, then run their MFMA cluster; waves
 //         0-3 run their MFMA cluster first and issue the DMA afterwards.  Between two barriers one wave of every
 //         SIMD is in its matrix cluster while its partner issues loads - the role split of the 8-phase GEMM schedule.
+//
+// Measured and NOT kept: chaining the forward's vocabulary tiles (the last two steps of a tile stage the first two
+// stages of the next, so the pipeline never refills).  17.2 ms against 14.6 for the same loop with the refill: the
+// refill is what keeps the 32 workgroups of an XCD in step, and in step they share every weight tile (8 workgroups)
+// and hidden tile (4 workgroups) in the XCD's L2.  Chained, they drift apart and L2 misses go from 137 M to 669 M
+// requests per forward (HBM fetch 8.6 -> 41 GB; profiles/r02p_lmhead_fwd_chained_vs_refill_pmc.txt).
 template <int MODE = 0>
 __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
                                                    const Geom& g, int m0, int n0, char* lds) {
@@ -685,20 +691,40 @@ struct GemmArgs {
   int64_t ldc;
   int out_bf16;     // 1: bf16 store, 0: fp32
   int accumulate;   // fp32 only: out += acc
+  // split-K: workgroup (tile, kz) contracts steps [kz * ksteps, ...) of every term and stores its fp32 partial
+  // tile to partial[kz][M][N]; splitk_reduce_kernel adds the slices in a fixed order.  ksplit == 1: off.
+  int ksplit, ksteps;
+  float* partial;
 };
 
 template <class C, bool DUAL = false>
 __global__ __launch_bounds__(C::NT, 2) void gemm_nt_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int tm, tn;
-  tile_coords(blockIdx.x, a.mt, a.nt, tm, tn);
+  const int tiles = a.mt * a.nt;
+  const int kz = a.ksplit > 1 ? (int)blockIdx.x / tiles : 0;
+  tile_coords(a.ksplit > 1 ? (int)blockIdx.x - kz * tiles : (int)blockIdx.x, a.mt, a.nt, tm, tn);
   constexpr int NJ = C::NJ;
   const int m0 = tm * C::BM, n0 = tn * C::BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
   f32x16 acc[2][NJ];
   zero_acc<NJ>(acc);
-  run_mainloop<C, DUAL>(acc, a.terms, a.geo, m0, n0, lds);
+  if (a.ksplit > 1) {
+    Terms t = a.terms;
+    Geom g = a.geo;
+    const int k0 = kz * a.ksteps * BK;
+    const int left = g.Kc - k0;
+    g.Kc = left < a.ksteps * BK ? left : a.ksteps * BK;
+#pragma unroll
+    for (int k = 0; k < MAX_TERMS; ++k) {
+      t.a[k] += k0;
+      t.b[k] += k0;
+    }
+    run_mainloop<C, DUAL>(acc, t, g, m0, n0, lds);
+  } else {
+    run_mainloop<C, DUAL>(acc, a.terms, a.geo, m0, n0, lds);
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -709,6 +735,10 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_nt_kernel(GemmArgs a) {
       for (int j = 0; j < NJ; ++j) {
         const int col = n0 + acc_col(lane, wcol0, j);  // 32 consecutive lanes -> 32 consecutive columns
         if (col >= a.geo.N) continue;
+        if (a.ksplit > 1) {
+          a.partial[((int64_t)kz * a.geo.M + row) * a.geo.N + col] = acc[i][j][r];
+          continue;
+        }
         const int64_t o = (int64_t)row * a.ldc + col;
         if (a.out_bf16) {
           static_cast<uint16_t*>(a.out)[o] = to_bf16(acc[i][j][r]);
@@ -718,6 +748,27 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_nt_kernel(GemmArgs a) {
         }
       }
     }
+}
+
+// out[m, n] = sum over kz (ascending) of partial[kz][m][n]; M * N is a multiple of 4 (N = hidden is a multiple of 64)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t quads, int64_t plane, int ksplit, const float* __restrict__ partial,
+                                                            void* out, int out_bf16) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= quads) return;
+  float4 sum = reinterpret_cast<const float4*>(partial)[u];
+  for (int k = 1; k < ksplit; ++k) {
+    const float4 x = reinterpret_cast<const float4*>(partial + (int64_t)k * plane)[u];
+    sum.x += x.x;
+    sum.y += x.y;
+    sum.z += x.z;
+    sum.w += x.w;
+  }
+  if (out_bf16) {
+    reinterpret_cast<uint2*>(out)[u] = uint2{(uint32_t)to_bf16(sum.x) | ((uint32_t)to_bf16(sum.y) << 16),
+                                             (uint32_t)to_bf16(sum.z) | ((uint32_t)to_bf16(sum.w) << 16)};
+  } else {
+    reinterpret_cast<float4*>(out)[u] = sum;
+  }
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -829,8 +880,31 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdLayout {
   int chunk_pad;
-  size_t hT, dl_hi, dl_lo, dlT_hi, dlT_lo, total;
+  size_t hT, dl_hi, dl_lo, dlT_hi, dlT_lo, dh_partial, total;
 };
+
+// Split-K factor of the d hidden product: its grid (chunk rows / 256 x hidden / 256 = 224 tiles at the 7B shape)
+// leaves CUs idle in the one round it runs, while the contraction is 152 064 x 3 long.  Pick the factor (<= 8)
+// whose grid fills whole rounds of 256 workgroups best; every slice keeps at least 64 steps.
+constexpr int kMaxKSplit = 8;
+int pick_ksplit(int tiles, int ksteps_total) {
+  if (const char* e = getenv("PRL_LMHEAD_KSPLIT")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= kMaxKSplit && v <= ksteps_total) return v;
+  }
+  int best = 1;
+  double best_eff = 0.0;
+  for (int ks = 1; ks <= kMaxKSplit; ++ks) {
+    if (ks > 1 && ksteps_total / ks < 64) break;
+    const int64_t wg = (int64_t)tiles * ks;
+    const double eff = (double)wg / (double)(((wg + 255) / 256) * 256);
+    if (eff > best_eff + 0.02) {  // a larger factor has to buy at least 2 %
+      best_eff = eff;
+      best = ks;
+    }
+  }
+  return best;
+}
 
 BwdLayout bwd_layout(int64_t hidden, int64_t vocab, int64_t chunk_rows) {
   BwdLayout L;
@@ -847,6 +921,8 @@ BwdLayout bwd_layout(int64_t hidden, int64_t vocab, int64_t chunk_rows) {
   o += plane;
   L.dlT_lo = o;
   o += plane;
+  L.dh_partial = o;
+  o += align256((size_t)kMaxKSplit * L.chunk_pad * hidden * 4);
   L.total = o;
   return L;
 }
@@ -1040,7 +1116,18 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       g.out_bf16 = grad_hidden_dtype == PRL_DTYPE_BF16;
       g.accumulate = 0;
       g.out = static_cast<char*>(grad_hidden) + (size_t)r0 * hidden * (g.out_bf16 ? 2 : 4);
-      if (int rc = PRL_LAUNCH_CFG(shape, gemm_nt_kernel, g.mt * g.nt, g, s, "gemm_nt_kernel(d hidden)")) return rc;
+      const int steps = (int)(vocab / BK);
+      g.ksplit = pick_ksplit(g.mt * g.nt, steps);
+      g.ksteps = ceil_div(steps, g.ksplit);
+      g.ksplit = ceil_div(steps, g.ksteps);  // no empty slice
+      g.partial = reinterpret_cast<float*>(ws + L.dh_partial);
+      if (int rc = PRL_LAUNCH_CFG(shape, gemm_nt_kernel, g.mt * g.nt * g.ksplit, g, s, "gemm_nt_kernel(d hidden)")) return rc;
+      if (g.ksplit > 1) {
+        const int64_t quads = m * hidden / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(quads, 256)), dim3(256), 0, s, quads, m * hidden, g.ksplit,
+                           g.partial, g.out, g.out_bf16);
+        PRL_LAUNCH_CHECK("splitk_reduce_kernel");
+      }
     }
     // ---- 3. d W += dl^T h  (contraction over the chunk's rows; hidden is exact in bf16)
     if (grad_weight) {
@@ -1062,6 +1149,9 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       g.out_bf16 = 0;
       g.accumulate = 1;
       g.out = grad_weight;
+      g.ksplit = 1;
+      g.ksteps = 0;
+      g.partial = nullptr;
       if (use_dual(shape, g.terms)) {
         if (int rc = PRL_LAUNCH_DUAL((gemm_nt_kernel<CfgDual, true>), g.mt * g.nt, g, s, "gemm_nt_kernel(d weight, dual)")) return rc;
       } else if (int rc = PRL_LAUNCH_CFG(shape, gemm_nt_kernel, g.mt * g.nt, g, s, "gemm_nt_kernel(d weight)")) {

@@ -104,8 +104,14 @@ if not args.skip_bwd:
         emit(what="fused backward (d hidden + d W)", tile=tile, chunk_rows=args.chunk_rows,
              ms=round(med, 3), best_ms=round(best, 3), mfma_tflops=round(terms * gemm / med / 1e9, 1), fp32_equiv_tflops=round(3 * gemm / med / 1e9, 1))
     os.environ.pop("PRL_LMHEAD_TILE", None)
-    med, _ = timeit(lambda: head.backward_from_token_grads(h, ids, 1.0, lse2, ent, g_nlp, None, None, want_hidden=True, grad_weight=None), iters=2)
-    emit(what="fused backward, d hidden only", ms=round(med, 3))
+    for ks in (None, "1", "4"):
+        if ks is None:
+            os.environ.pop("PRL_LMHEAD_KSPLIT", None)
+        else:
+            os.environ["PRL_LMHEAD_KSPLIT"] = ks
+        med, _ = timeit(lambda: head.backward_from_token_grads(h, ids, 1.0, lse2, ent, g_nlp, None, None, want_hidden=True, grad_weight=None), iters=2)
+        emit(what="fused backward, d hidden only", ksplit=ks or "default", ms=round(med, 3))
+    os.environ.pop("PRL_LMHEAD_KSPLIT", None)
     head.hidden_grad_terms = 1
     gw = torch.zeros(V, H, device=dev)
     med, best = timeit(lambda: head.backward_from_token_grads(h, ids, 1.0, lse2, ent, g_nlp, None, None, grad_weight=gw), iters=2)

@@ -100,12 +100,15 @@ def test_small_ragged_shapes(libprl, cuda_device, monkeypatch, tile, T, H, V):
     _compare(loss, stats, gh, gw, want)
 
 
-def test_forward_values_and_split_count_independence(libprl, cuda_device, monkeypatch):
+@pytest.mark.parametrize("V", [8192, 8200], ids=["whole_tiles", "partial_last_tile"])
+def test_forward_values_and_split_count_independence(libprl, cuda_device, monkeypatch, V):
     """new_logprobs / entropy against fp64 directly, for every vocabulary-split count (the partial
-    online-softmax states merge to the same answer), with a spiky row that forces running-max rescales."""
+    online-softmax states merge to the same answer; with few splits a workgroup sweeps many vocabulary tiles and
+    the dual-plane core chains them without refilling its pipeline), with a spiky row that forces running-max
+    rescales."""
     from pipelinerl_amd.fused_head import FusedLmHead
 
-    T, H, V = 200, 256, 8192
+    T, H = 200, 256
     hidden, W, batch, logits64 = _problem(T, H, V, cuda_device, seed=5)
     W = W.clone()
     W[4000] = hidden[0, 17].float() * 0.5  # token 17's logit for id 4000 towers over the rest (~ |h|^2 / 2)
@@ -172,6 +175,36 @@ def test_chunked_backward_and_upstream_scale(libprl, cuda_device, monkeypatch, t
     for chunk, scale in ((None, 1.0), (128, 1.0), (100, 0.25), (299, 3.0)):
         loss, stats, gh, gw, _ = _run(hidden, W, batch, chunk_rows=chunk, grad_scale=scale)
         _compare(loss, stats, gh, gw, want, scale)
+
+
+@pytest.mark.parametrize("tile", ["256x256", "256", "128"], ids=["tile256x256", "tile256x128_ring3", "tile128x128"])
+@pytest.mark.parametrize("ksplit", ["2", "3", "8"])
+def test_split_k_hidden_gradient(libprl, cuda_device, monkeypatch, tile, ksplit):
+    """d hidden contracts over the vocabulary; its split-K path (slices of the vocabulary reduced in a fixed order)
+    gives the same result for even and uneven slices (65 steps of 64: 33 + 32, 22 + 22 + 21, 7 x 9 + 2)."""
+    from pipelinerl_amd.finetune.rl import RLConfig, grpo_loss_from_logprobs, make_loss_config
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.fused_head import FusedLmHead
+
+    monkeypatch.setenv("PRL_LMHEAD_TILE", tile)
+    hidden, W, batch, logits64 = _problem(300, 128, 4160, cuda_device, seed=33)
+    want = _oracle(hidden, W, batch, logits64)
+    pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(cuda_device)
+    head = FusedLmHead(W)
+    nlp, ent, lse2, h = head.logprob_entropy(hidden, pb.input_ids, CFG["temperature"])
+    c_cfg, _, _ = make_loss_config(RLConfig(**CFG), 2, 10)
+    _, _, g_nlp, g_ent = grpo_loss_from_logprobs(c_cfg, pb, nlp, ent)
+    out = {}
+    for ks in ("1", ksplit):
+        monkeypatch.setenv("PRL_LMHEAD_KSPLIT", ks)
+        for dt in (torch.float32, torch.bfloat16):
+            gh = head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, grad_hidden_dtype=dt)
+            torch.cuda.synchronize()
+            out[ks, dt] = gh[0].float().cpu().numpy()
+            assert rel_err(out[ks, dt], want["d_hidden"]) <= (FP_TOL if dt == torch.float32 else 4e-3)
+    # the slices are added in a fixed order: run to run the split result is bitwise stable
+    gh = head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, grad_hidden_dtype=torch.float32)
+    assert np.array_equal(gh[0].cpu().numpy(), out[ksplit, torch.float32])
 
 
 def test_leading_term_hidden_gradient(libprl, cuda_device):
@@ -254,4 +287,5 @@ def test_workspace_too_small_and_bad_shapes_are_refused(libprl, cuda_device):
     assert libprl.prl_lm_head_logprob_bwd(1, 128, 64, 1000, P, P, None, P, None, P, 1.0, P, P, P, None, None, P, 1, None, 128, 0, P, 1 << 20, s) == _lib.PRL_EINVAL  # vocab % 64
     fwd, bwd = ctypes.c_size_t(), ctypes.c_size_t()
     _lib.check(libprl.prl_lm_head_workspace_bytes(1, 8192, 3584, 152064, 2048, ctypes.byref(fwd), ctypes.byref(bwd)))
-    assert fwd.value < 2 << 20 and 2.4e9 < bwd.value < 2.6e9  # 4 bf16 planes of 2048 x 152064 + the transposed hidden chunk
+    # 4 bf16 planes of 2048 x 152064 + the transposed hidden chunk + 8 fp32 split-K slices of the d hidden chunk
+    assert fwd.value < 2 << 20 and 2.7e9 < bwd.value < 2.8e9
