@@ -196,6 +196,15 @@ class _FusedHeadLossFn(torch.autograd.Function):
         return gh, gw, None, None, None, None, None
 
 
+def _host_stats(stats_dev: torch.Tensor, batch: PipelineBatchEncoding, kl_coef: float, ent_coef: float):
+    stats = stats_dev.cpu().tolist()
+    check_finite(stats)
+    input_size = batch.input_ids.numel()
+    if int(stats[STAT_INDEX["num_output_tokens_sum"]]) == 0:
+        return {"input_size": float(input_size)}
+    return stats_to_dict(stats, kl_coef, ent_coef, input_size)
+
+
 def fused_head_loss(hidden: torch.Tensor, weight: torch.Tensor, head: FusedLmHead, batch: PipelineBatchEncoding,
                     config: RLConfig, current_step: int, max_step: int, chunk_rows: int | None = None):
     """Loss + stats from last hidden states and the head weight; same return contract as `rl_step`."""
@@ -203,33 +212,84 @@ def fused_head_loss(hidden: torch.Tensor, weight: torch.Tensor, head: FusedLmHea
         raise NotImplementedError("the fused head covers ppo / reinforce; gspo goes through rl_step")
     cfg, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
     loss, stats_dev = _FusedHeadLossFn.apply(hidden, weight, head, batch, cfg, config.temperature, chunk_rows)
-    stats = stats_dev.cpu().tolist()
-    check_finite(stats)
-    input_size = batch.input_ids.numel()
-    if int(stats[STAT_INDEX["num_output_tokens_sum"]]) == 0:
-        return loss, {"input_size": float(input_size)}
-    return loss, stats_to_dict(stats, kl_coef, ent_coef, input_size)
+    return loss, _host_stats(stats_dev, batch, kl_coef, ent_coef)
 
 
 _heads: dict[int, FusedLmHead] = {}
+
+
+def _body_and_head(model: Any):
+    body = getattr(model, "model", None)
+    lm_head = getattr(model, "lm_head", None)
+    if body is None or lm_head is None or getattr(lm_head, "bias", None) is not None:
+        raise TypeError("the fused head needs model.model (body) and a bias-free model.lm_head")
+    return body, lm_head
+
+
+def _hidden_states(body: Any, batch: PipelineBatchEncoding) -> torch.Tensor:
+    inputs = {"input_ids": batch.input_ids, "attention_mask": batch.attention_mask}
+    if batch.is_packed:
+        inputs["position_ids"] = batch.position_ids
+    out = body(**inputs)
+    return out[0] if isinstance(out, (tuple, list)) else getattr(out, "last_hidden_state", out)
+
+
+def _head_for(weight: torch.Tensor, chunk_rows: int, hidden_grad_terms: int = 3) -> FusedLmHead:
+    head = _heads.get(id(weight))
+    if head is None or head.weight is not weight:
+        head = _heads[id(weight)] = FusedLmHead(weight, backward=True, chunk_rows=chunk_rows, hidden_grad_terms=hidden_grad_terms)
+    return head
+
+
+def install_fused_head(model: Any, chunk_rows: int = 4096, hidden_grad_terms: int = 3) -> Any:
+    """Teach a causal LM (`.model` body + bias-free `.lm_head`, the Hugging Face layout) to compute the RL loss
+    INSIDE its own forward: `model(rl_batch=batch, rl_config=config, current_step=s, max_step=m)` returns
+    `(loss, stats_device)`; every other call is the model's original forward.  Call this BEFORE wrapping the
+    model in DistributedDataParallel / FSDP / `accelerator.prepare`: those wrappers arm their gradient
+    reduction in THEIR forward, so the loss has to be produced by a call that goes through them -
+    `rl_step_fused_head(wrapped, ...)` does exactly that.  Parameter names are unchanged (the weight-update
+    path keeps seeing `model.*` / `lm_head.weight`)."""
+    _body_and_head(model)
+    if getattr(model, "_prl_fused_head", None) is not None:
+        return model
+    original = model.forward
+
+    def forward(*args, rl_batch: PipelineBatchEncoding | None = None, rl_config: RLConfig | None = None,
+                current_step: int = 0, max_step: int = 1, **kwargs):
+        if rl_batch is None:
+            return original(*args, **kwargs)
+        if rl_config.policy_loss == "gspo":
+            raise NotImplementedError("the fused head covers ppo / reinforce; gspo goes through rl_step")
+        body, lm_head = _body_and_head(model)
+        hidden = _hidden_states(body, rl_batch)
+        w = lm_head.weight
+        cfg, _, _ = make_loss_config(rl_config, current_step, max_step)
+        opts = model._prl_fused_head
+        return _FusedHeadLossFn.apply(hidden, w, _head_for(w, opts["chunk_rows"], opts["hidden_grad_terms"]), rl_batch, cfg,
+                                      rl_config.temperature, opts["chunk_rows"])
+
+    model._prl_fused_head = {"chunk_rows": int(chunk_rows), "hidden_grad_terms": int(hidden_grad_terms)}
+    model.forward = forward
+    return model
 
 
 def rl_step_fused_head(model: Any, batch: PipelineBatchEncoding, current_step: int, max_step: int, config: RLConfig,
                        seq_parallel_group=None, chunk_rows: int = 4096):
     """`rl_step` (reference rl/__init__.py:136-143, same signature and return value) for a causal LM
     that exposes its body and head separately, as Hugging Face models do (`model.model`,
-    `model.lm_head`): the body runs as usual, the head never produces logits."""
-    body = getattr(model, "model", None)
-    lm_head = getattr(model, "lm_head", None)
-    if body is None or lm_head is None or getattr(lm_head, "bias", None) is not None:
-        raise TypeError("rl_step_fused_head needs model.model (body) and a bias-free model.lm_head")
-    inputs = {"input_ids": batch.input_ids, "attention_mask": batch.attention_mask}
-    if batch.is_packed:
-        inputs["position_ids"] = batch.position_ids
-    out = body(**inputs)
-    hidden = out[0] if isinstance(out, (tuple, list)) else getattr(out, "last_hidden_state", out)
+    `model.lm_head`): the body runs as usual, the head never produces logits.
+
+    A bare model is driven directly.  A model prepared with `install_fused_head` - bare or inside
+    DistributedDataParallel / FSDP / an accelerate wrapper (anything that exposes it as `.module`) - is driven
+    through ITS forward, which is what data-parallel training needs."""
+    inner = model
+    while getattr(inner, "_prl_fused_head", None) is None and hasattr(inner, "module"):
+        inner = inner.module
+    if getattr(inner, "_prl_fused_head", None) is not None:
+        _, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
+        loss, stats_dev = model(rl_batch=batch, rl_config=config, current_step=current_step, max_step=max_step)
+        return loss, _host_stats(stats_dev, batch, kl_coef, ent_coef)
+    body, lm_head = _body_and_head(model)
+    hidden = _hidden_states(body, batch)
     w = lm_head.weight
-    head = _heads.get(id(w))
-    if head is None or head.weight is not w:
-        head = _heads[id(w)] = FusedLmHead(w, backward=True, chunk_rows=chunk_rows)
-    return fused_head_loss(hidden, w, head, batch, config, current_step, max_step, chunk_rows)
+    return fused_head_loss(hidden, w, _head_for(w, chunk_rows), batch, config, current_step, max_step, chunk_rows)
