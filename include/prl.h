@@ -470,6 +470,23 @@ int prl_bucket_scatter(const void* bucket, int64_t bucket_bytes, const struct pr
  * bf16 MFMA GEMMs with fp32 accumulation (pipelinerl_amd/lm_head.py).  Device pointers. */
 int prl_split_bf16(int64_t n, const float* src, uint16_t* hi, uint16_t* lo, void* stream);
 
+/*
+ * prl_fused_logits_loss with the gradient delivered as those two planes: grad_hi / grad_lo
+ * [rows*cols, plane_row_stride] bf16, hi + lo = d loss / d logits to ~2^-17 relative, bit for bit
+ * what prl_split_bf16 makes of prl_fused_logits_loss's fp32 gradient - without the fp32 gradient
+ * and without the extra pass over it.  fp32 logits only; the planes must not alias the logits
+ * (a row's planes are written while later rows are still being read).
+ */
+int prl_fused_logits_loss_planes(const prl_loss_config* cfg, int64_t rows, int64_t cols,
+                                 int64_t vocab, const float* logits, int64_t logits_row_stride,
+                                 float temperature, const int64_t* input_ids,
+                                 const int64_t* labels, const float* old_logprobs,
+                                 const float* ref_logprobs, const float* advantages,
+                                 const float* rewards, const float* group_tokens,
+                                 const float* overflow, float* new_logprobs, float* entropy,
+                                 float* lse2, uint16_t* grad_hi, uint16_t* grad_lo,
+                                 int64_t plane_row_stride, prl_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* Fused output head: hidden states -> new_logprobs / entropy, logits never   */
 /* written (reference rl/__init__.py:204-233 after the model's */

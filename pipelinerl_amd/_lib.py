@@ -120,6 +120,7 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_grpo_loss_workspace_bytes": (c_int32, [c_int64, c_int64, POINTER(c_size_t)]),
     "prl_grpo_loss_fwd_bwd": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64] + [_P] * 13 + [_P, _P, _P, _P, _P, c_size_t, _P]),
     "prl_fused_logits_loss": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64, c_int64, _P, c_int32, c_int64, c_float] + [_P] * 8 + [_P, _P, _P, _P, _P]),
+    "prl_fused_logits_loss_planes": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64, c_int64, _P, c_int64, c_float] + [_P] * 8 + [_P, _P, _P, _P, _P, c_int64, _P]),
     "prl_last_fused_kernel": (c_char_p, []),
     "prl_scale_unless": (c_int32, [_P, c_int64, c_int32, _P, c_float, _P]),
     "prl_segment_sums": (c_int32, [c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -157,12 +157,55 @@ __device__ __forceinline__ void store_vec(V* p, const V& v) {
   }
 }
 
+// ---- where a row of d logits goes.  DenseOut: the logits' own dtype and layout (may alias the logits).
+// PlanesOut: two bf16 planes hi + lo = the fp32 value to ~2^-17 relative - the operand format of the split-bf16
+// head GEMMs (lm_head.py), so the gradient never exists in fp32 and needs no separate split pass.
+template <class T>
+struct DenseOut {
+  typename T::scalar* p;
+  __device__ __forceinline__ DenseOut row(int64_t q, int64_t stride) const { return DenseOut{p + q * stride}; }
+  template <bool NT>
+  __device__ __forceinline__ void put(int j, const float (&o)[T::NV]) const {
+    store_vec<NT>(&reinterpret_cast<typename T::vec*>(p)[j], T::pack(o));
+  }
+  __device__ __forceinline__ void put1(int j, float x) const { p[j] = T::from_float(x); }
+};
+
+__device__ __forceinline__ void split_hi_lo(float x, uint16_t& hi, uint16_t& lo) {
+  hi = BF16::from_float(x);
+  lo = BF16::from_float(x - BF16::to_float(hi));
+}
+
+struct PlanesOut {  // fp32 logits only: groups of 4 values -> 8 bytes per plane
+  uint16_t* hi;
+  uint16_t* lo;
+  int64_t stride;  // row stride of the planes, elements
+  __device__ __forceinline__ PlanesOut row(int64_t q, int64_t) const { return PlanesOut{hi + q * stride, lo + q * stride, stride}; }
+  template <bool NT>
+  __device__ __forceinline__ void put(int j, const float (&o)[4]) const {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 h, l;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f32x2 x = {o[2 * i], o[2 * i + 1]};
+      h[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));  // v_cvt_pk_bf16_f32, RNE
+      const f32x2 r = {x[0] - __uint_as_float(h[i] << 16), x[1] - __uint_as_float(h[i] & 0xffff0000u)};
+      l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+    }
+    store_vec<NT>(&reinterpret_cast<u32x2*>(hi)[j], h);
+    store_vec<NT>(&reinterpret_cast<u32x2*>(lo)[j], l);
+  }
+  __device__ __forceinline__ void put1(int j, float x) const { split_hi_lo(x, hi[j], lo[j]); }
+};
+
 // REVERSE walks the row back to front: in the fused kernel the tail of the row is what pass 1
 // touched last, i.e. what is most likely still in L2 / Infinity Cache.  NT marks the gradient
 // stores non-temporal so they do not evict the logits lines pass 2 is about to re-read.
-template <class T, int BLOCK, int UNROLL, bool REVERSE = false, bool NT = false>
+template <class T, int BLOCK, int UNROLL, bool REVERSE = false, bool NT = false, class OUT = DenseOut<T>>
 __device__ __forceinline__ void row_write_grad(const typename T::scalar* row,
-                                               typename T::scalar* out, int vocab, float k2,
+                                               OUT out, int vocab, float k2,
                                                float inv_temp, float lse2, float H, float g,
                                                float gH, int id, bool vec_ok) {
   using vec = typename T::vec;
@@ -183,7 +226,6 @@ __device__ __forceinline__ void row_write_grad(const typename T::scalar* row,
   int done = 0;
   if (vec_ok) {
     const vec* rv = reinterpret_cast<const vec*>(row);
-    vec* ov = reinterpret_cast<vec*>(out);
     const int nvec = vocab / NV;
     constexpr int TILE = BLOCK * UNROLL;
     const int nfull = (nvec / TILE) * TILE;
@@ -193,7 +235,7 @@ __device__ __forceinline__ void row_write_grad(const typename T::scalar* row,
         T::unpack(rv[j], f);
 #pragma unroll
         for (int i = 0; i < NV; ++i) o[i] = one(f[i], j * NV + i);
-        store_vec<NT>(&ov[j], T::pack(o));
+        out.template put<NT>(j, o);
       }
     };
     if constexpr (REVERSE) tail();
@@ -209,33 +251,29 @@ __device__ __forceinline__ void row_write_grad(const typename T::scalar* row,
         T::unpack(v[k], f);
 #pragma unroll
         for (int i = 0; i < NV; ++i) o[i] = one(f[i], j * NV + i);
-        store_vec<NT>(&ov[j], T::pack(o));
+        out.template put<NT>(j, o);
       }
     }
     if constexpr (!REVERSE) tail();
     done = nvec * NV;
   }
-  for (int j = done + tid; j < vocab; j += BLOCK)
-    out[j] = T::from_float(one(T::to_float(row[j]), j));
+  for (int j = done + tid; j < vocab; j += BLOCK) out.put1(j, one(T::to_float(row[j]), j));
 }
 
-template <class T, int BLOCK>
-__device__ __forceinline__ void row_write_zero(typename T::scalar* out, int vocab, bool vec_ok) {
-  using vec = typename T::vec;
+template <class T, int BLOCK, class OUT>
+__device__ __forceinline__ void row_write_zero(OUT out, int vocab, bool vec_ok) {
   constexpr int NV = T::NV;
   const int tid = threadIdx.x;
   int done = 0;
   if (vec_ok) {
-    vec* ov = reinterpret_cast<vec*>(out);
     const int nvec = vocab / NV;
     float z[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) z[i] = 0.0f;
-    const vec zv = T::pack(z);
-    for (int j = tid; j < nvec; j += BLOCK) ov[j] = zv;
+    for (int j = tid; j < nvec; j += BLOCK) out.template put<false>(j, z);
     done = nvec * NV;
   }
-  for (int j = done + tid; j < vocab; j += BLOCK) out[j] = T::from_float(0.0f);
+  for (int j = done + tid; j < vocab; j += BLOCK) out.put1(j, 0.0f);
 }
 
 struct RowGeom {
@@ -288,7 +326,7 @@ __global__ __launch_bounds__(BLOCK) void logprob_entropy_bwd_kernel(
     const float* __restrict__ upstream, typename T::scalar* grad) {
   const int64_t q = blockIdx.x;
   const int64_t col = q % geo.cols;
-  typename T::scalar* out = grad + q * geo.stride;
+  const DenseOut<T> out{grad + q * geo.stride};
   float g = 0.0f, gH = 0.0f;
   const int64_t u = q + 1;
   if (col != geo.cols - 1) {
@@ -325,17 +363,17 @@ struct FusedArgs {
   float up;  // expected upstream factor d objective / d loss (prl_loss_config.upstream_scale)
 };
 
-template <class T, int BLOCK, int UNROLL, bool REVERSE, bool NT>
+template <class T, int BLOCK, int UNROLL, bool REVERSE, bool NT, class OUT = DenseOut<T>>
 __global__ __launch_bounds__(BLOCK) void fused_logits_loss_kernel(
     RowGeom geo, FusedArgs a, const typename T::scalar* logits, float k2, float inv_temp,
-    typename T::scalar* grad) {
+    OUT grad) {
   // The launch may request extra (unused) dynamic LDS to cap the workgroups resident per CU, so
   // that all rows in flight (256 CUs x k x 608 KB) fit the 256 MB Infinity Cache for pass 2.
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
   Osm* lds = reinterpret_cast<Osm*>(dyn_lds);
   const int64_t q = blockIdx.x;
   const int64_t col = q % geo.cols;
-  typename T::scalar* out = grad + q * geo.stride;
+  const OUT out = grad.row(q, geo.stride);
   if (col == 0 && threadIdx.x == 0) {  // token-aligned column 0 has no prediction
     a.nlp[q] = 0.0f;
     a.ent[q] = 0.0f;
@@ -405,14 +443,15 @@ __device__ __forceinline__ float grad_one(const GradParams& p, float x, int v) {
   return r;
 }
 
-template <class T>
-__device__ __forceinline__ typename T::vec grad_vec(const GradParams& p, const typename T::vec& in, int j) {
+// gradient of the 16-byte group j of a row, non-temporal store to wherever the row's gradient goes
+template <class T, class OUT>
+__device__ __forceinline__ void put_grad(const OUT& out, const GradParams& p, const typename T::vec& in, int j) {
   constexpr int NV = T::NV;
   float f[NV], o[NV];
   T::unpack(in, f);
 #pragma unroll
   for (int i = 0; i < NV; ++i) o[i] = grad_one(p, f[i], j * NV + i);
-  return T::pack(o);
+  out.template put<true>(j, o);
 }
 
 template <class T>
@@ -436,10 +475,10 @@ __device__ __forceinline__ V load_vec(const V* p) {
 
 // NTHEAD: the chip-resident head is read exactly once -> stream it past the caches so that the
 // tail (which IS re-read) keeps its lines in L2 / Infinity Cache.
-template <class T, int BLOCK, int UNROLL, int KREG, int KLDS, bool NTHEAD = false>
+template <class T, int BLOCK, int UNROLL, int KREG, int KLDS, bool NTHEAD = false, class OUT = DenseOut<T>>
 __global__ __launch_bounds__(BLOCK) void fused_logits_loss_keep_kernel(
     RowGeom geo, FusedArgs a, const typename T::scalar* logits, float k2, float inv_temp,
-    typename T::scalar* grad) {
+    OUT grad) {
   using vec = typename T::vec;
   constexpr int NV = T::NV;
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
@@ -448,7 +487,7 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_keep_kernel(
   const int tid = threadIdx.x;
   const int64_t q = blockIdx.x;
   const int64_t col = q % geo.cols;
-  typename T::scalar* out = grad + q * geo.stride;
+  const OUT out = grad.row(q, geo.stride);
   if (col == 0 && tid == 0) {
     a.nlp[q] = 0.0f;
     a.ent[q] = 0.0f;
@@ -466,7 +505,6 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_keep_kernel(
   if (id >= 0) y_sel = T::to_float(row[id]) * k2;
 
   const vec* rv = reinterpret_cast<const vec*>(row);
-  vec* ov = reinterpret_cast<vec*>(out);
   const int nvec = geo.vocab / NV;                 // host guarantees nvec >= (KREG + KLDS) * BLOCK
   constexpr int HEAD = (KREG + KLDS) * BLOCK;      // vectors kept on chip
   constexpr int TILE = BLOCK * UNROLL;
@@ -526,9 +564,8 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_keep_kernel(
 
   // ---- pass 2: tail (re-read, back to front) -> LDS part -> register part ------------------
   GradParams p{k2, lse2, H, -g * inv_temp, -gH * inv_temp, g * inv_temp, id, gH != 0.0f};
-  for (int j = nvec * NV + tid; j < geo.vocab; j += BLOCK)
-    out[j] = T::from_float(grad_one(p, T::to_float(row[j]), j));
-  for (int j = HEAD + nfull + tid; j < nvec; j += BLOCK) store_vec<true>(&ov[j], grad_vec<T>(p, rv[j], j));
+  for (int j = nvec * NV + tid; j < geo.vocab; j += BLOCK) out.put1(j, grad_one(p, T::to_float(row[j]), j));
+  for (int j = HEAD + nfull + tid; j < nvec; j += BLOCK) put_grad<T>(out, p, rv[j], j);
   for (int it = 0; it < nfull; it += TILE) {
     const int base = HEAD + (nfull - TILE - it);
     vec v[UNROLL];
@@ -537,18 +574,18 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_keep_kernel(
 #pragma unroll
     for (int k = 0; k < UNROLL; ++k) {
       const int j = base + k * BLOCK + tid;
-      store_vec<true>(&ov[j], grad_vec<T>(p, v[k], j));
+      put_grad<T>(out, p, v[k], j);
     }
   }
 #pragma unroll
   for (int k = KLDS - 1; k >= 0; --k) {
     const int j = (KREG + k) * BLOCK + tid;
-    store_vec<true>(&ov[j], grad_vec<T>(p, lds_keep[k * BLOCK + tid], j));
+    put_grad<T>(out, p, lds_keep[k * BLOCK + tid], j);
   }
 #pragma unroll
   for (int k = KREG - 1; k >= 0; --k) {
     const int j = k * BLOCK + tid;
-    store_vec<true>(&ov[j], grad_vec<T>(p, keep[k], j));
+    put_grad<T>(out, p, keep[k], j);
   }
 }
 
@@ -731,7 +768,7 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
       attr_set = true;                                                                              \
     }                                                                                               \
     hipLaunchKernelGGL(kfn, grid, dim3(BLK), lds_bytes, s, geo, a, static_cast<const ST*>(logits), k2, \
-                       inv_temp, static_cast<ST*>(grad_logits));                                    \
+                       inv_temp, DenseOut<TT>{static_cast<ST*>(grad_logits)});                      \
   } while (0)
 #define PRL_KEEP_LAUNCH(TT, ST, BLK, UNR, KR, KL) PRL_KEEP_LAUNCH2(TT, ST, BLK, UNR, KR, KL, false)
 #define PRL_KEEP_LAUNCH2(TT, ST, BLK, UNR, KR, KL, NTH)                                                     \
@@ -751,7 +788,7 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
       attr_set = true;                                                                              \
     }                                                                                               \
     hipLaunchKernelGGL(kfn, grid, dim3(BLK), lds_bytes, s, geo, a, static_cast<const ST*>(logits), k2, \
-                       inv_temp, static_cast<ST*>(grad_logits));                                    \
+                       inv_temp, DenseOut<TT>{static_cast<ST*>(grad_logits)});                      \
   } while (0)
 #define PRL_FUSED_DISPATCH(TT, ST)                                              \
   switch (variant) {                                                            \
@@ -776,5 +813,72 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
 #undef PRL_KEEP_LAUNCH2
 #undef PRL_FUSED_LAUNCH
   PRL_LAUNCH_CHECK("fused_logits_loss_kernel");
+  return PRL_OK;
+}
+
+// d logits as two bf16 planes (hi + lo), straight from the fused pass: fp32 logits in, never an fp32 gradient.
+extern "C" int prl_fused_logits_loss_planes(const prl_loss_config* cfg, int64_t rows, int64_t cols,
+                                            int64_t vocab, const float* logits, int64_t logits_row_stride,
+                                            float temperature, const int64_t* input_ids, const int64_t* labels,
+                                            const float* old_logprobs, const float* ref_logprobs,
+                                            const float* advantages, const float* rewards,
+                                            const float* group_tokens, const float* overflow,
+                                            float* new_logprobs, float* entropy, float* lse2,
+                                            uint16_t* grad_hi, uint16_t* grad_lo, int64_t plane_row_stride,
+                                            prl_stream_t stream) {
+  RowGeom geo;
+  if (int rc = check_geom(rows, cols, vocab, logits, PRL_DTYPE_F32, logits_row_stride, &geo)) return rc;
+  PRL_CHECK_ARG(cfg != nullptr, "cfg is null");
+  PRL_CHECK_ARG(cfg->policy_loss == PRL_POLICY_PPO || cfg->policy_loss == PRL_POLICY_REINFORCE,
+                "unknown policy_loss %d", cfg->policy_loss);
+  PRL_CHECK_ARG(input_ids && labels && old_logprobs && ref_logprobs && advantages && rewards &&
+                    group_tokens && overflow && new_logprobs && entropy && lse2 && grad_hi && grad_lo,
+                "null pointer");
+  PRL_CHECK_ARG(temperature > 0.0f, "temperature must be > 0");
+  PRL_CHECK_ARG(plane_row_stride >= vocab, "plane_row_stride %lld < vocab %lld", (long long)plane_row_stride, (long long)vocab);
+  {  // the planes are written while other rows' logits are still being read: they must not overlap them
+    const char* l0 = reinterpret_cast<const char*>(logits);
+    const char* l1 = l0 + (size_t)geo.n * logits_row_stride * 4;
+    const size_t pb = (size_t)geo.n * plane_row_stride * 2;
+    auto overlaps = [&](const uint16_t* q) {
+      const char* a0 = reinterpret_cast<const char*>(q);
+      return a0 < l1 && a0 + pb > l0;
+    };
+    PRL_CHECK_ARG(!overlaps(grad_hi) && !overlaps(grad_lo), "the gradient planes must not alias the logits");
+  }
+  // groups of four values are stored as 8 bytes per plane
+  geo.vec_ok = geo.vec_ok && (reinterpret_cast<uintptr_t>(grad_hi) & 7u) == 0 && (reinterpret_cast<uintptr_t>(grad_lo) & 7u) == 0 &&
+               (plane_row_stride * 2) % 8 == 0;
+  FusedArgs a{*cfg,      input_ids, labels,       old_logprobs, ref_logprobs, advantages,
+              rewards,   group_tokens, overflow,  new_logprobs, entropy,      lse2,
+              cfg->upstream_scale == 0.0f ? 1.0f : cfg->upstream_scale};
+  const float k2 = kLog2e / temperature;
+  const float inv_temp = 1.0f / temperature;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)geo.n);
+  const PlanesOut out{grad_hi, grad_lo, plane_row_stride};
+  constexpr int BLK = 1024, KR = 16, KL = 9;
+  if (geo.vec_ok && geo.vocab / F32::NV >= (KR + KL) * BLK) {  // the row-resident shape of prl_fused_logits_loss (variant 21)
+    auto kfn = fused_logits_loss_keep_kernel<F32, BLK, 2, KR, KL, true, PlanesOut>;
+    g_last_fused = "fused_logits_loss_keep_kernel<F32,1024,2,16,9,true,planes>";
+    const size_t lds_bytes = 256 + (size_t)KL * BLK * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+      PRL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(BLK), lds_bytes, s, geo, a, logits, k2, inv_temp, out);
+  } else {
+    auto kfn = fused_logits_loss_kernel<F32, BLK, 4, true, true, PlanesOut>;
+    g_last_fused = "fused_logits_loss_kernel<F32,1024,4,true,true,planes>";
+    const size_t lds_bytes = 96 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+      PRL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(BLK), lds_bytes, s, geo, a, logits, k2, inv_temp, out);
+  }
+  PRL_LAUNCH_CHECK("fused_logits_loss_kernel(planes)");
   return PRL_OK;
 }

@@ -167,6 +167,17 @@ class _FusedHeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hidden, weight, head: FusedLmHead, batch, cfg, temperature, chunk_rows):  # type: ignore[override]
+        ctx.sentinel = bool(batch.sentinel)
+        if ctx.sentinel:
+            # a sentinel batch has no labelled token (finetune/utils.py:17-78): loss 0, statistics of an empty
+            # batch, gradient 0 - no GEMM forward or backward, the wrappers still see a gradient for every input
+            _lib.require_device(hidden, weight)
+            B, L, _ = hidden.shape
+            zeros = torch.zeros((B, L), dtype=torch.float32, device=hidden.device)
+            loss, stats, _, _ = grpo_loss_from_logprobs(cfg, batch, zeros, zeros, want_grad=False)
+            ctx.shapes = (hidden.shape, hidden.dtype, weight.shape, weight.dtype, hidden.device)
+            ctx.mark_non_differentiable(stats)
+            return loss, stats
         nlp, ent, lse2, h = head.logprob_entropy(hidden, batch.input_ids, temperature)
         need_grad = hidden.requires_grad or weight.requires_grad
         loss, stats, g_nlp, g_ent = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=need_grad)
@@ -180,6 +191,11 @@ class _FusedHeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_stats):  # type: ignore[override]
+        if ctx.sentinel:
+            hs, hd, ws_, wd, dev = ctx.shapes
+            gh = torch.zeros(hs, dtype=hd, device=dev) if ctx.needs_input_grad[0] else None
+            gw = torch.zeros(ws_, dtype=wd, device=dev) if ctx.needs_input_grad[1] else None
+            return gh, gw, None, None, None, None, None
         h, ids, lse2, ent, g_nlp, g_ent = ctx.saved_tensors
         head: FusedLmHead = ctx.head
         want_h, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]

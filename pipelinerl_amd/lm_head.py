@@ -76,12 +76,9 @@ class _SplitBf16Linear(torch.autograd.Function):
         if x.dtype != torch.bfloat16:
             raise TypeError("split_bf16_linear expects bf16 hidden states (they are exact bf16 operands)")
         x2 = x.reshape(-1, x.shape[-1])
-        if w_cat is not None:
-            # sum_k x @ W_k^T as ONE GEMM over the concatenated inner dimension: [x | x | ..] @ [W_0 | W_1 | ..]^T.
-            # The partial products meet in the MFMA accumulators instead of a 5 GB read-modify-write pass.
-            out = torch.mm(torch.cat([x2] * len(w_parts), dim=1), w_cat.t(), out_dtype=torch.float32)
-        else:
-            out = _mm_acc([x2], [p.t() for p in w_parts], [(0, j) for j in range(len(w_parts))])
+        # with w_cat: sum_k x @ W_k^T as ONE GEMM over the concatenated inner dimension, [x | x | ..] @ [W_0 | W_1 | ..]^T -
+        # the partial products meet in the MFMA accumulators instead of a 5 GB read-modify-write pass
+        out = _split_logits(x2, w_parts, w_cat)
         ctx.save_for_backward(x2, *w_parts)
         ctx.x_shape = x.shape
         ctx.dx_terms = dx_terms
@@ -93,20 +90,108 @@ class _SplitBf16Linear(torch.autograd.Function):
         x2, *w_parts = ctx.saved_tensors
         g = grad_out.reshape(-1, grad_out.shape[-1])
         g_parts = split_bf16(g, 2) if g.dtype == torch.float32 else [g.to(torch.bfloat16)]
-        n_g, n_w = len(g_parts), len(w_parts)
-        # d x = G W: keep the terms down to the second order of the splits (hi*hi, hi*lo, lo*hi)
-        pairs = [(i, j) for i in range(n_g) for j in range(n_w) if i + j < max(n_g, n_w)][: ctx.dx_terms]
-        dx = _mm_acc(g_parts, list(w_parts), pairs).to(torch.bfloat16).reshape(ctx.x_shape)
-        dw = None
-        if ctx.needs_w:  # d W = G^T x, x exact (returned in fp32; autograd casts it to a bf16 parameter's dtype)
-            stacked = (n_g == 2 and g_parts[0].is_contiguous() and g_parts[1].is_contiguous()
-                       and g_parts[1].data_ptr() == g_parts[0].data_ptr() + g_parts[0].numel() * 2)
-            if stacked:  # the two planes are one [2T, V] buffer: G_hi^T x + G_lo^T x as ONE GEMM over 2T
-                g_cat = torch.as_strided(g_parts[0], (2 * g.shape[0], g.shape[1]), (g.shape[1], 1))
-                dw = torch.mm(g_cat.t(), torch.cat([x2, x2], dim=0), out_dtype=torch.float32)
+        dx, dw = _head_grads(g_parts, x2, w_parts, ctx.dx_terms, ctx.needs_w)
+        return dx.to(torch.bfloat16).reshape(ctx.x_shape), dw, None, None, None
+
+
+def _head_grads(g_parts, x2: torch.Tensor, w_parts, dx_terms: int, needs_w: bool):
+    """fp32 (d hidden [T, H], d W [V, H] or None) from the bf16 planes of d logits [T, V], the bf16 hidden
+    states and the bf16 planes of the weight - every GEMM on the bf16 cores, fp32 accumulation."""
+    n_g, n_w = len(g_parts), len(w_parts)
+    # d x = G W: keep the terms down to the second order of the splits (hi*hi, hi*lo, lo*hi)
+    pairs = [(i, j) for i in range(n_g) for j in range(n_w) if i + j < max(n_g, n_w)][:dx_terms]
+    dx = _mm_acc(g_parts, list(w_parts), pairs)
+    dw = None
+    if needs_w:  # d W = G^T x, x exact (returned in fp32; autograd casts it to a bf16 parameter's dtype)
+        T, V = g_parts[0].shape
+        stacked = (n_g == 2 and g_parts[0].is_contiguous() and g_parts[1].is_contiguous()
+                   and g_parts[1].data_ptr() == g_parts[0].data_ptr() + g_parts[0].numel() * 2)
+        if stacked:  # the two planes are one [2T, V] buffer: G_hi^T x + G_lo^T x as ONE GEMM over 2T
+            g_cat = torch.as_strided(g_parts[0], (2 * T, V), (V, 1))
+            dw = torch.mm(g_cat.t(), torch.cat([x2, x2], dim=0), out_dtype=torch.float32)
+        else:
+            dw = _mm_acc([p.t() for p in g_parts], [x2], [(i, 0) for i in range(n_g)])
+    return dx, dw
+
+
+def _split_logits(x2: torch.Tensor, w_parts, w_cat) -> torch.Tensor:
+    if w_cat is not None:
+        return torch.mm(torch.cat([x2] * len(w_parts), dim=1), w_cat.t(), out_dtype=torch.float32)
+    return _mm_acc([x2], [p.t() for p in w_parts], [(0, j) for j in range(len(w_parts))])
+
+
+class _SplitHeadLossFn(torch.autograd.Function):
+    """(hidden [1, T, H] bf16, weight) -> (loss, stats) with the library head GEMMs: the fp32 logits exist only
+    between the head GEMM and ONE fused pass over them that leaves log-probs / entropy and d logits as two bf16
+    planes (`prl_fused_logits_loss_planes`) - the operand format of the backward GEMMs, so no fp32 gradient
+    and no separate split pass (1.9 ms per 8192 x 152 064 micro-batch) exist."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, w_parts, w_cat, dx_terms, batch, cfg, temperature):  # type: ignore[override]
+        import ctypes
+
+        from . import _lib
+        from .finetune.rl import grpo_loss_from_logprobs
+
+        if hidden.dtype != torch.bfloat16:
+            raise TypeError("the split head expects bf16 hidden states (they are exact bf16 operands)")
+        if hidden.dim() != 3 or hidden.shape[0] != batch.input_ids.shape[0] or hidden.shape[1] != batch.input_ids.shape[1]:
+            raise ValueError("hidden states [B, L, H] do not match the batch")
+        _lib.require_device(hidden, weight, batch.input_ids)
+        lib = _lib.load()
+        B, L, _ = hidden.shape
+        x2 = hidden.detach().reshape(B * L, hidden.shape[-1])
+        dev = hidden.device
+        V = w_parts[0].shape[0]
+        nlp = torch.empty((B, L), dtype=torch.float32, device=dev)
+        ent, lse2 = torch.empty_like(nlp), torch.empty_like(nlp)
+        need_grad = hidden.requires_grad or weight.requires_grad
+        ctx.sentinel = bool(batch.sentinel)
+        if ctx.sentinel or not need_grad:
+            planes = None
+            if ctx.sentinel:
+                nlp.zero_()
+                ent.zero_()
             else:
-                dw = _mm_acc([p.t() for p in g_parts], [x2], [(i, 0) for i in range(n_g)])
-        return dx, dw, None, None, None
+                from .finetune.rl import logprob_entropy
+
+                nlp, ent, _, _ = logprob_entropy(_split_logits(x2, w_parts, w_cat).reshape(B, L, V), batch.input_ids, temperature)
+        else:
+            logits = _split_logits(x2, w_parts, w_cat)
+            planes = torch.empty((2, B * L, V), dtype=torch.bfloat16, device=dev)
+            cont = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
+            with torch.cuda.device(dev):
+                _lib.check(lib.prl_fused_logits_loss_planes(
+                    ctypes.byref(cfg), B, L, V, logits.data_ptr(), V, float(temperature), cont(batch.input_ids).data_ptr(),
+                    cont(batch.labels).data_ptr(), cont(batch.old_logprobs).data_ptr(), cont(batch.ref_logprobs).data_ptr(),
+                    cont(batch.advantages).data_ptr(), cont(batch.rewards).data_ptr(), cont(batch.group_tokens).data_ptr(),
+                    cont(batch.overflow).data_ptr(), nlp.data_ptr(), ent.data_ptr(), lse2.data_ptr(), planes[0].data_ptr(),
+                    planes[1].data_ptr(), V, _lib.current_stream_ptr(dev)))
+            del logits
+        loss, stats, _, _ = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=False)
+        ctx.planes = planes
+        ctx.save_for_backward(x2, *w_parts)
+        ctx.meta = (hidden.shape, weight.shape, weight.dtype, dx_terms)
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_stats):  # type: ignore[override]
+        x2, *w_parts = ctx.saved_tensors
+        h_shape, w_shape, w_dtype, dx_terms = ctx.meta
+        want_h, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        planes, ctx.planes = ctx.planes, None
+        if planes is None:  # sentinel batch: zero gradient, no GEMM
+            dx = torch.zeros(h_shape, dtype=torch.bfloat16, device=x2.device) if want_h else None
+            dw = torch.zeros(w_shape, dtype=w_dtype, device=x2.device) if want_w else None
+            return dx, dw, None, None, None, None, None, None
+        dx, dw = _head_grads([planes[0], planes[1]], x2, w_parts, dx_terms, want_w)
+        # the upstream factor of the loss is applied to the small results ([T, H], [V, H]), never to [T, V]
+        up = grad_loss.to(torch.float32)
+        dx = (dx * up).to(torch.bfloat16).reshape(h_shape) if want_h else None
+        if dw is not None:
+            dw = dw.mul_(up)
+        return dx, dw, None, None, None, None, None, None
 
 
 def _weight_key(w: torch.Tensor) -> tuple:
@@ -168,6 +253,51 @@ class SplitBf16LmHead(torch.nn.Module):
     def forward(self, hidden: torch.Tensor) -> torch.Tensor:
         parts = self._split()
         return _SplitBf16Linear.apply(hidden.to(torch.bfloat16) if hidden.dtype != torch.bfloat16 else hidden, self.weight, parts, self._cat, self.hidden_grad_terms)
+
+    def rl_loss(self, hidden: torch.Tensor, batch, config, current_step: int, max_step: int):
+        """Hidden states -> (loss, stats), the `rl_step` contract (reference rl/__init__.py:136-143), without an
+        fp32 d-logits tensor: head GEMM, one fused pass that leaves d logits as bf16 planes, backward GEMMs on
+        those planes.  ppo / reinforce (the policies of the fused logits kernel)."""
+        from .finetune.rl import STAT_INDEX, check_finite, make_loss_config, stats_to_dict
+
+        if config.policy_loss == "gspo":
+            raise NotImplementedError("the plane-emitting pass covers ppo / reinforce; gspo goes through rl_step")
+        cfg, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
+        parts = self._split()
+        h = hidden if hidden.dtype == torch.bfloat16 else hidden.to(torch.bfloat16)
+        loss, stats_dev = _SplitHeadLossFn.apply(h, self.weight, parts, self._cat, self.hidden_grad_terms, batch, cfg, config.temperature)
+        stats = stats_dev.cpu().tolist()
+        check_finite(stats)
+        input_size = batch.input_ids.numel()
+        if int(stats[STAT_INDEX["num_output_tokens_sum"]]) == 0:
+            return loss, {"input_size": float(input_size)}
+        return loss, stats_to_dict(stats, kl_coef, ent_coef, input_size)
+
+
+_split_heads: dict[int, SplitBf16LmHead] = {}
+
+
+def rl_step_split_head(model, batch, current_step: int, max_step: int, config, seq_parallel_group=None):
+    """`rl_step` (same signature and return value) for a causal LM with `.model` (body) and an fp32 bias-free
+    `.lm_head`, on the LIBRARY head GEMMs: body -> hidden states -> `SplitBf16LmHead.rl_loss`.  Against
+    `rl_step` + `apply_fp32_lm_head` it saves the fp32 d-logits tensor and the pass that splits it; against
+    `fused_head.rl_step_fused_head` it keeps the `[T, V]` logits (5 GB per 7B micro-batch) and in exchange
+    needs no recomputation in backward."""
+    body, lin = getattr(model, "model", None), getattr(model, "lm_head", None)
+    if body is None or lin is None or getattr(lin, "bias", None) is not None:
+        raise TypeError("rl_step_split_head needs model.model (body) and a bias-free model.lm_head")
+    inputs = {"input_ids": batch.input_ids, "attention_mask": batch.attention_mask}
+    if batch.is_packed:
+        inputs["position_ids"] = batch.position_ids
+    out = body(**inputs)
+    hidden = out[0] if isinstance(out, (tuple, list)) else getattr(out, "last_hidden_state", out)
+    w = lin.weight
+    if w.dtype != torch.float32:
+        raise TypeError("rl_step_split_head is for an fp32 head weight; a bf16 (tied) head needs no split: use rl_step")
+    head = _split_heads.get(id(w))
+    if head is None or head.weight is not w:
+        head = _split_heads[id(w)] = SplitBf16LmHead(w)
+    return head.rl_loss(hidden, batch, config, current_step, max_step)
 
 
 def apply_fp32_lm_head(model: torch.nn.Module, layer_prefix: str = "lm_head", hidden_grad_terms: int = 3) -> torch.nn.Module:

@@ -276,6 +276,38 @@ def test_rl_step_fused_head_on_a_huggingface_style_model(libprl, cuda_device):
     assert rel_err(b.lm_head.weight.grad.cpu().numpy(), a.lm_head.weight.grad.cpu().numpy()) <= 1e-3
 
 
+def test_sentinel_batch_skips_the_head(libprl, cuda_device):
+    """A sentinel batch (every label masked, reference finetune/utils.py:17-78) gives loss 0, the empty-batch
+    statistics and zero gradients for hidden states and weight without running a GEMM - same as `rl_step`."""
+    from pipelinerl_amd import _lib
+    from pipelinerl_amd.finetune.rl import RLConfig, rl_step
+    from pipelinerl_amd.finetune.utils import create_sentinel_batch
+    from pipelinerl_amd.fused_head import FusedLmHead, fused_head_loss
+
+    V, H = 1024, 128
+    torch.manual_seed(1)
+    sb = create_sentinel_batch(cuda_device)
+    T = sb.input_ids.shape[1]
+    hidden = torch.randn(1, T, H, device=cuda_device).to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(V, H, device=cuda_device) * 0.1).requires_grad_(True)
+    head = FusedLmHead(w)
+    loss, stats = fused_head_loss(hidden, w, head, sb, RLConfig(**CFG), 2, 10)
+    assert head.w_hi is None  # nothing was prepared, no kernel of the head ran
+    loss.backward()
+    assert loss.item() == 0.0 and stats == {"input_size": float(T)}
+    assert torch.count_nonzero(hidden.grad) == 0 and torch.count_nonzero(w.grad) == 0
+    assert hidden.grad.dtype == torch.bfloat16 and w.grad.shape == w.shape
+
+    class LM(torch.nn.Module):
+        def forward(self, input_ids=None, **kw):
+            import types
+
+            return types.SimpleNamespace(logits=(hidden.float() @ w.t()))
+
+    l2, s2 = rl_step(LM(), sb, 2, 10, RLConfig(**CFG))
+    assert l2.item() == 0.0 and s2 == stats
+
+
 def test_workspace_too_small_and_bad_shapes_are_refused(libprl, cuda_device):
     from pipelinerl_amd import _lib
 
