@@ -525,6 +525,8 @@ int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidden, int64_t 
                             float* lse2, void* workspace, size_t workspace_bytes,
                             prl_stream_t stream);
 
+#define PRL_LM_HEAD_DW_OVERWRITE 2    /* flags: grad_weight = d W (uninitialised memory is fine) instead of +=: saves the caller
+                                         a zero fill and the first chunk a read of the [vocab, hidden] fp32 buffer */
 #define PRL_LM_HEAD_DH_LEADING_TERM 1 /* flags: d hidden from the leading bf16 product only (d logits_hi x W_hi):
                                          2^-9 relative error, the size of a bf16 rounding - meant for bf16 grad_hidden */
 
@@ -534,7 +536,8 @@ int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidden, int64_t 
  * d logits of prl_logprob_entropy_bwd pushed through the head:
  *   grad_hidden [rows*cols, hidden] (bf16 or f32, overwritten; nullable)
  *                 = d logits (w_hi + w_lo)
- *   grad_weight [vocab, hidden] f32 (ACCUMULATED: +=; nullable) = d logits^T hidden
+ *   grad_weight [vocab, hidden] f32 (ACCUMULATED: +=, or overwritten with
+ *                 PRL_LM_HEAD_DW_OVERWRITE; nullable) = d logits^T hidden
  * Works chunk by chunk over `chunk_rows` logits rows: the logits of a chunk are recomputed,
  * its d logits live as bf16 (hi, lo) planes in the workspace only.  vocab and hidden must be
  * multiples of 64.

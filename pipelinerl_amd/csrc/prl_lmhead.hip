@@ -1147,7 +1147,7 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       g.nt = ceil_div(hidden, shape_bn(shape));
       g.ldc = hidden;
       g.out_bf16 = 0;
-      g.accumulate = 1;
+      g.accumulate = (r0 == 0 && (flags & PRL_LM_HEAD_DW_OVERWRITE)) ? 0 : 1;  // later chunks add to the first
       g.out = grad_weight;
       g.ksplit = 1;
       g.ksteps = 0;

@@ -137,9 +137,10 @@ class FusedLmHead:
     def backward_from_token_grads(self, h: torch.Tensor, input_ids: torch.Tensor, temperature: float, lse2: torch.Tensor,
                                   ent: torch.Tensor, g_nlp: torch.Tensor, g_ent: torch.Tensor | None, upstream: torch.Tensor | None,
                                   want_hidden: bool = True, grad_weight: torch.Tensor | None = None,
-                                  grad_hidden_dtype: torch.dtype = torch.bfloat16, chunk_rows: int | None = None):
-        """d hidden (returned) and d W (ACCUMULATED into `grad_weight`, fp32 [V, H]) from the token-aligned
-        gradients of new_logprobs / entropy."""
+                                  grad_hidden_dtype: torch.dtype = torch.bfloat16, chunk_rows: int | None = None,
+                                  overwrite_weight_grad: bool = False):
+        """d hidden (returned) and d W (ACCUMULATED into `grad_weight`, fp32 [V, H]; with `overwrite_weight_grad`
+        the buffer may be uninitialised and is overwritten) from the token-aligned gradients of new_logprobs / entropy."""
         if not self.backward:
             raise RuntimeError("this FusedLmHead was built with backward=False")
         lib = _lib.load()
@@ -157,7 +158,8 @@ class FusedLmHead:
                 B, L, H, self.vocab, h.data_ptr(), self.w_hi.data_ptr(), _lib.ptr(self.w_lo), self.wt_hi.data_ptr(), _lib.ptr(self.wt_lo),
                 ids.data_ptr(), float(temperature), lse2.data_ptr(), ent.data_ptr(), g_nlp.data_ptr(), _lib.ptr(g_ent), _lib.ptr(upstream),
                 _lib.ptr(gh), 0 if grad_hidden_dtype == torch.float32 else 1, _lib.ptr(grad_weight), chunk,
-                _lib.PRL_LM_HEAD_DH_LEADING_TERM if self.hidden_grad_terms == 1 else 0, ws.data_ptr(), ws.numel(),
+                (_lib.PRL_LM_HEAD_DH_LEADING_TERM if self.hidden_grad_terms == 1 else 0) | (_lib.PRL_LM_HEAD_DW_OVERWRITE if overwrite_weight_grad else 0),
+                ws.data_ptr(), ws.numel(),
                 _lib.current_stream_ptr(dev)))
         return gh
 
@@ -199,10 +201,10 @@ class _FusedHeadLossFn(torch.autograd.Function):
         h, ids, lse2, ent, g_nlp, g_ent = ctx.saved_tensors
         head: FusedLmHead = ctx.head
         want_h, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        gw = torch.zeros((head.vocab, head.hidden), dtype=torch.float32, device=h.device) if want_w else None
+        gw = torch.empty((head.vocab, head.hidden), dtype=torch.float32, device=h.device) if want_w else None
         up = grad_loss.to(torch.float32).contiguous()
         gh = head.backward_from_token_grads(h, ids, ctx.temperature, lse2, ent, g_nlp, g_ent if ctx.has_g_ent else None, up,
-                                            want_hidden=want_h, grad_weight=gw,
+                                            want_hidden=want_h, grad_weight=gw, overwrite_weight_grad=True,
                                             grad_hidden_dtype=torch.float32 if ctx.hidden_dtype == torch.float32 else torch.bfloat16,
                                             chunk_rows=ctx.chunk_rows)
         if gh is not None and gh.dtype != ctx.hidden_dtype:

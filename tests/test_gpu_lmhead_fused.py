@@ -276,6 +276,29 @@ def test_rl_step_fused_head_on_a_huggingface_style_model(libprl, cuda_device):
     assert rel_err(b.lm_head.weight.grad.cpu().numpy(), a.lm_head.weight.grad.cpu().numpy()) <= 1e-3
 
 
+def test_weight_gradient_accumulates_or_overwrites(libprl, cuda_device):
+    """`grad_weight` is `+=` by contract (gradient accumulation over micro-batches); PRL_LM_HEAD_DW_OVERWRITE stores
+    instead, into memory that may hold anything - with several row chunks (the later chunks still add)."""
+    from pipelinerl_amd.finetune.rl import RLConfig, grpo_loss_from_logprobs, make_loss_config
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.fused_head import FusedLmHead
+
+    hidden, W, batch, logits64 = _problem(300, 128, 1024, cuda_device, seed=41)
+    want = _oracle(hidden, W, batch, logits64)
+    pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(cuda_device)
+    head = FusedLmHead(W, chunk_rows=128)
+    nlp, ent, lse2, h = head.logprob_entropy(hidden, pb.input_ids, CFG["temperature"])
+    c_cfg, _, _ = make_loss_config(RLConfig(**CFG), 2, 10)
+    _, _, g_nlp, g_ent = grpo_loss_from_logprobs(c_cfg, pb, nlp, ent)
+    gw = torch.full((1024, 128), float("nan"), device=cuda_device)
+    head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, want_hidden=False, grad_weight=gw, overwrite_weight_grad=True)
+    once = gw.clone()
+    assert rel_err(once.cpu().numpy(), want["d_weight"]) <= FP_TOL
+    head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, want_hidden=False, grad_weight=gw)
+    assert rel_err(gw.cpu().numpy(), 2 * want["d_weight"]) <= FP_TOL
+    assert torch.allclose(gw, 2 * once, rtol=1e-6, atol=0)
+
+
 def test_sentinel_batch_skips_the_head(libprl, cuda_device):
     """A sentinel batch (every label masked, reference finetune/utils.py:17-78) gives loss 0, the empty-batch
     statistics and zero gradients for hidden states and weight without running a GEMM - same as `rl_step`."""
