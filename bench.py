@@ -259,7 +259,7 @@ def fused_head_probe(dev: torch.device, seq_length: int, vocab: int, hidden: int
     del gw, head, W
     torch.cuda.empty_cache()
     return {
-        "bound": "mfma", "kernel": "lmhead_fwd_kernel<256x256x64, 8 waves, v_mfma_f32_32x32x16_bf16>", "achieved": fwd_tf, "peak": MFMA_BF16_PEAK_TFLOPS,
+        "bound": "mfma", "kernel": "lmhead_fwd_kernel<CfgDual: 256x256x32 dual-plane tile, 3 LDS stages, 8 waves with staggered roles, v_mfma_f32_32x32x16_bf16>", "achieved": fwd_tf, "peak": MFMA_BF16_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": fwd_tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
         "flops_per_launch": 2 * gemm, "ms_per_launch": fwd_ms,
         "config": {"tokens": T, "hidden": H, "vocab": V, "weight": "fp32 as two bf16 planes (fp32-GEMM accuracy)", "logits_materialised_bytes": 0},

@@ -296,7 +296,7 @@ def test_weight_gradient_accumulates_or_overwrites(libprl, cuda_device):
     assert rel_err(once.cpu().numpy(), want["d_weight"]) <= FP_TOL
     head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, want_hidden=False, grad_weight=gw)
     assert rel_err(gw.cpu().numpy(), 2 * want["d_weight"]) <= FP_TOL
-    assert torch.allclose(gw, 2 * once, rtol=1e-6, atol=0)
+    assert torch.allclose(gw, 2 * once, rtol=1e-5, atol=1e-6 * once.abs().max().item())  # only the fp32 order of the additions differs
 
 
 def test_sentinel_batch_skips_the_head(libprl, cuda_device):
