@@ -12,11 +12,12 @@
 //                  mutex, commit futex word, reader cursor table
 //   /<name>.<k>    segment k: header + records back to back, each [u64 nbytes][payload][pad to 8]
 //
-// Writers serialise on a futex mutex in the control block (its owner pid is recorded, a lock whose
+// Writers serialise on a futex mutex in the control block (its owner's thread id is recorded, a lock whose
 // owner died is taken over), append into the last segment and publish with a release store of the
-// segment's `committed` offset, then bump the commit futex.  A record that does not fit opens the next
-// segment (sized for the record if it is larger than the default) BEFORE the old one is sealed, so a
-// reader that finds `sealed` can always open the successor.  Readers keep (segment, offset) privately,
+// segment's `committed` offset, then bump the commit futex.  A record that does not fit creates the next
+// segment (sized for the record if it is larger than the default), THEN seals the old one, THEN publishes
+// the new segment count: a reader that finds `sealed` can always open the successor, and a writer that
+// finds the last counted segment sealed (its predecessor died in between) adopts the successor.  Readers keep (segment, offset) privately,
 // start at the first retained segment, and park on the commit futex when they reach the tail - no
 // polling.  Records are returned as pointers into the mapping (zero copy) valid until the next read.
 //
@@ -305,40 +306,53 @@ extern "C" int prl_log_append(prl_log* l, const void* data, uint64_t nbytes) {
   const uint64_t need = 8 + pad8(nbytes);
   lock_ctl(c);
   int rc = PRL_OK;
-  const uint64_t last = c->n_segments.load(std::memory_order_acquire) - 1;
-  if (l->wseg_index != last) {
-    rc = open_segment(l->name, last, &l->wseg);
-    if (rc == PRL_OK) l->wseg_index = last;
+  SegHeader* h = nullptr;
+  uint64_t off = 0;
+  for (;;) {  // find (or open) the segment this record goes to
+    const uint64_t last = c->n_segments.load(std::memory_order_acquire) - 1;
+    if (l->wseg_index != last) {
+      rc = open_segment(l->name, last, &l->wseg);
+      if (rc != PRL_OK) break;
+      l->wseg_index = last;
+    }
+    h = seg_hdr(l->wseg);
+    if (h->sealed.load(std::memory_order_acquire)) {
+      // a writer died between sealing this segment and publishing its successor (which exists: it is created
+      // before the seal, and readers may already be waiting in it): adopt the successor
+      Mapping next;
+      rc = open_segment(l->name, last + 1, &next);
+      if (rc != PRL_OK) break;
+      c->n_segments.store(last + 2, std::memory_order_release);
+      l->wseg.reset();
+      l->wseg = next;
+      l->wseg_index = last + 1;
+      continue;
+    }
+    off = h->committed.load(std::memory_order_relaxed);
+    if (off + need <= h->capacity) break;
+    // the record does not fit.  Order: create the successor, seal this segment, publish the new count - a reader
+    // that sees `sealed` finds the successor, and a writer that finds `sealed` on the last counted segment knows
+    // its predecessor stopped between the last two steps
+    Mapping next;
+    const uint64_t cap = need > c->segment_bytes ? need : c->segment_bytes;
+    rc = create_segment(l->name, last + 1, cap, &next);
+    if (rc != PRL_OK) break;
+    h->sealed.store(1, std::memory_order_release);
+    c->n_segments.store(last + 2, std::memory_order_release);
+    l->wseg.reset();
+    l->wseg = next;
+    l->wseg_index = last + 1;
+    trim(l);
   }
   if (rc == PRL_OK) {
-    SegHeader* h = seg_hdr(l->wseg);
-    uint64_t off = h->committed.load(std::memory_order_relaxed);
-    if (off + need > h->capacity) {
-      // open the successor first, then seal: a reader that sees `sealed` finds the next segment
-      Mapping next;
-      const uint64_t cap = need > c->segment_bytes ? need : c->segment_bytes;
-      rc = create_segment(l->name, last + 1, cap, &next);
-      if (rc == PRL_OK) {
-        c->n_segments.store(last + 2, std::memory_order_release);
-        h->sealed.store(1, std::memory_order_release);
-        l->wseg.reset();
-        l->wseg = next;
-        l->wseg_index = last + 1;
-        h = seg_hdr(l->wseg);
-        off = 0;
-        trim(l);
-      }
-    }
-    if (rc == PRL_OK) {
-      uint8_t* p = seg_data(l->wseg) + off;
-      memcpy(p, &nbytes, 8);
-      if (nbytes) memcpy(p + 8, data, nbytes);
-      h->committed.store(off + need, std::memory_order_release);
-      c->n_records.fetch_add(1, std::memory_order_relaxed);
-      c->n_bytes.fetch_add(nbytes, std::memory_order_relaxed);
-      c->commits.fetch_add(1, std::memory_order_release);
-      futex_wake_all(&c->commits);
-    }
+    uint8_t* p = seg_data(l->wseg) + off;
+    memcpy(p, &nbytes, 8);
+    if (nbytes) memcpy(p + 8, data, nbytes);
+    h->committed.store(off + need, std::memory_order_release);
+    c->n_records.fetch_add(1, std::memory_order_relaxed);
+    c->n_bytes.fetch_add(nbytes, std::memory_order_relaxed);
+    c->commits.fetch_add(1, std::memory_order_release);
+    futex_wake_all(&c->commits);
   }
   unlock_ctl(c);
   return rc;

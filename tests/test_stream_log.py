@@ -260,3 +260,53 @@ def test_reader_timeout_and_nonblocking(tmp_path):
     finally:
         w.close()
         Log.unlink_name(name)
+
+
+def test_writer_that_died_between_seal_and_publish_is_recovered(tmp_path):
+    """Rollover order is: create the successor, seal the full segment, publish the new segment count.  A writer
+    killed between the last two steps leaves a sealed segment that is still counted as the last one, with readers
+    possibly parked in the successor already.  The next writer must adopt that successor - not append to the
+    sealed segment (readers have left it) and not recreate the successor (readers hold the old object)."""
+    import mmap
+    import struct
+
+    from pipelinerl_amd.ring import Log
+
+    name = f"prl_test_{time.time_ns()}"
+    w = Log(name, create=True, segment_bytes=256)
+    try:
+        w.append(b"a" * 100)
+        w.append(b"b" * 100)  # 2 x (8 + 104) = 224 of 256 bytes used: the next 100-byte record does not fit
+        w.close()
+        # what the dying writer managed: the successor exists and is initialised, segment 0 is sealed, the count still says 1
+        seg_hdr = struct.Struct("<QQQQI")  # magic, index, capacity, committed, sealed (csrc/prl_log.cpp SegHeader, 64-byte aligned)
+        with open(f"/dev/shm/{name}.0", "r+b") as f0:
+            m0 = mmap.mmap(f0.fileno(), 0)
+            magic, idx, cap, committed, sealed = seg_hdr.unpack_from(m0, 0)
+            assert (idx, cap, committed, sealed) == (0, 256, 224, 0)
+            with open(f"/dev/shm/{name}.1", "w+b") as f1:
+                f1.truncate(64 + 256)
+                m1 = mmap.mmap(f1.fileno(), 0)
+                seg_hdr.pack_into(m1, 0, magic, 1, 256, 0, 0)
+                m1.flush()
+                m1.close()
+            struct.pack_into("<I", m0, 32, 1)
+            m0.flush()
+            m0.close()
+        r = Log(name, reader=True)  # a reader walks through the sealed segment into the orphaned successor and parks there
+        assert r.read(block=False) == b"a" * 100 and r.read(block=False) == b"b" * 100
+        with pytest.raises(queue.Empty):
+            r.read(block=False)
+        w2 = Log(name, create=True, segment_bytes=256)
+        w2.append(b"c" * 20)  # would have fitted into the sealed segment's last 32 bytes
+        w2.append(b"d" * 100)
+        assert r.read(timeout=2) == b"c" * 20 and r.read(timeout=2) == b"d" * 100
+        st = w2.stats()
+        assert st["segments"] == 2 and st["records"] == 4
+        late = Log(name, reader=True)
+        assert [late.read(block=False) for _ in range(4)] == [b"a" * 100, b"b" * 100, b"c" * 20, b"d" * 100]
+        late.close()
+        r.close()
+        w2.close()
+    finally:
+        Log.unlink_name(name)
