@@ -266,7 +266,13 @@ def install_fused_head(model: Any, chunk_rows: int = 4096, hidden_grad_terms: in
     model in DistributedDataParallel / FSDP / `accelerator.prepare`: those wrappers arm their gradient
     reduction in THEIR forward, so the loss has to be produced by a call that goes through them -
     `rl_step_fused_head(wrapped, ...)` does exactly that.  Parameter names are unchanged (the weight-update
-    path keeps seeing `model.*` / `lm_head.weight`)."""
+    path keeps seeing `model.*` / `lm_head.weight`).
+
+    The head reads `lm_head.weight` directly, `lm_head.forward` is never called.  DDP, FSDP (the weight is part of
+    a unit that is unsharded while the wrapped forward runs) and ZeRO stages 1-2 are fine with that; ZeRO-3
+    gathers a parameter in its module's pre-forward hook, which a bypassed module never fires - there the call
+    has to sit inside `deepspeed.zero.GatheredParameters([model.lm_head.weight])` (a partitioned placeholder is
+    refused by shape, not silently used)."""
     _body_and_head(model)
     if getattr(model, "_prl_fused_head", None) is not None:
         return model
