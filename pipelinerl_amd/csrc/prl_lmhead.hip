@@ -323,6 +323,14 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
 // refill is what keeps the 32 workgroups of an XCD in step, and in step they share every weight tile (8 workgroups)
 // and hidden tile (4 workgroups) in the XCD's L2.  Chained, they drift apart and L2 misses go from 137 M to 669 M
 // requests per forward (HBM fetch 8.6 -> 41 GB; profiles/r02p_lmhead_fwd_chained_vs_refill_pmc.txt).
+//
+// Also measured and NOT kept: the barrier in the MIDDLE of the step (between the MFMAs of its two 16-deep halves,
+// synchronising for tile s + 1), fragment reads always half a step ahead of their MFMAs - across the step boundary
+// too - with inline-asm ds_read_b128 and counted lgkmcnt(8) waits (the compiler's own bookkeeping waits for ALL reads,
+// and its scheduler sinks the reads behind the MFMAs to share one register set).  The instruction stream came out as
+// intended (reads x 8, lgkmcnt(8), MFMA x 16, barrier, reads x 8, MFMA x 16; 248 VGPRs, no scratch) and was 3 % SLOWER:
+// forward 14.5 vs 14.0 ms, backward 60.9 vs 59.5 ms (profiles/r02w_lmhead_midstep_barrier_ab.txt).  The exposed LDS
+// latency after the barrier is not what the schedule is waiting for.
 template <int MODE = 0>
 __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
                                                    const Geom& g, int m0, int n0, char* lds) {
