@@ -51,6 +51,10 @@ class ParameterInfo(BaseModel):
     name: str
     shape: list[int]
     dtype: str
+    # transport "sharded" only (tp_shard.TpShard): the engine splits this parameter into `shard_parts` equal pieces along
+    # `shard_dim`; None = replicated.  `shape` stays the FULL shape, as in the reference's message.
+    shard_dim: int | None = None
+    shard_parts: int = 1
 
 
 class WeightUpdateRequest(BaseModel):
@@ -59,13 +63,15 @@ class WeightUpdateRequest(BaseModel):
     parameters_info: list[ParameterInfo]
     timestamp: float = Field(default_factory=time.time)
     # MI355X extensions: how the bytes travel ("per_tensor" = reference behaviour, "bucketed" = RCCL
-    # buckets, "ipc" = trainer and worker share one GPU: the request carries HIP IPC handles).
+    # buckets, "ipc" = trainer and worker share one GPU: the request carries HIP IPC handles,
+    # "sharded" = RCCL buckets per tensor-parallel rank: a worker receives only its TP slices).
     # A request WITHOUT the field comes from an unmodified reference trainer, hence the default;
     # this package's WeightUpdateManager always states its transport.
     transport: str = "per_tensor"
     bucket_bytes: int = 1 << 30
     ipc_handles: list[str] = Field(default_factory=list)
     ipc_nbytes: list[int] = Field(default_factory=list)
+    tp_size: int = 1
 
 
 class WeightUpdateSuccess(BaseModel):
@@ -302,7 +308,11 @@ class WeightUpdateManager:
     def __init__(self, llm_urls: list[str], accelerated_model: Any, update_stream: SingleStreamSpec | None,
                  actor_update_group: Any, is_main_process: bool = True, named_parameters_fn: Callable | None = None,
                  transport: str = "bucketed", bucket_bytes: int = 1 << 30, post: Callable | None = None,
-                 parameter_source: ParameterSource | None = None):
+                 parameter_source: ParameterSource | None = None, tp_shards: dict | None = None, kv_heads: int | None = None):
+        """`transport="sharded"`: `actor_update_group` is the LIST of per-TP-rank communicators
+        (`WeightSyncGroup.tp_shard_groups`); every worker receives only the slices its TP rank stores.  The cut of each
+        parameter comes from `tp_shard.plan_tp_shards` (Llama / Qwen layout; `kv_heads` for grouped-query models with
+        fewer KV heads than TP ranks) or from `tp_shards` (name -> TpShard) for other engines."""
         self.llm_urls = llm_urls
         self.accelerated_model = accelerated_model
         self.update_stream = update_stream
@@ -311,6 +321,7 @@ class WeightUpdateManager:
         self.source = parameter_source or parameter_source_for(accelerated_model, named_parameters_fn)
         self.transport = transport
         self.bucket_bytes = bucket_bytes
+        self.tp_shards, self.kv_heads = tp_shards, kv_heads
         self.thread_pool = ThreadPoolExecutor(max_workers=max(1, len(llm_urls)))
         self._post = post or _http_post
         self._sender = None
@@ -341,9 +352,19 @@ class WeightUpdateManager:
         described = src.describe()
         specs = [ParamSpec(n, tuple(shape), dt) for n, shape, dt in described]
         futures = []
+        shards, tp_size = None, 1
+        if self.transport == "sharded":
+            from .tp_shard import plan_tp_shards
+
+            groups = self.actor_update_group if isinstance(self.actor_update_group, (list, tuple)) else [self.actor_update_group]
+            tp_size = len(groups)
+            shards = plan_tp_shards([(sp.name, sp.shape) for sp in specs], tp_size, self.kv_heads, self.tp_shards)
         if self.is_main_process:
-            info = [ParameterInfo(name=sp.name, shape=list(sp.shape), dtype=str(sp.dtype)) for sp in specs]
-            message = WeightUpdateRequest(version=version, parameters_info=info, transport=self.transport, bucket_bytes=self.bucket_bytes)
+            info = [ParameterInfo(name=sp.name, shape=list(sp.shape), dtype=str(sp.dtype),
+                                  shard_dim=shards[sp.name].dim if shards else None, shard_parts=shards[sp.name].parts if shards else 1)
+                    for sp in specs]
+            message = WeightUpdateRequest(version=version, parameters_info=info, transport=self.transport, bucket_bytes=self.bucket_bytes,
+                                          tp_size=tp_size)
             if self.transport == "ipc":
                 # colocated: fill the exported buckets first, the request then carries their handles
                 from .weight_sync import ColocatedSender
@@ -357,14 +378,22 @@ class WeightUpdateManager:
             futures = self.request_weight_updates(message)
         if self.transport == "ipc":
             pass  # the POST returns when the worker has copied the buckets
-        elif self.transport == "bucketed":
+        elif self.transport in ("bucketed", "sharded"):
+            # a sharded update gathers in groups of bucket_bytes * tp_size of FULL parameters: one bucket per TP rank each
+            gather_bytes = self.bucket_bytes * tp_size
             if self.is_main_process:
                 if self._sender is None:
-                    self._sender = BucketedSender(self.actor_update_group, self.bucket_bytes)
-                self._sender.send_streamed(specs, src.fetch)
+                    from .weight_sync import ShardedSender
+
+                    self._sender = (ShardedSender(groups, self.bucket_bytes) if self.transport == "sharded"
+                                    else BucketedSender(self.actor_update_group, self.bucket_bytes))
+                if self.transport == "sharded":
+                    self._sender.send_streamed(specs, shards, src.fetch)
+                else:
+                    self._sender.send_streamed(specs, src.fetch)
             elif not isinstance(src, PlainParameters):
                 # the other trainer ranks take part in the same gathers, bucket by bucket
-                for bucket in plan_buckets(specs, self.bucket_bytes):
+                for bucket in plan_buckets(specs, gather_bytes):
                     with src.fetch([sp for sp, _ in bucket]):
                         pass
         else:  # the reference's one-broadcast-per-parameter protocol (:230-238, :276-282)

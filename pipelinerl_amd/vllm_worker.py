@@ -38,15 +38,38 @@ class WorkerExtension:
         invalidates its fp32 lm_head cache here, vllm1.py:126)."""
 
     def init_actor_update_group(self, actor_idx: int, actor_ngpus: int, weight_update_group_init_method: str,
-                                weight_update_group_world_size: int) -> None:
+                                weight_update_group_world_size: int, tp_sharded: bool = False) -> None:
+        """`tp_sharded`: join the communicator of THIS worker's tensor-parallel rank (trainer + the same TP rank of every
+        engine) instead of the one spanning all workers: updates then arrive as this rank's slices only
+        (`transport: sharded`, tp_shard.py).  The engine's TP degree is `actor_ngpus`."""
         # rank layout of the reference (vllm1.py:71): trainer = 0, worker = 1 + llm index * gpus + local rank
         self.pg_rank = 1 + actor_idx * actor_ngpus + self.rank
         logger.info(f"[INIT_ACTOR_UPDATE_GROUP]: actor {actor_idx}, ngpus {actor_ngpus}, rank {self.rank}, pg_rank {self.pg_rank}, "
-                    f"init {weight_update_group_init_method}, world {weight_update_group_world_size}")
-        self.model_update_group = WeightSyncGroup.from_init_method(
-            weight_update_group_init_method, rank=self.pg_rank, world_size=weight_update_group_world_size, device=self.device
-        )
+                    f"init {weight_update_group_init_method}, world {weight_update_group_world_size}, tp_sharded {tp_sharded}")
+        if tp_sharded:
+            self.model_update_group = WeightSyncGroup.tp_shard_groups(
+                weight_update_group_init_method, rank=self.pg_rank, world_size=weight_update_group_world_size, tp_size=actor_ngpus,
+                device=self.device)[0]
+            self.tp_rank, self.tp_size = self.rank, actor_ngpus
+        else:
+            self.model_update_group = WeightSyncGroup.from_init_method(
+                weight_update_group_init_method, rank=self.pg_rank, world_size=weight_update_group_world_size, device=self.device
+            )
         self._receiver = None
+
+    def _load_weight_shards(self, shards):
+        """`transport: sharded`: `shards` = [(name, tensor, TpShard)] where `tensor` is THIS TP rank's slice of the
+        trainer's parameter `name` (already the shape a tensor-parallel engine stores; fused parameters such as
+        qkv_proj / gate_up_proj take the slices of their parts side by side).  Engine specific: vLLM's `load_weights`
+        expects full tensors and cannot be used here.  Register destinations (`_weight_shard_destinations`) or
+        override this."""
+        raise NotImplementedError("this worker has no loader for tensor-parallel slices: override _load_weight_shards "
+                                  "or return the slices' storage from _weight_shard_destinations")
+
+    def _weight_shard_destinations(self) -> dict[str, torch.Tensor] | None:
+        """name (trainer side) -> the tensor that stores this TP rank's slice of it: filled straight from the
+        received bucket by the scatter-copy kernel."""
+        return None
 
     def receive_weight_update(self, request_json: str) -> None:
         request = WeightUpdateRequest.model_validate_json(request_json) if isinstance(request_json, str) else WeightUpdateRequest(**request_json)
@@ -82,6 +105,22 @@ class WorkerExtension:
                 self._ipc_receiver = ColocatedReceiver(self.device, request.bucket_bytes)
             self._ipc_receiver.receive([i.model_dump() for i in request.parameters_info], request.ipc_handles, request.ipc_nbytes, load,
                                        destinations=self._weight_destinations())
+        elif request.transport == "sharded":
+            from .tp_shard import TpShard
+            from .weight_sync import ParamSpec, plan_shard_buckets
+
+            tp_rank, tp_size = getattr(self, "tp_rank", None), getattr(self, "tp_size", None)
+            if tp_rank is None:
+                raise RuntimeError("a sharded weight update arrived but init_actor_update_group was not called with tp_sharded=True")
+            if tp_size != request.tp_size:
+                raise ValueError(f"the update is cut for TP {request.tp_size}, this engine runs TP {tp_size}")
+            specs = [ParamSpec(i.name, tuple(i.shape), string_to_dtype(i.dtype)) for i in request.parameters_info]
+            cuts = {i.name: TpShard(i.shard_dim, i.shard_parts) for i in request.parameters_info}
+            _, plan = plan_shard_buckets(specs, cuts, tp_rank, tp_size, request.bucket_bytes)
+            if getattr(self, "_receiver", None) is None or self._receiver.bucket_bytes != request.bucket_bytes:
+                self._receiver = BucketedReceiver(self.model_update_group, request.bucket_bytes)
+            self._receiver.receive_planned(plan, lambda views: self._load_weight_shards([(n, t, cuts[n]) for n, t in views]),
+                                           destinations=self._weight_shard_destinations())
         elif request.transport == "bucketed":
             if getattr(self, "_receiver", None) is None or self._receiver.bucket_bytes != request.bucket_bytes:
                 self._receiver = BucketedReceiver(self.model_update_group, request.bucket_bytes)
@@ -133,3 +172,20 @@ class StandaloneWeightReceiver(WorkerExtension):
         """One pass over a whole bucket; returns the names this module does not have."""
         done = set(self._load_weights(weights))
         return [n for n, _ in weights if n not in done]
+
+
+class StandaloneShardReceiver(WorkerExtension):
+    """One tensor-parallel rank of a plain-PyTorch "engine" (tests, non-vLLM engines): holds, for every trainer
+    parameter, the slice `tp_shard.plan_tp_shards` assigns to `tp_rank`, and takes sharded updates straight into them."""
+
+    def __init__(self, named_shapes, dtype_of, device: torch.device, tp_rank: int, tp_size: int, kv_heads: int | None = None):
+        """`named_shapes`: [(name, full shape)], `dtype_of`: name -> dtype."""
+        from .tp_shard import plan_tp_shards
+
+        self.device = device
+        self.rank = tp_rank
+        self.cuts = plan_tp_shards(named_shapes, tp_size, kv_heads)
+        self.slices = {n: torch.zeros(self.cuts[n].shard_shape(shape), dtype=dtype_of(n), device=device) for n, shape in named_shapes}
+
+    def _weight_shard_destinations(self):
+        return self.slices

@@ -72,6 +72,25 @@ def bucket_nbytes(bucket: Sequence[tuple[ParamSpec, int]]) -> int:
     return off + _align(sp.nbytes)
 
 
+def plan_shard_buckets(specs: Sequence[ParamSpec], shards: dict, tp_rank: int, tp_size: int,
+                       bucket_bytes: int = DEFAULT_BUCKET_BYTES):
+    """Bucket plan of the TP-aware update, derived identically by the trainer (for every TP rank) and by each worker
+    (for its own): parameters are grouped by their FULL size into groups of `bucket_bytes * tp_size` - one
+    gather of a sharded trainer and one bucket per TP rank each - and inside a group TP rank t's bucket holds
+    its slice of every parameter (tp_shard.TpShard; replicated parameters whole), 256-byte aligned.
+    Returns (groups of full specs, this rank's buckets of (slice spec, offset))."""
+    groups = plan_buckets(specs, bucket_bytes * tp_size)
+    mine = []
+    for grp in groups:
+        cur, used = [], 0
+        for sp, _ in grp:
+            ssp = ParamSpec(sp.name, shards[sp.name].shard_shape(sp.shape), sp.dtype)
+            cur.append((ssp, used))
+            used += _align(ssp.nbytes)
+        mine.append(cur)
+    return groups, mine
+
+
 class WeightSyncGroup:
     """An RCCL communicator of `world_size` ranks: rank 0 is the trainer, ranks 1.. are the
     inference-worker GPUs (reference rank layout vllm1.py:71, world.py:192)."""
@@ -124,6 +143,34 @@ class WeightSyncGroup:
         grp = cls._init(uid, rank, world_size, device)
         grp._store = store  # keep the server alive for late joiners
         return grp
+
+    @classmethod
+    def tp_shard_groups(cls, init_method: str, rank: int, world_size: int, tp_size: int, device: torch.device,
+                        timeout_s: float = 300.0) -> list["WeightSyncGroup"]:
+        """Communicators of the TP-aware update (tp_shard.py): ONE per tensor-parallel rank t, made of the trainer
+        (rank 0 in each) and the workers that hold TP rank t of their engine - global rank r >= 1 is TP rank
+        (r - 1) % tp_size of engine (r - 1) // tp_size, the reference layout (vllm1.py:71).  The trainer gets all
+        `tp_size` groups, a worker a one-element list.  Same `tcp://host:port` rendezvous as `from_init_method`:
+        one store, one unique id per TP rank."""
+        from torch.distributed import TCPStore
+
+        if (world_size - 1) % tp_size:
+            raise ValueError(f"{world_size - 1} workers do not form engines of {tp_size} TP ranks")
+        n_engines = (world_size - 1) // tp_size
+        u = urlparse(init_method)
+        store = TCPStore(u.hostname or "127.0.0.1", u.port or 9000, world_size, is_master=(rank == 0),
+                         timeout=datetime.timedelta(seconds=timeout_s), wait_for_workers=False)
+        if rank == 0:
+            uids = [cls._new_uid() for _ in range(tp_size)]
+            for t, uid in enumerate(uids):
+                store.set(f"prl_wsync_uid/tp{t}", uid)
+            groups = [cls._init(uid, 0, 1 + n_engines, device) for uid in uids]  # group t completes when its workers joined
+        else:
+            t, engine = (rank - 1) % tp_size, (rank - 1) // tp_size
+            groups = [cls._init(bytes(store.get(f"prl_wsync_uid/tp{t}")), 1 + engine, 1 + n_engines, device)]
+        for g in groups:
+            g._store = store
+        return groups
 
     @classmethod
     def from_torch_distributed(cls, rank: int, world_size: int, device: torch.device, group: Any = None) -> "WeightSyncGroup":
@@ -336,6 +383,60 @@ class BucketedSender:
         return list(specs)
 
 
+class ShardedSender:
+    """Trainer side of the TP-aware update (the reference sends every full tensor to every TP rank,
+    vllm1.py:110-127): `groups[t]` reaches the workers that hold TP rank t, and carries only their slices.
+    Per group of parameters the full tensors are fetched ONCE (a collective for ZeRO-3 / FSDP trainers), each TP
+    rank's slices are flattened into its own staging buffer, and the `tp_size` transfers run concurrently on their
+    own streams - different peers, different xGMI links.  Bytes per worker: S / tp_size (+ replicated norms)
+    instead of S."""
+
+    def __init__(self, groups: Sequence[WeightSyncGroup], bucket_bytes: int = DEFAULT_BUCKET_BYTES, mode: str = "scatter_allgather"):
+        self.groups = list(groups)
+        self.tp_size = len(self.groups)
+        self.bucket_bytes = bucket_bytes
+        self.mode = mode
+        self._staging: list[list[torch.Tensor]] = []
+        self.bytes_sent = [0] * self.tp_size  # per TP rank, last update
+
+    def send_streamed(self, specs: Sequence[ParamSpec], shards: dict, fetch: Callable[[list[ParamSpec]], Any]) -> list[ParamSpec]:
+        from .tp_shard import shard_view
+
+        tp, dev = self.tp_size, self.groups[0].device
+        full_groups = None
+        plans = []
+        for t in range(tp):
+            full_groups, mine = plan_shard_buckets(list(specs), shards, t, tp, self.bucket_bytes)
+            plans.append(mine)
+        if not self._staging:
+            self._staging = [[torch.empty(max(bucket_nbytes(b) for b in plans[t]), dtype=torch.uint8, device=dev) for _ in range(2)]
+                             for t in range(tp)]
+        pipes = [_TwoStreamPipe(dev) for _ in range(tp)]
+        self.bytes_sent = [0] * tp
+        for k, grp in enumerate(full_groups):
+            bufs = []
+            with fetch([sp for sp, _ in grp]) as tensors:
+                for t in range(tp):
+                    bucket = plans[t][k]
+                    buf = self._staging[t][k % 2][: bucket_nbytes(bucket)]
+                    views = {sp.name: shard_view(tensors[sp.name], shards[sp.name], t, tp) for sp, _ in grp}
+                    pipes[t].local(k, lambda buf=buf, bucket=bucket, views=views: gather_into_bucket(buf, bucket, views), after_wire=k - 2)
+                    bufs.append(buf)
+                    self.bytes_sent[t] += buf.numel()
+            for t in range(tp):
+                pipes[t].wire(k, lambda t=t, buf=bufs[t]: self.groups[t].broadcast_bucket(buf, mode=self.mode), after_local=k)
+        for p in pipes:
+            p.finish()
+        return list(specs)
+
+    def send(self, named_parameters: Iterable[tuple[str, torch.Tensor]], shards: dict) -> list[ParamSpec]:
+        import contextlib
+
+        params = {n: p.detach() for n, p in named_parameters}
+        specs = [ParamSpec(n, tuple(p.shape), p.dtype) for n, p in params.items()]
+        return self.send_streamed(specs, shards, lambda wanted: contextlib.nullcontext({sp.name: params[sp.name] for sp in wanted}))
+
+
 class BucketedReceiver:
     """Worker side: receive the buckets implied by `parameters_info` and hand (name, tensor) views
     to `load_weights` (or scatter them into registered destinations), bucket by bucket; transfers
@@ -353,9 +454,14 @@ class BucketedReceiver:
             p if isinstance(p, ParamSpec) else ParamSpec(p["name"], tuple(p["shape"]), string_to_dtype(p["dtype"]))
             for p in parameters_info
         ]
-        plan = plan_buckets(specs, self.bucket_bytes)
-        if not self._staging:
-            cap = max(bucket_nbytes(b) for b in plan)
+        return self.receive_planned(plan_buckets(specs, self.bucket_bytes), load_weights, destinations)
+
+    def receive_planned(self, plan: Sequence[Sequence[tuple[ParamSpec, int]]],
+                        load_weights: Callable[[list[tuple[str, torch.Tensor]]], Any] | None,
+                        destinations: dict[str, torch.Tensor] | None = None) -> int:
+        """`receive` for a bucket plan made elsewhere (the TP-aware update: `plan_shard_buckets`)."""
+        cap = max(bucket_nbytes(b) for b in plan)
+        if not self._staging or self._staging[0].numel() < cap:
             self._staging = [torch.empty(cap, dtype=torch.uint8, device=self.group.device) for _ in range(2)]
         n = 0
         pipe = _TwoStreamPipe(self.group.device)

@@ -8,6 +8,8 @@ visible): the RCCL weight broadcast that has to cross a link, and the learner st
   * `BucketedSender` / `BucketedReceiver`: the whole Qwen2.5-7B parameter set (339 tensors, 15.2 GB) through
     1 GiB buckets and the two-stream pipeline, EVERY tensor compared on every receiver
     (reference finetune_loop.py:205-292, vllm1.py:110-127);
+  * the TP-aware update (`WeightSyncGroup.tp_shard_groups`, `ShardedSender`): one communicator per tensor-parallel
+    rank, every worker receives only its slices of the 7B parameter set (needs 3 / 5 GPUs);
   * `NativeLearnerStep` under DistributedDataParallel over RCCL with the HIP loss (same check as
     tests/test_gpu_native_ddp.py, which runs it with two processes on one GPU over gloo)."""
 
@@ -88,6 +90,75 @@ def test_rccl_weight_broadcast_is_byte_exact(libprl, world):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_wsync_worker, args=(r, world, port, q), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        results = dict(q.get(timeout=600) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for r in range(world):
+        assert not results[r], (r, results[r])
+
+
+def _tp_shard_worker(rank: int, world: int, port: int, tp: int, out_q) -> None:
+    """rank 0 = trainer; ranks 1.. = TP rank (r - 1) % tp of engine (r - 1) // tp, one GPU each."""
+    try:
+        from pipelinerl_amd.tp_shard import plan_tp_shards, shard_view
+        from pipelinerl_amd.vllm_worker import StandaloneShardReceiver
+        from pipelinerl_amd.finetune_loop import ParameterInfo, WeightUpdateRequest
+        from pipelinerl_amd.weight_sync import ShardedSender, WeightSyncGroup
+        from pipelinerl_amd.weight_sync_probe import qwen25_shapes
+
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        groups = WeightSyncGroup.tp_shard_groups(f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, tp_size=tp, device=dev, timeout_s=120)
+        shapes = qwen25_shapes("7b")
+        cuts = plan_tp_shards(shapes, tp, kv_heads=4)
+        gen = torch.Generator(device=dev).manual_seed(91)  # the same tensors on every rank: the workers check against them
+        params = [(n, torch.empty(s, dtype=torch.bfloat16, device=dev).normal_(generator=gen)) for n, s in shapes]
+        errs = []
+        if rank == 0:
+            sender = ShardedSender(groups, 1 << 30)
+            sender.send(params, cuts)
+            torch.cuda.synchronize()
+            total = sum(t.numel() * 2 for _, t in params)
+            if not all(b < 0.52 * total for b in sender.bytes_sent):
+                errs.append(f"bytes per TP rank {sender.bytes_sent} of {total}")
+        else:
+            t = (rank - 1) % tp
+            w = StandaloneShardReceiver(shapes, lambda n: torch.bfloat16, dev, t, tp, kv_heads=4)
+            w.model_update_group, w.tp_rank, w.tp_size = groups[0], t, tp
+            req = WeightUpdateRequest(version=1, transport="sharded", bucket_bytes=1 << 30, tp_size=tp,
+                                      parameters_info=[ParameterInfo(name=n, shape=list(s), dtype="torch.bfloat16", shard_dim=cuts[n].dim,
+                                                                     shard_parts=cuts[n].parts) for n, s in shapes])
+            w.receive_weight_update(req.model_dump_json())
+            torch.cuda.synchronize()
+            wrong = [n for n, x in params if not torch.equal(w.slices[n], shard_view(x, cuts[n], t, tp))]
+            if wrong:
+                errs.append(f"{len(wrong)} slices differ on rank {rank} (TP rank {t}), first {wrong[:3]}")
+        for g in groups:
+            g.close()
+        out_q.put((rank, errs))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        out_q.put((rank, [f"{type(e).__name__}: {e}", traceback.format_exc()]))
+
+
+@pytest.mark.parametrize("engines,tp", [(1, 2), (2, 2)])
+def test_tp_aware_update_over_rccl(libprl, engines, tp):
+    """The TP-aware update over RCCL: one communicator per TP rank, every worker receives half of the 7B parameter set
+    (its own slices), verified slice by slice."""
+    world = 1 + engines * tp
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tp_shard_worker, args=(r, world, port, tp, q), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     try:
