@@ -30,7 +30,7 @@ from typing import Any, Callable, Literal
 
 import numpy as np
 import torch
-from pydantic import BaseModel, Field
+from pydantic import BaseModel, Field, model_serializer
 
 from .finetune.rl import RLConfig, rl_step as _rl_step
 from .finetune.rl.utils import aggregate_rl_stats, effective_sample_size
@@ -55,6 +55,16 @@ class ParameterInfo(BaseModel):
     # `shard_dim`; None = replicated.  `shape` stays the FULL shape, as in the reference's message.
     shard_dim: int | None = None
     shard_parts: int = 1
+
+    @model_serializer(mode="wrap")
+    def _reference_wire_format(self, handler):
+        """Uncut parameters serialise exactly as the reference's {name, shape, dtype} (finetune_loop.py:95-99): an
+        unmodified reference receiver sees the message it knows."""
+        d = handler(self)
+        if self.shard_dim is None and self.shard_parts == 1:
+            d.pop("shard_dim", None)
+            d.pop("shard_parts", None)
+        return d
 
 
 class WeightUpdateRequest(BaseModel):
