@@ -348,10 +348,9 @@ class BucketedSender:
         params = [(n, p.detach()) for n, p in named_parameters]
         specs = [ParamSpec(n, tuple(p.shape), p.dtype) for n, p in params]
         plan = plan_buckets(specs, self.bucket_bytes)
-        if len(self._staging) < 2:  # double buffer: flatten bucket k+1 while bucket k is on the wire
-            dev = self.group.device
-            cap = max(bucket_nbytes(b) for b in plan)
-            self._staging = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)]
+        cap = max(bucket_nbytes(b) for b in plan)
+        if len(self._staging) < 2 or self._staging[0].numel() < cap:  # double buffer: flatten bucket k+1 while bucket k is on the wire
+            self._staging = [torch.empty(cap, dtype=torch.uint8, device=self.group.device) for _ in range(2)]
         tensors = dict(params)
         pipe = _TwoStreamPipe(self.group.device)
         for k, bucket in enumerate(plan):
@@ -370,8 +369,8 @@ class BucketedSender:
         than one bucket of full parameters alive, where the reference gathers and sends parameter by
         parameter (finetune_loop.py:230-238)."""
         plan = plan_buckets(list(specs), self.bucket_bytes)
-        if len(self._staging) < 2:
-            cap = max(bucket_nbytes(b) for b in plan)
+        cap = max(bucket_nbytes(b) for b in plan)
+        if len(self._staging) < 2 or self._staging[0].numel() < cap:
             self._staging = [torch.empty(cap, dtype=torch.uint8, device=self.group.device) for _ in range(2)]
         pipe = _TwoStreamPipe(self.group.device)
         for k, bucket in enumerate(plan):
@@ -408,9 +407,9 @@ class ShardedSender:
         for t in range(tp):
             full_groups, mine = plan_shard_buckets(list(specs), shards, t, tp, self.bucket_bytes)
             plans.append(mine)
-        if not self._staging:
-            self._staging = [[torch.empty(max(bucket_nbytes(b) for b in plans[t]), dtype=torch.uint8, device=dev) for _ in range(2)]
-                             for t in range(tp)]
+        caps = [max(bucket_nbytes(b) for b in plans[t]) for t in range(tp)]
+        if not self._staging or any(self._staging[t][0].numel() < caps[t] for t in range(tp)):
+            self._staging = [[torch.empty(caps[t], dtype=torch.uint8, device=dev) for _ in range(2)] for t in range(tp)]
         pipes = [_TwoStreamPipe(dev) for _ in range(tp)]
         self.bytes_sent = [0] * tp
         for k, grp in enumerate(full_groups):

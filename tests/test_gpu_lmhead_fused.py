@@ -276,6 +276,61 @@ def test_rl_step_fused_head_on_a_huggingface_style_model(libprl, cuda_device):
     assert rel_err(b.lm_head.weight.grad.cpu().numpy(), a.lm_head.weight.grad.cpu().numpy()) <= 1e-3
 
 
+@pytest.mark.parametrize("cfg_name,cfg", [
+    ("grpo_no_kl_no_entropy", dict(policy_loss="ppo", epsilon_low=0.02, epsilon_high=0.02, kl_coef=0.0, final_kl_coef=0.0, temperature=1.0,
+                                   batch_size=4096, clamp_log_ratio_ref_new_value=5, divide_advantage_by_std=False)),
+    ("reinforce_kl", dict(policy_loss="reinforce", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.02, final_kl_coef=0.02, temperature=1.3,
+                          batch_size=64, clamp_log_ratio_ref_new_value=5, divide_advantage_by_std=False)),
+])
+def test_other_loss_configurations_vs_oracle(libprl, cuda_device, cfg_name, cfg):
+    """The BASELINE GRPO loss (no KL, no entropy bonus: the entropy gradient is absent and PPO-clipped rows carry a zero
+    gradient through the whole backward) and REINFORCE with KL at another temperature."""
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.fused_head import FusedLmHead, fused_head_loss
+
+    T, H, V = 300, 128, 1088
+    g = torch.Generator(device="cpu").manual_seed(77)
+    hidden = torch.randn(1, T, H, generator=g).to(torch.bfloat16).to(cuda_device)
+    W = (torch.randn(V, H, generator=g) * (2.0 / H ** 0.5)).to(cuda_device)
+    rng = np.random.default_rng(78)
+    ids = rng.integers(0, V, size=(1, T), dtype=np.int64)
+    labels = ids.copy()
+    labels[0, :30] = -100
+    half = T // 2
+    labels[0, half] = -100
+    pos = np.concatenate([np.arange(half), np.arange(T - half)])[None].astype(np.int64)
+    logits64 = hidden[0].double() @ W.double().t()
+    lp = torch.log_softmax(logits64 / cfg["temperature"], -1)
+    nlp = np.concatenate([[0.0], lp[torch.arange(T - 1), torch.from_numpy(ids[0, 1:]).to(cuda_device)].cpu().numpy()])
+    old = nlp + rng.normal(0, 0.01, T)
+    adv = rng.normal(0, 1, T)
+    for t in range(40, 60):  # far outside the clip range on the clipping side: zero gradient when kl = entropy = 0
+        up = t % 2 == 0
+        old[t] = nlp[t] - (0.5 if up else -0.5)
+        adv[t] = abs(adv[t]) + 0.1 if up else -abs(adv[t]) - 0.1
+    f32 = lambda a: np.asarray(a, dtype=np.float32)[None]  # noqa: E731
+    batch = {"input_ids": ids, "labels": labels, "position_ids": pos, "attention_mask": np.ones_like(ids), "old_logprobs": f32(old),
+             "ref_logprobs": f32(old + rng.normal(0, 0.05, T)), "advantages": f32(adv), "rewards": f32(rng.integers(0, 2, T)),
+             "group_tokens": f32(np.full(T, 31.0)), "num_labels": f32(np.full(T, float((labels != -100).sum()))), "overflow": f32(np.zeros(T))}
+    want = orl.rl_step(logits64.float().cpu().numpy()[None], batch, cfg, 2, 10, True)
+    dl = torch.from_numpy(want["grad_logits"][0]).to(cuda_device).double()
+    if cfg_name == "grpo_no_kl_no_entropy":
+        assert not want["grad_logits"][0][39:59].any()  # the clipped rows (row q predicts token q + 1)
+    pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(cuda_device)
+    h = hidden.clone().requires_grad_(True)
+    w = W.clone().requires_grad_(True)
+    loss, stats = fused_head_loss(h, w, FusedLmHead(w), pb, RLConfig(**cfg), 2, 10)
+    loss.backward()
+    assert abs(loss.item() - float(want["loss"])) <= FP_TOL * abs(float(want["loss"]))
+    for k, v in want["stats"].items():
+        assert abs(float(stats[k]) - float(v)) <= FP_TOL * max(abs(float(v)), 1.0), k
+    assert rel_err(w.grad.cpu().numpy(), (dl.t() @ hidden[0].double()).cpu().numpy()) <= FP_TOL
+    assert rel_err(h.grad[0].float().cpu().numpy(), (dl @ W.double()).cpu().numpy()) <= 4e-3  # delivered in bf16
+    if cfg_name == "grpo_no_kl_no_entropy":
+        assert torch.count_nonzero(h.grad[0, 39:59]) == 0
+
+
 def test_weight_gradient_accumulates_or_overwrites(libprl, cuda_device):
     """`grad_weight` is `+=` by contract (gradient accumulation over micro-batches); PRL_LM_HEAD_DW_OVERWRITE stores
     instead, into memory that may hold anything - with several row chunks (the later chunks still add)."""
