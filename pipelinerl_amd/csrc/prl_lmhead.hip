@@ -879,9 +879,21 @@ int fwd_nsplit(int token_tiles, int vocab_tiles, bool one_per_cu) {
     const int v = atoi(e);
     if (v >= 1) return v < vocab_tiles ? v : vocab_tiles;
   }
-  int ns = ceil_div(one_per_cu ? 256 : 512, token_tiles);
-  if (ns < 1) ns = 1;
-  return ns < vocab_tiles ? ns : vocab_tiles;
+  // workgroups = token_tiles x splits run in rounds of `slots`; pick the split count (up to four rounds) whose last
+  // round is fullest - 24 token tiles: 11 splits would be 264 workgroups = a second round for 8 of them, 32 splits
+  // are three full rounds.  Ties go to fewer workgroups (longer vocabulary sweeps per workgroup).
+  const int slots = one_per_cu ? 256 : 512;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int ns = 1; ns <= vocab_tiles && (int64_t)token_tiles * ns <= 4 * slots; ++ns) {
+    const int64_t wg = (int64_t)token_tiles * ns;
+    const double eff = (double)wg / (double)(((wg + slots - 1) / slots) * slots);
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      best = ns;
+    }
+  }
+  return best;
 }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1071,6 +1083,7 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
 
   for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
     const int64_t m = (n - r0) < chunk_rows ? (n - r0) : chunk_rows;
+    const int m_pad = ceil_div(m, 128) * 128;  // <= L.chunk_pad
     // ---- 1. d logits planes of this chunk (recompute the logits tile by tile)
     {
       DlArgs d;
@@ -1095,9 +1108,11 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       d.dl_lo = dl_lo;
       d.dlT_hi = dlT_hi;
       d.dlT_lo = dlT_lo;
-      const Shape shape = pick_shape(vocab, L.chunk_pad);
+      const Shape shape = pick_shape(vocab, m_pad);
       d.vt = ceil_div(vocab, shape_bm(shape));
-      d.tt = ceil_div(L.chunk_pad, shape_bn(shape));  // token tiles of the chunk buffers (pad rows are written as zeros)
+      // token tiles of THIS chunk: its rows rounded up to 128 (the pad rows are written as zeros and are what the
+      // d W contraction below runs over); a short last chunk does not pay for the whole buffer
+      d.tt = ceil_div(m_pad, shape_bn(shape));
       if (use_dual(shape, d.terms)) {
         if (int rc = PRL_LAUNCH_DUAL((lmhead_dlogits_kernel<CfgDual, true>), d.vt * d.tt, d, s, "lmhead_dlogits_kernel(dual)")) return rc;
       } else if (int rc = PRL_LAUNCH_CFG(shape, lmhead_dlogits_kernel, d.vt * d.tt, d, s, "lmhead_dlogits_kernel")) {
@@ -1149,7 +1164,7 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       g.terms.a[1] = dlT_lo;
       g.terms.a[2] = dlT_lo;
       g.terms.b[0] = g.terms.b[1] = g.terms.b[2] = hT;
-      g.geo = Geom{(int)vocab, (int)hidden, L.chunk_pad, L.chunk_pad, L.chunk_pad};
+      g.geo = Geom{(int)vocab, (int)hidden, m_pad, L.chunk_pad, L.chunk_pad};  // contraction over the chunk's (padded) rows
       const Shape shape = pick_shape(vocab, hidden);
       g.mt = ceil_div(vocab, shape_bm(shape));
       g.nt = ceil_div(hidden, shape_bn(shape));

@@ -39,10 +39,14 @@ class FusedLmHead:
     Refreshed when the weight changes (version counter / storage address); writers that go through
     `.data.copy_()` must call `invalidate()` - same contract as lm_head.SplitBf16LmHead."""
 
-    def __init__(self, weight: torch.Tensor, backward: bool = True, chunk_rows: int = 4096, hidden_grad_terms: int = 3):
+    def __init__(self, weight: torch.Tensor, backward: bool = True, chunk_rows: int = 4096, hidden_grad_terms: int = 3,
+                 skip_unlabelled: bool = True):
         """`chunk_rows`: logits rows whose d logits planes live in the workspace at a time (4 x chunk x V x 2 bytes).
         `hidden_grad_terms`: 3 = d hidden from every bf16 product (fp32-GEMM accuracy before the final rounding),
-        1 = leading product only (2^-9 relative, the size of the bf16 rounding of d hidden; two GEMM passes less)."""
+        1 = leading product only (2^-9 relative, the size of the bf16 rounding of d hidden; two GEMM passes less).
+        `skip_unlabelled` (loss path only, `fused_head_loss`): rows whose next token carries no label (prompt and
+        observation tokens, sequence starts, padding) enter neither the loss nor any statistic - the head runs,
+        forward and backward, on the labelled rows only; see `_FusedHeadLossFn`."""
         if weight.dim() != 2:
             raise ValueError("lm_head weight must be [vocab, hidden]")
         if weight.dtype not in (torch.float32, torch.bfloat16):
@@ -51,6 +55,7 @@ class FusedLmHead:
         self.backward = backward
         self.chunk_rows = int(chunk_rows)
         self.hidden_grad_terms = int(hidden_grad_terms)
+        self.skip_unlabelled = bool(skip_unlabelled)
         self._key = None
         self.w_hi = self.w_lo = self.wt_hi = self.wt_lo = None
         self._ws: dict[Any, torch.Tensor] = {}
@@ -164,15 +169,38 @@ class FusedLmHead:
         return gh
 
 
+# below this fraction of unlabelled rows the gather / scatter around the compact problem is not worth it
+_MIN_SKIP_FRACTION = 1.0 / 32.0
+
+
+def _labelled_rows(labels: torch.Tensor) -> torch.Tensor:
+    """Flat indices q = b * L + c of the logits rows that predict a labelled token (labels[b, c + 1] != -100)."""
+    live = torch.zeros_like(labels, dtype=torch.bool)
+    live[:, :-1] = labels[:, 1:] != -100
+    return live.flatten().nonzero().squeeze(1)  # the one host synchronisation of this path
+
+
 class _FusedHeadLossFn(torch.autograd.Function):
-    """(hidden, weight) -> (loss, stats): K1 inside the head GEMM, K2+K3, hand-written backward."""
+    """(hidden, weight) -> (loss, stats): K1 inside the head GEMM, K2+K3, hand-written backward.
+
+    With `head.skip_unlabelled` the head sees a COMPACT problem: the hidden states of the rows that predict a labelled
+    token, gathered into one row-major block (plus one closing row that predicts nothing), with their target ids next
+    to them.  The reference computes log-probabilities for every position and masks afterwards
+    (rl/__init__.py:207-233, 238-250: every term and statistic carries the `labels != -100` mask), so loss, statistics
+    and gradients are unchanged - the unlabelled positions of `new_logprobs` / `entropy` are simply 0 instead of values
+    nobody reads, d hidden of those rows is exactly 0 as before, and forward + backward cost what the LABELLED tokens
+    cost.  The kernels are the same ones; only which rows they are handed changes (one `nonzero()` = one host sync)."""
 
     @staticmethod
     def forward(ctx, hidden, weight, head: FusedLmHead, batch, cfg, temperature, chunk_rows):  # type: ignore[override]
-        ctx.sentinel = bool(batch.sentinel)
+        rows = None
+        if head.skip_unlabelled and not batch.sentinel:
+            _lib.require_device(hidden, batch.labels)
+            rows = _labelled_rows(batch.labels)
+        ctx.sentinel = bool(batch.sentinel) or (rows is not None and rows.numel() == 0)
         if ctx.sentinel:
-            # a sentinel batch has no labelled token (finetune/utils.py:17-78): loss 0, statistics of an empty
-            # batch, gradient 0 - no GEMM forward or backward, the wrappers still see a gradient for every input
+            # a sentinel batch (finetune/utils.py:17-78), or any batch without a labelled token: loss 0, statistics of an
+            # empty batch, gradient 0 - no GEMM forward or backward, the wrappers still see a gradient for every input
             _lib.require_device(hidden, weight)
             B, L, _ = hidden.shape
             zeros = torch.zeros((B, L), dtype=torch.float32, device=hidden.device)
@@ -180,12 +208,38 @@ class _FusedHeadLossFn(torch.autograd.Function):
             ctx.shapes = (hidden.shape, hidden.dtype, weight.shape, weight.dtype, hidden.device)
             ctx.mark_non_differentiable(stats)
             return loss, stats
-        nlp, ent, lse2, h = head.logprob_entropy(hidden, batch.input_ids, temperature)
         need_grad = hidden.requires_grad or weight.requires_grad
+        B, L, H = hidden.shape
+        idx = rows if (rows is not None and rows.numel() <= (1.0 - _MIN_SKIP_FRACTION) * B * L) else None
+        if idx is None:
+            nlp, ent, lse2, h = head.logprob_entropy(hidden, batch.input_ids, temperature)
+            ids = batch.input_ids
+        else:
+            n = idx.numel()
+            dev = hidden.device
+            hc = torch.zeros((1, n + 1, H), dtype=torch.bfloat16, device=dev)  # + one closing row (predicts nothing)
+            hc[0, :n] = hidden.detach().reshape(B * L, H).index_select(0, idx)
+            ids = torch.zeros((1, n + 1), dtype=torch.int64, device=dev)
+            ids[0, 1:] = batch.input_ids.reshape(-1).index_select(0, idx + 1)  # row j predicts ids[j + 1]
+            nlp_c, ent_c, lse2, h = head.logprob_entropy(hc, ids, temperature)
+            nlp = torch.zeros((B, L), dtype=torch.float32, device=dev)
+            ent = torch.zeros_like(nlp)
+            nlp.view(-1).index_copy_(0, idx + 1, nlp_c[0, 1:])  # token-aligned: the value for token u = q + 1
+            ent.view(-1).index_copy_(0, idx + 1, ent_c[0, 1:])
         loss, stats, g_nlp, g_ent = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=need_grad)
         if need_grad:
-            ctx.save_for_backward(h, batch.input_ids, lse2, ent, g_nlp, g_ent if g_ent is not None else torch.empty(0, device=h.device))
+            if idx is not None:  # the token gradients of the compact rows, token-aligned to the compact problem
+                def compact(g):
+                    out = torch.zeros((1, idx.numel() + 1), dtype=torch.float32, device=g.device)
+                    out[0, 1:] = g.reshape(-1).index_select(0, idx + 1)
+                    return out
+
+                g_nlp, g_ent, ent = compact(g_nlp), (compact(g_ent) if g_ent is not None else None), ent_c
+            ctx.save_for_backward(h, ids, lse2, ent, g_nlp, g_ent if g_ent is not None else torch.empty(0, device=h.device),
+                                  idx if idx is not None else torch.empty(0, dtype=torch.int64, device=h.device))
         ctx.has_g_ent = g_ent is not None
+        ctx.compact = idx is not None
+        ctx.hidden_shape = tuple(hidden.shape)
         ctx.head, ctx.temperature, ctx.chunk_rows = head, float(temperature), chunk_rows
         ctx.hidden_dtype, ctx.weight_dtype = hidden.dtype, weight.dtype
         ctx.mark_non_differentiable(stats)
@@ -198,7 +252,7 @@ class _FusedHeadLossFn(torch.autograd.Function):
             gh = torch.zeros(hs, dtype=hd, device=dev) if ctx.needs_input_grad[0] else None
             gw = torch.zeros(ws_, dtype=wd, device=dev) if ctx.needs_input_grad[1] else None
             return gh, gw, None, None, None, None, None
-        h, ids, lse2, ent, g_nlp, g_ent = ctx.saved_tensors
+        h, ids, lse2, ent, g_nlp, g_ent, idx = ctx.saved_tensors
         head: FusedLmHead = ctx.head
         want_h, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gw = torch.empty((head.vocab, head.hidden), dtype=torch.float32, device=h.device) if want_w else None
@@ -207,6 +261,11 @@ class _FusedHeadLossFn(torch.autograd.Function):
                                             want_hidden=want_h, grad_weight=gw, overwrite_weight_grad=True,
                                             grad_hidden_dtype=torch.float32 if ctx.hidden_dtype == torch.float32 else torch.bfloat16,
                                             chunk_rows=ctx.chunk_rows)
+        if gh is not None and ctx.compact:  # rows without a label have no gradient
+            B, L, H = ctx.hidden_shape
+            full = torch.zeros((B * L, H), dtype=gh.dtype, device=gh.device)
+            full.index_copy_(0, idx, gh[0, :-1])
+            gh = full.view(B, L, H)
         if gh is not None and gh.dtype != ctx.hidden_dtype:
             gh = gh.to(ctx.hidden_dtype)
         if gw is not None and gw.dtype != ctx.weight_dtype:

@@ -331,6 +331,49 @@ def test_other_loss_configurations_vs_oracle(libprl, cuda_device, cfg_name, cfg)
         assert torch.count_nonzero(h.grad[0, 39:59]) == 0
 
 
+@pytest.mark.parametrize("layout", ["packed", "padded_2_rows"])
+def test_unlabelled_rows_are_skipped_without_changing_the_result(libprl, cuda_device, layout):
+    """`skip_unlabelled` hands the kernels only the rows that predict a labelled token (here ~60 % of them: long prompts):
+    loss, statistics and gradients equal the full computation and the oracle; d hidden of the skipped rows is exactly 0."""
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.fused_head import FusedLmHead, fused_head_loss
+
+    T, H, V = 320, 128, 1088
+    hidden, W, batch, logits64 = _problem(T, H, V, cuda_device, seed=55)
+    batch = {k: v.copy() for k, v in batch.items()}
+    batch["labels"][0, :70] = -100          # a long prompt in the first sequence
+    batch["labels"][0, 160:230] = -100      # and in the second
+    packed = layout == "packed"
+    if not packed:  # the same tokens as two padded rows [2, 160]: row boundaries replace the packed sequence start
+        batch = {k: v.reshape(2, T // 2) for k, v in batch.items()}
+        batch.pop("position_ids")
+        hidden = hidden.reshape(2, T // 2, H)
+        logits64 = logits64.reshape(2, T // 2, V)
+    nl = float((batch["labels"][:, 1:] != -100).sum())
+    batch["num_labels"] = np.full_like(batch["num_labels"], nl)
+    want = orl.rl_step(logits64.float().cpu().numpy().reshape(hidden.shape[0], hidden.shape[1], V), batch, CFG, 2, 10, packed)
+    pb = PipelineBatchEncoding(**{k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}, model_version=0, is_packed=packed).to_device(cuda_device)
+    out = {}
+    for skip in (True, False):
+        h = hidden.clone().requires_grad_(True)
+        w = W.clone().requires_grad_(True)
+        head = FusedLmHead(w, skip_unlabelled=skip)
+        loss, stats = fused_head_loss(h, w, head, pb, RLConfig(**CFG), 2, 10)
+        loss.backward()
+        out[skip] = (loss.item(), stats, h.grad.float().cpu().numpy(), w.grad.cpu().numpy())
+        assert abs(loss.item() - float(want["loss"])) <= FP_TOL * abs(float(want["loss"]))
+        for k, v in want["stats"].items():
+            assert abs(float(stats[k]) - float(v)) <= FP_TOL * max(abs(float(v)), 1.0), (skip, k)
+    a, b = out[True], out[False]
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0]) and list(a[1]) == list(b[1])
+    assert rel_err(a[3], b[3]) <= 1e-5 and rel_err(a[2], b[2]) <= 1e-5
+    dead = (np.concatenate([batch["labels"][:, 1:], np.full((batch["labels"].shape[0], 1), -100)], axis=1) == -100)
+    assert dead.mean() > 0.5 and not a[2][dead].any() and not b[2][dead].any()
+    dl = torch.from_numpy(want["grad_logits"]).to(cuda_device).double().reshape(-1, V)
+    assert rel_err(a[3], (dl.t() @ hidden.reshape(-1, H).double()).cpu().numpy()) <= FP_TOL
+
+
 def test_weight_gradient_accumulates_or_overwrites(libprl, cuda_device):
     """`grad_weight` is `+=` by contract (gradient accumulation over micro-batches); PRL_LM_HEAD_DW_OVERWRITE stores
     instead, into memory that may hold anything - with several row chunks (the later chunks still add)."""
