@@ -471,7 +471,9 @@ int prl_bucket_scatter(const void* bucket, int64_t bucket_bytes, const struct pr
 int prl_split_bf16(int64_t n, const float* src, uint16_t* hi, uint16_t* lo, void* stream);
 
 /*
- * prl_fused_logits_loss with the gradient delivered as those two planes: grad_hi / grad_lo
+ * prl_fused_logits_loss (reference: rl_step's K1 + the autograd backward of rl/__init__.py:207-233
+ * into the logits of an fp32 lm_head, finetune/checkpoints.py:87-103) with the gradient delivered as
+ * those two planes: grad_hi / grad_lo
  * [rows*cols, plane_row_stride] bf16, hi + lo = d loss / d logits to ~2^-17 relative, bit for bit
  * what prl_split_bf16 makes of prl_fused_logits_loss's fp32 gradient - without the fp32 gradient
  * and without the extra pass over it.  fp32 logits only; the planes must not alias the logits
