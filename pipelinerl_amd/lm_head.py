@@ -147,6 +147,7 @@ class _SplitHeadLossFn(torch.autograd.Function):
         ent, lse2 = torch.empty_like(nlp), torch.empty_like(nlp)
         need_grad = hidden.requires_grad or weight.requires_grad
         ctx.sentinel = bool(batch.sentinel)
+        idx = None
         if ctx.sentinel or not need_grad:
             planes = None
             if ctx.sentinel:
@@ -157,19 +158,52 @@ class _SplitHeadLossFn(torch.autograd.Function):
 
                 nlp, ent, _, _ = logprob_entropy(_split_logits(x2, w_parts, w_cat).reshape(B, L, V), batch.input_ids, temperature)
         else:
-            logits = _split_logits(x2, w_parts, w_cat)
-            planes = torch.empty((2, B * L, V), dtype=torch.bfloat16, device=dev)
-            cont = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
+            from .fused_head import _MIN_SKIP_FRACTION, _labelled_rows
+
+            # only the rows that predict a labelled token enter the loss (rl/__init__.py:238-250): gather them (and their
+            # token columns) into a compact problem, as fused_head._FusedHeadLossFn does - GEMMs and the plane pass then
+            # cost what the labelled tokens cost
+            rows = _labelled_rows(batch.labels)
+            if 0 < rows.numel() <= (1.0 - _MIN_SKIP_FRACTION) * B * L:
+                idx = rows
+                n = idx.numel()
+                xc = torch.zeros((n + 1, x2.shape[1]), dtype=torch.bfloat16, device=dev)  # + a closing row that predicts nothing
+                xc[:n] = x2.index_select(0, idx)
+
+                def col(t, fill=0):  # token-aligned column of the compact problem: entry j + 1 belongs to compact row j
+                    out = torch.full((1, n + 1), fill, dtype=t.dtype, device=dev)
+                    out[0, 1:] = t.reshape(-1).index_select(0, idx + 1)
+                    return out
+
+                c_ids, c_lab = col(batch.input_ids), col(batch.labels, -100)
+                cols = [col(t) for t in (batch.old_logprobs, batch.ref_logprobs, batch.advantages, batch.rewards, batch.group_tokens, batch.overflow)]
+                rows_k, cols_k, x_used = 1, n + 1, xc
+            else:
+                cont = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
+                c_ids, c_lab = cont(batch.input_ids), cont(batch.labels)
+                cols = [cont(t) for t in (batch.old_logprobs, batch.ref_logprobs, batch.advantages, batch.rewards, batch.group_tokens, batch.overflow)]
+                rows_k, cols_k, x_used = B, L, x2
+            logits = _split_logits(x_used, w_parts, w_cat)
+            planes = torch.empty((2, rows_k * cols_k, V), dtype=torch.bfloat16, device=dev)
+            k_nlp = torch.empty((rows_k, cols_k), dtype=torch.float32, device=dev)
+            k_ent, k_lse = torch.empty_like(k_nlp), torch.empty_like(k_nlp)
             with torch.cuda.device(dev):
                 _lib.check(lib.prl_fused_logits_loss_planes(
-                    ctypes.byref(cfg), B, L, V, logits.data_ptr(), V, float(temperature), cont(batch.input_ids).data_ptr(),
-                    cont(batch.labels).data_ptr(), cont(batch.old_logprobs).data_ptr(), cont(batch.ref_logprobs).data_ptr(),
-                    cont(batch.advantages).data_ptr(), cont(batch.rewards).data_ptr(), cont(batch.group_tokens).data_ptr(),
-                    cont(batch.overflow).data_ptr(), nlp.data_ptr(), ent.data_ptr(), lse2.data_ptr(), planes[0].data_ptr(),
+                    ctypes.byref(cfg), rows_k, cols_k, V, logits.data_ptr(), V, float(temperature), c_ids.data_ptr(), c_lab.data_ptr(),
+                    *[c.data_ptr() for c in cols], k_nlp.data_ptr(), k_ent.data_ptr(), k_lse.data_ptr(), planes[0].data_ptr(),
                     planes[1].data_ptr(), V, _lib.current_stream_ptr(dev)))
             del logits
+            if idx is not None:
+                nlp.zero_()
+                ent.zero_()
+                nlp.view(-1).index_copy_(0, idx + 1, k_nlp[0, 1:])
+                ent.view(-1).index_copy_(0, idx + 1, k_ent[0, 1:])
+                x2 = xc
+            else:
+                nlp, ent = k_nlp, k_ent
         loss, stats, _, _ = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=False)
         ctx.planes = planes
+        ctx.rows = idx
         ctx.save_for_backward(x2, *w_parts)
         ctx.meta = (hidden.shape, weight.shape, weight.dtype, dx_terms)
         ctx.mark_non_differentiable(stats)
@@ -188,7 +222,15 @@ class _SplitHeadLossFn(torch.autograd.Function):
         dx, dw = _head_grads([planes[0], planes[1]], x2, w_parts, dx_terms, want_w)
         # the upstream factor of the loss is applied to the small results ([T, H], [V, H]), never to [T, V]
         up = grad_loss.to(torch.float32)
-        dx = (dx * up).to(torch.bfloat16).reshape(h_shape) if want_h else None
+        if want_h:
+            dx = (dx * up).to(torch.bfloat16)
+            if ctx.rows is not None:  # compact rows back to their places; rows without a label have no gradient
+                full = torch.zeros((h_shape[0] * h_shape[1], h_shape[2]), dtype=torch.bfloat16, device=dx.device)
+                full.index_copy_(0, ctx.rows, dx[:-1])
+                dx = full
+            dx = dx.reshape(h_shape)
+        else:
+            dx = None
         if dw is not None:
             dw = dw.mul_(up)
         return dx, dw, None, None, None, None, None, None
