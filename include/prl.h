@@ -127,7 +127,12 @@ typedef struct prl_loss_config {
                                   back to back (one launch per optimizer step); a position
                                   with position_ids == 0 then starts a micro-batch or a
                                   masked sequence and carries no prediction                */
-  int32_t reserved0;
+  int32_t skip_unlabelled;     /* prl_fused_logits_loss(_planes) only.  1: a row whose next token has
+                                  labels == -100 (prompt / observation tokens, sequence starts, padding)
+                                  is not read at all: its new_logprobs / entropy / lse2 are written as 0 and
+                                  its gradient row as zeros.  Every term of the loss and every statistic
+                                  carries the label mask (rl/__init__.py:238-250), so loss, statistics and
+                                  gradients do not change.  0: the outputs of K1 at every position        */
   float token_weight;          /* fp32(1)/fp32(batch_size)                       (:250)    */
   float clip_lo;               /* fp32(1 - epsilon_low)                          (:300)    */
   float clip_hi;               /* fp32(1 + epsilon_high)                         (:300,306)*/

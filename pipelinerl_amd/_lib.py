@@ -86,7 +86,7 @@ class PrlLossConfig(ctypes.Structure):
         ("overlong_filtering", c_int32),
         ("use_entropy_loss", c_int32),
         ("flat_micro_batches", c_int32),
-        ("reserved0", c_int32),
+        ("skip_unlabelled", c_int32),
         ("token_weight", c_float),
         ("clip_lo", c_float),
         ("clip_hi", c_float),

@@ -384,6 +384,15 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_kernel(
     return;
   }
   const int64_t u = q + 1;
+  if (a.cfg.skip_unlabelled && a.labels[u] == -100) {  // nothing downstream reads this row's outputs: do not read the row
+    if (threadIdx.x == 0) {
+      a.nlp[u] = 0.0f;
+      a.ent[u] = 0.0f;
+      a.lse2[u] = 0.0f;
+    }
+    row_write_zero<T, BLOCK>(out, geo.vocab, geo.vec_ok);
+    return;
+  }
   const typename T::scalar* row = logits + q * geo.stride;
   // read the selected logit BEFORE pass 1's barrier: with grad aliasing logits, pass 2 of a
   // faster wave may already overwrite row[id] once the barrier has been passed.
@@ -498,6 +507,15 @@ __global__ __launch_bounds__(BLOCK) void fused_logits_loss_keep_kernel(
     return;
   }
   const int64_t u = q + 1;
+  if (a.cfg.skip_unlabelled && a.labels[u] == -100) {  // nothing downstream reads this row's outputs: do not read the row
+    if (tid == 0) {
+      a.nlp[u] = 0.0f;
+      a.ent[u] = 0.0f;
+      a.lse2[u] = 0.0f;
+    }
+    row_write_zero<T, BLOCK>(out, geo.vocab, true);
+    return;
+  }
   const typename T::scalar* row = logits + q * geo.stride;
   const int64_t id64 = a.ids[u];
   const int id = (id64 >= 0 && id64 < geo.vocab) ? (int)id64 : -1;

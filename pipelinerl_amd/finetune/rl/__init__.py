@@ -339,6 +339,7 @@ class _GrpoLossFn(torch.autograd.Function):
                 lse2 = torch.empty_like(nlp)
                 kcfg = type(cfg).from_buffer_copy(cfg)
                 kcfg.upstream_scale = float(expected_scale)
+                kcfg.skip_unlabelled = 1  # rows that predict an unlabelled token reach neither the loss nor a statistic: not read
                 cont = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
                 with torch.cuda.device(dev):
                     _lib.check(

@@ -58,6 +58,7 @@ class HotPathStep:
         self.config = config
         self.eos_token_id = eos_token_id
         self.cfg, self.kl_coef, self.ent_coef = make_loss_config(config, current_step, max_step)
+        self.cfg.skip_unlabelled = 1  # the logits kernel does not read rows whose next token is unlabelled (prl.h)
         self.group = group
         self.batches: Any = []
         self.step_batch: PipelineBatchEncoding | None = None

@@ -204,6 +204,46 @@ def test_rl_step_at_full_vocab_and_scaled_loss(libprl, cuda_device, monkeypatch,
         assert rel_err(lt.grad.float().cpu().numpy(), want["grad_logits"] * applied) <= tol, (expected, applied)
 
 
+@pytest.mark.parametrize("V,T", [(152064, 40), (1003, 50)])
+@pytest.mark.parametrize("inplace", [False, True])
+def test_unlabelled_rows_are_not_read(libprl, cuda_device, V, T, inplace):
+    """`prl_loss_config.skip_unlabelled`: rows whose next token carries no label are not read - their log-prob / entropy
+    come out as 0 and their gradient rows as zeros; everything else is bit for bit the skip = 0 result (row-resident
+    kernel at V = 152 064, two-sweep kernel at V = 1003)."""
+    from pipelinerl_amd import _lib
+    from pipelinerl_amd.finetune.rl import RLConfig, make_loss_config
+
+    logits, batch, want, g64 = _case(V, T, "kl_ent_temp", "f32")
+    lt = torch.from_numpy(logits).to(cuda_device)
+    d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(cuda_device) for k, v in batch.items()}
+    out = {}
+    for skip in (0, 1):
+        c_cfg, _, _ = make_loss_config(RLConfig(**CONFIGS["kl_ent_temp"]), 2, 10)
+        c_cfg.skip_unlabelled = skip
+        nlp, ent, lse = (torch.full((1, T), 7.0, device=cuda_device) for _ in range(3))
+        src = lt.clone()
+        src[0, 3] = float("nan")  # row 3 predicts token 4, which is unlabelled: with skip = 1 the row must not be touched
+        grad = src if inplace else torch.full_like(src, 3.0)
+        _lib.check(libprl.prl_fused_logits_loss(
+            ctypes.byref(c_cfg), 1, T, V, src.data_ptr(), 0, V, CONFIGS["kl_ent_temp"]["temperature"], d["input_ids"].data_ptr(),
+            d["labels"].data_ptr(), d["old_logprobs"].data_ptr(), d["ref_logprobs"].data_ptr(), d["advantages"].data_ptr(),
+            d["rewards"].data_ptr(), d["group_tokens"].data_ptr(), d["overflow"].data_ptr(), nlp.data_ptr(), ent.data_ptr(),
+            lse.data_ptr(), grad.data_ptr(), _lib.current_stream_ptr(cuda_device)))
+        torch.cuda.synchronize()
+        out[skip] = (nlp.cpu().numpy(), ent.cpu().numpy(), grad.cpu().numpy())
+    lab = np.asarray(batch["labels"])[0] != -100
+    assert not lab[4]
+    a, b = out[0], out[1]
+    assert np.array_equal(a[0][0, lab], b[0][0, lab]) and np.array_equal(a[1][0, lab], b[1][0, lab])
+    assert not b[0][0, ~lab].any() and not b[1][0, ~lab].any()
+    assert np.isnan(a[0][0, 4]) and b[0][0, 4] == 0  # skip = 0 computed a log-prob from the NaN row, skip = 1 never read it
+    keep = np.ones(T, dtype=bool)
+    keep[3] = False
+    assert np.array_equal(a[2][0, keep], b[2][0, keep])  # every gradient row, bit for bit
+    assert not b[2][0, 3].any()
+    np.testing.assert_allclose(b[0][0, 1:][lab[1:]], want["new_logprobs"][0][lab[1:]], rtol=FP_TOL, atol=2e-5)
+
+
 def test_sentinel_batch_skips_the_logits_kernel(libprl, cuda_device):
     """finetune_loop.py:784-786: a sentinel batch is forwarded, its loss multiplied by 0 and
     back-propagated.  The fused path neither reads the logits nor launches the [T, V] kernel for it;
