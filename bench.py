@@ -510,9 +510,13 @@ def main():
 
     kernels = timer.summary()
     V4 = vocab * 4
+    # rows whose next token is unlabelled (the prompts) are not read by the fused kernel, only their gradient row is
+    # zeroed: they count V*4 bytes, not 2*V*4 (the average over this rank's launches; one sequence per launch)
+    labelled = int((rag.labels != -100).sum().item())
+    live_frac = labelled / float(tokens_per_rank)
     algo = {
         # algorithmic bytes per launch
-        "fused_logits_loss": seq_length * (2 * V4 + 56),          # logits read once + d logits written once
+        "fused_logits_loss": seq_length * ((1.0 + live_frac) * V4 + 56),  # logits of labelled rows read once + d logits written once
         "grpo_loss_step": tokens_per_rank * 52,                   # 56 B/token minus the unwritten 4 B gradient
         "preprocess_K5_K6": tokens_per_rank * (84 + 8),           # K6 16 B read + 68 B written; K5 scan 8 B read
         "pack_collate_kernel": tokens_per_rank * 84,              # the K6 kernel alone
@@ -601,7 +605,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "global_batch": bs, "seq_len": seq_length, "vocab": vocab,
                        "tokens_per_step": bs * seq_length, "parallelism": f"dp{world}", "logits_mode": args.logits_mode,
-                       "policy_loss": "ppo", "kl_coef": 0.0, "old_logprob_sigma": sigma,
+                       "policy_loss": "ppo", "kl_coef": 0.0, "old_logprob_sigma": sigma, "labelled_token_fraction": live_frac,
                        "grad_allreduce_bytes_per_step": sum(b.numel() * 2 for b in grad_buckets) if grad_buckets else 0,
                        "h2d_ragged_input": {"bytes": h2d_bytes, "ms": 1e3 * t_h2d, "ms_pinned": 1e3 * t_h2d_pinned,
                                             "note": "one step's ragged rollouts, pageable vs page-locked host memory; not part of value"}},
