@@ -535,8 +535,8 @@ def main():
         try:
             table = json.loads(pmc.read_text())
             traffic = table.get(dom, {}).get("hbm_bytes_per_launch")
-            traffic_source = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round 1, committed; "
-                              "NOT measured in this run)")
+            traffic_source = ("profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over scripts/kernel_sweep.py, "
+                              "fused-kernel entry re-measured on the round-2 tree; committed, NOT measured in this run)")
             # per-token PMC figures of the two step-scale kernels, scaled to this launch
             if "grpo_loss_step" in kernels and "hbm_bytes_per_token" in table.get("grpo_loss_step", {}):
                 kernels["grpo_loss_step"]["traffic"] = table["grpo_loss_step"]["hbm_bytes_per_token"] * tokens_per_rank
