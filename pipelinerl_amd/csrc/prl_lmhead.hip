@@ -638,14 +638,15 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
   const float up = a.upstream ? *a.upstream : 1.0f;
   const int64_t V = a.geo.M;
   const int vbase = m0 + acc_row(lane, wrow0, 0, 0);
+  // ---- d logits of this lane's 2 x NJ x 16 accumulator values, each as (hi | lo << 16): bf16 planes hi + lo = value
+  uint32_t pk[2][NJ][16];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int lrow = n0 + acc_col(lane, wcol0, j);  // row inside the chunk buffers
-    if (lrow >= a.chunk_pad) continue;               // a 256-row tile may overhang a chunk padded to 128
     const int64_t q = a.row_base + lrow;
     float g = 0.0f, gH = 0.0f, l2 = 0.0f, H = 0.0f;
     int id = -1;
-    if (lrow < a.geo.N && (q % a.cols) != a.cols - 1) {
+    if (lrow < a.geo.N && (q % a.cols) != a.cols - 1) {  // rows past the chunk's end (padding) come out as zeros
       const int64_t u = q + 1;
       g = a.g_nlp[u] * up;
       gH = a.g_ent ? a.g_ent[u] * up : 0.0f;
@@ -659,32 +660,87 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {  // four consecutive vocabulary rows: registers 4 rg .. 4 rg + 3
-        const int v0 = vbase + i * 32 + 8 * rg;
-        uint16_t hi[4], lo[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float val = 0.0f;
-          if (live) {
-            const float d2 = __builtin_fmaf(acc[i][j][rg * 4 + e], a.k2, -l2);  // log2 p
-            const float p = fast_exp2(d2);
-            val = ngi * p;
-            if (gH != 0.0f) val = __builtin_fmaf(nhi * p, __builtin_fmaf(d2, kLn2, H), val);
-            if (v0 + e == id) val += gi;
-          }
-          split2(val, hi[e], lo[e]);
+      for (int r = 0; r < 16; ++r) {
+        float val = 0.0f;
+        if (live) {
+          const float d2 = __builtin_fmaf(acc[i][j][r], a.k2, -l2);  // log2 p
+          const float p = fast_exp2(d2);
+          val = ngi * p;
+          if (gH != 0.0f) val = __builtin_fmaf(nhi * p, __builtin_fmaf(d2, kLn2, H), val);
+          if (vbase + i * 32 + (r & 3) + 8 * (r >> 2) == id) val += gi;
         }
-        if (v0 + 3 < V) {  // V is a multiple of 4: a group of four is inside or outside as a whole
-          const int64_t o = (int64_t)lrow * V + v0;  // 8-byte aligned: V % 4 == 0, v0 % 4 == 0
-          *reinterpret_cast<uint2*>(a.dl_hi + o) = uint2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
-          *reinterpret_cast<uint2*>(a.dl_lo + o) = uint2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            a.dlT_hi[(int64_t)(v0 + e) * a.chunk_pad + lrow] = hi[e];
-            a.dlT_lo[(int64_t)(v0 + e) * a.chunk_pad + lrow] = lo[e];
-          }
-        }
+        uint16_t hi, lo;
+        split2(val, hi, lo);
+        pk[i][j][r] = (uint32_t)hi | ((uint32_t)lo << 16);
       }
+  }
+
+  // ---- the four planes leave through LDS, one tile image at a time, so that every global store is 16 bytes per lane
+  // and a wave writes whole 512-byte row segments.  Storing straight from the accumulator layout (8-byte pieces of the
+  // row-major planes, 2-byte pieces of the transposed ones) left partially written sectors behind: 8.8 GB written and
+  // 6.3 GB fetched per chunk for 4.98 GB of planes, ~8 ms of a 60 ms backward (profiles/r02ai_*, r02aj_*).
+  constexpr int BM = C::BM, BN = C::BN;
+  constexpr int RS = BM * 2 + 8;  // row-major image [token row][vocabulary]: + 8 bytes per row, conflict-free 8-byte writes
+  constexpr int TS = BN * 2 + 8;  // transposed image [vocabulary][token row]
+  unsigned char* img = reinterpret_cast<unsigned char*>(lds);
+  const int half = lane >> 5, l31 = lane & 31;
+  __syncthreads();  // every wave is done with the main loop's LDS tiles
+#pragma unroll 1
+  for (int plane = 0; plane < 2; ++plane) {  // 0: hi, 1: lo
+    const int sh = plane * 16;
+    uint16_t* const out_r = plane ? a.dl_lo : a.dl_hi;
+    uint16_t* const out_t = plane ? a.dlT_lo : a.dlT_hi;
+    // -- row-major: lane writes its 4 consecutive vocabulary entries (registers 4 rg .. 4 rg + 3) as 8 bytes
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = wcol0 + j * 32 + l31, vloc = wrow0 + i * 32 + 8 * rg + 4 * half;
+          const uint32_t w0 = ((pk[i][j][rg * 4 + 0] >> sh) & 0xffffu) | (((pk[i][j][rg * 4 + 1] >> sh) & 0xffffu) << 16);
+          const uint32_t w1 = ((pk[i][j][rg * 4 + 2] >> sh) & 0xffffu) | (((pk[i][j][rg * 4 + 3] >> sh) & 0xffffu) << 16);
+          *reinterpret_cast<uint2*>(img + row * RS + vloc * 2) = uint2{w0, w1};
+        }
+    __syncthreads();
+    for (int c = tid; c < BN * (BM / 8); c += C::NT) {
+      const int row = c / (BM / 8), k = c % (BM / 8);
+      const int lrow = n0 + row, v = m0 + k * 8;
+      if (lrow < a.chunk_pad && v + 7 < V) {  // V and chunk_pad are multiples of 8: a group of eight is inside or outside as a whole
+        const uint2 x0 = *reinterpret_cast<const uint2*>(img + row * RS + k * 16);
+        const uint2 x1 = *reinterpret_cast<const uint2*>(img + row * RS + k * 16 + 8);
+        *reinterpret_cast<uint4*>(out_r + (int64_t)lrow * V + v) = uint4{x0.x, x0.y, x1.x, x1.y};
+      }
+    }
+    __syncthreads();
+    // -- transposed: two neighbouring lanes hold neighbouring token rows of the same vocabulary entries; they trade one
+    // value so that each writes 4 bytes (two rows of one entry) instead of two 2-byte pieces
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const uint32_t x0 = (pk[i][j][rg * 4 + e] >> sh) & 0xffffu, x1 = (pk[i][j][rg * 4 + e + 1] >> sh) & 0xffffu;
+            const bool odd = lane & 1;
+            const uint32_t got = __shfl_xor(odd ? x0 : x1, 1, 64);  // even lane receives the neighbour's x0, odd lane the neighbour's x1
+            const int row = wcol0 + j * 32 + (l31 & ~1), vloc = wrow0 + i * 32 + 8 * rg + 4 * half + e + (odd ? 1 : 0);
+            const uint32_t w = odd ? (got | (x1 << 16)) : (x0 | (got << 16));  // (row, row + 1) of entry vloc
+            *reinterpret_cast<uint32_t*>(img + vloc * TS + row * 2) = w;
+          }
+    __syncthreads();
+    for (int c = tid; c < BM * (BN / 8); c += C::NT) {
+      const int vloc = c / (BN / 8), k = c % (BN / 8);
+      const int v = m0 + vloc, lrow = n0 + k * 8;
+      if (v < V && lrow + 7 < a.chunk_pad) {
+        const uint2 x0 = *reinterpret_cast<const uint2*>(img + vloc * TS + k * 16);
+        const uint2 x1 = *reinterpret_cast<const uint2*>(img + vloc * TS + k * 16 + 8);
+        *reinterpret_cast<uint4*>(out_t + (int64_t)v * a.chunk_pad + lrow) = uint4{x0.x, x0.y, x1.x, x1.y};
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -865,6 +921,18 @@ int launch_tiles(K kfn, int threads, int lds_bytes, int blocks, const A& args, h
 
 #define PRL_LAUNCH_DUAL(KERNEL, blocks, args, s, name) \
   launch_tiles(KERNEL, CfgDual::NT, CfgDual::LDS_BYTES, blocks, args, s, name)
+
+// the d-logits kernel also stages a whole output tile in LDS (its epilogue): [BN][BM * 2 + 8] or [BM][BN * 2 + 8] bytes
+template <class C>
+constexpr int dl_lds_bytes() {
+  constexpr int r = C::BN * (C::BM * 2 + 8), t = C::BM * (C::BN * 2 + 8);
+  constexpr int e = r > t ? r : t;
+  return e > C::LDS_BYTES ? e : C::LDS_BYTES;
+}
+#define PRL_LAUNCH_DL(shape, blocks, args, s, name)                                                                                  \
+  ((shape) == kWide  ? launch_tiles(lmhead_dlogits_kernel<CfgWide>, CfgWide::NT, dl_lds_bytes<CfgWide>(), blocks, args, s, name)      \
+   : (shape) == kBig ? launch_tiles(lmhead_dlogits_kernel<CfgBig>, CfgBig::NT, dl_lds_bytes<CfgBig>(), blocks, args, s, name)         \
+                     : launch_tiles(lmhead_dlogits_kernel<CfgSmall>, CfgSmall::NT, dl_lds_bytes<CfgSmall>(), blocks, args, s, name))
 
 #define PRL_LAUNCH_CFG(shape, KERNEL, blocks, args, s, name)                                                            \
   ((shape) == kWide  ? launch_tiles(KERNEL<CfgWide>, CfgWide::NT, CfgWide::LDS_BYTES, blocks, args, s, name)            \
@@ -1114,8 +1182,9 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       // d W contraction below runs over); a short last chunk does not pay for the whole buffer
       d.tt = ceil_div(m_pad, shape_bn(shape));
       if (use_dual(shape, d.terms)) {
-        if (int rc = PRL_LAUNCH_DUAL((lmhead_dlogits_kernel<CfgDual, true>), d.vt * d.tt, d, s, "lmhead_dlogits_kernel(dual)")) return rc;
-      } else if (int rc = PRL_LAUNCH_CFG(shape, lmhead_dlogits_kernel, d.vt * d.tt, d, s, "lmhead_dlogits_kernel")) {
+        if (int rc = launch_tiles(lmhead_dlogits_kernel<CfgDual, true>, CfgDual::NT, dl_lds_bytes<CfgDual>(), d.vt * d.tt, d, s,
+                                  "lmhead_dlogits_kernel(dual)")) return rc;
+      } else if (int rc = PRL_LAUNCH_DL(shape, d.vt * d.tt, d, s, "lmhead_dlogits_kernel")) {
         return rc;
       }
     }
