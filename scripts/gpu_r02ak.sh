@@ -1,7 +1,7 @@
 #!/bin/bash
 # full validation: every GPU test, smoke, the default bench line, rocprofv3 kernel stats of the same command
 set -u
-OUT=gpurun_out/r02ae
+OUT=gpurun_out/r02ak
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -15,7 +15,7 @@ echo "== bench default (N=1)"
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "exit $?"; python - <<'PY'
 import json
-d=json.loads(open("gpurun_out/r02ae/bench_default.json").read().splitlines()[-1])
+d=json.loads(open("gpurun_out/r02ak/bench_default.json").read().splitlines()[-1])
 print({k:d[k] for k in ("value","ms_per_step","steps","warmup")})
 print("roofline", d["roofline"])
 print("roofline_mfma", {k:v for k,v in (d["roofline_mfma"] or {}).items() if k not in ("note","config")})
