@@ -69,6 +69,11 @@ class RLConfig(BaseModel):
     expected_loss_scale: float = Field(default=1.0, description="factor the caller applies to the returned loss before backward "
                                        "(1/gradient_accumulation under accelerate, a loss scaler): the fused kernel folds it into d logits "
                                        "in the forward launch; any other factor is repaired on device in backward, without a host sync")
+    skip_unlabelled_rows: bool = Field(default=False, description="fused logits kernel only: do not READ logits rows whose next token "
+                                       "carries no label (prompt / observation tokens, sequence starts, padding).  Their log-prob, entropy "
+                                       "and gradient are zeros and every labelled value is bit-identical, but the reference's assert over "
+                                       "ALL positions (rl/__init__.py:213) can then no longer see a non-finite value in such a row - so the "
+                                       "drop-in default is False; the native loops (HotPathStep, NativeLearnerStep, fused_head_loss) turn it on")
 
 
 def make_rl_data_callback(args: Any, current_dir: Any, rl_config: "RLConfig | None", model: Any):
@@ -319,7 +324,7 @@ class _GrpoLossFn(torch.autograd.Function):
     """logits -> (loss, stats) with a hand-written backward to the logits."""
 
     @staticmethod
-    def forward(ctx, logits, batch, cfg, temperature, fused, inplace, sp_group=None, expected_scale=1.0):  # type: ignore[override]
+    def forward(ctx, logits, batch, cfg, temperature, fused, inplace, sp_group=None, expected_scale=1.0, skip_unlabelled=False):  # type: ignore[override]
         lib = _lib.load()
         B, L, V = logits.shape
         dev = logits.device
@@ -339,7 +344,9 @@ class _GrpoLossFn(torch.autograd.Function):
                 lse2 = torch.empty_like(nlp)
                 kcfg = type(cfg).from_buffer_copy(cfg)
                 kcfg.upstream_scale = float(expected_scale)
-                kcfg.skip_unlabelled = 1  # rows that predict an unlabelled token reach neither the loss nor a statistic: not read
+                # opt-in (RLConfig.skip_unlabelled_rows): rows that predict an unlabelled token reach neither the loss nor a
+                # statistic and need not be read - but then their finiteness is not checked either (reference :213 checks it)
+                kcfg.skip_unlabelled = 1 if skip_unlabelled else 0
                 cont = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
                 with torch.cuda.device(dev):
                     _lib.check(
@@ -385,14 +392,14 @@ class _GrpoLossFn(torch.autograd.Function):
                 lg = ctx.zero_like
                 ctx.zero_like = None
                 grad = lg.zero_() if ctx.inplace else torch.zeros_like(lg)
-                return grad, None, None, None, None, None, None, None
+                return grad, None, None, None, None, None, None, None, None
             # d logits already carries `expected_scale`; any other upstream factor is applied by a
             # kernel that returns after one scalar load when the guess was right (no host sync).
             up = grad_loss.to(torch.float32).contiguous()
             with torch.cuda.device(grad.device):
                 _lib.check(_lib.load().prl_scale_unless(_lib.ptr(grad), grad.numel(), _logits_dtype_code(grad), _lib.ptr(up),
                                                         ctx.expected_scale, _lib.current_stream_ptr(grad.device)))
-            return grad, None, None, None, None, None, None, None
+            return grad, None, None, None, None, None, None, None, None
         lib = _lib.load()
         lg, ids, lse2, ent, g_nlp, g_ent = ctx.saved_tensors
         B, L, V = lg.shape
@@ -407,7 +414,7 @@ class _GrpoLossFn(torch.autograd.Function):
                     _lib.ptr(up), _lib.ptr(grad), _lib.current_stream_ptr(dev),
                 )
             )
-        return grad, None, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None, None
 
 
 _STAT_KEYS_IN_ORDER = [
@@ -479,7 +486,7 @@ def rl_step(
         logits, batch, cfg, config.temperature,
         bool(config.fused_logits_grad) and config.policy_loss != "gspo" and logits.requires_grad and torch.is_grad_enabled(),
         bool(config.inplace_logits_grad), seq_parallel_group if config.policy_loss == "gspo" else None,
-        float(config.expected_loss_scale) or 1.0,
+        float(config.expected_loss_scale) or 1.0, bool(config.skip_unlabelled_rows),
     )
     stats = stats_dev.cpu().tolist()  # the single device->host sync of the step
     check_finite(stats)

@@ -227,6 +227,12 @@ class _FusedHeadLossFn(torch.autograd.Function):
             nlp.view(-1).index_copy_(0, idx + 1, nlp_c[0, 1:])  # token-aligned: the value for token u = q + 1
             ent.view(-1).index_copy_(0, idx + 1, ent_c[0, 1:])
         loss, stats, g_nlp, g_ent = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=need_grad)
+        if idx is not None:
+            # The reference asserts isfinite(new_logprobs) over EVERY position (rl/__init__.py:213).  Rows that were not handed
+            # to the head cannot show up in the kernel's counter, so the check moves to their inputs: a non-finite hidden state
+            # is what makes a logits row non-finite.  One pass over [T, H] (58 MB for a 7B micro-batch), no host sync - the
+            # flag joins the statistics vector that `check_finite` reads after the step's single device->host copy.
+            stats[STAT_INDEX["nonfinite_new_logprobs"]] += (~torch.isfinite(hidden.detach())).any().to(stats.dtype)
         if need_grad:
             if idx is not None:  # the token gradients of the compact rows, token-aligned to the compact problem
                 def compact(g):
@@ -292,8 +298,6 @@ def fused_head_loss(hidden: torch.Tensor, weight: torch.Tensor, head: FusedLmHea
     return loss, _host_stats(stats_dev, batch, kl_coef, ent_coef)
 
 
-_heads: dict[int, FusedLmHead] = {}
-
 
 def _body_and_head(model: Any):
     body = getattr(model, "model", None)
@@ -311,10 +315,19 @@ def _hidden_states(body: Any, batch: PipelineBatchEncoding) -> torch.Tensor:
     return out[0] if isinstance(out, (tuple, list)) else getattr(out, "last_hidden_state", out)
 
 
-def _head_for(weight: torch.Tensor, chunk_rows: int, hidden_grad_terms: int = 3) -> FusedLmHead:
-    head = _heads.get(id(weight))
-    if head is None or head.weight is not weight:
-        head = _heads[id(weight)] = FusedLmHead(weight, backward=True, chunk_rows=chunk_rows, hidden_grad_terms=hidden_grad_terms)
+def _head_for(owner: Any, weight: torch.Tensor, chunk_rows: int, hidden_grad_terms: int = 3) -> FusedLmHead:
+    """The FusedLmHead of `owner` (the lm_head module).  It lives ON the module - one per head, gone with the model - and is
+    re-bound when the module hands out a new tensor object for its weight (FSDP with use_orig_params=False and re-created
+    models do, on every forward): the planes and workspaces are reused, only the split is redone."""
+    head = getattr(owner, "_prl_fused_lm_head", None)
+    stale = head is None or tuple(head.weight.shape) != tuple(weight.shape) or head.weight.dtype != weight.dtype \
+        or head.weight.device != weight.device or head.hidden_grad_terms != hidden_grad_terms
+    if stale:
+        head = FusedLmHead(weight, backward=True, chunk_rows=chunk_rows, hidden_grad_terms=hidden_grad_terms)
+        object.__setattr__(owner, "_prl_fused_lm_head", head)
+    elif head.weight is not weight:
+        head.weight = weight
+        head.invalidate()
     return head
 
 
@@ -348,7 +361,7 @@ def install_fused_head(model: Any, chunk_rows: int = 4096, hidden_grad_terms: in
         w = lm_head.weight
         cfg, _, _ = make_loss_config(rl_config, current_step, max_step)
         opts = model._prl_fused_head
-        return _FusedHeadLossFn.apply(hidden, w, _head_for(w, opts["chunk_rows"], opts["hidden_grad_terms"]), rl_batch, cfg,
+        return _FusedHeadLossFn.apply(hidden, w, _head_for(lm_head, w, opts["chunk_rows"], opts["hidden_grad_terms"]), rl_batch, cfg,
                                       rl_config.temperature, opts["chunk_rows"])
 
     model._prl_fused_head = {"chunk_rows": int(chunk_rows), "hidden_grad_terms": int(hidden_grad_terms)}
@@ -375,4 +388,4 @@ def rl_step_fused_head(model: Any, batch: PipelineBatchEncoding, current_step: i
     body, lm_head = _body_and_head(model)
     hidden = _hidden_states(body, batch)
     w = lm_head.weight
-    return fused_head_loss(hidden, w, _head_for(w, chunk_rows), batch, config, current_step, max_step, chunk_rows)
+    return fused_head_loss(hidden, w, _head_for(lm_head, w, chunk_rows), batch, config, current_step, max_step, chunk_rows)

@@ -316,9 +316,6 @@ class SplitBf16LmHead(torch.nn.Module):
         return loss, stats_to_dict(stats, kl_coef, ent_coef, input_size)
 
 
-_split_heads: dict[int, SplitBf16LmHead] = {}
-
-
 def rl_step_split_head(model, batch, current_step: int, max_step: int, config, seq_parallel_group=None):
     """`rl_step` (same signature and return value) for a causal LM with `.model` (body) and an fp32 bias-free
     `.lm_head`, on the LIBRARY head GEMMs: body -> hidden states -> `SplitBf16LmHead.rl_loss`.  Against
@@ -336,9 +333,10 @@ def rl_step_split_head(model, batch, current_step: int, max_step: int, config, s
     w = lin.weight
     if w.dtype != torch.float32:
         raise TypeError("rl_step_split_head is for an fp32 head weight; a bf16 (tied) head needs no split: use rl_step")
-    head = _split_heads.get(id(w))
+    head = getattr(lin, "_prl_split_lm_head", None)  # lives on the module: one per head, gone with the model
     if head is None or head.weight is not w:
-        head = _split_heads[id(w)] = SplitBf16LmHead(w)
+        head = SplitBf16LmHead(w)
+        object.__setattr__(lin, "_prl_split_lm_head", head)
     return head.rl_loss(hidden, batch, config, current_step, max_step)
 
 
