@@ -387,7 +387,12 @@ class WeightUpdateManager:
                 message.ipc_handles, message.ipc_nbytes = desc["ipc_handles"], desc["ipc_nbytes"]
             futures = self.request_weight_updates(message)
         if self.transport == "ipc":
-            pass  # the POST returns when the worker has copied the buckets
+            # the POST returns when the worker has copied the buckets.  The other trainer ranks of a SHARDED
+            # source still have to enter the gather the main rank ran above: `fetch` is a collective there
+            # (GatheredParameters / the FSDP state dict), a rank that skips it deadlocks the step.
+            if not self.is_main_process and not isinstance(src, PlainParameters):
+                with src.fetch(specs):
+                    pass
         elif self.transport in ("bucketed", "sharded"):
             # a sharded update gathers in groups of bucket_bytes * tp_size of FULL parameters: one bucket per TP rank each
             gather_bytes = self.bucket_bytes * tp_size

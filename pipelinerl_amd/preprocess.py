@@ -544,11 +544,16 @@ class PreprocessorLoop:
             slices = batch.make_slices(sp) if sp > 1 else [batch]
             for off, piece in enumerate(slices):
                 writer.write(piece, partition=mb.trainer_id + off)
-        # chunks whose samples have all been scheduled or dropped can go
+        self._prune_chunks()
+        return done
+
+    def _prune_chunks(self) -> None:
+        """Release the device-resident chunks whose samples have all been scheduled or dropped.  Called after every
+        publish AND after every ring admission: while the back-pressure rule holds publishing back, the ring keeps
+        dropping old samples, and their chunk tensors must not stay alive until the trainer catches up."""
         alive = {s.chunk for s in self.ring.entries} | {s.chunk for s in self.sched._current} | {s.chunk for s in self.buffer}
         for c in [c for c in self.chunks if c not in alive]:
             del self.chunks[c]
-        return done
 
     def _maybe_write_stats(self, stats_writer, batch_done: bool, raw_queue_chunks: int) -> None:
         pub = self.sched.published_samples
@@ -593,6 +598,7 @@ class PreprocessorLoop:
                 if len(self.buffer) < cfg.dataset_buffer_size:
                     continue
                 self.ring.admit(self.buffer)
+                self._prune_chunks()
                 if ts is not None and ts.samples_processed is not None:
                     if self.sched.published_samples - ts.samples_processed > cfg.max_ready_samples_per_lead * cfg.num_trainers:
                         continue  # wait for the finetune loop to catch up

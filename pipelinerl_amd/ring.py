@@ -4,12 +4,15 @@ shared-memory record log (`prl_log_*`, csrc/prl_log.cpp)."""
 from __future__ import annotations
 
 import ctypes
+import logging
 import os
 import queue
 import time
 import uuid
 
 from . import _lib
+
+logger = logging.getLogger(__name__)
 
 
 class Ring:
@@ -106,24 +109,39 @@ class Log:
     reopened, readers park on a futex.  One handle is either used for `append` or for `read`."""
 
     def __init__(self, name: str, create: bool = False, truncate: bool = False, reader: bool = False, trim: bool = False,
-                 segment_bytes: int = 64 << 20, wait: float | None = None):
+                 segment_bytes: int = 64 << 20, wait: float | None = None, takeover_after: float | None = 5.0):
         """`wait`: seconds to keep retrying while the log does not exist yet (None = forever for readers,
-        no retry for writers that create)."""
+        no retry for writers that create).
+        `takeover_after` (writers that may create): a control block that exists but stays uninitialised this long
+        belongs to a creator that died between `shm_open` and publishing the magic word - nobody can ever have
+        read or written a record of it - so it is removed and created again instead of being waited for forever."""
         lib = _lib.load()
         self.name = name
         flags = (_lib.PRL_LOG_CREATE if create else 0) | (_lib.PRL_LOG_TRUNCATE if truncate else 0) \
             | (_lib.PRL_LOG_READER if reader else 0) | (_lib.PRL_LOG_TRIM if trim else 0)
         h = ctypes.c_void_p()
         deadline = None if wait is None else time.time() + wait
+        stuck_since, warned = None, 0.0
         while True:
             rc = lib.prl_log_open(name.encode(), segment_bytes, flags, ctypes.byref(h))
             if rc == _lib.PRL_OK:
                 break
             # EAGAIN: another process is creating it right now; EFAULT: not there yet (readers wait)
             if rc == _lib.PRL_EAGAIN or (rc == _lib.PRL_EFAULT and not create):
-                if deadline is not None and time.time() > deadline:
+                now = time.time()
+                if deadline is not None and now > deadline:
                     _lib.check(rc)
                 flags &= ~_lib.PRL_LOG_TRUNCATE  # never truncate twice
+                if rc == _lib.PRL_EAGAIN and create and takeover_after is not None:
+                    stuck_since = stuck_since or now
+                    if now - stuck_since > takeover_after:
+                        logger.warning(f"shm log {name}: control block uninitialised for {now - stuck_since:.1f} s, its creator "
+                                       "is gone - removing it and creating the log again")
+                        lib.prl_log_unlink(name.encode())
+                        stuck_since = None
+                    elif now - warned > 1.0:
+                        logger.info(f"shm log {name} is being created by another process, waiting")
+                        warned = now
                 time.sleep(0.002)
                 continue
             _lib.check(rc)

@@ -79,10 +79,33 @@ def reset_streams_backend() -> None:
 
 
 def unlink_shm_stream(stream: "SingleStreamSpec") -> None:
-    """Remove the shared-memory log of a stream (cleanup of runs started with `keep=True`)."""
+    """Remove the shared-memory log of one stream."""
     from .ring import Log
 
     Log.unlink_name(ring_name(stream))
+
+
+def clean_shm_streams(exp_path: "str | Path") -> int:
+    """Remove EVERY shared-memory log of an experiment (all topics, instances, partitions, whoever created
+    them); returns the number of shm objects removed.  This is the shm counterpart of the reference launcher
+    deleting `<exp_path>/streams` before a run (launch.py:463) - call it from the process that owns the run
+    (launcher) at start-up, so that a run that was SIGKILLed cannot leak its records (stale `SamplesProcessed`,
+    `TrainingDone`, `WeightUpdateSuccess`) into the next one, and when the run is over.  Logs are never removed
+    behind the back of a live run: stream writers do NOT unlink anything when they exit."""
+    prefix = _exp_prefix(exp_path)
+    n = 0
+    try:
+        names = os.listdir("/dev/shm")
+    except OSError:
+        return 0
+    for f in names:
+        if f.startswith(prefix):
+            try:
+                os.unlink(os.path.join("/dev/shm", f))
+                n += 1
+            except OSError:
+                pass
+    return n
 
 
 def raise_if_backend_not_set() -> None:
@@ -258,10 +281,16 @@ class FileStreamReader(StreamReader):
 # ---------------------------------------------------------------------------------------------
 
 
+def _exp_prefix(exp_path: "str | Path") -> str:
+    return "prl_" + hashlib.sha1(str(Path(exp_path).resolve()).encode()).hexdigest()[:12] + "_"
+
+
 def ring_name(stream: SingleStreamSpec) -> str:
-    """Deterministic shared-memory object name of a stream (both ends derive it from the spec)."""
-    key = f"{Path(stream.exp_path).resolve()}|{stream.topic}|{stream.instance}|{stream.partition}"
-    return "prl_" + hashlib.sha1(key.encode()).hexdigest()[:24]
+    """Deterministic shared-memory object name of a stream (both ends derive it from the spec):
+    `prl_<experiment hash>_<stream hash>`; its segments are `<name>.<k>`.  The experiment prefix lets the
+    owner of a run find all its logs (`clean_shm_streams`)."""
+    key = f"{stream.topic}|{stream.instance}|{stream.partition}"
+    return _exp_prefix(stream.exp_path) + hashlib.sha1(key.encode()).hexdigest()[:16]
 
 
 DEFAULT_TRIM_TOPICS = ("training_data", "actor")
@@ -273,19 +302,21 @@ def _shm_options(topic: str) -> tuple[int, bool]:
     return seg, topic in tuple(trim_topics)
 
 
-_created_logs: set[str] = set()
+_owned_experiments: set[str] = set()
 
 
-def _unlink_at_exit(name: str) -> None:
-    """A log outlives its writers (a reader may attach after the producer finished, like a file on
-    disk); the process that first opened it for writing removes it when it exits."""
+def _own_experiment(exp_path: "str | Path") -> None:
+    """`set_streams_backend("shm", owner=True)`: THIS process owns the runs whose streams it touches (the
+    launcher, a single-process test) and removes all their logs when it exits.  Every other process leaves
+    them alone: a log must outlive its writers - a reader that is still in an earlier segment, or one that
+    attaches after the producer finished, has to find every record, exactly as with a file on disk or a
+    Redis stream."""
     import atexit
 
-    from .ring import Log
-
-    if name not in _created_logs:
-        _created_logs.add(name)
-        atexit.register(Log.unlink_name, name)
+    key = str(Path(exp_path).resolve())
+    if key not in _owned_experiments:
+        _owned_experiments.add(key)
+        atexit.register(clean_shm_streams, key)
 
 
 class ShmStreamWriter(StreamWriter):
@@ -309,9 +340,10 @@ class ShmStreamWriter(StreamWriter):
 
         name = ring_name(self.stream)
         seg, trim = _shm_options(self.stream.topic)
-        self._log = Log(name, create=True, truncate=self.mode == "w", trim=trim, segment_bytes=seg)
-        if not _backend_options.get("keep", False):
-            _unlink_at_exit(name)
+        self._log = Log(name, create=True, truncate=self.mode == "w", trim=trim, segment_bytes=seg,
+                        takeover_after=float(_backend_options.get("creator_timeout", 5.0)))
+        if _backend_options.get("owner", False):
+            _own_experiment(self.stream.exp_path)
         if self._mirror is not None:
             self._mirror.__enter__()
         return self
@@ -349,6 +381,8 @@ class ShmStreamReader(StreamReader):
         while True:
             try:
                 self._log = Log(ring_name(self.stream), reader=True, wait=_RECHECK_DELAY)
+                if _backend_options.get("owner", False):
+                    _own_experiment(self.stream.exp_path)
                 return self
             except _lib.PrlError:
                 if time.time() - warned > _RECHECK_DELAY:

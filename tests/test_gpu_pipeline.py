@@ -37,7 +37,7 @@ def test_replay_actor_stream_through_preprocessor_and_learner(libprl, cuda_devic
     from pipelinerl_amd.synthetic import make_entries
 
     streams.reset_streams_backend()
-    streams.set_streams_backend(backend, **({"segment_bytes": 1 << 20} if backend == "shm" else {}))
+    streams.set_streams_backend(backend, **({"segment_bytes": 1 << 20, "owner": True} if backend == "shm" else {}))
     try:
         attempts, V = 4, 64
         raw = make_entries(6, attempts=attempts, seq_length=48, vocab=V, seed=21, prompt_min=3, prompt_max=8)
@@ -349,7 +349,7 @@ def test_preprocessor_unpacked_mode_publishes_padded_batches(libprl, cuda_device
     from pipelinerl_amd.synthetic import make_entries
 
     streams.reset_streams_backend()
-    streams.set_streams_backend("shm")
+    streams.set_streams_backend("shm", owner=True)
     try:
         attempts = 4
         raw = make_entries(4, attempts=attempts, seq_length=40, vocab=64, seed=5, prompt_min=3, prompt_max=8)
@@ -383,7 +383,7 @@ def test_preprocessor_sequence_parallel_slices_and_counts(libprl, cuda_device, t
     from pipelinerl_amd.synthetic import make_entries
 
     streams.reset_streams_backend()
-    streams.set_streams_backend("shm")
+    streams.set_streams_backend("shm", owner=True)
     try:
         attempts = 4
         raw = make_entries(4, attempts=attempts, seq_length=31, vocab=64, seed=9, prompt_min=3, prompt_max=8)
@@ -422,7 +422,7 @@ def test_preprocessor_drops_old_samples_and_reports_stats(libprl, cuda_device, t
     from pipelinerl_amd.synthetic import make_entries
 
     streams.reset_streams_backend()
-    streams.set_streams_backend("shm")
+    streams.set_streams_backend("shm", owner=True)
     try:
         attempts = 4
         raw = make_entries(6, attempts=attempts, seq_length=40, vocab=64, seed=11, prompt_min=3, prompt_max=8)

@@ -21,7 +21,7 @@ def streams(tmp_path):
     from pipelinerl_amd import streams as s
 
     s.reset_streams_backend()
-    s.set_streams_backend("shm", segment_bytes=1 << 16)
+    s.set_streams_backend("shm", segment_bytes=1 << 16, owner=True)
     yield s
     s.reset_streams_backend()
 
@@ -163,7 +163,7 @@ def test_three_trainer_state_followers_reach_the_reference_state(tmp_path):
     messages = [json.loads(l) for l in lines]
     want = g["state_trace"][-1]  # the reference TrainerState after the last message
     streams.reset_streams_backend()
-    streams.set_streams_backend("shm")
+    streams.set_streams_backend("shm", owner=True)
     try:
         spec = streams.SingleStreamSpec(exp_path=tmp_path, topic=TRAINER_TOPIC)
         followers = [TrainerState(tmp_path) for _ in range(3)]
@@ -193,7 +193,7 @@ def test_three_trainer_state_followers_reach_the_reference_state(tmp_path):
 def _child_reader(exp_path, topic, n, out_q):
     from pipelinerl_amd import streams
 
-    streams.set_streams_backend("shm", segment_bytes=1 << 16)
+    streams.set_streams_backend("shm", segment_bytes=1 << 16)  # a child owns nothing: it must not remove the log when it exits
     spec = streams.SingleStreamSpec(exp_path=exp_path, topic=topic)
     got = []
     with streams.read_stream(spec) as r:
@@ -207,7 +207,7 @@ def _child_reader(exp_path, topic, n, out_q):
 def _child_writer(exp_path, topic, lo, hi):
     from pipelinerl_amd import streams
 
-    streams.set_streams_backend("shm", segment_bytes=1 << 16, keep=True)
+    streams.set_streams_backend("shm", segment_bytes=1 << 16)  # a child owns nothing: it must not remove the log when it exits
     spec = streams.SingleStreamSpec(exp_path=exp_path, topic=topic)
     with streams.write_to_streams(spec) as w:
         for i in range(lo, hi):
@@ -308,5 +308,100 @@ def test_writer_that_died_between_seal_and_publish_is_recovered(tmp_path):
         late.close()
         r.close()
         w2.close()
+    finally:
+        Log.unlink_name(name)
+
+
+def _child_short_lived_writer(exp_path, topic, n):
+    from pipelinerl_amd import streams
+
+    streams.set_streams_backend("shm", segment_bytes=4096)
+    spec = streams.SingleStreamSpec(exp_path=exp_path, topic=topic)
+    with streams.write_to_streams(spec) as w:
+        for i in range(n):
+            w.write({"i": i, "pad": "p" * 900})  # four records per 4 KB segment
+
+
+def test_log_outlives_the_writer_process(tmp_path):
+    """A log is many `/name.k` segments that readers open by name as they advance.  The process that wrote it must
+    not remove them when it exits: a reader still in an early segment, and a reader that attaches after the producer
+    is gone, find every record - like a file on disk or a Redis stream (reference streams.py:120-192, 281-346).
+    (Round-2 advisor finding: with an at-exit unlink in the writer, a reader got 4 of 20 records.)"""
+    from pipelinerl_amd import streams
+
+    streams.reset_streams_backend()
+    streams.set_streams_backend("shm", segment_bytes=4096)
+    try:
+        spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="outlive")
+        ctx = mp.get_context("spawn")
+        n = 20
+        got = []
+        with streams.write_to_streams(spec) as w:  # the log exists before the reader attaches
+            pass
+        with streams.read_stream(spec) as r:
+            it = r.read()
+            wp = ctx.Process(target=_child_short_lived_writer, args=(tmp_path, "outlive", n))
+            wp.start()
+            got.append(next(it)["i"])  # this reader is now parked inside segment 0 ...
+            wp.join(30)                # ... and the writer process is gone
+            assert wp.exitcode == 0
+            while len(got) < n:
+                got.append(next(it)["i"])
+        assert got == list(range(n))
+        late = _take(streams.read_stream(spec), n)  # attaches after the producer exited
+        assert [x["i"] for x in late] == list(range(n))
+        # the owner of the run removes it - all topics at once
+        with streams.write_to_streams(streams.SingleStreamSpec(exp_path=tmp_path, topic="other", partition=3)) as w:
+            w.write({"x": 1})
+        removed = streams.clean_shm_streams(tmp_path)
+        assert removed >= 2 + 6  # two control blocks, >= 5 + 1 segments
+        assert streams.clean_shm_streams(tmp_path) == 0
+    finally:
+        streams.clean_shm_streams(tmp_path)
+        streams.reset_streams_backend()
+
+
+def test_clean_at_start_hides_a_killed_run(tmp_path):
+    """A run that died without cleanup leaves its logs behind; the next run on the same exp_path calls
+    `clean_shm_streams` first (the reference launcher deletes <exp_path>/streams, launch.py:463) and its readers see
+    only the new records."""
+    from pipelinerl_amd import streams
+
+    streams.reset_streams_backend()
+    streams.set_streams_backend("shm", segment_bytes=1 << 16)
+    try:
+        spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="stats")
+        with streams.write_to_streams(spec) as w:
+            w.write({"kind": "training_done", "run": "old"})
+        assert _take(streams.read_stream(spec), 1)[0]["run"] == "old"  # what a new run would replay without the cleanup
+        assert streams.clean_shm_streams(tmp_path) == 2
+        with streams.write_to_streams(spec) as w:
+            w.write({"kind": "samples_processed", "run": "new"})
+        assert _take(streams.read_stream(spec), 1)[0]["run"] == "new"
+    finally:
+        streams.clean_shm_streams(tmp_path)
+        streams.reset_streams_backend()
+
+
+def test_writer_takes_over_a_control_block_whose_creator_died(tmp_path):
+    """A creator killed between shm_open and publishing the magic word leaves a control block that answers EAGAIN
+    forever.  A later writer waits `takeover_after`, removes it and creates the log; a reader that was already waiting
+    for the log then attaches."""
+    from pipelinerl_amd.ring import Log
+
+    name = f"prl_test_{time.time_ns()}"
+    with open(f"/dev/shm/{name}", "wb") as f:
+        f.truncate(4096)  # sized, zero-filled: no magic
+    try:
+        t0 = time.time()
+        with pytest.raises(Exception):
+            Log(name, create=True, segment_bytes=4096, wait=0.3, takeover_after=None)  # the old behaviour: never comes up
+        w = Log(name, create=True, segment_bytes=4096, takeover_after=0.3)
+        assert 0.25 < time.time() - t0 < 5
+        w.append(b"x")
+        r = Log(name, reader=True, wait=2)
+        assert r.read(block=False) == b"x"
+        r.close()
+        w.close()
     finally:
         Log.unlink_name(name)

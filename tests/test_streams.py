@@ -132,7 +132,7 @@ def test_partitioned_writer(streams, tmp_path):
 
 
 def test_shm_backend_roundtrip(streams, tmp_path, libprl):
-    streams.set_streams_backend("shm", segment_bytes=1 << 16)
+    streams.set_streams_backend("shm", segment_bytes=1 << 16, owner=True)
     batch, want = _batch()
     spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data", partition=1)
     with streams.write_to_streams(spec) as w:
@@ -272,7 +272,7 @@ def test_shm_backend_jsonl_mirror_allows_replay(streams, tmp_path):
 
     rag, _ = make_ragged(2, attempts=3, seq_length=40, vocab=60, seed=4, prompt_min=3, prompt_max=8, with_ref=True)
     batch, want_batch = _batch()
-    streams.set_streams_backend("shm", segment_bytes=1 << 20, mirror_jsonl=["actor", "training_data"])
+    streams.set_streams_backend("shm", segment_bytes=1 << 20, mirror_jsonl=["actor", "training_data"], owner=True)
     a = streams.SingleStreamSpec(exp_path=tmp_path, topic="actor")
     t = streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data")
     s = streams.SingleStreamSpec(exp_path=tmp_path, topic="stats")
