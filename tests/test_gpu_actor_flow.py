@@ -1,0 +1,110 @@
+"""Plugin surface -> `actor` stream -> PreprocessorLoop (K5, scheduler, K6) -> `training_data` -> LearnerStep on the GPU
+(round-2 review row J1).  A user's `generate_rollout` / `load_problems` pair (tests/plugins/guessing_plugin.py, the
+reference's canonical guessing domain re-stated, multi-turn: one training text per turn) is resolved from the config by
+dotted path and driven by `ActorHarness` exactly as reference actor.py:141, 176-225, 648-652, 803-808 would; the records
+then take the hot path with the sample accounting of finetune_loop.py:627-646 asserted at the end."""
+
+import queue
+import threading
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = {
+    "attempts": 4,
+    "actor": {"rollout_policy": "plugins.guessing_plugin.generate_guessing_rollout", "rollout_retry_initial_delay_s": 0.001},
+    "dataset_loader": "plugins.guessing_plugin.load_problems",
+    "train_dataset_names": ["train"],
+    "train_subset": {"begin": 0, "end": 8},
+}
+
+
+class TinyLM(torch.nn.Module):
+    def __init__(self, vocab=64, dim=16):
+        super().__init__()
+        self.emb = torch.nn.Embedding(vocab, dim)
+        self.head = torch.nn.Linear(dim, vocab)
+
+    def forward(self, input_ids=None, **kw):
+        return types.SimpleNamespace(logits=self.head(self.emb(input_ids)).float())
+
+
+@pytest.mark.parametrize("wire", ["ragged", "jsonl"])
+def test_plugins_to_learner(libprl, cuda_device, tmp_path, wire):
+    from pipelinerl_amd import streams
+    from pipelinerl_amd.actor_harness import ActorHarness
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.finetune_loop import TRAINER_TOPIC, LearnerStep, run_data_loader
+    from pipelinerl_amd.preprocess import PreprocessorConfig, PreprocessorLoop
+    from pipelinerl_amd.state import TrainerState
+    from plugins.guessing_plugin import ScriptedLLM
+
+    streams.reset_streams_backend()
+    streams.set_streams_backend("shm", segment_bytes=1 << 20, mirror_jsonl=["actor"], owner=True)
+    try:
+        V, accumulate = 64, 16
+        state = types.SimpleNamespace(propagated_weight_version=3)
+        harness = ActorHarness(CFG, [ScriptedLLM(vocab=V, flaky_calls=(5,)), ScriptedLLM(vocab=V)], tmp_path, trainer_state=state,
+                               scheduler_name="actor0", wire=wire, shuffle_seed=1)
+        n_actor = harness.run()  # 8 problems x 4 attempts, several turns each
+        assert harness.published_groups == 8 and n_actor >= 2 * accumulate and harness.retries == 1
+        rl = RLConfig(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0,
+                      divide_advantage_by_std=False, clamp_log_ratio_ref_new_value=5)
+        cfg = PreprocessorConfig(exp_path=tmp_path, num_trainers=1, train_batch_size=1, gradient_accumulation_passes=accumulate,
+                                 seq_length=512, attempts=4, rl=rl, eos_token_id=2, chunk_n_groups=2)
+        published, errors = {}, []
+
+        def preprocessor():
+            try:
+                published["n"] = PreprocessorLoop(cfg, cuda_device).run(max_published_samples=2 * accumulate, idle_timeout=3.0)
+            except Exception:  # noqa: BLE001 - surfaced by the main thread
+                import traceback
+
+                errors.append(traceback.format_exc())
+                raise
+
+        t = threading.Thread(target=preprocessor, daemon=True)
+        t.start()
+        torch.manual_seed(0)
+        model = TinyLM(V).to(cuda_device)
+        before = [p.detach().clone() for p in model.parameters()]
+        step = LearnerStep(model, torch.optim.SGD(model.parameters(), lr=0.5), rl, train_batch_size=1, gradient_accumulation_passes=accumulate,
+                           max_train_steps=10, send_weight_updates=False,
+                           trainer_stream=streams.SingleStreamSpec(exp_path=tmp_path, topic=TRAINER_TOPIC))
+        q: queue.Queue = queue.Queue(maxsize=2)
+        data_spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data", partition=0)
+        threading.Thread(target=run_data_loader, args=(data_spec, q, cuda_device), daemon=True).start()
+        steps, versions, seen_tokens = 0, set(), 0
+        while steps < 2:
+            while True:
+                try:
+                    batch = q.get(timeout=0.5)
+                    break
+                except queue.Empty:
+                    assert not errors, errors[0]
+                    assert t.is_alive() or not q.empty(), "preprocessor exited without producing the expected batches"
+            if isinstance(batch, Exception):
+                raise batch
+            assert batch.input_ids.is_cuda and batch.input_ids.shape[1] <= 512
+            versions.add(int(batch.model_version))
+            seen_tokens += int((batch.labels != -100).sum().item())
+            res = step.step(batch)
+            assert torch.isfinite(res["loss"]).item()
+            steps += int(res["did_optimizer_step"])
+        # sample accounting: two optimizer steps of `accumulate` samples each, every sample one training text of a rollout
+        assert step.metrics.samples == 2 * accumulate and step.metrics.completed_steps == 2
+        assert versions == {3}, "model_version stamped by the harness reaches the trainer"
+        assert seen_tokens > 0 and any(not torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+        step.finish()
+        t.join(timeout=20)
+        assert published["n"] == 2 * accumulate
+        st = TrainerState(tmp_path)
+        st.start_listening()
+        assert st.wait_for_training_done(timeout=10) and st.samples_processed == 2 * accumulate
+        # the JSONL mirror of the actor topic is the reference's text record: one line per group
+        assert len((tmp_path / "streams" / "actor" / "0" / "0" / "0.jsonl").read_text().splitlines()) == 8
+    finally:
+        streams.reset_streams_backend()
