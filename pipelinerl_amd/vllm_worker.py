@@ -189,3 +189,54 @@ class StandaloneShardReceiver(WorkerExtension):
 
     def _weight_shard_destinations(self):
         return self.slices
+
+
+class StackedShardReceiver(WorkerExtension):
+    """One tensor-parallel rank of an engine that stores its weights the way vLLM does for the Llama / Qwen family:
+    STACKED per layer - `qkv_proj` = [q rows of this rank; k rows; v rows] (`QKVParallelLinear`), `gate_up_proj` =
+    [gate rows; up rows] (`MergedColumnParallelLinear`) - with `o_proj` / `down_proj` cut along their input dimension,
+    `embed_tokens` / `lm_head` along the vocabulary and the norms replicated.  The reference gets there by handing
+    every FULL tensor to `load_weights`, which cuts and stacks (vllm1.py:110-127); here
+    `_weight_shard_destinations()` maps each TRAINER-side name to the VIEW of the stacked storage its slice belongs
+    in, so a sharded update (`transport: sharded`) lands in place - no full tensors, no `load_weights`, no copy after
+    the scatter kernel.
+
+    With fewer KV heads than TP ranks the k / v rows are replicated in groups (`plan_tp_shards(kv_heads=...)`): the
+    stacked tensor then has `q / tp + 2 * kv / kv_heads` rows, like vLLM's `num_kv_head_replicas` layout."""
+
+    _STACKS = (("qkv_proj", ("q_proj", "k_proj", "v_proj")), ("gate_up_proj", ("gate_proj", "up_proj")))
+
+    def __init__(self, named_shapes, dtype_of, device: torch.device, tp_rank: int, tp_size: int, kv_heads: int | None = None):
+        from .tp_shard import plan_tp_shards
+
+        self.device, self.rank = device, tp_rank
+        named_shapes = [(n, tuple(s)) for n, s in named_shapes]
+        self.cuts = plan_tp_shards(named_shapes, tp_size, kv_heads)
+        shard_shape = {n: self.cuts[n].shard_shape(s) for n, s in named_shapes}
+        self.storage: dict[str, torch.Tensor] = {}    # the engine's own (stacked) parameters
+        self._views: dict[str, torch.Tensor] = {}     # trainer name -> view into `storage`
+        by_name = dict(named_shapes)
+        grouped: set[str] = set()
+        for stacked, parts in self._STACKS:
+            for n in by_name:
+                head, _, tail = n.rpartition(f".{parts[0]}.")
+                if not tail or n in grouped:
+                    continue
+                members = [f"{head}.{p}.{tail}" for p in parts]
+                if not all(m in by_name for m in members):
+                    continue
+                rows = [shard_shape[m][0] for m in members]
+                rest = shard_shape[members[0]][1:]
+                buf = torch.zeros((sum(rows), *rest), dtype=dtype_of(members[0]), device=device)
+                self.storage[f"{head}.{stacked}.{tail}"] = buf
+                at = 0
+                for m, r in zip(members, rows):
+                    self._views[m] = buf.narrow(0, at, r)  # row blocks of a row-major tensor: contiguous views
+                    at += r
+                grouped.update(members)
+        for n, _ in named_shapes:
+            if n not in grouped:
+                self.storage[n] = self._views[n] = torch.zeros(shard_shape[n], dtype=dtype_of(n), device=device)
+
+    def _weight_shard_destinations(self):
+        return self._views

@@ -249,3 +249,88 @@ def test_five_processes_two_engines_of_two_tp_ranks(tmp_path):
     mp.spawn(_rank_main, args=(5, port, str(tmp_path)), nprocs=5, join=True)
     res = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(1, 5)]
     assert all(r["ok"] for r in res) and [r["tp_rank"] for r in res] == [0, 1, 0, 1]
+
+
+def _vllm_style_rank_storage(full: dict, tp_rank: int, tp: int, heads: int, kv_heads: int, head_dim: int):
+    """What vLLM's `load_weights` leaves on TP rank `tp_rank` when it is handed the FULL tensors (the reference path,
+    vllm1.py:110-127) - written from the head arithmetic of QKVParallelLinear / MergedColumnParallelLinear /
+    RowParallelLinear / VocabParallelEmbedding, without `tp_shard`."""
+    out = {}
+    q_per = heads // tp
+    kv_per = max(1, kv_heads // tp)
+    kv_rep = max(1, tp // kv_heads)            # ranks that share one KV head
+    kv_first = (tp_rank // kv_rep) * kv_per    # first KV head of this rank
+    for name, t in full.items():
+        if ".q_proj." in name or ".k_proj." in name or ".v_proj." in name:
+            if ".q_proj." not in name:
+                continue
+            rows = []
+            for proj, first, n in (("q_proj", tp_rank * q_per, q_per), ("k_proj", kv_first, kv_per), ("v_proj", kv_first, kv_per)):
+                x = full[name.replace("q_proj", proj)]
+                rows.append(x[first * head_dim:(first + n) * head_dim])
+            out[name.replace("q_proj", "qkv_proj")] = torch.cat(rows, 0)
+        elif ".gate_proj." in name:
+            up = full[name.replace("gate_proj", "up_proj")]
+            n = t.shape[0] // tp
+            out[name.replace("gate_proj", "gate_up_proj")] = torch.cat([t[tp_rank * n:(tp_rank + 1) * n], up[tp_rank * n:(tp_rank + 1) * n]], 0)
+        elif ".up_proj." in name:
+            continue
+        elif name.endswith("o_proj.weight") or name.endswith("down_proj.weight"):
+            n = t.shape[1] // tp
+            out[name] = t[:, tp_rank * n:(tp_rank + 1) * n]
+        elif name.endswith("embed_tokens.weight") or name.endswith("lm_head.weight"):
+            n = t.shape[0] // tp
+            out[name] = t[tp_rank * n:(tp_rank + 1) * n]
+        else:
+            out[name] = t
+    return out
+
+
+@pytest.mark.parametrize("tp,heads,kv_heads", [(2, 4, 2), (4, 8, 2), (4, 4, 4)], ids=["tp2", "tp4_kv2_replicated", "tp4_kv4"])
+def test_sharded_update_lands_in_the_engines_stacked_storage(tp, heads, kv_heads):
+    """The engine's REAL layout (round-2 review item 7a): per-rank stacked `qkv_proj` [(q + 2 kv) / tp, H] and
+    `gate_up_proj`, including the grouped-query case kv_heads < tp.  `WeightUpdateManager(transport="sharded")` ->
+    request -> `StackedShardReceiver`: every byte of the engine's storage equals what vLLM's `load_weights` would have
+    produced from the full tensors the reference broadcasts."""
+    from pipelinerl_amd.vllm_worker import StackedShardReceiver
+
+    torch.manual_seed(tp * 10 + kv_heads)
+    head_dim, hidden, inter = 16, 64, 160
+    shapes = qwen_shapes(layers=2, hidden=hidden, inter=inter, heads=heads, kv_heads=kv_heads, head_dim=head_dim, vocab=96)
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ps = torch.nn.ParameterDict({n.replace(".", "__"): torch.nn.Parameter(torch.randn(s).to(torch.bfloat16)) for n, s in shapes})
+
+        def named_parameters(self, *a, **k):
+            return [(n.replace("__", "."), p) for n, p in self.ps.items()]
+
+    model = Model()
+    loops = LoopGroups(tp)
+    requests = []
+    mgr = WeightUpdateManager(["http://e0"], model, None, loops.groups, transport="sharded", bucket_bytes=4096,
+                              post=lambda url, payload: requests.append((url, payload)), kv_heads=kv_heads)
+    mgr.send_weight_update(3)
+    mgr.shutdown()
+    full = {n: p.detach() for n, p in model.named_parameters()}
+    received = 0
+    for tp_rank in range(tp):
+        w = StackedShardReceiver(shapes, lambda n: torch.bfloat16, torch.device("cpu"), tp_rank, tp, kv_heads=kv_heads)
+        q_rows, kv_rows = heads * head_dim // tp, kv_heads * head_dim // min(tp, kv_heads)
+        assert tuple(w.storage["model.layers.0.self_attn.qkv_proj.weight"].shape) == (q_rows + 2 * kv_rows, hidden)
+        assert tuple(w.storage["model.layers.1.mlp.gate_up_proj.weight"].shape) == (2 * inter // tp, hidden)
+        assert not any(".q_proj." in n or ".gate_proj." in n for n in w.storage)
+        w.model_update_group = loops.groups[tp_rank].reader((0, tp_rank))
+        w.tp_rank, w.tp_size = tp_rank, tp
+        for t in w.storage.values():
+            t.fill_(7.0)  # every byte must be overwritten
+        w.receive_weight_update(json.dumps(requests[0][1]))
+        want = _vllm_style_rank_storage(full, tp_rank, tp, heads, kv_heads, head_dim)
+        assert set(want) == set(w.storage)
+        for n, t in want.items():
+            assert torch.equal(w.storage[n], t), (tp_rank, n)
+        received += sum(t.numel() * 2 for t in w.storage.values())
+    # the TP ranks together received the parameter set once (+ the replicated tensors tp times), not tp times
+    total = sum(p.numel() * 2 for p in full.values())
+    assert received < 1.35 * total if kv_heads >= tp else received < 1.6 * total
