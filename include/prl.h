@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 5
+#define PRL_ABI_VERSION 6
 
 #define PRL_OK 0
 #define PRL_EINVAL (-22)   /* bad argument                                  */
@@ -443,6 +443,10 @@ int prl_wsync_bcast_bucket(prl_wsync* w, void* bucket, uint64_t nbytes, int32_t 
  */
 int prl_wsync_bcast_bucket_sag(prl_wsync* w, void* bucket, uint64_t nbytes,
                                prl_stream_t stream);
+/* What RCCL itself reports for this communicator (ncclCommCount / ncclCommUserRank): lets a caller - bench.py's
+ * N > 1 line - state the communicator size from the library instead of from its own launch arguments.  The reference
+ * has no counterpart (it trusts `world_size` of stateless_init_process_group, torch_utils.py:70-94). */
+int prl_wsync_comm_size(prl_wsync* w, int32_t* world_size, int32_t* rank);
 int prl_wsync_destroy(prl_wsync* w);
 
 /* Colocated hand-off (trainer and inference worker are two processes on ONE GPU, BASELINE config

@@ -13,7 +13,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl.so"
 
-PRL_ABI_VERSION = 5
+PRL_ABI_VERSION = 6
 PRL_OK = 0
 PRL_EINVAL = -22
 PRL_ENOMEM = -12
@@ -154,6 +154,7 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_wsync_init": (c_int32, [POINTER(c_uint8), c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     "prl_wsync_bcast_bucket": (c_int32, [c_void_p, c_void_p, c_uint64, c_int32, c_void_p]),
     "prl_wsync_bcast_bucket_sag": (c_int32, [c_void_p, c_void_p, c_uint64, c_void_p]),
+    "prl_wsync_comm_size": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
     "prl_wsync_destroy": (c_int32, [c_void_p]),
     "prl_ipc_alloc": (c_int32, [c_uint64, POINTER(c_void_p)]),
     "prl_ipc_free": (c_int32, [c_void_p]),

@@ -23,6 +23,7 @@
 #include <rccl/rccl.h>
 
 #include "prl_common.h"
+#include "prl_wsync_plan.h"
 
 namespace {
 
@@ -37,6 +38,8 @@ struct Rccl {
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   bool ok = false;
 };
 
@@ -64,6 +67,8 @@ void load_rccl() {
   PRL_SYM(Recv, "ncclRecv")
   PRL_SYM(GroupStart, "ncclGroupStart")
   PRL_SYM(GroupEnd, "ncclGroupEnd")
+  PRL_SYM(CommCount, "ncclCommCount")
+  PRL_SYM(CommUserRank, "ncclCommUserRank")
 #undef PRL_SYM
   g_rccl.ok = true;
 }
@@ -134,40 +139,57 @@ extern "C" int prl_wsync_bcast_bucket(prl_wsync* w, void* bucket, uint64_t nbyte
   return PRL_OK;
 }
 
+namespace {
+
+// One RCCL group around a list of point-to-point ops.  A failing ncclSend / ncclRecv must not leave the group open
+// (every later call on this thread would silently queue into it): the group is closed on every path and the FIRST
+// error is the one reported.
+template <class Ops>
+int run_group(prl_wsync* w, uint8_t* base, hipStream_t s, Ops&& for_each_op) {
+  PRL_NCCL_CHECK(g_rccl.GroupStart());
+  ncclResult_t first = ncclSuccess;
+  const char* what = "";
+  for_each_op([&](const prl::wsync::Op& op) {
+    if (first != ncclSuccess) return;
+    const ncclResult_t r = op.send ? g_rccl.Send(base + op.off, (size_t)op.len, ncclUint8, op.peer, w->comm, s)
+                                   : g_rccl.Recv(base + op.off, (size_t)op.len, ncclUint8, op.peer, w->comm, s);
+    if (r != ncclSuccess) {
+      first = r;
+      what = op.send ? "ncclSend" : "ncclRecv";
+    }
+  });
+  const ncclResult_t end = g_rccl.GroupEnd();
+  if (first != ncclSuccess) return prl::set_error(PRL_EFAULT, "%s failed: %s", what, g_rccl.GetErrorString(first));
+  if (end != ncclSuccess) return prl::set_error(PRL_EFAULT, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(end));
+  return PRL_OK;
+}
+
+}  // namespace
+
 extern "C" int prl_wsync_bcast_bucket_sag(prl_wsync* w, void* bucket, uint64_t nbytes,
                                           prl_stream_t stream) {
   PRL_CHECK_ARG(w && (bucket || nbytes == 0), "null argument");
   if (nbytes == 0 || w->world == 1) return PRL_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int R = w->world - 1;  // receivers are ranks 1..world-1
   uint8_t* base = static_cast<uint8_t*>(bucket);
-  // slice boundaries, 256-byte aligned so every slice starts on a full cache line pair
-  const uint64_t per = ((nbytes + R - 1) / R + 255) / 256 * 256;
-  auto lo = [&](int i) { uint64_t b = per * (uint64_t)i; return b < nbytes ? b : nbytes; };
-  auto len = [&](int i) { return lo(i + 1) - lo(i); };
-
+  // the plan (slice boundaries, who sends what to whom) lives in prl_wsync_plan.h and is executed against simulated
+  // ranks by tests/harness/wsync_plan_host.cpp
   // phase 1: scatter.  rank 0 -> receiver i+1 gets slice i, every transfer on its own link.
-  PRL_NCCL_CHECK(g_rccl.GroupStart());
-  if (w->rank == 0) {
-    for (int i = 0; i < R; ++i)
-      if (len(i)) PRL_NCCL_CHECK(g_rccl.Send(base + lo(i), (size_t)len(i), ncclUint8, i + 1, w->comm, s));
-  } else {
-    const int i = w->rank - 1;
-    if (len(i)) PRL_NCCL_CHECK(g_rccl.Recv(base + lo(i), (size_t)len(i), ncclUint8, 0, w->comm, s));
-  }
-  PRL_NCCL_CHECK(g_rccl.GroupEnd());
-
+  if (int rc = run_group(w, base, s, [&](auto&& emit) { prl::wsync::scatter_ops(w->rank, w->world, nbytes, emit); })) return rc;
   // phase 2: all-gather among the receivers (stream order makes the received slice visible).
-  if (R > 1 && w->rank != 0) {
-    const int me = w->rank - 1;
-    PRL_NCCL_CHECK(g_rccl.GroupStart());
-    for (int j = 0; j < R; ++j) {
-      if (j == me) continue;
-      if (len(me)) PRL_NCCL_CHECK(g_rccl.Send(base + lo(me), (size_t)len(me), ncclUint8, j + 1, w->comm, s));
-      if (len(j)) PRL_NCCL_CHECK(g_rccl.Recv(base + lo(j), (size_t)len(j), ncclUint8, j + 1, w->comm, s));
-    }
-    PRL_NCCL_CHECK(g_rccl.GroupEnd());
+  if (w->world > 2 && w->rank != 0) {
+    if (int rc = run_group(w, base, s, [&](auto&& emit) { prl::wsync::allgather_ops(w->rank, w->world, nbytes, emit); })) return rc;
   }
+  return PRL_OK;
+}
+
+extern "C" int prl_wsync_comm_size(prl_wsync* w, int32_t* world_size, int32_t* rank) {
+  PRL_CHECK_ARG(w && world_size && rank, "null argument");
+  int n = 0, r = 0;
+  PRL_NCCL_CHECK(g_rccl.CommCount(w->comm, &n));
+  PRL_NCCL_CHECK(g_rccl.CommUserRank(w->comm, &r));
+  *world_size = n;
+  *rank = r;
   return PRL_OK;
 }
 

@@ -101,6 +101,12 @@ class WeightSyncGroup:
         self.world_size = world_size
         self.device = device
 
+    def comm_size(self) -> tuple[int, int]:
+        """(ranks, this rank) as RCCL reports them for the communicator (ncclCommCount / ncclCommUserRank)."""
+        n, r = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(_lib.load().prl_wsync_comm_size(self._h, ctypes.byref(n), ctypes.byref(r)))
+        return n.value, r.value
+
     # -- bootstrap ------------------------------------------------------------------------------
     @classmethod
     def _init(cls, uid: bytes, rank: int, world_size: int, device: torch.device) -> "WeightSyncGroup":

@@ -414,6 +414,7 @@ def test_wsync_single_rank_group(libprl, cuda_device):
     from pipelinerl_amd.weight_sync import BucketedReceiver, BucketedSender, WeightSyncGroup
 
     grp = WeightSyncGroup._init(WeightSyncGroup._new_uid(), 0, 1, cuda_device)
+    assert grp.comm_size() == (1, 0)  # what RCCL itself reports for the communicator
     params = [("a.weight", torch.randn(33, 7, device=cuda_device).bfloat16()), ("a.bias", torch.randn(7, device=cuda_device)),
               ("b.weight", torch.randn(1025, device=cuda_device).half())]
     sender = BucketedSender(grp, bucket_bytes=4096)
