@@ -9,9 +9,10 @@ Record = 8-byte magic/kind + payload.
         u32 header_len | header JSON | raw buffers, each 16-byte aligned
      header = {"scalars": {model_version, sentinel, padding, is_packed},
                "tensors": [[name, dtype, shape, offset, nbytes], ...]}
-     int64 / fp32 / int32 buffers are copied verbatim, so decoding is `torch.frombuffer` views over
-     one bytes object: no per-token Python objects on either side (the reference's JSONL costs
-     ~114 bytes of text and a list->tensor conversion per token).
+     int64 / fp32 / int32 buffers are copied verbatim.  Copies per record: encode = each tensor once into the record
+     buffer (a device tensor's D2H lands there directly) + the append into the shared-memory segment; decode = one
+     copy out of the segment (`Log.read`) + `torch.frombuffer` VIEWS over that buffer.  No per-token Python objects on
+     either side (the reference's JSONL costs ~114 bytes of text and a list->tensor conversion per token).
 """
 
 from __future__ import annotations
@@ -36,84 +37,78 @@ def encode_json(text: str) -> bytes:
     return MAGIC_JSON + text.encode("utf-8")
 
 
-def _frame(magic: bytes, scalars: dict, named_arrays) -> bytes:
-    tensors = []
-    blobs = []
+def _frame(magic: bytes, scalars: dict, named_tensors) -> bytearray:
+    """One record buffer, filled in place: the layout is fixed first, then every tensor is copied ONCE from where it
+    lives (host or device - a device tensor's D2H lands directly in the record) into its 16-byte aligned slot."""
+    layout = []
     offset = 0
-    for name, a in named_arrays:
-        a = np.ascontiguousarray(a)
-        raw = a.tobytes()
-        pad = (-offset) % _ALIGN
-        if pad:
-            blobs.append(b"\0" * pad)
-            offset += pad
-        tensors.append([name, str(a.dtype), list(a.shape), offset, len(raw)])
-        blobs.append(raw)
-        offset += len(raw)
-    header = json.dumps({"scalars": scalars, "tensors": tensors}).encode("utf-8")
-    head = magic + struct.pack("<I", len(header)) + header
-    head += b"\0" * ((-len(head)) % _ALIGN)
-    return head + b"".join(blobs)
+    for name, t in named_tensors:
+        t = t.detach()
+        offset += (-offset) % _ALIGN
+        nbytes = t.numel() * t.element_size()
+        layout.append((name, t, offset, nbytes))
+        offset += nbytes
+    header = json.dumps({"scalars": scalars,
+                         "tensors": [[name, str(t.dtype).replace("torch.", ""), list(t.shape), off, nb] for name, t, off, nb in layout]}).encode("utf-8")
+    base = 12 + len(header)
+    base += (-base) % _ALIGN
+    buf = bytearray(base + offset)
+    buf[:8] = magic
+    struct.pack_into("<I", buf, 8, len(header))
+    buf[12:12 + len(header)] = header
+    for _, t, off, nb in layout:
+        if not nb:
+            continue
+        if t.device.type == "cpu" and t.is_contiguous():
+            # plain memcpy: torch's copy_ hands anything above 32 K elements to its intra-op thread pool, whose wake-up
+            # costs more than the copy (measured 70 ms per 256 KB column under a CPU quota)
+            np.frombuffer(buf, dtype=np.uint8, count=nb, offset=base + off)[:] = t.view(torch.uint8).reshape(-1).numpy()
+        else:
+            torch.frombuffer(buf, dtype=t.dtype, count=t.numel(), offset=base + off).view(t.shape).copy_(t)
+    return buf
 
 
 _ROLLOUT_FIELDS = ("tokens", "labels", "logprobs", "ref_logprobs", "seq_off", "lp_off", "reward", "group_index", "step_index",
                    "rollout_index", "model_version", "finished", "finish_code")
 
 
-def encode_rollouts(rollouts) -> bytes:
+def encode_rollouts(rollouts) -> bytearray:
     """RaggedRollouts -> one binary record."""
-    arrays = []
-    for name in _ROLLOUT_FIELDS:
-        t = getattr(rollouts, name)
-        if t is not None:
-            arrays.append((name, t.detach().cpu().numpy()))
-    return _frame(MAGIC_ROLLOUTS, {"group_ids": list(rollouts.group_ids)}, arrays)
+    tensors = [(name, getattr(rollouts, name)) for name in _ROLLOUT_FIELDS if getattr(rollouts, name) is not None]
+    return _frame(MAGIC_ROLLOUTS, {"group_ids": list(rollouts.group_ids)}, tensors)
 
 
-def encode_batch(batch: PipelineBatchEncoding) -> bytes:
-    tensors = []
-    blobs = []
-    offset = 0
-    for name, t in batch.tensors():
-        a = t.detach().cpu().contiguous().numpy()
-        raw = a.tobytes()
-        pad = (-offset) % _ALIGN
-        if pad:
-            blobs.append(b"\0" * pad)
-            offset += pad
-        tensors.append([name, str(a.dtype), list(a.shape), offset, len(raw)])
-        blobs.append(raw)
-        offset += len(raw)
-    header = json.dumps({
-        "scalars": {"model_version": batch.model_version, "sentinel": batch.sentinel, "padding": batch.padding, "is_packed": batch.is_packed},
-        "tensors": tensors,
-    }).encode("utf-8")
-    head = MAGIC_BATCH + struct.pack("<I", len(header)) + header
-    head += b"\0" * ((-len(head)) % _ALIGN)
-    return head + b"".join(blobs)
+def encode_batch(batch: PipelineBatchEncoding) -> bytearray:
+    scalars = {"model_version": batch.model_version, "sentinel": batch.sentinel, "padding": batch.padding, "is_packed": batch.is_packed}
+    return _frame(MAGIC_BATCH, scalars, list(batch.tensors()))
 
 
-def decode(record: bytes) -> Any:
-    """bytes -> dict (JSON records; batch records decode to the kwargs of PipelineBatchEncoding,
-    exactly what the file backend's `json.loads` line gives `PipelineBatchEncoding(**d)`, but with
-    tensors instead of nested lists)."""
-    magic = record[:8]
+def decode(record: "bytes | bytearray") -> Any:
+    """record -> dict (JSON records; batch records decode to the kwargs of PipelineBatchEncoding, exactly what the
+    file backend's `json.loads` line gives `PipelineBatchEncoding(**d)`, but with tensors instead of nested lists).
+
+    The tensors are VIEWS into `record` (`torch.frombuffer`, no per-tensor copy): pass the `bytearray` that
+    `ring.Log.read` returns - the one copy out of the shared-memory segment, whose mapping the reader releases when it
+    moves on - and keep nothing else alive.  An immutable `bytes` record is copied once first (torch needs a writable
+    buffer)."""
+    magic = bytes(record[:8])
     if magic == MAGIC_JSON:
-        return json.loads(record[8:].decode("utf-8"))
+        return json.loads(bytes(record[8:]).decode("utf-8"))
     if magic not in (MAGIC_BATCH, MAGIC_ROLLOUTS):
         raise ValueError(f"unknown record kind {magic!r}")
+    if not isinstance(record, bytearray):
+        record = bytearray(record)
     (hlen,) = struct.unpack_from("<I", record, 8)
-    header = json.loads(record[12 : 12 + hlen].decode("utf-8"))
+    header = json.loads(bytes(record[12: 12 + hlen]).decode("utf-8"))
     base = 12 + hlen
     base += (-base) % _ALIGN
     out: dict[str, Any] = dict(header["scalars"])
-    buf = memoryview(record)
     for name, dtype, shape, off, nbytes in header["tensors"]:
         if nbytes == 0:
             out[name] = torch.empty(shape, dtype=_TORCH[dtype])
             continue
-        a = np.frombuffer(buf, dtype=np.dtype(dtype), count=nbytes // np.dtype(dtype).itemsize, offset=base + off)
-        out[name] = torch.from_numpy(a.reshape(shape).copy())
+        dt = _TORCH[dtype]
+        out[name] = torch.frombuffer(record, dtype=dt, count=nbytes // dt.itemsize, offset=base + off).view(shape)
     if magic == MAGIC_ROLLOUTS:
         from .ragged import RaggedRollouts
 

@@ -148,17 +148,27 @@ class Log:
         self._h = h
 
     def append(self, data: bytes | bytearray | memoryview) -> None:
-        buf = data if isinstance(data, bytes) else (ctypes.c_char * len(data)).from_buffer_copy(data)
+        if isinstance(data, bytes):
+            buf = data
+        elif isinstance(data, bytearray):
+            buf = (ctypes.c_char * len(data)).from_buffer(data) if len(data) else b""  # no copy: the library reads it in place
+        else:
+            buf = (ctypes.c_char * len(data)).from_buffer_copy(data)
         _lib.check(_lib.load().prl_log_append(self._h, buf, len(data)))
 
-    def read(self, block: bool = True, timeout: float | None = None) -> bytes:
-        """Next record of this handle's cursor (a copy).  Raises `queue.Empty` at the tail when not blocking."""
+    def read(self, block: bool = True, timeout: float | None = None) -> bytearray:
+        """Next record of this handle's cursor: ONE copy out of the shared-memory segment into a `bytearray` the caller
+        owns (the reader's mapping of a segment is released when it moves on to the next one, so a view into the
+        segment could not outlive the call).  `batch_codec.decode` builds its tensors as views over that buffer.
+        Raises `queue.Empty` at the tail when not blocking."""
         p, n = ctypes.c_void_p(), ctypes.c_uint64()
         rc = _lib.load().prl_log_read(self._h, ctypes.byref(p), ctypes.byref(n), Ring._timeout_ms(block, timeout))
         if rc in (_lib.PRL_EAGAIN, _lib.PRL_ETIMEDOUT):
             raise queue.Empty()
         _lib.check(rc)
-        return ctypes.string_at(p.value, n.value)
+        if n.value == 0:
+            return bytearray()
+        return bytearray((ctypes.c_char * n.value).from_address(p.value))
 
     def stats(self) -> dict[str, int]:
         v = [ctypes.c_uint64() for _ in range(4)]
