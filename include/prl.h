@@ -66,6 +66,29 @@ extern "C" {
 typedef void* prl_stream_t; /* hipStream_t */
 
 int prl_abi_version(void);
+
+/* Diagnostic launch overrides (A/B measurements, tests that force a fallback shape).  A process-wide table of integers
+ * read by the launch code - there is NO getenv() on any launch path; the Python host maps its PRL_* environment
+ * variables onto this call.  `value` PRL_TUNE_UNSET restores the built-in choice.  No reference counterpart. */
+enum prl_tune_key {
+  PRL_TUNE_FUSED_VARIANT = 0,       /* prl_fused_logits_loss: 0 two-sweep 256 threads | 4 two-sweep 2 x 512 (bf16 default) |
+                                       6 two-sweep 1024 (fallback of short / unaligned rows) | 21 row-resident (fp32 default) */
+  PRL_TUNE_LMHEAD_TILE = 1,         /* fused head: 128 | 256 (256 x 128, ring of 3) | 512 (256 x 256) */
+  PRL_TUNE_LMHEAD_DUAL = 2,         /* 0: generic core where the dual-plane core would be taken */
+  PRL_TUNE_LMHEAD_NSPLIT = 3,       /* vocabulary splits of the forward */
+  PRL_TUNE_LMHEAD_KSPLIT = 4,       /* split-K factor of the d hidden product */
+  PRL_TUNE_LMHEAD_EXP = 5,          /* timing ablations of the forward (wrong results), see prl_lmhead.hip */
+  PRL_TUNE_LOSS_FAST_STATS = 6,     /* 0: always-nan_to_num statistics path */
+  PRL_TUNE_LOSS_TPL = 7,            /* tokens per lane of the loss kernel: 2 | 4 */
+  PRL_TUNE_LOSS_BLOCKS_PER_CU = 8,
+  PRL_TUNE_PACK_NT = 9,             /* 0: plain stores in the pack kernel */
+  PRL_TUNE_PACK_TPL = 10,           /* tokens per lane of the pack kernel: 2 | 4 */
+  PRL_TUNE_LMHEAD_BWD = 11,         /* backward structure of the fused head, see prl_lmhead.hip */
+  PRL_TUNE_COUNT = 12
+};
+#define PRL_TUNE_UNSET INT64_MIN
+int prl_set_tuning(int32_t key, int64_t value);
+int prl_get_tuning(int32_t key, int64_t* value);
 const char* prl_last_error(void);
 
 /* ------------------------------------------------------------------------- */

@@ -115,6 +115,8 @@ _P = c_void_p  # every device / host buffer pointer crosses the ABI as void*
 # the declarations in include/prl.h.
 PROTOTYPES: dict[str, tuple] = {
     "prl_abi_version": (c_int32, []),
+    "prl_set_tuning": (c_int32, [c_int32, c_int64]),
+    "prl_get_tuning": (c_int32, [c_int32, POINTER(c_int64)]),
     "prl_last_error": (c_char_p, []),
     "prl_logprob_entropy_fwd": (c_int32, [c_int64, c_int64, c_int64, _P, c_int32, c_int64, _P, c_float, _P, _P, _P, _P]),
     "prl_logprob_entropy_bwd": (c_int32, [c_int64, c_int64, c_int64, _P, c_int32, c_int64, _P, c_float, _P, _P, _P, _P, _P, _P, _P]),
@@ -196,8 +198,57 @@ def load() -> ctypes.CDLL:
     got = lib.prl_abi_version()
     if got != PRL_ABI_VERSION:
         raise ImportError(f"libprl.so ABI version {got} != expected {PRL_ABI_VERSION}; rebuild")
+    for name in _ENV_TUNED_ENTRY_POINTS:
+        setattr(lib, name, _with_env_tuning(lib, getattr(lib, name)))
     _lib = lib
     return lib
+
+
+# ---- diagnostic launch overrides -----------------------------------------------------------------------
+# The C library reads an integer table (prl_set_tuning), never the environment.  The PRL_* variables the
+# measurement scripts and tests use are mapped onto it HERE, on the Python side of the entry points they
+# influence: a dictionary lookup per call in the host language, nothing on the C launch path.
+TUNE_KEYS = {"fused_variant": 0, "lmhead_tile": 1, "lmhead_dual": 2, "lmhead_nsplit": 3, "lmhead_ksplit": 4, "lmhead_exp": 5,
+             "loss_fast_stats": 6, "loss_tpl": 7, "loss_blocks_per_cu": 8, "pack_nt": 9, "pack_tpl": 10, "lmhead_bwd": 11}
+PRL_TUNE_UNSET = -(1 << 63)
+_ENV_OF_KEY = {"fused_variant": "PRL_FUSED_VARIANT", "lmhead_tile": "PRL_LMHEAD_TILE", "lmhead_dual": "PRL_LMHEAD_DUAL",
+               "lmhead_nsplit": "PRL_LMHEAD_NSPLIT", "lmhead_ksplit": "PRL_LMHEAD_KSPLIT", "lmhead_exp": "PRL_LMHEAD_EXP",
+               "loss_fast_stats": "PRL_LOSS_FAST_STATS", "loss_tpl": "PRL_LOSS_TPL", "loss_blocks_per_cu": "PRL_LOSS_BLOCKS_PER_CU",
+               "pack_nt": "PRL_PACK_NT", "pack_tpl": "PRL_PACK_TPL", "lmhead_bwd": "PRL_LMHEAD_BWD"}
+_ENV_TUNED_ENTRY_POINTS = ("prl_fused_logits_loss", "prl_lm_head_logprob_fwd", "prl_lm_head_logprob_bwd", "prl_lm_head_workspace_bytes",
+                           "prl_grpo_loss_fwd_bwd", "prl_pack_collate")
+_env_seen: tuple | None = None
+
+
+def set_tuning(key: str, value: int | None) -> None:
+    """`value` None restores the library's own choice."""
+    check(load().prl_set_tuning(TUNE_KEYS[key], PRL_TUNE_UNSET if value is None else int(value)))
+
+
+def _parse_tuning(key: str, text: str) -> int:
+    if key == "lmhead_tile":  # "128" | "256" | "256x256"
+        return {"128": 128, "256": 256, "256x256": 512}.get(text.strip(), 0)
+    return int(text)
+
+
+def _sync_env_tuning(lib) -> None:
+    global _env_seen
+    now = tuple(os.environ.get(v) for v in _ENV_OF_KEY.values())
+    if now == _env_seen:
+        return
+    for (key, _), text in zip(_ENV_OF_KEY.items(), now):
+        lib.prl_set_tuning(TUNE_KEYS[key], PRL_TUNE_UNSET if text is None or text == "" else _parse_tuning(key, text))
+    _env_seen = now
+
+
+def _with_env_tuning(lib, fn):
+    def call(*args):
+        _sync_env_tuning(lib)
+        return fn(*args)
+
+    call.__name__ = getattr(fn, "__name__", "prl_entry")
+    call.raw = fn
+    return call
 
 
 def check(rc: int) -> None:

@@ -1,4 +1,7 @@
 // libprl.so: ABI version and thread-local error reporting.
+#include <atomic>
+#include <cstdint>
+
 #include "prl_common.h"
 
 namespace prl {
@@ -16,7 +19,33 @@ int set_error(int code, const char* fmt, ...) {
   return code;
 }
 
+namespace {
+std::atomic<int64_t> g_tuning[PRL_TUNE_COUNT];
+struct TuningInit {
+  TuningInit() {
+    for (auto& t : g_tuning) t.store(PRL_TUNE_UNSET, std::memory_order_relaxed);
+  }
+} g_tuning_init;
+}  // namespace
+
+int64_t tuning(int key, int64_t dflt) {
+  const int64_t v = g_tuning[key].load(std::memory_order_relaxed);
+  return v == PRL_TUNE_UNSET ? dflt : v;
+}
+
 }  // namespace prl
+
+extern "C" int prl_set_tuning(int32_t key, int64_t value) {
+  PRL_CHECK_ARG(key >= 0 && key < PRL_TUNE_COUNT, "unknown tuning key %d", key);
+  prl::g_tuning[key].store(value, std::memory_order_relaxed);
+  return PRL_OK;
+}
+
+extern "C" int prl_get_tuning(int32_t key, int64_t* value) {
+  PRL_CHECK_ARG(key >= 0 && key < PRL_TUNE_COUNT && value, "unknown tuning key %d", key);
+  *value = prl::g_tuning[key].load(std::memory_order_relaxed);
+  return PRL_OK;
+}
 
 extern "C" int prl_abi_version(void) { return PRL_ABI_VERSION; }
 

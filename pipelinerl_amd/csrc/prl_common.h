@@ -13,6 +13,9 @@ namespace prl {
 char* error_buffer();
 int set_error(int code, const char* fmt, ...);
 
+// prl_set_tuning table (prl_api.cpp): the value of `key`, or `dflt` when unset.  One relaxed atomic load.
+int64_t tuning(int key, int64_t dflt);
+
 }  // namespace prl
 
 #define PRL_CHECK_ARG(cond, ...)                         \

@@ -875,14 +875,15 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(int64_t R, int64_t
   }
 }
 
-// Workgroup shape per launch.  PRL_LMHEAD_TILE = 128 | 256 | 256x256 forces one (read per call, so one
-// process can A/B them); default: the largest tile whose grid still fills the 256 CUs.
+// Workgroup shape per launch.  PRL_TUNE_LMHEAD_TILE = 128 | 256 | 512 (= 256 x 256) forces one (a table read, no
+// getenv: one process can A/B them); default: the largest tile whose grid still fills the 256 CUs.
 enum Shape { kSmall = 0, kBig = 1, kWide = 2 };
 Shape pick_shape(int64_t m_rows, int64_t n_cols) {
-  if (const char* e = getenv("PRL_LMHEAD_TILE")) {
-    if (!strcmp(e, "128")) return kSmall;
-    if (!strcmp(e, "256")) return kBig;
-    if (!strcmp(e, "256x256")) return kWide;
+  switch (prl::tuning(PRL_TUNE_LMHEAD_TILE, 0)) {
+    case 128: return kSmall;
+    case 256: return kBig;
+    case 512: return kWide;
+    default: break;
   }
   const int64_t m256 = (m_rows + 255) / 256;
   if (m256 * ((n_cols + 255) / 256) >= 200) return kWide;
@@ -891,11 +892,10 @@ Shape pick_shape(int64_t m_rows, int64_t n_cols) {
 }
 // The dual-plane core applies when a launch has exactly two terms that share their B operand (W_hi / W_lo
 // against the hidden states; d logits hi / lo against the transposed hidden states) and the 256 x 256 shape
-// was chosen.  PRL_LMHEAD_DUAL=0 keeps the generic core (A/B reference).
+// was chosen.  PRL_TUNE_LMHEAD_DUAL = 0 keeps the generic core (A/B reference).
 bool use_dual(Shape shape, const Terms& t) {
   if (shape != kWide || t.n != 2 || t.b[0] != t.b[1]) return false;
-  const char* e = getenv("PRL_LMHEAD_DUAL");
-  return !(e && atoi(e) == 0);
+  return prl::tuning(PRL_TUNE_LMHEAD_DUAL, 1) != 0;
 }
 int shape_bm(Shape s) { return s == kSmall ? 128 : 256; }
 int shape_bn(Shape s) { return s == kWide ? 256 : 128; }
@@ -943,8 +943,8 @@ int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // vocabulary splits of the forward: enough workgroups to fill 256 CUs (x 2 for the small shape)
 int fwd_nsplit(int token_tiles, int vocab_tiles, bool one_per_cu) {
-  if (const char* e = getenv("PRL_LMHEAD_NSPLIT")) {
-    const int v = atoi(e);
+  {
+    const int v = (int)prl::tuning(PRL_TUNE_LMHEAD_NSPLIT, 0);
     if (v >= 1) return v < vocab_tiles ? v : vocab_tiles;
   }
   // workgroups = token_tiles x splits run in rounds of `slots`; pick the split count (up to four rounds) whose last
@@ -976,8 +976,8 @@ struct BwdLayout {
 // whose grid fills whole rounds of 256 workgroups best; every slice keeps at least 64 steps.
 constexpr int kMaxKSplit = 8;
 int pick_ksplit(int tiles, int ksteps_total) {
-  if (const char* e = getenv("PRL_LMHEAD_KSPLIT")) {
-    const int v = atoi(e);
+  {
+    const int v = (int)prl::tuning(PRL_TUNE_LMHEAD_KSPLIT, 0);
     if (v >= 1 && v <= kMaxKSplit && v <= ksteps_total) return v;
   }
   int best = 1;
@@ -1088,8 +1088,7 @@ extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidde
   a.part = static_cast<float*>(workspace);
   a.ysel = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_bytes);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int exp_bits = 0;
-  if (const char* e = getenv("PRL_LMHEAD_EXP")) exp_bits = atoi(e);
+  const int exp_bits = (int)prl::tuning(PRL_TUNE_LMHEAD_EXP, 0);
   if (shape == kWide && exp_bits && exp_bits != 256) {  // timing ablations, generic 256 x 256 forward only
     int rc = PRL_EINVAL;
 #define PRL_EXP_CASE(E)                                                                                                  \

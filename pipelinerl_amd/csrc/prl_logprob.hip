@@ -759,21 +759,17 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
   const float inv_temp = 1.0f / temperature;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)geo.n);
-  // Variant selection (PRL_FUSED_VARIANT, read per call so one process can sweep them):
-  //   0: 256 threads x unroll 4, forward order          1: + reversed second pass
-  //   2: + non-temporal gradient stores                 3: 1024 threads, 1 workgroup per CU, reversed, NT
-  //   4: 512 threads, 2 workgroups per CU, reversed, NT 6: as 3 with unroll 4
-  //   11 / 21 / 22 / 23: row-resident (KREG vectors per lane in VGPRs + KLDS in LDS stay on chip);
-  //   21 = 11 with non-temporal head loads, 22 = registers only, 23 = 16 + 2 vectors
-  // The other geometries of the round-1 sweeps (5, 7-10, 12-20: forward order, plain stores, 256 /
-  // 512 / 768-thread retention shapes) measured slower and were removed from the build; their
-  // numbers stay in profiles/r01[c-f]_kernel_sweep*.txt.
-  int variant = kDefaultFusedVariant;
-  // bf16 rows carry twice the exp/convert work per byte and a whole step's rows (304 KB x 256 CUs)
-  // sit in the Infinity Cache, so the row-resident structure loses to the two-sweep kernel with two
-  // 512-thread workgroups per CU (profiles/r01r_kernel_sweep_bf16.txt: 1091 vs 1664 us)
-  if (logits_dtype == PRL_DTYPE_BF16) variant = 4;
-  if (const char* e = getenv("PRL_FUSED_VARIANT")) variant = atoi(e);
+  // Launch shape (PRL_TUNE_FUSED_VARIANT overrides the built-in choice; no getenv on this path):
+  //   21  row-resident: 16 sixteen-byte vectors per lane in VGPRs + 9 in LDS stay on chip between the two passes,
+  //       non-temporal head loads - the fp32 default (profiles/r01_kernel_sweep.txt)
+  //    4  two-sweep, 512 threads, 2 workgroups per CU, reversed second pass, non-temporal stores - the bf16 default:
+  //       bf16 rows carry twice the exp / convert work per byte and a whole step's rows (304 KB x 256 CUs) sit in the
+  //       Infinity Cache, so the row-resident structure loses (profiles/r01r_kernel_sweep_bf16.txt: 1091 vs 1664 us)
+  //    6  two-sweep, 1024 threads - what rows too short or unaligned for the row-resident shape fall back to
+  //    0  two-sweep, 256 threads, forward order, plain stores - the simplest geometry, kept as the tests' A/B witness
+  // The 19 other geometries of the round-1 / round-2 sweeps are no longer built; their numbers stay in
+  // profiles/r01[c-f]_kernel_sweep*.txt.
+  const int variant = (int)prl::tuning(PRL_TUNE_FUSED_VARIANT, logits_dtype == PRL_DTYPE_BF16 ? 4 : kDefaultFusedVariant);
 #define PRL_FUSED_LAUNCH(TT, ST, BLK, UNR, REV, NTS, LDSB)                                            \
   do {                                                                                              \
     auto kfn = fused_logits_loss_kernel<TT, BLK, UNR, REV, NTS>;                                    \
@@ -810,16 +806,11 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
   } while (0)
 #define PRL_FUSED_DISPATCH(TT, ST)                                              \
   switch (variant) {                                                            \
-    case 11: PRL_KEEP_LAUNCH(TT, ST, 1024, 2, 16, 9); break;                    \
     case 21: PRL_KEEP_LAUNCH2(TT, ST, 1024, 2, 16, 9, true); break;             \
-    case 22: PRL_KEEP_LAUNCH2(TT, ST, 1024, 2, 16, 0, true); break;             \
-    case 23: PRL_KEEP_LAUNCH2(TT, ST, 1024, 2, 16, 2, true); break;             \
-    case 1: PRL_FUSED_LAUNCH(TT, ST, 256, 4, true, false, 0); break;            \
-    case 2: PRL_FUSED_LAUNCH(TT, ST, 256, 4, true, true, 0); break;             \
-    case 3: PRL_FUSED_LAUNCH(TT, ST, 1024, 2, true, true, 96 * 1024); break;    \
     case 4: PRL_FUSED_LAUNCH(TT, ST, 512, 4, true, true, 64 * 1024); break;     \
     case 6: PRL_FUSED_LAUNCH(TT, ST, 1024, 4, true, true, 96 * 1024); break;    \
-    default: PRL_FUSED_LAUNCH(TT, ST, 256, 4, false, false, 0); break;          \
+    case 0: PRL_FUSED_LAUNCH(TT, ST, 256, 4, false, false, 0); break;           \
+    default: return prl::set_error(PRL_EINVAL, "fused variant %d is not built (0, 4, 6, 21)", variant); \
   }
   if (logits_dtype == PRL_DTYPE_F32) {
     PRL_FUSED_DISPATCH(F32, float)

@@ -463,25 +463,16 @@ __global__ __launch_bounds__(kFinalBlock) void grpo_loss_finalize_kernel(const d
   }
 }
 
-// PRL_LOSS_FAST_STATS=0 selects the always-nan_to_num statistics path (A/B measurements only).
-bool fast_stats() {
-  static const bool on = [] {
-    const char* e = getenv("PRL_LOSS_FAST_STATS");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+// PRL_TUNE_LOSS_FAST_STATS = 0 selects the always-nan_to_num statistics path (A/B measurements only).
+bool fast_stats() { return prl::tuning(PRL_TUNE_LOSS_FAST_STATS, 1) != 0; }
 
 // Tokens per lane and iteration.  Two make every load wave-contiguous (the int64 columns are 16
 // bytes per lane at a 16-byte stride instead of two loads at a 32-byte stride) and fit 3 waves per
 // SIMD: 7 % faster for the statistics-only launch of a whole step (347 vs 375 us); with the
 // gradient written as well four tokens per lane (16-byte stores) stay ahead (390 vs 399 us).
-// PRL_LOSS_TPL=2|4 overrides (A/B measurements).
+// PRL_TUNE_LOSS_TPL = 2 | 4 overrides (A/B measurements).
 int tokens_per_lane(bool writes_gradient) {
-  static const int forced = [] {
-    const char* e = getenv("PRL_LOSS_TPL");
-    return e ? atoi(e) : 0;
-  }();
+  const int forced = (int)prl::tuning(PRL_TUNE_LOSS_TPL, 0);
   if (forced == 2 || forced == 4) return forced;
   return writes_gradient ? 4 : 2;
 }
@@ -497,16 +488,21 @@ int grid_for(int64_t n, int vec) {
 // min(wanted, CUs x resident blocks per CU) for `kernel`; the occupancy query runs once per kernel.
 template <void (*kernel)(LossArgs)>
 int resident_grid(int wanted) {
-  static const int cap = [] {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return kMaxBlocks;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return kMaxBlocks;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu <= 0) return kMaxBlocks;
-    const char* e = getenv("PRL_LOSS_BLOCKS_PER_CU");  // measurement override
-    if (e && atoi(e) > 0) per_cu = atoi(e);
-    const int64_t c = (int64_t)cus * per_cu;
-    return (int)(c < kMaxBlocks ? c : kMaxBlocks);
+  struct Probe {
+    int cus = 0, per_cu = 0;
+  };
+  static const Probe probe = [] {  // the occupancy query runs once per kernel
+    Probe p;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return p;
+    if (hipDeviceGetAttribute(&p.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || p.cus <= 0) return Probe{};
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.per_cu, kernel, kBlock, 0) != hipSuccess || p.per_cu <= 0) return Probe{};
+    return p;
   }();
+  if (probe.cus <= 0) return wanted < kMaxBlocks ? wanted : kMaxBlocks;
+  const int64_t forced = prl::tuning(PRL_TUNE_LOSS_BLOCKS_PER_CU, 0);  // measurement override
+  const int64_t c = (int64_t)probe.cus * (forced > 0 ? forced : probe.per_cu);
+  const int cap = (int)(c < kMaxBlocks ? c : kMaxBlocks);
   return wanted < cap ? wanted : cap;
 }
 

@@ -554,10 +554,8 @@ extern "C" int prl_pack_collate(int32_t m, int64_t total_tokens, const int32_t* 
                    prl::aligned16(out_old_logprobs) && prl::aligned16(out_group_tokens) &&
                    prl::aligned16(out_num_labels) && prl::aligned16(out_overflow);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const char* nt_env = getenv("PRL_PACK_NT");
-  const bool nt = nt_env ? (atoi(nt_env) != 0) : kPackNtDefault;
-  const char* tpl_env = getenv("PRL_PACK_TPL");  // measurement override: 4 = four tokens per lane
-  const int tpl = (tpl_env && atoi(tpl_env) == 4) ? 4 : 2;
+  const bool nt = prl::tuning(PRL_TUNE_PACK_NT, kPackNtDefault ? 1 : 0) != 0;
+  const int tpl = prl::tuning(PRL_TUNE_PACK_TPL, 2) == 4 ? 4 : 2;  // measurement override: 4 = four tokens per lane
   const int nb = blocks_for((total_tokens + tpl - 1) / tpl);
   if (vec && nt && tpl == 2) {
     hipLaunchKernelGGL((pack_collate_kernel<true, true, 2>), dim3(nb), dim3(kBlock), 0, s, a);

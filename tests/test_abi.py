@@ -35,6 +35,7 @@ def test_library_exports_every_declared_symbol(libprl):
     assert set(declared) == set(PROTOTYPES), set(declared) ^ set(PROTOTYPES)
     for name, n_params in declared.items():
         fn = getattr(libprl, name)  # raises AttributeError when the symbol is missing
+        fn = getattr(fn, "raw", fn)  # entry points with PRL_* diagnostic overrides are wrapped on the Python side (_lib.py)
         assert isinstance(fn, ctypes._CFuncPtr)
         assert len(PROTOTYPES[name][1]) == n_params, f"{name}: prototype has {len(PROTOTYPES[name][1])} params, header {n_params}"
 
@@ -90,3 +91,34 @@ def test_missing_extension_fails_loudly(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "IMPORT_ERRORS 3" in out.stdout, out.stdout + out.stderr[-1000:]
+
+
+def test_tuning_table_and_environment_mapping(libprl, monkeypatch):
+    """Launch overrides live in an integer table of the library (no getenv on any launch path); the PRL_* variables are
+    mapped onto it by the Python host in front of the entry points they influence."""
+    import ctypes as c
+
+    from pipelinerl_amd import _lib
+
+    def get(key):
+        v = c.c_int64()
+        _lib.check(libprl.prl_get_tuning(_lib.TUNE_KEYS[key], c.byref(v)))
+        return v.value
+
+    _lib.set_tuning("lmhead_ksplit", 4)
+    assert get("lmhead_ksplit") == 4
+    _lib.set_tuning("lmhead_ksplit", None)
+    assert get("lmhead_ksplit") == _lib.PRL_TUNE_UNSET
+    assert libprl.prl_set_tuning(999, 1) != 0
+    monkeypatch.setenv("PRL_LMHEAD_TILE", "256x256")
+    monkeypatch.setenv("PRL_FUSED_VARIANT", "6")
+    fwd, bwd = c.c_size_t(), c.c_size_t()
+    _lib.check(libprl.prl_lm_head_workspace_bytes(1, 512, 64, 1024, 256, c.byref(fwd), c.byref(bwd)))  # a wrapped entry point: syncs
+    assert get("lmhead_tile") == 512 and get("fused_variant") == 6
+    monkeypatch.delenv("PRL_LMHEAD_TILE")
+    monkeypatch.delenv("PRL_FUSED_VARIANT")
+    _lib.check(libprl.prl_lm_head_workspace_bytes(1, 512, 64, 1024, 256, c.byref(fwd), c.byref(bwd)))
+    assert get("lmhead_tile") == _lib.PRL_TUNE_UNSET and get("fused_variant") == _lib.PRL_TUNE_UNSET
+    import subprocess
+    src = "\n".join(p.read_text() for p in (ROOT / "pipelinerl_amd" / "csrc").glob("*.hip"))
+    assert "getenv(" not in src, "no environment reads in the kernel launch sources"

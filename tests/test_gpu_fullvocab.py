@@ -148,7 +148,7 @@ def test_default_fused_dispatch_vs_oracle(libprl, cuda_device, monkeypatch, voca
     _check_against_oracle(nlp, ent, grad, want, g64, dtype, cfg_name)
 
 
-@pytest.mark.parametrize("dtype,variant", list(itertools.product(["f32", "bf16"], [0, 1, 2, 3, 4, 6, 11, 21, 22, 23])))
+@pytest.mark.parametrize("dtype,variant", list(itertools.product(["f32", "bf16"], [0, 4, 6, 21])))
 def test_every_fused_variant_vs_oracle(libprl, cuda_device, monkeypatch, variant, dtype):
     """Each selectable launch geometry against the oracle itself (not against variant 0)."""
     monkeypatch.setenv("PRL_FUSED_VARIANT", str(variant))
@@ -157,8 +157,8 @@ def test_every_fused_variant_vs_oracle(libprl, cuda_device, monkeypatch, variant
     if dtype == "bf16":
         lt = lt.to(torch.bfloat16)
     nlp, ent, grad, kernel = _launch_fused(libprl, cuda_device, lt, batch, "kl_ent_temp", False)
-    # a bf16 row is 19 008 sixteen-byte vectors: the 25-vector-per-lane heads of 11 / 21 do not fit and fall back
-    if variant in (22, 23) or (variant in (11, 21) and dtype == "f32"):
+    # a bf16 row is 19 008 sixteen-byte vectors: the 25-vector-per-lane head of the row-resident shape does not fit and falls back
+    if variant == 21 and dtype == "f32":
         assert "keep_kernel" in kernel, kernel
     _check_against_oracle(nlp, ent, grad, want, g64, dtype, "kl_ent_temp")
 

@@ -432,7 +432,7 @@ def test_wsync_single_rank_group(libprl, cuda_device):
     grp.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 11, 21, 22, 23])
+@pytest.mark.parametrize("variant", [4, 6, 21])
 def test_fused_kernel_variants_agree(libprl, cuda_device, variant, monkeypatch):
     """The launch-geometry variants of the fused logits kernel (block size, reversed second pass,
     non-temporal stores, residency cap) are the same arithmetic per element: bitwise equal."""
