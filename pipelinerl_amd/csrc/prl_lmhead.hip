@@ -441,6 +441,116 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
   }
 }
 
+// -----------------------------------------------------------------------------------------------
+// triple-plane main loop (d hidden): acc += A1 B1^T + A2 B1^T + A1 B2^T over Kc - the three bf16 products of
+// (A1 + A2)(B1 + B2) without the 2^-18 lo x lo term - from FOUR staged tiles per 32-deep stage (A1, A2, B1, B2, 16 KB each).
+// -----------------------------------------------------------------------------------------------
+// The generic core runs the three products one after the other and stages a (A, B) pair per product: 192 KB through the
+// LDS DMA per 64 of contraction for 6144 MFMA cycles per SIMD - 32 bytes per clock and CU, more than the DMA path sustains
+// (~24, profiles/r02c), so its matrix pipes sat at 55 % (profiles/r02aj).  Here every staged tile feeds two products:
+// 128 KB per 64 of contraction = 21 bytes per clock and CU for the same 6144 MFMA cycles.  64 KB per stage leaves room for
+// a ring of two (128 KB): the loads of stage s + 1 are issued while stage s is computed (3072 MFMA cycles per SIMD).
+// Waves 4-7 issue the DMA right after the barrier, waves 0-3 after their MFMA cluster (the staggered roles of the
+// dual-plane core).
+struct CfgTriple {
+  static constexpr int BM = 256, BN = 256, NT = 512, STAGES = 2;
+  static constexpr int NJ = 4, WCOLS = 128;
+  static constexpr int Q = 2;                       // 16-byte chunks per thread, tile and stage
+  static constexpr int LOADS = 4 * Q;
+  static constexpr int TILE_BYTES = 256 * ROW_BYTES32;  // 16 KB
+  static constexpr int STAGE_BYTES = 4 * TILE_BYTES;    // 64 KB
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;  // 128 KB
+};
+
+__device__ __forceinline__ void gemm_mainloop_triple(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B1,
+                                                     const uint16_t* B2, const Geom& g, int m0, int n0, char* lds) {
+  using C = CfgTriple;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kcol = stage_kcol32(tid);
+  int64_t offA[C::Q], offB[C::Q];
+#pragma unroll
+  for (int q = 0; q < C::Q; ++q) {
+    int ra = m0 + stage_row32(tid, q, C::NT);
+    ra = ra < g.M ? ra : g.M - 1;
+    int rb = n0 + stage_row32(tid, q, C::NT);
+    rb = rb < g.N ? rb : g.N - 1;
+    offA[q] = (int64_t)ra * g.lda + kcol;
+    offB[q] = (int64_t)rb * g.ldb + kcol;
+  }
+  int rdA[2], rdB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    rdA[ks] = frag_lds_byte32(lane, wm * 64, 0, ks);
+    rdB[ks] = 2 * C::TILE_BYTES + frag_lds_byte32(lane, wn * C::WCOLS, 0, ks);
+  }
+  const int total = g.Kc / BK32;
+  int st_k = 0;  // contraction offset of the NEXT tile to stage
+  auto stage_piece = [&](int buf, int idx) {  // idx 0..7: A1 q0 q1, A2 q0 q1, B1 q0 q1, B2 q0 q1
+    const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
+    const int tile = idx / C::Q, q = idx % C::Q;
+    const uint16_t* src = tile == 0 ? A1 + offA[q] : tile == 1 ? A2 + offA[q] : tile == 2 ? B1 + offB[q] : B2 + offB[q];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + st_k),
+                                     (__attribute__((address_space(3))) void*)(lds + dst + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
+  };
+  const bool dma_first = wave >= 4;
+  auto compute = [&](int buf, int sbuf) {
+    const char* base = lds + buf * C::STAGE_BYTES;
+    if (sbuf >= 0 && dma_first) {
+#pragma unroll
+      for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a1[2], a2[2], b1[4], b2[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a1[i] = *reinterpret_cast<const bf16x8*>(base + rdA[ks] + i * 32 * ROW_BYTES32);
+        a2[i] = *reinterpret_cast<const bf16x8*>(base + C::TILE_BYTES + rdA[ks] + i * 32 * ROW_BYTES32);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        b1[j] = *reinterpret_cast<const bf16x8*>(base + rdB[ks] + j * 32 * ROW_BYTES32);
+        b2[j] = *reinterpret_cast<const bf16x8*>(base + C::TILE_BYTES + rdB[ks] + j * 32 * ROW_BYTES32);
+      }
+      // product by product: the MFMAs that accumulate into the same tile are 8 instructions apart
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b1[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b2[j], acc[i][j], 0, 0, 0);
+    }
+    if (sbuf >= 0 && !dma_first) {
+#pragma unroll
+      for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
+    }
+  };
+  __syncthreads();  // whoever used the LDS before (previous segment, an epilogue) is done with it
+  if (total > 0) {
+#pragma unroll
+    for (int idx = 0; idx < C::LOADS; ++idx) stage_piece(0, idx);
+    st_k += BK32;
+  }
+  int cur = 0;
+  for (int s = 0; s < total; ++s) {
+    // ring of two: stage s has landed when NONE of this wave's loads is outstanding (the loads of s + 1 are issued after
+    // this barrier); every wave has finished computing stage s - 1 when it passes it, so that buffer is free
+    wait_tile_then_barrier<0>();
+    compute(cur, s + 1 < total ? (cur ^ 1) : -1);
+    st_k += BK32;
+    cur ^= 1;
+  }
+}
+
 // One call site for both cores: DUAL runs the dual-plane loop on (terms.a[0], terms.a[1], terms.b[0])
 template <class C, bool DUAL, int EXP = 0>
 __device__ __forceinline__ void run_mainloop(f32x16 (&acc)[2][C::NJ], const Terms& t, const Geom& g, int m0, int n0, char* lds) {

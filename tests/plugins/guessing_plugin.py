@@ -34,7 +34,10 @@ class ScriptedLLM:
     that turn on."""
 
     def __init__(self, vocab: int = 64, flaky_calls: tuple = (), always_fail: bool = False, malformed_after: int | None = None,
-                 eos_token_id: int = 2):
+                 eos_token_id: int = 2, split: float = 0.5):
+        """`split`: where inside the remaining interval the next guess lands (0.5 = bisection; another value needs more turns,
+        so two differently scripted llms give the rollouts of one group different rewards)."""
+        self.split = split
         self.vocab, self.flaky_calls, self.always_fail = vocab, set(flaky_calls), always_fail
         self.malformed_after, self.eos = malformed_after, eos_token_id
         self.calls = 0
@@ -52,7 +55,7 @@ class ScriptedLLM:
             for guess, relation in re.findall(r"(\d+), which is (lower|higher)", m["content"]):
                 turns += 1
                 lo, hi = (max(lo, int(guess) + 1), hi) if relation == "lower" else (lo, min(hi, int(guess) - 1))
-        guess = (lo + hi) // 2
+        guess = lo + int((hi - lo) * self.split)
         text = f"my guess {guess}" if (self.malformed_after is not None and turns >= self.malformed_after) else f"I think <answer>{guess}</answer>"
         prompt_ids = self._ids(" ".join(m["content"] for m in messages))
         out_ids = self._ids(text) + [self.eos]

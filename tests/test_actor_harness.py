@@ -77,7 +77,7 @@ def test_groups_are_rolled_out_stamped_and_published(streams, tmp_path, libprl, 
 
     streams.set_streams_backend(backend, **({"mirror_jsonl": ["actor"]} if backend == "shm" else {}))
     state = types.SimpleNamespace(propagated_weight_version=7)
-    llms = [ScriptedLLM(flaky_calls=(3, 17, 18)), ScriptedLLM()]
+    llms = [ScriptedLLM(flaky_calls=(3, 17, 18)), ScriptedLLM(split=0.4)]
     h = ActorHarness(CFG, llms, tmp_path, trainer_state=state, scheduler_name="sched3", wire=wire, shuffle_seed=0)
     problems = h.load_problems()
     assert len(problems) == 6 and problems[0]["answer"] == (2 * 10 * 191) % 1024 + 1  # train_subset applied
@@ -94,6 +94,7 @@ def test_groups_are_rolled_out_stamped_and_published(streams, tmp_path, libprl, 
             if len(groups) == 6:
                 break
     assert sum(len(g) for g in groups) == n
+    rewards_seen = set()
     for gi, g in enumerate(groups):
         assert {e["group_id"] for e in g} == {f"sched3_{gi}"}
         assert {e["metadata"]["rollout_index"] for e in g} == {0, 1, 2, 3}  # `attempts` rollouts, shuffled
@@ -104,9 +105,11 @@ def test_groups_are_rolled_out_stamped_and_published(streams, tmp_path, libprl, 
             if wire == "jsonl":
                 TrainingText(**e).check_consistency()
         assert all(steps == list(range(len(steps))) for steps in by_rollout.values())  # one text per turn, in order
-        # bisection finds 1..1024 within 10 guesses: reward 2 - (turns - 1) / 10, the same on every text of a rollout
+        # the interval search finds 1..1024 within 13 guesses: reward 2 - (turns - 1) / 10, the same on every text of a rollout
         assert all(e["reward"] == pytest.approx(2 - (len(by_rollout[e["metadata"]["rollout_index"]]) - 1) / 10) for e in g)
         assert RaggedRollouts.from_entries(g).n_seqs == len(g)  # directly ingestible by the preprocessor
+        rewards_seen.update(e["reward"] for e in g)
+    assert len(rewards_seen) > 1, "two differently scripted llms: the group baseline has something to subtract"
     if backend == "shm":  # the JSONL mirror holds the reference's text record: replayable with backend=files
         lines = (tmp_path / "streams" / "actor" / "0" / "0" / "0.jsonl").read_text().splitlines()
         assert len(lines) == 6 and len(json.loads(lines[0])) == len(groups[0])

@@ -39,8 +39,16 @@ def test_bench_json_contract(libprl, cuda_device):
     assert "error" not in m, m
     assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and m["peak"] == 2500.0 and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-12
     assert m["config"]["logits_materialised_bytes"] == 0 and m["backward"]["ms"] > 0
-    ra = c["reference_autograd"]
-    assert ra is None or (ra["source"].startswith("profiles/") and ra["us_per_token"] > 0)
+    # BASELINE.md §2, leg by leg: the port on this box next to the reference's own function (a committed constant)
+    legs = c["legs"]
+    assert {"preprocess", "collate_packed", "wire", "loss_v8", "logprob_fwd", "logprob_fwd_bwd_closed_form"} <= set(legs)
+    assert all(leg["us_per_token"] > 0 for leg in legs.values())
+    ref = c["reference"]
+    assert ref is None or (ref["source"].startswith("profiles/") and all(leg["reference_us_per_token"] > 0 for leg in legs.values()))
+    t = d["transport"]  # shm log vs files backend, host side
+    assert "error" not in t, t
+    assert 0 < t["shm_us_per_token"] < t["files_us_per_token"] and 60 < t["shm_bytes_per_token"] < 80 < t["files_bytes_per_token"]
+    assert t["rollout_record"]["PRLROL01_bytes_per_token"] < t["rollout_record"]["jsonl_bytes_per_token"]
     w = d["weight_sync"]  # N = 1: colocated hand-off over HIP IPC
     assert "error" not in w, w
     assert w["metric"] == "trainer_to_actor_weight_sync_ms" and w["median_ms"] > 0 and w["gbytes"] > 0.9
