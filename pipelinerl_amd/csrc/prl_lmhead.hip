@@ -924,6 +924,74 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_nt_kernel(GemmArgs a) {
     }
 }
 
+// d hidden on the triple-plane core.  Work item = (output tile, contraction slice kz).  With 8 slices every XCD works on
+// ONE slice (block b runs on XCD b % 8): the 32 workgroups an XCD runs at a time are an 8 x 4 patch of output tiles that
+// all walk the same 1/8 of the vocabulary, so each staged d-logits tile is wanted by 4 of them and each weight tile by 8,
+// out of the XCD's own L2 - provided they stay together.  One tile is ~600 stages long; workgroups that never wait for
+// each other drift apart and every one of them misses L2 on its own (the generic kernel: L2 hit 64 %, HBM fetch 7 x the
+// operands, profiles/r02aj).  So the contraction runs in SEGMENTS of kSegSteps stages with an empty pipeline in between
+// (the forward's per-tile refill, which is what keeps its workgroups in step): whoever is ahead waits for the first
+// loads of the next segment, which are misses for the leader and hits for the rest.
+constexpr int kSegSteps = 64;  // 32-deep stages per segment (2048 of contraction)
+
+struct Dh3Args {
+  const uint16_t *a1, *a2, *b1, *b2;  // d logits hi / lo [M, K], W^T hi / lo [N, K]
+  Geom geo;                            // M = rows, N = hidden, Kc = vocab
+  int mt, nt;
+  int ksplit, ksteps;                  // stages (of 32) per slice
+  float* partial;                      // [ksplit][M][N] (ksplit > 1) or the fp32 output itself (ksplit == 1)
+};
+
+__global__ __launch_bounds__(CfgTriple::NT, 2) void gemm_dh3_kernel(Dh3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  using C = CfgTriple;
+  const int tiles = a.mt * a.nt;
+  int kz, L;
+  if (a.ksplit == 8) {  // slice = XCD; the tile list of a slice is walked in groups of 8 row tiles, row-fastest
+    kz = (int)blockIdx.x & 7;
+    L = (int)blockIdx.x >> 3;
+  } else {
+    kz = (int)blockIdx.x / tiles;
+    L = (int)blockIdx.x - kz * tiles;
+  }
+  constexpr int GM = 8;
+  const int per_group = GM * a.nt;
+  const int grp = L / per_group;
+  const int first_m = grp * GM;
+  const int gsz = (a.mt - first_m) < GM ? (a.mt - first_m) : GM;
+  const int in = L - grp * per_group;
+  const int tm = first_m + in % gsz, tn = in / gsz;
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
+  f32x16 acc[2][4];
+  zero_acc<4>(acc);
+  const int total_steps = a.geo.Kc / BK32;
+  const int s0 = kz * a.ksteps;
+  int s1 = s0 + a.ksteps;
+  s1 = s1 < total_steps ? s1 : total_steps;
+  for (int s = s0; s < s1; s += kSegSteps) {
+    const int n = (s1 - s) < kSegSteps ? (s1 - s) : kSegSteps;
+    Geom g = a.geo;
+    g.Kc = n * BK32;
+    const int64_t k0 = (int64_t)s * BK32;
+    gemm_mainloop_triple(acc, a.a1 + k0, a.a2 + k0, a.b1 + k0, a.b2 + k0, g, m0, n0, lds);
+  }
+  float* out = a.partial + (a.ksplit > 1 ? (int64_t)kz * a.geo.M * a.geo.N : 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + acc_row(lane, wrow0, i, r);
+      if (row >= a.geo.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + acc_col(lane, wcol0, j);  // 32 consecutive lanes -> 32 consecutive columns
+        if (col < a.geo.N) out[(int64_t)row * a.geo.N + col] = acc[i][j][r];
+      }
+    }
+}
+
 // out[m, n] = sum over kz (ascending) of partial[kz][m][n]; M * N is a multiple of 4 (N = hidden is a multiple of 64)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t quads, int64_t plane, int ksplit, const float* __restrict__ partial,
                                                             void* out, int out_bf16) {
@@ -1317,15 +1385,33 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       g.out_bf16 = grad_hidden_dtype == PRL_DTYPE_BF16;
       g.accumulate = 0;
       g.out = static_cast<char*>(grad_hidden) + (size_t)r0 * hidden * (g.out_bf16 ? 2 : 4);
-      const int steps = (int)(vocab / BK);
-      g.ksplit = pick_ksplit(g.mt * g.nt, steps);
-      g.ksteps = ceil_div(steps, g.ksplit);
-      g.ksplit = ceil_div(steps, g.ksteps);  // no empty slice
       g.partial = reinterpret_cast<float*>(ws + L.dh_partial);
-      if (int rc = PRL_LAUNCH_CFG(shape, gemm_nt_kernel, g.mt * g.nt * g.ksplit, g, s, "gemm_nt_kernel(d hidden)")) return rc;
-      if (g.ksplit > 1) {
+      // PRL_TUNE_LMHEAD_BWD bit 0: 1 = the round-2 structure (generic core, the three products one after the other)
+      const bool triple = g.terms.n == 3 && (prl::tuning(PRL_TUNE_LMHEAD_BWD, 0) & 1) == 0;
+      int slices = 1;       // fp32 slices in g.partial to be added (and converted) into g.out; 0: the kernel wrote g.out itself
+      if (triple) {
+        Dh3Args d3{dl_hi, dl_lo, wt_hi, wt_lo, g.geo, ceil_div(m, CfgTriple::BM), ceil_div(hidden, CfgTriple::BN), 1, 0, nullptr};
+        const int steps32 = (int)(vocab / BK32);
+        d3.ksplit = pick_ksplit(d3.mt * d3.nt, steps32 / 2);
+        // one slice per XCD whenever the grid then still fills whole rounds and a slice keeps at least two segments
+        if (prl::tuning(PRL_TUNE_LMHEAD_KSPLIT, 0) == 0 && ((int64_t)d3.mt * d3.nt * 8) % 256 == 0 && steps32 / 8 >= 2 * kSegSteps) d3.ksplit = 8;
+        d3.ksteps = ceil_div(steps32, d3.ksplit);
+        d3.ksplit = ceil_div(steps32, d3.ksteps);  // no empty slice
+        const bool direct = d3.ksplit == 1 && !g.out_bf16;  // a single fp32 slice IS the output
+        d3.partial = direct ? static_cast<float*>(g.out) : g.partial;
+        if (int rc = launch_tiles(gemm_dh3_kernel, CfgTriple::NT, CfgTriple::LDS_BYTES, d3.mt * d3.nt * d3.ksplit, d3, s, "gemm_dh3_kernel(d hidden)")) return rc;
+        slices = direct ? 0 : d3.ksplit;
+      } else {
+        const int steps = (int)(vocab / BK);
+        g.ksplit = pick_ksplit(g.mt * g.nt, steps);
+        g.ksteps = ceil_div(steps, g.ksplit);
+        g.ksplit = ceil_div(steps, g.ksteps);  // no empty slice
+        if (int rc = PRL_LAUNCH_CFG(shape, gemm_nt_kernel, g.mt * g.nt * g.ksplit, g, s, "gemm_nt_kernel(d hidden)")) return rc;
+        slices = g.ksplit > 1 ? g.ksplit : 0;
+      }
+      if (slices > 0) {
         const int64_t quads = m * hidden / 4;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(quads, 256)), dim3(256), 0, s, quads, m * hidden, g.ksplit,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(quads, 256)), dim3(256), 0, s, quads, m * hidden, slices,
                            g.partial, g.out, g.out_bf16);
         PRL_LAUNCH_CHECK("splitk_reduce_kernel");
       }

@@ -47,8 +47,9 @@ def test_plugins_to_learner(libprl, cuda_device, tmp_path, wire):
     try:
         V, accumulate = 64, 16
         state = types.SimpleNamespace(propagated_weight_version=3)
-        harness = ActorHarness(CFG, [ScriptedLLM(vocab=V, flaky_calls=(5,)), ScriptedLLM(vocab=V, split=0.3)]  # two styles: rewards differ inside a group, tmp_path, trainer_state=state,
+        harness = ActorHarness(CFG, [ScriptedLLM(vocab=V, flaky_calls=(5,)), ScriptedLLM(vocab=V, split=0.3)], tmp_path, trainer_state=state,
                                scheduler_name="actor0", wire=wire, shuffle_seed=1)
+        # two differently scripted llms: the rollouts of a group get different rewards, so advantages are not all zero
         n_actor = harness.run()  # 8 problems x 4 attempts, several turns each
         assert harness.published_groups == 8 and n_actor >= 2 * accumulate and harness.retries == 1
         rl = RLConfig(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0,
