@@ -587,6 +587,24 @@ int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidden, int64_t 
                             int64_t chunk_rows, int32_t flags, void* workspace,
                             size_t workspace_bytes, prl_stream_t stream);
 
+/*
+ * Mixed-precision form of the same head (reference lines as above: rl/__init__.py:204-233 on top of the fp32 lm_head of
+ * checkpoints.py:87-103): the fp32 weight is held as  W S_w = w16 + w8lo 2^-4  with w16 = f16(W S_w) and w8lo the
+ * fp8 (e4m3) rounding residual in the slot order of the MX instruction; the bf16 hidden states become f16 (exact) and an fp8
+ * copy.  logits S_w S_h = w16 h16^T (f16 MFMA) + 2^3 w8lo h8^T (MX-scaled fp8 MFMA at twice the f16 rate): 3/4 of the
+ * matrix-pipe time of the two-bf16-plane form at ~1e-5 instead of ~4e-6 relative error (fp32: 1e-7).
+ * `scales`: 4 device floats owned by the caller; prepare writes S_w to [0], every forward S_h to [1] ([2], [3]: scratch).
+ * A bf16 weight is f16-exact after scaling: pass w8lo = NULL.
+ */
+int prl_lm_head_prepare_mx(int64_t vocab, int64_t hidden, const void* weight, int32_t weight_dtype,
+                           uint16_t* w16, uint8_t* w8lo, float* scales, prl_stream_t stream);
+int prl_lm_head_mx_workspace_bytes(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, size_t* fwd_bytes);
+int prl_lm_head_logprob_fwd_mx(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
+                               const uint16_t* hidden_bf16, const uint16_t* w16, const uint8_t* w8lo,
+                               float* scales, const int64_t* input_ids, float temperature,
+                               float* new_logprobs, float* entropy, float* lse2, void* workspace,
+                               size_t workspace_bytes, prl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "prl_common.h"
 #include "prl_lmhead_layout.h"
@@ -49,6 +50,11 @@ using namespace prl::lmhead;
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MAX_TERMS = 3;
 
@@ -551,6 +557,168 @@ __device__ __forceinline__ void gemm_mainloop_triple(f32x16 (&acc)[2][4], const 
   }
 }
 
+// -----------------------------------------------------------------------------------------------
+// mixed-precision main loop: acc += A16 B16^T (f16 MFMA) + 2^s (A8 B8^T) (MX-scaled fp8 MFMA, twice the f16 rate)
+// -----------------------------------------------------------------------------------------------
+// The fp32 operand X is held as  X S = X16 + X8 2^-4  with X16 = f16(X S) (11 significant bits) and X8 = fp8_e4m3 of the
+// rounding residual (|residual| <= 2^-11 |X S|, 4 more bits): 15 bits where the two bf16 planes had 16, at 3/4 of the
+// matrix-pipe time.  In  (A16 + a)(B16 + b)  the cross terms are 2^-11 corrections, so they need 4 bits, not 11: the OTHER
+// operand enters them rounded to fp8 and the product runs on the MX instruction, whose 32 x 32 accumulator layout is the
+// f16 instruction's (both add into ONE accumulator).  Error of the result: the fp8 roundings, 2^-4 relative on a 2^-11
+// term - 2e-5 per term at worst, ~1e-5 of the result's scale over a contraction - against the 4e-6 of the two-bf16-plane
+// form; the fp32 GEMM both stand for is exact to 1e-7.  (Probe of instruction semantics, rates and the free choice of K
+// slots: profiles/r03b_mx_probe.txt.)
+//
+// This loop is the forward / recompute form: A16 (weight rows) and B16 (hidden states) are staged as f16, A8 (the weight's
+// residual plane) and B8 (the hidden states rounded to fp8) as fp8 in slot order (prl_lmhead_layout.h).  32-deep stages;
+// the MX instruction spans two of them (64 deep): the 16-bit tiles live in a ring of three (2 x 16 KB per stage), the fp8
+// tiles (2 x 8 KB per stage) in a ring of FOUR, because the tiles of the even stage are read at the end of the odd one,
+// when the 16-bit buffer of the even stage is already being refilled.
+// (Rounding B16 to fp8 in registers instead of staging B8 would save a sixth of the staged bytes, but the rounded
+// fragments of a stage pair have to stay in registers - 32 more per lane next to the 128 accumulators: 47 spilled.)
+struct CfgMx {
+  static constexpr int BM = 256, BN = 256, NT = 512, STAGES = 3, STAGES8 = 4;
+  static constexpr int NJ = 4, WCOLS = 128;
+  static constexpr int Q = 2;                            // 16-byte chunks per thread of a 16-bit tile
+  static constexpr int LOADS = 2 * Q + 2;                // + one chunk of each fp8 tile
+  static constexpr int TILE_BYTES = 256 * ROW_BYTES32;   // 16 KB
+  static constexpr int TILE8_BYTES = 256 * 32;           // 8 KB
+  static constexpr int STAGE_BYTES = 2 * TILE_BYTES;     // 32 KB of 16-bit tiles per stage
+  static constexpr int STAGE8_BYTES = 2 * TILE8_BYTES;   // 16 KB of fp8 tiles per stage
+  static constexpr int LDS8_BASE = STAGES * STAGE_BYTES;  // 96 KB
+  static constexpr int LDS_BYTES = LDS8_BASE + STAGES8 * STAGE8_BYTES;  // 160 KB: all of a CU's LDS
+};
+constexpr int kE8M0 = 127;                 // E8M0 exponent of scale 1
+constexpr float kHi8Div = 128.0f;          // an f16 plane value (<= 2^15) / 128 -> fp8 range (<= 256 < 448)
+constexpr int kHi8Exp = kE8M0 + 7;         // ... and the MX scale that undoes it
+constexpr float kLo8Mul = 16.0f;           // a residual (<= 16) * 16 -> fp8 range
+constexpr int kLo8Exp = kE8M0 - 4;
+
+__device__ __forceinline__ int e8m0x4(int e) { return e * 0x01010101; }
+
+template <bool HAS_LO>
+__device__ __forceinline__ void gemm_mainloop_mx(f32x16 (&acc)[2][4], const uint16_t* A16, const uint16_t* B16, const uint8_t* A8,
+                                                 const uint8_t* B8, const Geom& g, int m0, int n0, char* lds) {
+  using C = CfgMx;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kcol = stage_kcol32(tid);
+  int64_t offA[C::Q], offB[C::Q], offA8, offB8;
+#pragma unroll
+  for (int q = 0; q < C::Q; ++q) {
+    int ra = m0 + stage_row32(tid, q, C::NT);
+    ra = ra < g.M ? ra : g.M - 1;
+    int rb = n0 + stage_row32(tid, q, C::NT);
+    rb = rb < g.N ? rb : g.N - 1;
+    offA[q] = (int64_t)ra * g.lda + kcol;
+    offB[q] = (int64_t)rb * g.ldb + kcol;
+  }
+  {  // the fp8 planes have one byte per element: the row strides (in elements) are their row strides in bytes
+    int ra = m0 + mx8_stage_row(tid);
+    ra = ra < g.M ? ra : g.M - 1;
+    int rb = n0 + mx8_stage_row(tid);
+    rb = rb < g.N ? rb : g.N - 1;
+    offA8 = (int64_t)ra * g.lda + 16 * mx8_stage_half(tid);
+    offB8 = (int64_t)rb * g.ldb + 16 * mx8_stage_half(tid);
+  }
+  int rdA[2], rdB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    rdA[ks] = frag_lds_byte32(lane, wm * 64, 0, ks);
+    rdB[ks] = C::TILE_BYTES + frag_lds_byte32(lane, wn * C::WCOLS, 0, ks);
+  }
+  // tile i / j: + 32 rows * 32 bytes (the swizzle term depends on (row >> 3) & 1 only, which + 32 leaves unchanged)
+  const int rdA8 = mx8_frag_lds_byte(lane, wm * 64, 0), rdB8 = C::TILE8_BYTES + mx8_frag_lds_byte(lane, wn * C::WCOLS, 0);
+  const int total = g.Kc / BK32;  // even (Kc is a multiple of 64)
+  int st_k = 0;
+  auto stage_piece = [&](int buf, int buf8, int idx) {  // idx 0..5: A16 q0 q1, B16 q0 q1, A8, B8
+    const unsigned lane0 = stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
+    if (idx < 4) {
+      const int tile = idx >> 1, q = idx & 1;
+      const uint16_t* src = tile == 0 ? A16 + offA[q] : B16 + offB[q];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + st_k),
+                                       (__attribute__((address_space(3))) void*)(lds + buf * C::STAGE_BYTES + lane0 + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
+    } else if (HAS_LO) {
+      const uint8_t* src = idx == 4 ? A8 + offA8 : B8 + offB8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + st_k),
+                                       (__attribute__((address_space(3))) void*)(lds + C::LDS8_BASE + buf8 * C::STAGE8_BYTES + lane0 + (idx - 4) * C::TILE8_BYTES), 16, 0, 0);
+    }
+  };
+  constexpr int NLOADS = HAS_LO ? C::LOADS : C::LOADS - 2;
+  const bool dma_first = wave >= 4;
+  // one 32-deep stage: 16 f16 MFMAs; an ODD stage closes its pair with the 8 MX MFMAs over both stages' fp8 tiles
+  auto compute = [&](int buf, int buf8, int sbuf, int sbuf8, bool odd) {
+    const char* base = lds + buf * C::STAGE_BYTES;
+    if (sbuf >= 0 && dma_first) {
+#pragma unroll
+      for (int k = 0; k < NLOADS; ++k) stage_piece(sbuf, sbuf8, k);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 af[2], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f16x8*>(base + rdA[ks] + i * 32 * ROW_BYTES32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const f16x8*>(base + rdB[ks] + j * 32 * ROW_BYTES32);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (HAS_LO && odd) {
+      const char* even8 = lds + C::LDS8_BASE + ((buf8 + C::STAGES8 - 1) & (C::STAGES8 - 1)) * C::STAGE8_BYTES;
+      const char* odd8 = lds + C::LDS8_BASE + buf8 * C::STAGE8_BYTES;
+      i32x8 qa[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(even8 + rdA8 + i * 32 * 32);
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(odd8 + rdA8 + i * 32 * 32);
+        qa[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(even8 + rdB8 + j * 32 * 32);
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(odd8 + rdB8 + j * 32 * 32);
+        const i32x8 qb = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa[i], qb, acc[i][j], 0, 0, 0, e8m0x4(kLo8Exp), 0, e8m0x4(kHi8Exp));
+      }
+    }
+    if (sbuf >= 0 && !dma_first) {
+#pragma unroll
+      for (int k = 0; k < NLOADS; ++k) stage_piece(sbuf, sbuf8, k);
+    }
+  };
+
+  constexpr int D = C::STAGES - 1;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < D; ++p)
+    if (p < total) {
+#pragma unroll
+      for (int idx = 0; idx < NLOADS; ++idx) stage_piece(p, p, idx);
+      st_k += BK32;
+    }
+  int cur = 0, nxt = D % C::STAGES, cur8 = 0, nxt8 = D;
+  for (int s = 0; s < total; ++s) {
+    const bool more = s + D < total;
+    if (more || s + D - 1 < total) {
+      wait_tile_then_barrier<(D - 1) * NLOADS>();
+    } else {
+      wait_tile_then_barrier<0>();
+    }
+    compute(cur, cur8, more ? nxt : -1, nxt8, (s & 1) != 0);
+    st_k += BK32;
+    cur = cur + 1 == C::STAGES ? 0 : cur + 1;
+    nxt = nxt + 1 == C::STAGES ? 0 : nxt + 1;
+    cur8 = (cur8 + 1) & (C::STAGES8 - 1);
+    nxt8 = (nxt8 + 1) & (C::STAGES8 - 1);
+  }
+}
+
 // One call site for both cores: DUAL runs the dual-plane loop on (terms.a[0], terms.a[1], terms.b[0])
 template <class C, bool DUAL, int EXP = 0>
 __device__ __forceinline__ void run_mainloop(f32x16 (&acc)[2][C::NJ], const Terms& t, const Geom& g, int m0, int n0, char* lds) {
@@ -558,6 +726,19 @@ __device__ __forceinline__ void run_mainloop(f32x16 (&acc)[2][C::NJ], const Term
     gemm_mainloop_dual<(EXP & 256) ? 0 : 1>(acc, t.a[0], t.a[1], t.b[0], g, m0, n0, lds);
   } else {
     gemm_mainloop<C, EXP>(acc, t, g, m0, n0, lds);
+  }
+}
+
+// CORE: 0 generic, 1 dual-plane, 2 mixed precision (f16 + MX fp8: terms.a[0] = A16, terms.a[1] = A8 residual plane,
+// terms.b[0] = B16, terms.b[1] = B8 = B16 rounded to fp8), 3 mixed precision without a residual plane (an f16-exact weight)
+template <class C, int CORE, int EXP = 0>
+__device__ __forceinline__ void run_core(f32x16 (&acc)[2][C::NJ], const Terms& t, const Geom& g, int m0, int n0, char* lds) {
+  if constexpr (CORE == 2) {
+    gemm_mainloop_mx<true>(acc, t.a[0], t.b[0], reinterpret_cast<const uint8_t*>(t.a[1]), reinterpret_cast<const uint8_t*>(t.b[1]), g, m0, n0, lds);
+  } else if constexpr (CORE == 3) {
+    gemm_mainloop_mx<false>(acc, t.a[0], t.b[0], nullptr, nullptr, g, m0, n0, lds);
+  } else {
+    run_mainloop<C, CORE == 1, EXP>(acc, t, g, m0, n0, lds);
   }
 }
 
@@ -584,9 +765,10 @@ struct FwdArgs {
   int64_t padded;       // tt * BN
   float* part;          // [nsplit][padded][4]  (M, S, W, -)
   float* ysel;          // [padded] selected logit (base-2 units), written by whichever split owns the row
+  const float* scales;  // mixed-precision cores: device floats {S_w, S_h} the operands were multiplied by; nullptr otherwise
 };
 
-template <class C, int EXP = 0, bool DUAL = false>
+template <class C, int EXP = 0, int CORE = 0>
 __global__ __launch_bounds__(C::NT, 2) void lmhead_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int tok_tile, split;
@@ -598,6 +780,8 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_fwd_kernel(FwdArgs a) {
   const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
   const int V = a.geo.M;
 
+  // the mixed-precision operands carry power-of-two scales: exact to undo
+  const float k2 = a.scales ? a.k2 / (a.scales[0] * a.scales[1]) : a.k2;
   Osm st[NJ];
   int tgt[NJ];  // target vocabulary row of this lane's tokens, -1: none
 #pragma unroll
@@ -616,7 +800,7 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_fwd_kernel(FwdArgs a) {
   for (int tv = vt0; tv < vt1; ++tv) {
     const int m0 = tv * C::BM;
     zero_acc<NJ>(acc);
-    run_mainloop<C, DUAL, EXP>(acc, a.terms, a.geo, m0, n0, lds);
+    run_core<C, CORE, EXP>(acc, a.terms, a.geo, m0, n0, lds);
     const int vbase = m0 + acc_row(lane, wrow0, 0, 0);  // vocabulary row of acc[0][j][0]; + 32 i + (reg & 3) + 8 (reg >> 2)
     const bool full = m0 + C::BM <= V;
 #pragma unroll
@@ -625,7 +809,7 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_fwd_kernel(FwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[i * 16 + r] = acc[i][j][r] * a.k2;
+        for (int r = 0; r < 16; ++r) y[i * 16 + r] = acc[i][j][r] * k2;
       const int d = tgt[j] - vbase;
       if (d >= 0 && d < 64 && (d & 7) < 4) {  // the target row is one of this lane's 32
         float sel = 0.0f;
@@ -1053,6 +1237,95 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(int64_t R, int64_t
   }
 }
 
+// ---- mixed-precision operand preparation -------------------------------------------------------------------
+// max |x| of a tensor as the bit pattern of a non-negative float (orders like an unsigned integer): *out must be 0 before
+template <class SRC>
+__global__ __launch_bounds__(256) void absmax_kernel(int64_t n, const SRC* __restrict__ src, uint32_t* out) {
+  float m = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float x;
+    if constexpr (sizeof(SRC) == 4) {
+      x = src[i];
+    } else {
+      x = bf16_to_f32(src[i]);
+    }
+    x = fabsf(x);
+    m = (x == x && x < 3.0e38f) ? fmaxf(m, x) : m;  // NaN / inf do not define a scale (they still poison the product)
+  }
+  m = prl::wave_max(m);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    atomicMax(out, __float_as_uint(m));
+  }
+}
+
+// power-of-two scale S with max |x| S in [2^14, 2^15): f16 keeps 11 significant bits down to 2^-14, i.e. 2^-29 of the largest
+__device__ __forceinline__ float mx_scale_of(uint32_t max_bits) {
+  const float mx = __uint_as_float(max_bits);
+  if (!(mx > 0.0f)) return 1.0f;
+  int e;
+  frexpf(mx, &e);  // mx = m 2^e, m in [0.5, 1)
+  e = 15 - e;
+  e = e > 40 ? 40 : (e < -40 ? -40 : e);
+  return ldexpf(1.0f, e);
+}
+
+__device__ __forceinline__ uint16_t f16_bits(float x) {
+  const _Float16 h = (_Float16)x;  // round to nearest even
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float f16_value(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+
+// x [R, K] (fp32 or bf16) -> x16 = f16(x S) [R, K] and, optionally, the residual plane x8 = fp8_e4m3((x S - x16) * 16) in the
+// slot order of the MX core (prl_lmhead_layout.h: per row and 32-deep block [half 0: 16 bytes][half 1: 16 bytes]); the
+// transposed planes [K, ldt] likewise (their contraction index is the ROW of x).  One thread = 8 consecutive elements of a row.
+// S = mx_scale_of(*max_bits) is published to *scale_out by thread 0.
+// RESIDUAL false: x8 = fp8(x16 / 128), the plane itself rounded to fp8 (the partner of another operand's residual plane).
+template <class SRC, bool RESIDUAL>
+__global__ __launch_bounds__(256) void mx_convert_kernel(int64_t R, int64_t K, const SRC* __restrict__ src, const uint32_t* max_bits,
+                                                         float* scale_out, uint16_t* x16, uint8_t* x8) {
+  const float S = mx_scale_of(*max_bits);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && scale_out) *scale_out = S;
+  const int64_t groups = R * (K / 8);
+  for (int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = gidx / (K / 8), k0 = (gidx % (K / 8)) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if constexpr (sizeof(SRC) == 4) {
+        v[e] = src[row * K + k0 + e] * S;
+      } else {
+        v[e] = bf16_to_f32(src[row * K + k0 + e]) * S;
+      }
+    }
+    uint16_t h[8];
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      h[e] = f16_bits(v[e]);
+      r[e] = RESIDUAL ? (v[e] - f16_value(h[e])) * kLo8Mul : f16_value(h[e]) * (1.0f / kHi8Div);
+    }
+    uint4 pk;
+    pk.x = h[0] | ((uint32_t)h[1] << 16);
+    pk.y = h[2] | ((uint32_t)h[3] << 16);
+    pk.z = h[4] | ((uint32_t)h[5] << 16);
+    pk.w = h[6] | ((uint32_t)h[7] << 16);
+    *reinterpret_cast<uint4*>(x16 + row * K + k0) = pk;
+    if (x8) {
+      int d0 = 0, d1 = 0;
+      d0 = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], d0, false);
+      d0 = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], d0, true);
+      d1 = __builtin_amdgcn_cvt_pk_fp8_f32(r[4], r[5], d1, false);
+      d1 = __builtin_amdgcn_cvt_pk_fp8_f32(r[6], r[7], d1, true);
+      const int kb = (int)(k0 & 31);  // 0, 8, 16, 24: eight consecutive elements are eight consecutive slots
+      *reinterpret_cast<uint2*>(x8 + row * K + (k0 - kb) + mx_byte_in_block(kb)) = uint2{(uint32_t)d0, (uint32_t)d1};
+    }
+  }
+}
+
 // Workgroup shape per launch.  PRL_TUNE_LMHEAD_TILE = 128 | 256 | 512 (= 256 x 256) forces one (a table read, no
 // getenv: one process can A/B them); default: the largest tile whose grid still fills the 256 CUs.
 enum Shape { kSmall = 0, kBig = 1, kWide = 2 };
@@ -1265,6 +1538,7 @@ extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidde
   if (workspace_bytes < need) return prl::set_error(PRL_ENOMEM, "lm_head forward workspace: %zu bytes given, %zu needed", workspace_bytes, need);
   a.part = static_cast<float*>(workspace);
   a.ysel = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_bytes);
+  a.scales = nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int exp_bits = (int)prl::tuning(PRL_TUNE_LMHEAD_EXP, 0);
   if (shape == kWide && exp_bits && exp_bits != 256) {  // timing ablations, generic 256 x 256 forward only
@@ -1446,5 +1720,114 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       }
     }
   }
+  return PRL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mixed-precision head (f16 + MX fp8 residual plane): operand preparation and forward
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct MxFwdLayout {
+  size_t part, ysel, h16, h8, maxbits, total;
+  int64_t padded;
+  int nsplit, tt, vt;
+};
+
+MxFwdLayout mx_fwd_layout(int64_t n, int64_t hidden, int64_t vocab) {
+  MxFwdLayout L;
+  L.tt = ceil_div(n, CfgMx::BN);
+  L.vt = ceil_div(vocab, CfgMx::BM);
+  L.nsplit = fwd_nsplit(L.tt, L.vt, true);
+  L.padded = (int64_t)L.tt * CfgMx::BN;
+  size_t o = 0;
+  L.part = o;
+  o += align256((size_t)L.nsplit * L.padded * 16);
+  L.ysel = o;
+  o += align256((size_t)L.padded * 4);
+  L.h16 = o;
+  o += align256((size_t)n * hidden * 2);
+  L.h8 = o;
+  o += align256((size_t)n * hidden);
+  L.maxbits = o;
+  o += 256;
+  L.total = o;
+  return L;
+}
+
+template <class SRC, bool RESIDUAL>
+int mx_convert(int64_t R, int64_t K, const SRC* src, uint32_t* max_bits, float* scale_out, uint16_t* x16, uint8_t* x8, hipStream_t s) {
+  PRL_HIP_CHECK(hipMemsetAsync(max_bits, 0, 4, s));
+  const int64_t n = R * K;
+  const int blocks = (int)((n / 8 + 255) / 256 < 4096 ? (n / 8 + 255) / 256 : 4096);
+  hipLaunchKernelGGL((absmax_kernel<SRC>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, n, src, max_bits);
+  PRL_LAUNCH_CHECK("absmax_kernel");
+  hipLaunchKernelGGL((mx_convert_kernel<SRC, RESIDUAL>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, R, K, src, max_bits, scale_out, x16, x8);
+  PRL_LAUNCH_CHECK("mx_convert_kernel");
+  return PRL_OK;
+}
+
+}  // namespace
+
+extern "C" int prl_lm_head_mx_workspace_bytes(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, size_t* fwd_bytes) {
+  PRL_CHECK_ARG(rows >= 1 && cols >= 1 && hidden >= 1 && vocab >= 1 && fwd_bytes, "bad arguments");
+  *fwd_bytes = mx_fwd_layout(rows * cols, hidden, vocab).total;
+  return PRL_OK;
+}
+
+extern "C" int prl_lm_head_prepare_mx(int64_t vocab, int64_t hidden, const void* weight, int32_t weight_dtype, uint16_t* w16,
+                                      uint8_t* w8lo, float* scales, prl_stream_t stream) {
+  PRL_CHECK_ARG(vocab >= 1 && hidden >= 64 && hidden % 64 == 0 && weight && w16 && scales, "bad arguments");
+  PRL_CHECK_ARG(weight_dtype == PRL_DTYPE_F32 || weight_dtype == PRL_DTYPE_BF16, "unsupported weight dtype %d", weight_dtype);
+  PRL_CHECK_ARG(prl::aligned16(w16) && (!w8lo || prl::aligned16(w8lo)) && prl::aligned16(scales), "outputs must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uint32_t* max_bits = reinterpret_cast<uint32_t*>(scales + 2);  // scales[0] = S_w, [1] = S_h (per call), [2] scratch
+  if (weight_dtype == PRL_DTYPE_F32) return mx_convert<float, true>(vocab, hidden, static_cast<const float*>(weight), max_bits, scales, w16, w8lo, s);
+  return mx_convert<uint16_t, true>(vocab, hidden, static_cast<const uint16_t*>(weight), max_bits, scales, w16, w8lo, s);
+}
+
+extern "C" int prl_lm_head_logprob_fwd_mx(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
+                                          const uint16_t* w16, const uint8_t* w8lo, float* scales, const int64_t* input_ids,
+                                          float temperature, float* new_logprobs, float* entropy, float* lse2, void* workspace,
+                                          size_t workspace_bytes, prl_stream_t stream) {
+  PRL_CHECK_ARG(rows >= 1 && cols >= 1, "rows and cols must be >= 1");
+  PRL_CHECK_ARG(hidden >= 64 && hidden % 64 == 0, "hidden size %lld must be a multiple of 64", (long long)hidden);
+  PRL_CHECK_ARG(vocab >= 1 && vocab < ((int64_t)1 << 31) - 256 && rows * cols < ((int64_t)1 << 31) - 256, "shape out of range");
+  PRL_CHECK_ARG(hidden_bf16 && w16 && scales && input_ids && new_logprobs && entropy && lse2 && workspace, "null pointer");
+  PRL_CHECK_ARG(prl::aligned16(hidden_bf16) && prl::aligned16(w16) && (!w8lo || prl::aligned16(w8lo)), "operands must be 16-byte aligned");
+  PRL_CHECK_ARG(temperature > 0.0f, "temperature must be > 0");
+  const int64_t n = rows * cols;
+  const MxFwdLayout L = mx_fwd_layout(n, hidden, vocab);
+  if (workspace_bytes < L.total) return prl::set_error(PRL_ENOMEM, "lm_head mx forward workspace: %zu bytes given, %zu needed", workspace_bytes, L.total);
+  char* ws = static_cast<char*>(workspace);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uint16_t* h16 = reinterpret_cast<uint16_t*>(ws + L.h16);
+  uint8_t* h8 = w8lo ? reinterpret_cast<uint8_t*>(ws + L.h8) : nullptr;
+  if (int rc = mx_convert<uint16_t, false>(n, hidden, hidden_bf16, reinterpret_cast<uint32_t*>(ws + L.maxbits), scales + 1, h16, h8, s)) return rc;
+  FwdArgs a;
+  a.terms.n = w8lo ? 2 : 1;
+  for (int k = 0; k < MAX_TERMS; ++k) {
+    a.terms.a[k] = k == 1 ? reinterpret_cast<const uint16_t*>(w8lo) : w16;
+    a.terms.b[k] = k == 1 ? reinterpret_cast<const uint16_t*>(h8) : h16;
+  }
+  a.geo = Geom{(int)vocab, (int)n, (int)hidden, hidden, hidden};
+  a.cols = cols;
+  a.ids = input_ids;
+  a.k2 = kLog2e / temperature;
+  a.tt = L.tt;
+  a.vt = L.vt;
+  a.nsplit = L.nsplit;
+  a.padded = L.padded;
+  a.part = reinterpret_cast<float*>(ws + L.part);
+  a.ysel = reinterpret_cast<float*>(ws + L.ysel);
+  a.scales = scales;
+  if (w8lo) {
+    if (int rc = launch_tiles(lmhead_fwd_kernel<CfgMx, 0, 2>, CfgMx::NT, CfgMx::LDS_BYTES, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(mx)")) return rc;
+  } else if (int rc = launch_tiles(lmhead_fwd_kernel<CfgMx, 0, 3>, CfgMx::NT, CfgMx::LDS_BYTES, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(mx, f16-exact weight)")) {
+    return rc;
+  }
+  hipLaunchKernelGGL(lmhead_fwd_finish_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, n, cols, (int)vocab, a.nsplit,
+                     a.padded, a.part, a.ysel, input_ids, new_logprobs, entropy, lse2);
+  PRL_LAUNCH_CHECK("lmhead_fwd_finish_kernel");
   return PRL_OK;
 }

@@ -20,6 +20,7 @@ two-plane split reproduces the fp32 head to ~2^-17 relative.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Any
 
 import torch
@@ -40,7 +41,7 @@ class FusedLmHead:
     `.data.copy_()` must call `invalidate()` - same contract as lm_head.SplitBf16LmHead."""
 
     def __init__(self, weight: torch.Tensor, backward: bool = True, chunk_rows: int = 4096, hidden_grad_terms: int = 3,
-                 skip_unlabelled: bool = True):
+                 skip_unlabelled: bool = True, precision: str | None = None):
         """`chunk_rows`: logits rows whose d logits planes live in the workspace at a time (4 x chunk x V x 2 bytes).
         `hidden_grad_terms`: 3 = d hidden from every bf16 product (fp32-GEMM accuracy before the final rounding),
         1 = leading product only (2^-9 relative, the size of the bf16 rounding of d hidden; two GEMM passes less).
@@ -56,6 +57,12 @@ class FusedLmHead:
         self.chunk_rows = int(chunk_rows)
         self.hidden_grad_terms = int(hidden_grad_terms)
         self.skip_unlabelled = bool(skip_unlabelled)
+        # "bf16x2": the fp32 weight as two bf16 planes (~4e-6 relative); "f16_fp8": an f16 plane + an fp8 residual plane on the
+        # MX instruction (~1e-5 relative, 3/4 of the matrix-pipe time) - forward only so far, the backward keeps the bf16 planes
+        self.precision = precision or os.environ.get("PRL_LMHEAD_PRECISION", "bf16x2")
+        if self.precision not in ("bf16x2", "f16_fp8"):
+            raise ValueError(f"unknown precision {self.precision!r}")
+        self.w16 = self.w8lo = self.mx_scales = None
         self._key = None
         self.w_hi = self.w_lo = self.wt_hi = self.wt_lo = None
         self._ws: dict[Any, torch.Tensor] = {}
@@ -99,6 +106,13 @@ class FusedLmHead:
             with torch.cuda.device(dev):
                 _lib.check(lib.prl_lm_head_prepare(V, H, src.data_ptr(), 0 if w.dtype == torch.float32 else 1,
                                                    *[_lib.ptr(o) for o in outs], _lib.current_stream_ptr(dev)))
+        if self.precision == "f16_fp8":
+            self.w16 = torch.empty((V, H), dtype=torch.float16, device=dev)
+            self.w8lo = torch.empty((V, H), dtype=torch.uint8, device=dev) if w.dtype == torch.float32 else None
+            self.mx_scales = torch.zeros(4, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.prl_lm_head_prepare_mx(V, H, src.data_ptr(), 0 if w.dtype == torch.float32 else 1, self.w16.data_ptr(),
+                                                      _lib.ptr(self.w8lo), self.mx_scales.data_ptr(), _lib.current_stream_ptr(dev)))
         self._key = key
 
     def _workspace(self, kind: str, rows: int, cols: int, dev: torch.device, chunk_rows: int) -> torch.Tensor:
@@ -131,6 +145,18 @@ class FusedLmHead:
         nlp = torch.empty((B, L), dtype=torch.float32, device=dev)
         ent = torch.empty_like(nlp)
         lse2 = torch.empty_like(nlp)
+        if self.precision == "f16_fp8":
+            need = ctypes.c_size_t(0)
+            _lib.check(lib.prl_lm_head_mx_workspace_bytes(B, L, H, self.vocab, ctypes.byref(need)))
+            key = ("fwd_mx", dev, _lib.current_stream_ptr(dev))
+            ws = self._ws.get(key)
+            if ws is None or ws.numel() < need.value:
+                ws = self._ws[key] = torch.empty(need.value, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.prl_lm_head_logprob_fwd_mx(B, L, H, self.vocab, h.data_ptr(), self.w16.data_ptr(), _lib.ptr(self.w8lo),
+                                                          self.mx_scales.data_ptr(), ids.data_ptr(), float(temperature), nlp.data_ptr(),
+                                                          ent.data_ptr(), lse2.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev)))
+            return nlp, ent, lse2, h
         ws = self._workspace("fwd", B, L, dev, self.chunk_rows)
         with torch.cuda.device(dev):
             _lib.check(lib.prl_lm_head_logprob_fwd(B, L, H, self.vocab, h.data_ptr(), self.w_hi.data_ptr(), _lib.ptr(self.w_lo),
