@@ -386,23 +386,36 @@ def fused_head_probe(dev: torch.device, seq_length: int, vocab: int, hidden: int
     bwd_ms = timed(lambda: head.backward_from_token_grads(hb, ids, 1.0, lse2, ent, g_nlp, None, None, grad_weight=gw), 2)
     gemm = 2.0 * T * V * H
     fwd_tf = 2 * gemm / (fwd_ms * 1e-3) / 1e12
-    del gw, head, W
+    chunk_rows = head.chunk_rows
+    del gw, head
+    torch.cuda.empty_cache()
+    # the opt-in mixed-precision forward (f16 plane + fp8 residual plane on the MX instruction): same logits to ~1e-5
+    try:
+        head_mx = FusedLmHead(W, backward=False, precision="f16_fp8")
+        mx_ms = timed(lambda: head_mx.logprob_entropy(h, ids, 1.0), 5)
+        nlp_mx = head_mx.logprob_entropy(h, ids, 1.0)[0]
+        mixed = {"ms": mx_ms, "max_abs_logprob_difference_vs_bf16x2": float((nlp_mx - nlp).abs().max().item()),
+                 "what": "f16 plane on v_mfma_f32_32x32x16_f16 + fp8 residual plane on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the rate), one accumulator; "
+                         "FusedLmHead(precision='f16_fp8'), opt-in: ~1e-5 relative instead of ~4e-6"}
+        del head_mx, nlp_mx
+    except Exception as e:  # noqa: BLE001
+        mixed = {"error": f"{type(e).__name__}: {e}"}
+    del W
     torch.cuda.empty_cache()
     return {
         "bound": "mfma", "kernel": "lmhead_fwd_kernel<CfgDual: 256x256x32 dual-plane tile, 3 LDS stages, 8 waves with staggered roles, v_mfma_f32_32x32x16_bf16>", "achieved": fwd_tf, "peak": MFMA_BF16_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": fwd_tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
         "flops_per_launch": 2 * gemm, "ms_per_launch": fwd_ms,
         "config": {"tokens": T, "hidden": H, "vocab": V, "weight": "fp32 as two bf16 planes (fp32-GEMM accuracy)", "logits_materialised_bytes": 0},
-        "backward": {"ms": bwd_ms, "executed_tflops": 7 * gemm / (bwd_ms * 1e-3) / 1e12, "chunk_rows": head_chunk_rows(),
-                     "what": "recompute (2 products) + d hidden (3) + d W (2), d logits as bf16 planes of one row chunk"},
+        "backward": {"ms": bwd_ms, "executed_tflops": 7 * gemm / (bwd_ms * 1e-3) / 1e12, "chunk_rows": chunk_rows,
+                     "what": "recompute (2 plane products, d logits as two ROW-MAJOR bf16 planes of one row chunk) + d hidden (3 products on the "
+                             "triple-plane core, one contraction slice per XCD) + d W (2 products, fragments gathered from the row-major planes by "
+                             "ds_read_b64_tr_b16)"},
+        "forward_mixed_precision": mixed,
         "fp32_equivalent_tflops": gemm / (fwd_ms * 1e-3) / 1e12,
         "note": "second roofline object for the MFMA-bound fused output head (hidden -> log-prob/entropy, logits never in HBM); "
                 "`roofline` above stays the HBM-bound kernel that dominates `value`",
     }
-
-
-def head_chunk_rows() -> int:
-    return 4096
 
 
 def weight_sync_probe(rank: int, world: int, dev: torch.device, out: dict) -> dict:

@@ -604,6 +604,18 @@ int prl_lm_head_logprob_fwd_mx(int64_t rows, int64_t cols, int64_t hidden, int64
                                float* scales, const int64_t* input_ids, float temperature,
                                float* new_logprobs, float* entropy, float* lse2, void* workspace,
                                size_t workspace_bytes, prl_stream_t stream);
+/* Backward of the mixed-precision forward: the logits are RECOMPUTED on the same core (so the probabilities are those
+ * the saved lse2 / entropy belong to); d hidden and d W run on the bf16 planes exactly as in prl_lm_head_logprob_bwd
+ * (wt_hi / wt_lo from prl_lm_head_prepare, workspace of prl_lm_head_workspace_bytes). */
+int prl_lm_head_logprob_bwd_mx(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
+                               const uint16_t* hidden_bf16, const uint16_t* w16, const uint8_t* w8lo,
+                               float* scales, const uint16_t* wt_hi, const uint16_t* wt_lo,
+                               const int64_t* input_ids, float temperature, const float* lse2,
+                               const float* entropy, const float* grad_new_logprobs,
+                               const float* grad_entropy, const float* upstream, void* grad_hidden,
+                               int32_t grad_hidden_dtype, float* grad_weight, int64_t chunk_rows,
+                               int32_t flags, void* workspace, size_t workspace_bytes,
+                               prl_stream_t stream);
 
 #ifdef __cplusplus
 }

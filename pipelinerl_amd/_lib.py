@@ -172,6 +172,8 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_lm_head_prepare_mx": (c_int32, [c_int64, c_int64, _P, c_int32, _P, _P, _P, _P]),
     "prl_lm_head_mx_workspace_bytes": (c_int32, [c_int64, c_int64, c_int64, c_int64, POINTER(c_size_t)]),
     "prl_lm_head_logprob_fwd_mx": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
+    "prl_lm_head_logprob_bwd_mx": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P,
+                                             c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
     "prl_lm_head_logprob_bwd": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P,
                                           c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
 }
@@ -219,7 +221,7 @@ _ENV_OF_KEY = {"fused_variant": "PRL_FUSED_VARIANT", "lmhead_tile": "PRL_LMHEAD_
                "loss_fast_stats": "PRL_LOSS_FAST_STATS", "loss_tpl": "PRL_LOSS_TPL", "loss_blocks_per_cu": "PRL_LOSS_BLOCKS_PER_CU",
                "pack_nt": "PRL_PACK_NT", "pack_tpl": "PRL_PACK_TPL", "lmhead_bwd": "PRL_LMHEAD_BWD"}
 _ENV_TUNED_ENTRY_POINTS = ("prl_fused_logits_loss", "prl_lm_head_logprob_fwd", "prl_lm_head_logprob_bwd", "prl_lm_head_workspace_bytes",
-                           "prl_lm_head_logprob_fwd_mx", "prl_lm_head_mx_workspace_bytes",
+                           "prl_lm_head_logprob_fwd_mx", "prl_lm_head_mx_workspace_bytes", "prl_lm_head_logprob_bwd_mx",
                            "prl_grpo_loss_fwd_bwd", "prl_pack_collate")
 _env_seen: tuple | None = None
 

@@ -448,6 +448,114 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
 }
 
 // -----------------------------------------------------------------------------------------------
+// dual-plane main loop with a TRANSPOSED A operand (d W from the row-major d-logits planes)
+// -----------------------------------------------------------------------------------------------
+// acc[v][n] += sum over t of (A1 + A2)[t][m0 + v] B[n0 + n][t]: A1 / A2 are [K, lda] row-major with the contraction index
+// as their ROW (d logits hi / lo, [tokens, vocabulary]), B is contraction-contiguous as everywhere else.  The A tiles are
+// staged as they lie in memory (512-byte row segments) and the fragments come out of ds_read_b64_tr_b16 (layout header).
+// Same stage geometry, ring and wave roles as the dual-plane core.
+__device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
+                                                      const Geom& g, int m0, int n0, char* lds) {
+  using C = CfgDual;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kcol = stage_kcol32(tid);
+  int64_t offA[C::Q], offB[C::Q];
+#pragma unroll
+  for (int q = 0; q < C::Q; ++q) {
+    int v = m0 + 8 * tr_stage_chunk(tid, q, C::NT);
+    v = v + 8 <= g.M ? v : g.M - 8;  // entries past the edge re-read the last eight; their results are discarded (M % 8 == 0)
+    offA[q] = (int64_t)tr_stage_row(tid, q, C::NT) * g.lda + v;
+    int rb = n0 + stage_row32(tid, q, C::NT);
+    rb = rb < g.N ? rb : g.N - 1;
+    offB[q] = (int64_t)rb * g.ldb + kcol;
+  }
+  // tile i = 1 is 4 chunks further: bit 2 of the chunk index, which the swizzle may flip - an XOR with 64 bytes, not an add
+  int rdA[2], rdB[2];
+  rdA[0] = tr_frag_lds_byte(lane, wm * 64, 0, 0, 0);
+  rdA[1] = tr_frag_lds_byte(lane, wm * 64, 1, 0, 0);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) rdB[ks] = 2 * C::TILE_BYTES + frag_lds_byte32(lane, wn * C::WCOLS, 0, ks);
+  const int total = g.Kc / BK32;
+  int st_k = 0;  // contraction (token) offset of the NEXT tile to stage
+  auto stage_piece = [&](int buf, int idx) {  // idx 0..5: A1 q0 q1, A2 q0 q1, B q0 q1
+    const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
+    const int tile = idx / C::Q, q = idx % C::Q;
+    const uint16_t* src = tile == 0 ? A1 + offA[q] + (int64_t)st_k * g.lda : tile == 1 ? A2 + offA[q] + (int64_t)st_k * g.lda : B + offB[q] + st_k;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + dst + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
+  };
+  const bool dma_first = wave >= 4;
+  // 8 tokens of one entry: two transposing reads (tokens 0-3: + 0, tokens 4-7: + 4 rows = 2048 bytes); sub-step ks: + 16 rows
+  auto a_frag = [&](const char* tile_base, int i, int ks) {
+    const char* p0 = tile_base + rdA[i] + ks * (16 * 512);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * 512));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+  auto compute = [&](int buf, int sbuf) {
+    const char* base = lds + buf * C::STAGE_BYTES;
+    if (sbuf >= 0 && dma_first) {
+#pragma unroll
+      for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a1[2], a2[2], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a1[i] = a_frag(base, i, ks);
+        a2[i] = a_frag(base + C::TILE_BYTES, i, ks);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(base + rdB[ks] + j * 32 * ROW_BYTES32);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], bfr[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (sbuf >= 0 && !dma_first) {
+#pragma unroll
+      for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
+    }
+  };
+  constexpr int D = C::STAGES - 1;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < D; ++p)
+    if (p < total) {
+#pragma unroll
+      for (int idx = 0; idx < C::LOADS; ++idx) stage_piece(p, idx);
+      st_k += BK32;
+    }
+  int cur = 0, nxt = D % C::STAGES;
+  int s = 0;
+  for (; s + D < total; ++s) {
+    wait_tile_then_barrier<(D - 1) * C::LOADS>();
+    compute(cur, nxt);
+    st_k += BK32;
+    cur = cur + 1 == C::STAGES ? 0 : cur + 1;
+    nxt = nxt + 1 == C::STAGES ? 0 : nxt + 1;
+  }
+  for (; s < total; ++s) {
+    if (s + D - 1 < total) {
+      wait_tile_then_barrier<(D - 1) * C::LOADS>();
+    } else {
+      wait_tile_then_barrier<0>();
+    }
+    compute(cur, -1);
+    cur = cur + 1 == C::STAGES ? 0 : cur + 1;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------
 // triple-plane main loop (d hidden): acc += A1 B1^T + A2 B1^T + A1 B2^T over Kc - the three bf16 products of
 // (A1 + A2)(B1 + B2) without the 2^-18 lo x lo term - from FOUR staged tiles per 32-deep stage (A1, A2, B1, B2, 16 KB each).
 // -----------------------------------------------------------------------------------------------
@@ -914,9 +1022,10 @@ struct DlArgs {
   uint16_t* dl_lo;
   uint16_t* dlT_hi;     // [vocab, chunk_pad]
   uint16_t* dlT_lo;
+  const float* scales;  // mixed-precision recompute: device floats {S_w, S_h}; nullptr otherwise
 };
 
-template <class C, bool DUAL = false>
+template <class C, int CORE = 0>
 __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int tv, tk;
@@ -927,9 +1036,10 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
   const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
   f32x16 acc[2][NJ];
   zero_acc<NJ>(acc);
-  run_mainloop<C, DUAL>(acc, a.terms, a.geo, m0, n0, lds);
+  run_core<C, CORE>(acc, a.terms, a.geo, m0, n0, lds);
 
   const float up = a.upstream ? *a.upstream : 1.0f;
+  const float k2 = a.scales ? a.k2 / (a.scales[0] * a.scales[1]) : a.k2;  // power-of-two operand scales: exact to undo
   const int64_t V = a.geo.M;
   const int vbase = m0 + acc_row(lane, wrow0, 0, 0);
   // ---- d logits of this lane's 2 x NJ x 16 accumulator values, each as (hi | lo << 16): bf16 planes hi + lo = value
@@ -957,7 +1067,7 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
       for (int r = 0; r < 16; ++r) {
         float val = 0.0f;
         if (live) {
-          const float d2 = __builtin_fmaf(acc[i][j][r], a.k2, -l2);  // log2 p
+          const float d2 = __builtin_fmaf(acc[i][j][r], k2, -l2);  // log2 p
           const float p = fast_exp2(d2);
           val = ngi * p;
           if (gH != 0.0f) val = __builtin_fmaf(nhi * p, __builtin_fmaf(d2, kLn2, H), val);
@@ -1007,6 +1117,7 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
       }
     }
     __syncthreads();
+    if (out_t == nullptr) continue;  // d W reads the row-major planes with transposing LDS reads: nothing else to write
     // -- transposed: two neighbouring lanes hold neighbouring token rows of the same vocabulary entries; they trade one
     // value so that each writes 4 bytes (two rows of one entry) instead of two 2-byte pieces
 #pragma unroll
@@ -1172,6 +1283,35 @@ __global__ __launch_bounds__(CfgTriple::NT, 2) void gemm_dh3_kernel(Dh3Args a) {
       for (int j = 0; j < 4; ++j) {
         const int col = n0 + acc_col(lane, wcol0, j);  // 32 consecutive lanes -> 32 consecutive columns
         if (col < a.geo.N) out[(int64_t)row * a.geo.N + col] = acc[i][j][r];
+      }
+    }
+}
+
+// d W on the transposed-A dual-plane core: out[v, n] (+)= sum over the chunk's tokens t of (dl_hi + dl_lo)[t, v] hT[n, t].
+// terms.a[0] / a[1] = the ROW-MAJOR d-logits planes [Kc, lda], terms.b[0] = hidden^T [N, ldb].
+__global__ __launch_bounds__(CfgDual::NT, 2) void gemm_dw_tr_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  using C = CfgDual;
+  int tm, tn;
+  tile_coords((int)blockIdx.x, a.mt, a.nt, tm, tn);
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
+  f32x16 acc[2][4];
+  zero_acc<4>(acc);
+  gemm_mainloop_dual_tr(acc, a.terms.a[0], a.terms.a[1], a.terms.b[0], a.geo, m0, n0, lds);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + acc_row(lane, wrow0, i, r);
+      if (row >= a.geo.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + acc_col(lane, wcol0, j);
+        if (col >= a.geo.N) continue;
+        float* dst = static_cast<float*>(a.out) + (int64_t)row * a.ldc + col;
+        *dst = a.accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
       }
     }
 }
@@ -1419,7 +1559,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdLayout {
   int chunk_pad;
-  size_t hT, dl_hi, dl_lo, dlT_hi, dlT_lo, dh_partial, total;
+  size_t hT, dl_hi, dl_lo, dlT_hi, dlT_lo, dh_partial, h16, h8, maxbits, total;
 };
 
 // Split-K factor of the d hidden product: its grid (chunk rows / 256 x hidden / 256 = 224 tiles at the 7B shape)
@@ -1445,6 +1585,10 @@ int pick_ksplit(int tiles, int ksteps_total) {
   return best;
 }
 
+// PRL_TUNE_LMHEAD_BWD bit 1: 1 = the round-2 structure of d W (the recompute also writes TRANSPOSED d-logits planes, d W
+// runs on the plain dual-plane core); 0 = d W gathers its fragments from the row-major planes with ds_read_b64_tr_b16
+bool dw_from_row_major() { return (prl::tuning(PRL_TUNE_LMHEAD_BWD, 0) & 2) == 0; }
+
 BwdLayout bwd_layout(int64_t hidden, int64_t vocab, int64_t chunk_rows) {
   BwdLayout L;
   L.chunk_pad = ceil_div(chunk_rows, 128) * 128;
@@ -1457,11 +1601,18 @@ BwdLayout bwd_layout(int64_t hidden, int64_t vocab, int64_t chunk_rows) {
   L.dl_lo = o;
   o += plane;
   L.dlT_hi = o;
-  o += plane;
+  if (!dw_from_row_major()) o += plane;
   L.dlT_lo = o;
-  o += plane;
+  if (!dw_from_row_major()) o += plane;
   L.dh_partial = o;
   o += align256((size_t)kMaxKSplit * L.chunk_pad * hidden * 4);
+  // the mixed-precision recompute reads the chunk's hidden states as f16 + fp8
+  L.h16 = o;
+  o += align256((size_t)L.chunk_pad * hidden * 2);
+  L.h8 = o;
+  o += align256((size_t)L.chunk_pad * hidden);
+  L.maxbits = o;
+  o += 256;
   L.total = o;
   return L;
 }
@@ -1570,13 +1721,64 @@ extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidde
   return PRL_OK;
 }
 
-extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
-                                       const uint16_t* w_hi, const uint16_t* w_lo, const uint16_t* wt_hi,
-                                       const uint16_t* wt_lo, const int64_t* input_ids, float temperature,
-                                       const float* lse2, const float* entropy, const float* grad_new_logprobs,
-                                       const float* grad_entropy, const float* upstream, void* grad_hidden,
-                                       int32_t grad_hidden_dtype, float* grad_weight, int64_t chunk_rows, int32_t flags,
-                                       void* workspace, size_t workspace_bytes, prl_stream_t stream) {
+namespace {
+
+struct MxFwdLayout {
+  size_t part, ysel, h16, h8, maxbits, total;
+  int64_t padded;
+  int nsplit, tt, vt;
+};
+
+MxFwdLayout mx_fwd_layout(int64_t n, int64_t hidden, int64_t vocab) {
+  MxFwdLayout L;
+  L.tt = ceil_div(n, CfgMx::BN);
+  L.vt = ceil_div(vocab, CfgMx::BM);
+  L.nsplit = fwd_nsplit(L.tt, L.vt, true);
+  L.padded = (int64_t)L.tt * CfgMx::BN;
+  size_t o = 0;
+  L.part = o;
+  o += align256((size_t)L.nsplit * L.padded * 16);
+  L.ysel = o;
+  o += align256((size_t)L.padded * 4);
+  L.h16 = o;
+  o += align256((size_t)n * hidden * 2);
+  L.h8 = o;
+  o += align256((size_t)n * hidden);
+  L.maxbits = o;
+  o += 256;
+  L.total = o;
+  return L;
+}
+
+template <class SRC, bool RESIDUAL>
+int mx_convert(int64_t R, int64_t K, const SRC* src, uint32_t* max_bits, float* scale_out, uint16_t* x16, uint8_t* x8, hipStream_t s) {
+  PRL_HIP_CHECK(hipMemsetAsync(max_bits, 0, 4, s));
+  const int64_t n = R * K;
+  const int blocks = (int)((n / 8 + 255) / 256 < 4096 ? (n / 8 + 255) / 256 : 4096);
+  hipLaunchKernelGGL((absmax_kernel<SRC>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, n, src, max_bits);
+  PRL_LAUNCH_CHECK("absmax_kernel");
+  hipLaunchKernelGGL((mx_convert_kernel<SRC, RESIDUAL>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, R, K, src, max_bits, scale_out, x16, x8);
+  PRL_LAUNCH_CHECK("mx_convert_kernel");
+  return PRL_OK;
+}
+
+}  // namespace
+
+namespace {
+struct MxRecompute {  // operands of the mixed-precision recompute (prl_lm_head_prepare_mx); w16 == nullptr: off
+  const uint16_t* w16 = nullptr;
+  const uint8_t* w8lo = nullptr;
+  float* scales = nullptr;
+};
+}  // namespace
+
+static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
+                            const uint16_t* w_hi, const uint16_t* w_lo, const uint16_t* wt_hi,
+                            const uint16_t* wt_lo, const int64_t* input_ids, float temperature,
+                            const float* lse2, const float* entropy, const float* grad_new_logprobs,
+                            const float* grad_entropy, const float* upstream, void* grad_hidden,
+                            int32_t grad_hidden_dtype, float* grad_weight, int64_t chunk_rows, int32_t flags,
+                            void* workspace, size_t workspace_bytes, prl_stream_t stream, const MxRecompute& mx) {
   PRL_CHECK_ARG(rows >= 1 && cols >= 1, "rows and cols must be >= 1");
   PRL_CHECK_ARG(hidden >= BK && hidden % BK == 0, "hidden size %lld must be a multiple of %d", (long long)hidden, BK);
   PRL_CHECK_ARG(vocab >= BK && vocab % BK == 0 && vocab < ((int64_t)1 << 31) - 256,
@@ -1625,18 +1827,39 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       d.chunk_pad = L.chunk_pad;
       d.dl_hi = dl_hi;
       d.dl_lo = dl_lo;
-      d.dlT_hi = dlT_hi;
-      d.dlT_lo = dlT_lo;
+      const bool tr = dw_from_row_major() && vocab % 8 == 0;
+      d.dlT_hi = tr ? nullptr : dlT_hi;
+      d.dlT_lo = tr ? nullptr : dlT_lo;
+      d.scales = nullptr;
+      if (mx.w16) {  // recompute on the mixed-precision core: the logits are those of prl_lm_head_logprob_fwd_mx
+        uint16_t* h16 = reinterpret_cast<uint16_t*>(ws + L.h16);
+        uint8_t* h8 = mx.w8lo ? reinterpret_cast<uint8_t*>(ws + L.h8) : nullptr;
+        if (int rc = mx_convert<uint16_t, false>(m, hidden, hidden_bf16 + r0 * hidden, reinterpret_cast<uint32_t*>(ws + L.maxbits), mx.scales + 1, h16, h8, s)) return rc;
+        d.terms.n = mx.w8lo ? 2 : 1;
+        for (int k = 0; k < MAX_TERMS; ++k) {
+          d.terms.a[k] = k == 1 ? reinterpret_cast<const uint16_t*>(mx.w8lo) : mx.w16;
+          d.terms.b[k] = k == 1 ? reinterpret_cast<const uint16_t*>(h8) : h16;
+        }
+        d.scales = mx.scales;
+        d.vt = ceil_div(vocab, CfgMx::BM);
+        d.tt = ceil_div(m_pad, CfgMx::BN);
+        if (mx.w8lo) {
+          if (int rc = launch_tiles(lmhead_dlogits_kernel<CfgMx, 2>, CfgMx::NT, dl_lds_bytes<CfgMx>(), d.vt * d.tt, d, s, "lmhead_dlogits_kernel(mx)")) return rc;
+        } else if (int rc = launch_tiles(lmhead_dlogits_kernel<CfgMx, 3>, CfgMx::NT, dl_lds_bytes<CfgMx>(), d.vt * d.tt, d, s, "lmhead_dlogits_kernel(mx, f16-exact weight)")) {
+          return rc;
+        }
+      } else {
       const Shape shape = pick_shape(vocab, m_pad);
       d.vt = ceil_div(vocab, shape_bm(shape));
       // token tiles of THIS chunk: its rows rounded up to 128 (the pad rows are written as zeros and are what the
       // d W contraction below runs over); a short last chunk does not pay for the whole buffer
       d.tt = ceil_div(m_pad, shape_bn(shape));
       if (use_dual(shape, d.terms)) {
-        if (int rc = launch_tiles(lmhead_dlogits_kernel<CfgDual, true>, CfgDual::NT, dl_lds_bytes<CfgDual>(), d.vt * d.tt, d, s,
+        if (int rc = launch_tiles(lmhead_dlogits_kernel<CfgDual, 1>, CfgDual::NT, dl_lds_bytes<CfgDual>(), d.vt * d.tt, d, s,
                                   "lmhead_dlogits_kernel(dual)")) return rc;
       } else if (int rc = PRL_LAUNCH_DL(shape, d.vt * d.tt, d, s, "lmhead_dlogits_kernel")) {
         return rc;
+      }
       }
     }
     // ---- 2. d hidden[chunk] = dl W  (contraction over the vocabulary; hi x hi + lo x hi + hi x lo)
@@ -1713,7 +1936,14 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
       g.ksplit = 1;
       g.ksteps = 0;
       g.partial = nullptr;
-      if (use_dual(shape, g.terms)) {
+      if (dw_from_row_major()) {
+        g.terms.a[0] = dl_hi;
+        g.terms.a[1] = dl_lo;
+        g.geo = Geom{(int)vocab, (int)hidden, m_pad, vocab, L.chunk_pad};  // A: [tokens, vocab] row-major, its contraction index is the row
+        g.mt = ceil_div(vocab, CfgDual::BM);
+        g.nt = ceil_div(hidden, CfgDual::BN);
+        if (int rc = PRL_LAUNCH_DUAL(gemm_dw_tr_kernel, g.mt * g.nt, g, s, "gemm_dw_tr_kernel(d weight)")) return rc;
+      } else if (use_dual(shape, g.terms)) {
         if (int rc = PRL_LAUNCH_DUAL((gemm_nt_kernel<CfgDual, true>), g.mt * g.nt, g, s, "gemm_nt_kernel(d weight, dual)")) return rc;
       } else if (int rc = PRL_LAUNCH_CFG(shape, gemm_nt_kernel, g.mt * g.nt, g, s, "gemm_nt_kernel(d weight)")) {
         return rc;
@@ -1723,52 +1953,40 @@ extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidde
   return PRL_OK;
 }
 
+extern "C" int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
+                                       const uint16_t* w_hi, const uint16_t* w_lo, const uint16_t* wt_hi,
+                                       const uint16_t* wt_lo, const int64_t* input_ids, float temperature,
+                                       const float* lse2, const float* entropy, const float* grad_new_logprobs,
+                                       const float* grad_entropy, const float* upstream, void* grad_hidden,
+                                       int32_t grad_hidden_dtype, float* grad_weight, int64_t chunk_rows, int32_t flags,
+                                       void* workspace, size_t workspace_bytes, prl_stream_t stream) {
+  return lm_head_bwd_impl(rows, cols, hidden, vocab, hidden_bf16, w_hi, w_lo, wt_hi, wt_lo, input_ids, temperature, lse2, entropy,
+                          grad_new_logprobs, grad_entropy, upstream, grad_hidden, grad_hidden_dtype, grad_weight, chunk_rows, flags,
+                          workspace, workspace_bytes, stream, MxRecompute{});
+}
+
+extern "C" int prl_lm_head_logprob_bwd_mx(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
+                                          const uint16_t* w16, const uint8_t* w8lo, float* scales, const uint16_t* wt_hi,
+                                          const uint16_t* wt_lo, const int64_t* input_ids, float temperature,
+                                          const float* lse2, const float* entropy, const float* grad_new_logprobs,
+                                          const float* grad_entropy, const float* upstream, void* grad_hidden,
+                                          int32_t grad_hidden_dtype, float* grad_weight, int64_t chunk_rows, int32_t flags,
+                                          void* workspace, size_t workspace_bytes, prl_stream_t stream) {
+  PRL_CHECK_ARG(w16 && scales, "null pointer");
+  PRL_CHECK_ARG(prl::aligned16(w16) && (!w8lo || prl::aligned16(w8lo)), "operands must be 16-byte aligned");
+  MxRecompute mx;
+  mx.w16 = w16;
+  mx.w8lo = w8lo;
+  mx.scales = scales;
+  // the recompute reads (w16, w8lo); w_hi / w_lo of the plain entry point are not needed: the d hidden product runs on wt_hi / wt_lo
+  return lm_head_bwd_impl(rows, cols, hidden, vocab, hidden_bf16, w16, w8lo ? w16 : nullptr, wt_hi, wt_lo, input_ids, temperature, lse2, entropy,
+                          grad_new_logprobs, grad_entropy, upstream, grad_hidden, grad_hidden_dtype, grad_weight, chunk_rows, flags,
+                          workspace, workspace_bytes, stream, mx);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // mixed-precision head (f16 + MX fp8 residual plane): operand preparation and forward
 // ---------------------------------------------------------------------------------------------------
-namespace {
-
-struct MxFwdLayout {
-  size_t part, ysel, h16, h8, maxbits, total;
-  int64_t padded;
-  int nsplit, tt, vt;
-};
-
-MxFwdLayout mx_fwd_layout(int64_t n, int64_t hidden, int64_t vocab) {
-  MxFwdLayout L;
-  L.tt = ceil_div(n, CfgMx::BN);
-  L.vt = ceil_div(vocab, CfgMx::BM);
-  L.nsplit = fwd_nsplit(L.tt, L.vt, true);
-  L.padded = (int64_t)L.tt * CfgMx::BN;
-  size_t o = 0;
-  L.part = o;
-  o += align256((size_t)L.nsplit * L.padded * 16);
-  L.ysel = o;
-  o += align256((size_t)L.padded * 4);
-  L.h16 = o;
-  o += align256((size_t)n * hidden * 2);
-  L.h8 = o;
-  o += align256((size_t)n * hidden);
-  L.maxbits = o;
-  o += 256;
-  L.total = o;
-  return L;
-}
-
-template <class SRC, bool RESIDUAL>
-int mx_convert(int64_t R, int64_t K, const SRC* src, uint32_t* max_bits, float* scale_out, uint16_t* x16, uint8_t* x8, hipStream_t s) {
-  PRL_HIP_CHECK(hipMemsetAsync(max_bits, 0, 4, s));
-  const int64_t n = R * K;
-  const int blocks = (int)((n / 8 + 255) / 256 < 4096 ? (n / 8 + 255) / 256 : 4096);
-  hipLaunchKernelGGL((absmax_kernel<SRC>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, n, src, max_bits);
-  PRL_LAUNCH_CHECK("absmax_kernel");
-  hipLaunchKernelGGL((mx_convert_kernel<SRC, RESIDUAL>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, R, K, src, max_bits, scale_out, x16, x8);
-  PRL_LAUNCH_CHECK("mx_convert_kernel");
-  return PRL_OK;
-}
-
-}  // namespace
-
 extern "C" int prl_lm_head_mx_workspace_bytes(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, size_t* fwd_bytes) {
   PRL_CHECK_ARG(rows >= 1 && cols >= 1 && hidden >= 1 && vocab >= 1 && fwd_bytes, "bad arguments");
   *fwd_bytes = mx_fwd_layout(rows * cols, hidden, vocab).total;

@@ -74,6 +74,25 @@ PRL_LHD int frag_lds_byte32(int lane, int wave_row0, int i, int ks) {
   return r * ROW_BYTES32 + (((ks * 2 + (lane >> 5)) ^ ((r >> 2) & 3)) << 4);
 }
 
+// ---- d W from ROW-MAJOR d-logits planes: the contraction (token) index is the ROW of the staged tile, so the MFMA A
+// fragment (8 consecutive tokens of one vocabulary entry) is gathered by ds_read_b64_tr_b16: a 16-lane group reads a
+// [4 tokens][16 entries] block - lane q supplies the 8 bytes of token (q >> 2), entries 4 (q & 3) .. + 3 - and receives
+// entry q's 4 tokens (profiles/r03b_mx_probe.txt).  A stage is 32 tokens x 256 entries: 32 rows of 32 sixteen-byte
+// chunks, chunk c of row t at slot  t * 32 + (c ^ (4 (t & 3)))  - the 32 lanes of one LDS pass (4 rows x 4 chunks) then
+// touch 16 distinct bank quads.  global_load_lds writes slots lane-linearly: the swizzle goes on the SOURCE chunk.
+PRL_LHD int tr_stage_row(int tid, int q, int nt) { return (q * nt + tid) >> 5; }                        // token row 0..31
+PRL_LHD int tr_stage_chunk(int tid, int q, int nt) { return ((q * nt + tid) & 31) ^ (4 * (((q * nt + tid) >> 5) & 3)); }  // logical chunk
+// byte address of the tr read `r` (0: tokens 0-3 of the lane's 8, 1: tokens 4-7) of sub-step ks for MFMA tile i
+PRL_LHD int tr_frag_lds_byte(int lane, int wave_row0, int i, int ks, int r) {
+  const int g = lane >> 4, q = lane & 15;
+  const int t = 16 * ks + 8 * (g >> 1) + 4 * r + (q >> 2);
+  const int v = wave_row0 + 32 * i + 16 * (g & 1) + 4 * (q & 3);
+  return ((t * 32 + ((v >> 3) ^ (4 * (t & 3)))) << 4) + 8 * (q & 1);
+}
+// which (token, entry) the lane's four results are: entry = wave_row0 + 32 i + (lane & 31), tokens 16 ks + 8 (lane >> 5) + 4 r + 0..3
+PRL_LHD int tr_frag_entry(int lane, int wave_row0, int i) { return wave_row0 + 32 * i + (lane & 31); }
+PRL_LHD int tr_frag_token0(int lane, int ks, int r) { return 16 * ks + 8 * (lane >> 5) + 4 * r; }
+
 // ---- the mixed-precision (f16 + MX fp8) core.  The 16-bit planes use the 32-deep layout above.  An fp8 "lo" plane
 // accompanies them: one byte per element, consumed by v_mfma_scale_f32_32x32x64_f8f6f4, whose lane (row, half) supplies
 // 32 K-SLOTS of a 64-deep contraction.  Which contraction index sits in which slot is free as long as both operands

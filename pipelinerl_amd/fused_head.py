@@ -40,9 +40,10 @@ class FusedLmHead:
     Refreshed when the weight changes (version counter / storage address); writers that go through
     `.data.copy_()` must call `invalidate()` - same contract as lm_head.SplitBf16LmHead."""
 
-    def __init__(self, weight: torch.Tensor, backward: bool = True, chunk_rows: int = 4096, hidden_grad_terms: int = 3,
+    def __init__(self, weight: torch.Tensor, backward: bool = True, chunk_rows: int = 8192, hidden_grad_terms: int = 3,
                  skip_unlabelled: bool = True, precision: str | None = None):
-        """`chunk_rows`: logits rows whose d logits planes live in the workspace at a time (4 x chunk x V x 2 bytes).
+        """`chunk_rows`: logits rows whose d logits planes live in the workspace at a time (2 x chunk x V x 2 bytes: 5 GB for
+        8192 rows of a 152 064-entry vocabulary; one chunk per 8192-token micro-batch halves the d W epilogues).
         `hidden_grad_terms`: 3 = d hidden from every bf16 product (fp32-GEMM accuracy before the final rounding),
         1 = leading product only (2^-9 relative, the size of the bf16 rounding of d hidden; two GEMM passes less).
         `skip_unlabelled` (loss path only, `fused_head_loss`): rows whose next token carries no label (prompt and
@@ -99,7 +100,8 @@ class FusedLmHead:
             self.wt_hi, self.wt_lo = (plane(H, V) if self.backward else None), None
             outs = (None, None, self.wt_hi, None)
         else:
-            self.w_hi, self.w_lo = plane(V, H), plane(V, H)
+            # the row-major bf16 planes feed the forward / recompute of the bf16x2 form only
+            self.w_hi, self.w_lo = (plane(V, H), plane(V, H)) if self.precision == "bf16x2" else (None, None)
             self.wt_hi, self.wt_lo = (plane(H, V), plane(H, V)) if self.backward else (None, None)
             outs = (self.w_hi, self.w_lo, self.wt_hi, self.wt_lo)
         if any(o is not None for o in outs):
@@ -184,14 +186,17 @@ class FusedLmHead:
             raise ValueError("grad_weight must be a contiguous float32 [vocab, hidden] tensor")
         ws = self._workspace("bwd", B, L, dev, chunk)
         ids = input_ids if input_ids.is_contiguous() else input_ids.contiguous()
+        flags = (_lib.PRL_LM_HEAD_DH_LEADING_TERM if self.hidden_grad_terms == 1 else 0) | (_lib.PRL_LM_HEAD_DW_OVERWRITE if overwrite_weight_grad else 0)
+        tail = (ids.data_ptr(), float(temperature), lse2.data_ptr(), ent.data_ptr(), g_nlp.data_ptr(), _lib.ptr(g_ent), _lib.ptr(upstream),
+                _lib.ptr(gh), 0 if grad_hidden_dtype == torch.float32 else 1, _lib.ptr(grad_weight), chunk, flags, ws.data_ptr(), ws.numel(),
+                _lib.current_stream_ptr(dev))
         with torch.cuda.device(dev):
-            _lib.check(lib.prl_lm_head_logprob_bwd(
-                B, L, H, self.vocab, h.data_ptr(), self.w_hi.data_ptr(), _lib.ptr(self.w_lo), self.wt_hi.data_ptr(), _lib.ptr(self.wt_lo),
-                ids.data_ptr(), float(temperature), lse2.data_ptr(), ent.data_ptr(), g_nlp.data_ptr(), _lib.ptr(g_ent), _lib.ptr(upstream),
-                _lib.ptr(gh), 0 if grad_hidden_dtype == torch.float32 else 1, _lib.ptr(grad_weight), chunk,
-                (_lib.PRL_LM_HEAD_DH_LEADING_TERM if self.hidden_grad_terms == 1 else 0) | (_lib.PRL_LM_HEAD_DW_OVERWRITE if overwrite_weight_grad else 0),
-                ws.data_ptr(), ws.numel(),
-                _lib.current_stream_ptr(dev)))
+            if self.precision == "f16_fp8":  # the recompute runs on the core the forward ran on
+                _lib.check(lib.prl_lm_head_logprob_bwd_mx(B, L, H, self.vocab, h.data_ptr(), self.w16.data_ptr(), _lib.ptr(self.w8lo),
+                                                          self.mx_scales.data_ptr(), self.wt_hi.data_ptr(), _lib.ptr(self.wt_lo), *tail))
+            else:
+                _lib.check(lib.prl_lm_head_logprob_bwd(B, L, H, self.vocab, h.data_ptr(), self.w_hi.data_ptr(), _lib.ptr(self.w_lo),
+                                                       self.wt_hi.data_ptr(), _lib.ptr(self.wt_lo), *tail))
         return gh
 
 
@@ -357,7 +362,7 @@ def _head_for(owner: Any, weight: torch.Tensor, chunk_rows: int, hidden_grad_ter
     return head
 
 
-def install_fused_head(model: Any, chunk_rows: int = 4096, hidden_grad_terms: int = 3) -> Any:
+def install_fused_head(model: Any, chunk_rows: int = 8192, hidden_grad_terms: int = 3) -> Any:
     """Teach a causal LM (`.model` body + bias-free `.lm_head`, the Hugging Face layout) to compute the RL loss
     INSIDE its own forward: `model(rl_batch=batch, rl_config=config, current_step=s, max_step=m)` returns
     `(loss, stats_device)`; every other call is the model's original forward.  Call this BEFORE wrapping the
@@ -396,7 +401,7 @@ def install_fused_head(model: Any, chunk_rows: int = 4096, hidden_grad_terms: in
 
 
 def rl_step_fused_head(model: Any, batch: PipelineBatchEncoding, current_step: int, max_step: int, config: RLConfig,
-                       seq_parallel_group=None, chunk_rows: int = 4096):
+                       seq_parallel_group=None, chunk_rows: int = 8192):
     """`rl_step` (reference rl/__init__.py:136-143, same signature and return value) for a causal LM
     that exposes its body and head separately, as Hugging Face models do (`model.model`,
     `model.lm_head`): the body runs as usual, the head never produces logits.

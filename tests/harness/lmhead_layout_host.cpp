@@ -81,4 +81,35 @@ void lmh_emulate_tile(const uint16_t* a_src, const uint16_t* b_src, double* c_ou
       }
   }
 }
+
+// ---- d W from row-major planes (transposing LDS reads).  src is a [32 tokens][256 entries] stage tile, row-major.
+void lmh_stage_tr(const uint16_t* src, uint8_t* lds_out, int nthreads) {
+  for (int tid = 0; tid < nthreads; ++tid)
+    for (int q = 0; q < 2; ++q)
+      memcpy(lds_out + stage_lds_byte(tid, q, nthreads), src + tr_stage_row(tid, q, nthreads) * 256 + 8 * tr_stage_chunk(tid, q, nthreads), 16);
+}
+// ds_read_b64_tr_b16 as measured (profiles/r03b_mx_probe.txt): in a 16-lane group, lane q loads 8 bytes; result[q][e] =
+// element (q & 3) of what lane (4 e + (q >> 2)) loaded.  `addr` = the 64 per-lane byte addresses; out[lane][0..3].
+void lmh_tr_read(const uint8_t* lds, const int* addr, uint16_t* out /* [64][4] */) {
+  for (int lane = 0; lane < 64; ++lane) {
+    const int g = lane >> 4, q = lane & 15;
+    for (int e = 0; e < 4; ++e) {
+      const int src_lane = 16 * g + 4 * e + (q >> 2);
+      uint16_t piece[4];
+      memcpy(piece, lds + addr[src_lane], 8);
+      out[lane * 4 + e] = piece[q & 3];
+    }
+  }
+}
+int lmh_tr_frag_byte(int lane, int w, int i, int ks, int r) { return tr_frag_lds_byte(lane, w, i, ks, r); }
+int lmh_tr_frag_entry(int lane, int w, int i) { return tr_frag_entry(lane, w, i); }
+int lmh_tr_frag_token0(int lane, int ks, int r) { return tr_frag_token0(lane, ks, r); }
+
+// ---- mixed-precision core: slot order of the fp8 plane and its staged image
+int lmh_mx_byte_in_block(int k) { return mx_byte_in_block(k); }
+int lmh_mx_slot_k(int half, int slot) { return mx_slot_k(half, slot); }
+void lmh_stage_mx8(const uint8_t* src /* [256 rows][32 bytes] */, uint8_t* lds_out) {
+  for (int tid = 0; tid < 512; ++tid) memcpy(lds_out + tid * 16, src + mx8_stage_row(tid) * 32 + 16 * mx8_stage_half(tid), 16);
+}
+int lmh_mx8_frag_byte(int lane, int w, int i) { return mx8_frag_lds_byte(lane, w, i); }
 }

@@ -440,5 +440,7 @@ def test_workspace_too_small_and_bad_shapes_are_refused(libprl, cuda_device):
     assert libprl.prl_lm_head_logprob_bwd(1, 128, 64, 1000, P, P, None, P, None, P, 1.0, P, P, P, None, None, P, 1, None, 128, 0, P, 1 << 20, s) == _lib.PRL_EINVAL  # vocab % 64
     fwd, bwd = ctypes.c_size_t(), ctypes.c_size_t()
     _lib.check(libprl.prl_lm_head_workspace_bytes(1, 8192, 3584, 152064, 2048, ctypes.byref(fwd), ctypes.byref(bwd)))
-    # 4 bf16 planes of 2048 x 152064 + the transposed hidden chunk + 8 fp32 split-K slices of the d hidden chunk
-    assert fwd.value < 2 << 20 and 2.7e9 < bwd.value < 2.8e9
+    # 2 bf16 planes of 2048 x 152064 (row-major only: d W gathers its fragments with transposing LDS reads; round 2 wrote
+    # four) + the transposed hidden chunk + 8 fp32 split-K slices of the d hidden chunk + the f16 / fp8 copies of the chunk's
+    # hidden states for the mixed-precision recompute
+    assert fwd.value < 2 << 20 and 1.45e9 < bwd.value < 1.6e9

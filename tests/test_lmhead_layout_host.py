@@ -30,6 +30,13 @@ def lmh(tmp_path_factory):
     lib.lmh_frag_byte32.argtypes = [ctypes.c_int] * 4
     lib.lmh_frag_byte32.restype = ctypes.c_int
     lib.lmh_emulate_tile.argtypes = [U16, U16, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int]
+    lib.lmh_stage_tr.argtypes = [U16, U8, ctypes.c_int]
+    lib.lmh_tr_read.argtypes = [U8, ctypes.POINTER(ctypes.c_int), U16]
+    for name, n in (("lmh_tr_frag_byte", 5), ("lmh_tr_frag_entry", 3), ("lmh_tr_frag_token0", 3), ("lmh_mx_byte_in_block", 1), ("lmh_mx_slot_k", 2),
+                    ("lmh_mx8_frag_byte", 3)):
+        getattr(lib, name).argtypes = [ctypes.c_int] * n
+        getattr(lib, name).restype = ctypes.c_int
+    lib.lmh_stage_mx8.argtypes = [U8, U8]
     return lib
 
 
@@ -135,3 +142,67 @@ def test_32_deep_layout_of_the_dual_plane_core(lmh):
                 for group in B128_GROUPS:
                     slots = {(lmh.lmh_frag_byte32(l, row0, i, ks) % 256) // 16 for l in group}
                     assert len(slots) == 16
+
+
+def test_transposing_reads_feed_the_mfma_from_a_row_major_tile(lmh):
+    """d W from the ROW-MAJOR d-logits planes: the staged [32 tokens][256 entries] image and the per-lane addresses of
+    `ds_read_b64_tr_b16` (semantics as measured on the device, profiles/r03b_mx_probe.txt) hand lane l of wave row w,
+    tile i, sub-step ks exactly the operand the MFMA expects - entry w + 32 i + (l & 31), tokens 16 ks + 8 (l >> 5) + 0..7 -
+    and the 32 lanes of one LDS pass touch 64 distinct banks."""
+    src = (np.arange(32)[:, None] * 256 + np.arange(256)[None, :]).astype(np.uint16)  # value = token * 256 + entry
+    lds = np.zeros(32 * 512, dtype=np.uint8)
+    lmh.lmh_stage_tr(src.ctypes.data_as(U16), lds.ctypes.data_as(U8), 512)
+    assert sorted(np.frombuffer(lds.tobytes(), dtype=np.uint16).tolist()) == sorted(src.ravel().tolist())  # a permutation of the tile
+    for w in (0, 64, 128, 192):
+        for i in (0, 1):
+            for ks in (0, 1):
+                frag = np.zeros((64, 8), dtype=np.int64)
+                for r in (0, 1):
+                    addr = np.array([lmh.lmh_tr_frag_byte(l, w, i, ks, r) for l in range(64)], dtype=np.int32)
+                    assert (addr % 8 == 0).all() and addr.max() + 8 <= lds.size
+                    for half in (0, 1):  # one LDS pass = 32 lanes x 8 bytes: every 4-byte bank exactly once
+                        banks = np.concatenate([((addr[32 * half:32 * half + 32] + d) // 4) % 64 for d in (0, 4)])
+                        assert len(set(banks.tolist())) == 64, (w, i, ks, r, half)
+                    out = np.zeros(64 * 4, dtype=np.uint16)
+                    lmh.lmh_tr_read(lds.ctypes.data_as(U8), addr.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), out.ctypes.data_as(U16))
+                    frag[:, 4 * r:4 * r + 4] = out.reshape(64, 4)
+                for l in range(64):
+                    entry = lmh.lmh_tr_frag_entry(l, w, i)
+                    assert entry == w + 32 * i + (l & 31)
+                    want = [(16 * ks + 8 * (l >> 5) + e) * 256 + entry for e in range(8)]
+                    assert frag[l].tolist() == want, (w, i, ks, l)
+                    assert lmh.lmh_tr_frag_token0(l, ks, 1) == 16 * ks + 8 * (l >> 5) + 4
+
+
+def test_mx_slot_order_pairs_both_operands_and_reads_conflict_free(lmh):
+    """Mixed-precision core: the fp8 planes are stored in SLOT order - lane-half h of the MX instruction holds, for a
+    64-deep stage pair, the contraction indices an f16 fragment sequence of that lane-half would hold - so that the
+    staged residual plane and the other operand agree index by index; each 32-deep block is a bijection onto its 32
+    bytes; the staged 8 KB image is read by ds_read_b128 without bank conflicts."""
+    for block_k in range(32):
+        assert 0 <= lmh.lmh_mx_byte_in_block(block_k) < 32
+    assert sorted(lmh.lmh_mx_byte_in_block(k) for k in range(32)) == list(range(32))
+    seen = set()
+    for h in (0, 1):
+        for slot in range(32):
+            k = lmh.lmh_mx_slot_k(h, slot)
+            seen.add(k)
+            p, ks, e = slot >> 4, (slot >> 3) & 1, slot & 7
+            assert k == 32 * p + 16 * ks + 8 * h + e  # = the k of element e of the f16 fragment (stage p, sub-step ks, lane-half h)
+            assert lmh.lmh_mx_byte_in_block(k % 32) == 16 * h + (slot & 15)  # and where the prepared plane keeps it
+    assert seen == set(range(64))
+    src = (np.arange(256)[:, None] * 32 + np.arange(32)[None, :]).astype(np.uint16)  # value = row * 32 + byte; fits uint16? 8191 yes
+    src8 = (src % 251).astype(np.uint8)
+    lds = np.zeros(256 * 32, dtype=np.uint8)
+    lmh.lmh_stage_mx8(src8.ctypes.data_as(U8), lds.ctypes.data_as(U8))
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    for w in (0, 64, 128, 192):
+        for i in (0, 1):
+            addr = [lmh.lmh_mx8_frag_byte(l, w, i) for l in range(64)]
+            for l in range(64):
+                row, h = w + 32 * i + (l & 31), l >> 5
+                assert lds[addr[l]:addr[l] + 16].tolist() == src8[row, 16 * h:16 * h + 16].tolist()
+            for base in (0, 32):  # ds_read_b128 is served in groups of 16 lanes: 16 distinct 16-byte bank slots each
+                for grp in groups:
+                    slots = {(addr[base + l] // 16) % 16 for l in grp}
+                    assert len(slots) == 16, (w, i, base)
