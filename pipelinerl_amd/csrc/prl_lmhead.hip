@@ -1293,7 +1293,10 @@ __global__ __launch_bounds__(CfgDual::NT, 2) void gemm_dw_tr_kernel(GemmArgs a) 
   extern __shared__ __attribute__((aligned(16))) char lds[];
   using C = CfgDual;
   int tm, tn;
-  tile_coords((int)blockIdx.x, a.mt, a.nt, tm, tn);
+  // row-tile groups of a.ksteps (reused as the raster's group size here): the workgroups an XCD runs at a time should cover
+  // FEW vocabulary tiles and ALL hidden tiles - the d-logits planes (5 GB per micro-batch) then stream from HBM once instead of
+  // once per quartet of hidden tiles, while the re-read operand is the 58 MB of hidden^T that the Infinity Cache holds
+  tile_coords_g((int)blockIdx.x, a.mt, a.nt, a.ksteps > 0 ? a.ksteps : 8, tm, tn);
   const int m0 = tm * C::BM, n0 = tn * C::BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
@@ -1942,6 +1945,13 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
         g.geo = Geom{(int)vocab, (int)hidden, m_pad, vocab, L.chunk_pad};  // A: [tokens, vocab] row-major, its contraction index is the row
         g.mt = ceil_div(vocab, CfgDual::BM);
         g.nt = ceil_div(hidden, CfgDual::BN);
+        {  // raster group: ONE vocabulary tile with all its hidden tiles when there are many of those (measured at the 7B
+          // shape, 14 hidden tiles: groups of 1 / 2 / 3 / 4 / 8 vocabulary tiles -> 53.1 / 53.3 / 53.7 / 53.8 / 54.0 ms for the
+          // whole backward, profiles/r03h_dw_raster.txt); a narrow head takes as many as fill 16 CUs
+          const int64_t forced = prl::tuning(PRL_TUNE_LMHEAD_DW_GROUP, 0);
+          int gm = forced > 0 ? (int)forced : 16 / g.nt;
+          g.ksteps = gm < 1 ? 1 : gm;
+        }
         if (int rc = PRL_LAUNCH_DUAL(gemm_dw_tr_kernel, g.mt * g.nt, g, s, "gemm_dw_tr_kernel(d weight)")) return rc;
       } else if (use_dual(shape, g.terms)) {
         if (int rc = PRL_LAUNCH_DUAL((gemm_nt_kernel<CfgDual, true>), g.mt * g.nt, g, s, "gemm_nt_kernel(d weight, dual)")) return rc;

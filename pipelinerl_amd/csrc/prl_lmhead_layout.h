@@ -25,20 +25,20 @@ constexpr int ROW_BYTES = BK * 2;  // one tile row in LDS: 128 bytes = 8 chunks 
 // XCDs (each with its own L2): give every XCD a contiguous range of the tile list, and walk that
 // list in groups of 8 row tiles x all column tiles, row-fastest, so that the workgroups an XCD runs
 // at a time cover a compact patch of tiles and share each A / B panel in its L2.
-PRL_LHD void tile_coords(int bid, int mt, int nt, int& tm, int& tn) {
+PRL_LHD void tile_coords_g(int bid, int mt, int nt, int gm, int& tm, int& tn) {
   const int total = mt * nt;
   const int q = total >> 3, r = total & 7;
   const int xcd = bid & 7, idx = bid >> 3;
   const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  constexpr int GM = 8;
-  const int per_group = GM * nt;
+  const int per_group = gm * nt;
   const int grp = L / per_group;
-  const int first_m = grp * GM;
-  const int gsz = (mt - first_m) < GM ? (mt - first_m) : GM;
+  const int first_m = grp * gm;
+  const int gsz = (mt - first_m) < gm ? (mt - first_m) : gm;
   const int in = L - grp * per_group;
   tm = first_m + in % gsz;
   tn = in / gsz;
 }
+PRL_LHD void tile_coords(int bid, int mt, int nt, int& tm, int& tn) { tile_coords_g(bid, mt, nt, 8, tm, tn); }
 
 // ---- staging.  An operand tile of R rows is R * 8 chunks of 16 bytes; thread `tid` of an NT-thread
 // workgroup moves chunks q * NT + tid.  global_load_lds writes lane-linearly (wave base + lane * 16), so
