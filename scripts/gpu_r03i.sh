@@ -1,0 +1,28 @@
+#!/bin/bash
+# round 3: full validation of the tree - whole -m gpu suite, smoke, default bench line, rocprofv3 kernel stats of the same command
+set -u
+OUT=gpurun_out/r03i
+mkdir -p $OUT
+export TMPDIR=/tmp
+(rocminfo | grep -E "Marketing Name|gfx" | head -4; nproc; grep -m1 "model name" /proc/cpuinfo; free -g | head -2) > $OUT/env.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 --timeout 600 -p no:cacheprovider --durations=8 > $OUT/pytest_gpu.log 2>&1
+echo "pytest exit $?" | tee -a $OUT/pytest_gpu.log
+tail -25 $OUT/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+echo "smoke exit $?" | tee -a $OUT/smoke.log; tail -2 $OUT/smoke.log
+( time timeout 1500 python bench.py --steps 5 --warmup 2 ) > $OUT/bench_full.log 2> $OUT/bench_full.err
+echo "bench exit $?" | tee -a $OUT/bench_full.log
+python - <<'PY'
+import json
+line=[l for l in open('gpurun_out/r03i/bench_full.log') if l.startswith('{')][0]
+d=json.loads(line)
+print({k:d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'])
+m=d['roofline_mfma']; print({k:m[k] for k in ('ms_per_launch','achieved','frac')}, m['backward'], m.get('forward_mixed_precision'))
+e=d['e2e']; print({k:e.get(k) for k in ('s_per_step','samples_per_s','peak_memory_GB','source','error')})
+print(d['transport'])
+print({k:round(v['avg_us'],1) for k,v in d['kernels'].items()})
+PY
+tail -4 $OUT/bench_full.err
+cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-weight-sync --no-e2e --no-transport > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
+cd $GRAFT_REPO_ROOT; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do cut -c1-200 $f | head -14; cp $f $OUT/bench_kernel_stats.csv; done
+find $OUT/prof -name "*kernel_trace.csv" -delete
