@@ -1016,137 +1016,142 @@ struct DlArgs {
   const float* g_ent;   // nullable
   const float* upstream;  // nullable device scalar
   float k2, inv_temp;
-  int vt, tt;
+  int vt, tt, nsplit;   // vocabulary tiles, token tiles of the chunk, vocabulary ranges (workgroups = tt * nsplit)
   int chunk_pad;        // rows of the chunk buffers (multiple of 128)
   uint16_t* dl_hi;      // [chunk_pad, vocab]
   uint16_t* dl_lo;
-  uint16_t* dlT_hi;     // [vocab, chunk_pad]
-  uint16_t* dlT_lo;
   const float* scales;  // mixed-precision recompute: device floats {S_w, S_h}; nullptr otherwise
+  int ablate;           // timing ablations (wrong results), PRL_TUNE_LMHEAD_BWD bits 2 / 3: 1 = no global stores, 2 = no plane epilogue at all
 };
 
 template <class C, int CORE = 0>
 __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  int tv, tk;
-  tile_coords(blockIdx.x, a.vt, a.tt, tv, tk);
+  // A workgroup owns one tile of token rows and walks a RANGE of vocabulary tiles, like the forward (round 2 gave every
+  // (vocabulary tile, token tile) pair its own workgroup: 19 008 dispatches per 8192-row chunk, each with its own pipeline
+  // fill and its own loads of the token statistics; as a loop the recompute costs what the forward's main loop costs)
+  int tk, split;
+  tile_coords(blockIdx.x, a.tt, a.nsplit, tk, split);
   constexpr int NJ = C::NJ;
-  const int m0 = tv * C::BM, n0 = tk * C::BN;
+  const int n0 = tk * C::BN;
+  const int vt0 = (int)((int64_t)a.vt * split / a.nsplit), vt1 = (int)((int64_t)a.vt * (split + 1) / a.nsplit);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
-  f32x16 acc[2][NJ];
-  zero_acc<NJ>(acc);
-  run_core<C, CORE>(acc, a.terms, a.geo, m0, n0, lds);
-
   const float up = a.upstream ? *a.upstream : 1.0f;
   const float k2 = a.scales ? a.k2 / (a.scales[0] * a.scales[1]) : a.k2;  // power-of-two operand scales: exact to undo
   const int64_t V = a.geo.M;
-  const int vbase = m0 + acc_row(lane, wrow0, 0, 0);
-  // ---- d logits of this lane's 2 x NJ x 16 accumulator values, each as (hi | lo << 16): bf16 planes hi + lo = value
-  uint32_t pk[2][NJ][16];
+  // per-token quantities of this lane's NJ token rows
+  float t_gi[NJ], t_nhi[NJ], t_l2[NJ], t_H[NJ];
+  int t_id[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int lrow = n0 + acc_col(lane, wcol0, j);  // row inside the chunk buffers
     const int64_t q = a.row_base + lrow;
-    float g = 0.0f, gH = 0.0f, l2 = 0.0f, H = 0.0f;
-    int id = -1;
+    float g = 0.0f, gH = 0.0f;
+    t_l2[j] = 0.0f;
+    t_H[j] = 0.0f;
+    t_id[j] = -1;
     if (lrow < a.geo.N && (q % a.cols) != a.cols - 1) {  // rows past the chunk's end (padding) come out as zeros
       const int64_t u = q + 1;
       g = a.g_nlp[u] * up;
       gH = a.g_ent ? a.g_ent[u] * up : 0.0f;
-      l2 = a.lse2[u];
-      H = a.ent[u];
+      t_l2[j] = a.lse2[u];
+      t_H[j] = a.ent[u];
       const int64_t v = a.ids[u];
-      if (v >= 0 && v < V) id = (int)v;
+      if (v >= 0 && v < V) t_id[j] = (int)v;
     }
-    const float gi = g * a.inv_temp, ngi = -g * a.inv_temp, nhi = -gH * a.inv_temp;
-    const bool live = (g != 0.0f) || (gH != 0.0f);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float val = 0.0f;
-        if (live) {
-          const float d2 = __builtin_fmaf(acc[i][j][r], k2, -l2);  // log2 p
-          const float p = fast_exp2(d2);
-          val = ngi * p;
-          if (gH != 0.0f) val = __builtin_fmaf(nhi * p, __builtin_fmaf(d2, kLn2, H), val);
-          if (vbase + i * 32 + (r & 3) + 8 * (r >> 2) == id) val += gi;
-        }
-        uint16_t hi, lo;
-        split2(val, hi, lo);
-        pk[i][j][r] = (uint32_t)hi | ((uint32_t)lo << 16);
-      }
+    t_gi[j] = g * a.inv_temp;
+    t_nhi[j] = -gH * a.inv_temp;
   }
-
-  // ---- the four planes leave through LDS, one tile image at a time, so that every global store is 16 bytes per lane
-  // and a wave writes whole 512-byte row segments.  Storing straight from the accumulator layout (8-byte pieces of the
-  // row-major planes, 2-byte pieces of the transposed ones) left partially written sectors behind: 8.8 GB written and
-  // 6.3 GB fetched per chunk for 4.98 GB of planes, ~8 ms of a 60 ms backward (profiles/r02ai_*, r02aj_*).
-  constexpr int BM = C::BM, BN = C::BN;
-  constexpr int RS = BM * 2 + 8;  // row-major image [token row][vocabulary]: + 8 bytes per row, conflict-free 8-byte writes
-  constexpr int TS = BN * 2 + 8;  // transposed image [vocabulary][token row]
+  f32x16 acc[2][NJ];
+  for (int tv = vt0; tv < vt1; ++tv) {
+  const int m0 = tv * C::BM;
+  zero_acc<NJ>(acc);
+  run_core<C, CORE>(acc, a.terms, a.geo, m0, n0, lds);
+  const int vbase = m0 + acc_row(lane, wrow0, 0, 0);
+  // ---- d logits -> two bf16 planes (hi + lo = value), ROW-MAJOR [token row][vocabulary], through LDS images of the tile so
+  // that every global store is 16 bytes per lane and a wave writes whole 512-byte row segments (storing straight from the
+  // accumulator layout - 8-byte pieces at a row stride of V - left partially written sectors behind: 8.8 GB written for
+  // 4.98 GB of planes, profiles/r02ai_*).  The tile goes in two HALVES of token rows (this wave's token tiles j < NJ / 2,
+  // then the rest): only half of the values are alive as (hi, lo) pairs next to the accumulators - the whole tile at once
+  // spilled 22-98 registers - and both planes of a half share the LDS (2 x [BN / 2][BM * 2 + 8] bytes).
+  constexpr int BM = C::BM, BN = C::BN, JH = NJ / 2;
+  constexpr int RS = BM * 2 + 8;              // image row: + 8 bytes, conflict-free 8-byte writes
+  constexpr int IMG = (BN / 2) * RS;          // one plane of one half
   unsigned char* img = reinterpret_cast<unsigned char*>(lds);
-  const int half = lane >> 5, l31 = lane & 31;
-  __syncthreads();  // every wave is done with the main loop's LDS tiles
-#pragma unroll 1
-  for (int plane = 0; plane < 2; ++plane) {  // 0: hi, 1: lo
-    const int sh = plane * 16;
-    uint16_t* const out_r = plane ? a.dl_lo : a.dl_hi;
-    uint16_t* const out_t = plane ? a.dlT_lo : a.dlT_hi;
-    // -- row-major: lane writes its 4 consecutive vocabulary entries (registers 4 rg .. 4 rg + 3) as 8 bytes
+  // The image addresses below are invariant across the vocabulary tiles of this workgroup; hoisted out of that loop they
+  // stay alive through the main loop (32 + registers: 111 spilled).  An opaque copy of the lane id pins them to the tile.
+  int lane_here = lane, tid_here = tid;
+  asm volatile("" : "+v"(lane_here), "+v"(tid_here));
+  const int lhalf = lane_here >> 5, l31 = lane_here & 31;
+  const int wn = (tid_here >> 6) & 1;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+  for (int h = 0; h < 2; ++h) {
+    // the two halves are independent register work: without a fence the scheduler starts the second half's exponentials
+    // above the first half's stores and both sets of pairs are alive next to the accumulators (111 registers spilled)
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t pk[2][JH][16];  // (hi | lo << 16)
+#pragma unroll
+    for (int jj = 0; jj < JH; ++jj) {
+      const int j = h * JH + jj;
+      const float gi = t_gi[j], ngi = -t_gi[j], nhi = t_nhi[j], l2 = t_l2[j], H = t_H[j];
+      const int id = t_id[j];
+      const bool live = (gi != 0.0f) || (nhi != 0.0f);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float val = 0.0f;
+          if (live) {
+            const float d2 = __builtin_fmaf(acc[i][j][r], k2, -l2);  // log2 p
+            const float p = fast_exp2(d2);
+            val = ngi * p;
+            if (nhi != 0.0f) val = __builtin_fmaf(nhi * p, __builtin_fmaf(d2, kLn2, H), val);
+            if (vbase + i * 32 + (r & 3) + 8 * (r >> 2) == id) val += gi;
+          }
+          uint16_t hi, lo;
+          split2(val, hi, lo);
+          pk[i][jj][r] = (uint32_t)hi | ((uint32_t)lo << 16);
+        }
+    }
+    if (a.ablate & 2) {  // timing ablation: keep the values alive, skip the plane epilogue
+#pragma unroll
+      for (int jj = 0; jj < JH; ++jj)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(pk[i][jj][r]));
+      continue;
+    }
+    __syncthreads();  // every wave is done with the LDS: the main loop's tiles (h = 0) / the previous half's images
+    // lane writes its 4 consecutive vocabulary entries (registers 4 rg .. 4 rg + 3) of a token row as 8 bytes per plane
+#pragma unroll
+    for (int jj = 0; jj < JH; ++jj)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int row = wcol0 + j * 32 + l31, vloc = wrow0 + i * 32 + 8 * rg + 4 * half;
-          const uint32_t w0 = ((pk[i][j][rg * 4 + 0] >> sh) & 0xffffu) | (((pk[i][j][rg * 4 + 1] >> sh) & 0xffffu) << 16);
-          const uint32_t w1 = ((pk[i][j][rg * 4 + 2] >> sh) & 0xffffu) | (((pk[i][j][rg * 4 + 3] >> sh) & 0xffffu) << 16);
-          *reinterpret_cast<uint2*>(img + row * RS + vloc * 2) = uint2{w0, w1};
+          const int local = wn * (JH * 32) + jj * 32 + l31, vloc = (tid_here >> 7) * 64 + i * 32 + 8 * rg + 4 * lhalf;
+          const uint32_t p0 = pk[i][jj][rg * 4 + 0], p1 = pk[i][jj][rg * 4 + 1], p2 = pk[i][jj][rg * 4 + 2], p3 = pk[i][jj][rg * 4 + 3];
+          *reinterpret_cast<uint2*>(img + local * RS + vloc * 2) = uint2{(p0 & 0xffffu) | (p1 << 16), (p2 & 0xffffu) | (p3 << 16)};
+          *reinterpret_cast<uint2*>(img + IMG + local * RS + vloc * 2) = uint2{(p0 >> 16) | (p1 & 0xffff0000u), (p2 >> 16) | (p3 & 0xffff0000u)};
         }
     __syncthreads();
-    for (int c = tid; c < BN * (BM / 8); c += C::NT) {
-      const int row = c / (BM / 8), k = c % (BM / 8);
+    for (int c = tid_here; c < (BN / 2) * (BM / 8); c += C::NT) {
+      const int local = c / (BM / 8), k = c % (BM / 8);
+      const int row = (local / (JH * 32)) * C::WCOLS + h * (JH * 32) + local % (JH * 32);  // token row inside the tile
       const int lrow = n0 + row, v = m0 + k * 8;
-      if (lrow < a.chunk_pad && v + 7 < V) {  // V and chunk_pad are multiples of 8: a group of eight is inside or outside as a whole
-        const uint2 x0 = *reinterpret_cast<const uint2*>(img + row * RS + k * 16);
-        const uint2 x1 = *reinterpret_cast<const uint2*>(img + row * RS + k * 16 + 8);
-        *reinterpret_cast<uint4*>(out_r + (int64_t)lrow * V + v) = uint4{x0.x, x0.y, x1.x, x1.y};
+      if (lrow < a.chunk_pad && v + 7 < V && !(a.ablate & 1)) {  // V and chunk_pad are multiples of 8: a group of eight is inside or outside as a whole
+        const unsigned char* src = img + local * RS + k * 16;
+        const uint2 x0 = *reinterpret_cast<const uint2*>(src), x1 = *reinterpret_cast<const uint2*>(src + 8);
+        const uint2 y0 = *reinterpret_cast<const uint2*>(src + IMG), y1 = *reinterpret_cast<const uint2*>(src + IMG + 8);
+        *reinterpret_cast<uint4*>(a.dl_hi + (int64_t)lrow * V + v) = uint4{x0.x, x0.y, x1.x, x1.y};
+        *reinterpret_cast<uint4*>(a.dl_lo + (int64_t)lrow * V + v) = uint4{y0.x, y0.y, y1.x, y1.y};
       }
     }
-    __syncthreads();
-    if (out_t == nullptr) continue;  // d W reads the row-major planes with transposing LDS reads: nothing else to write
-    // -- transposed: two neighbouring lanes hold neighbouring token rows of the same vocabulary entries; they trade one
-    // value so that each writes 4 bytes (two rows of one entry) instead of two 2-byte pieces
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            const uint32_t x0 = (pk[i][j][rg * 4 + e] >> sh) & 0xffffu, x1 = (pk[i][j][rg * 4 + e + 1] >> sh) & 0xffffu;
-            const bool odd = lane & 1;
-            const uint32_t got = __shfl_xor(odd ? x0 : x1, 1, 64);  // even lane receives the neighbour's x0, odd lane the neighbour's x1
-            const int row = wcol0 + j * 32 + (l31 & ~1), vloc = wrow0 + i * 32 + 8 * rg + 4 * half + e + (odd ? 1 : 0);
-            const uint32_t w = odd ? (got | (x1 << 16)) : (x0 | (got << 16));  // (row, row + 1) of entry vloc
-            *reinterpret_cast<uint32_t*>(img + vloc * TS + row * 2) = w;
-          }
-    __syncthreads();
-    for (int c = tid; c < BM * (BN / 8); c += C::NT) {
-      const int vloc = c / (BN / 8), k = c % (BN / 8);
-      const int v = m0 + vloc, lrow = n0 + k * 8;
-      if (v < V && lrow + 7 < a.chunk_pad) {
-        const uint2 x0 = *reinterpret_cast<const uint2*>(img + vloc * TS + k * 16);
-        const uint2 x1 = *reinterpret_cast<const uint2*>(img + vloc * TS + k * 16 + 8);
-        *reinterpret_cast<uint4*>(out_t + (int64_t)v * a.chunk_pad + lrow) = uint4{x0.x, x0.y, x1.x, x1.y};
-      }
-    }
-    __syncthreads();
   }
+  __syncthreads();  // the images are read: the next vocabulary tile may stage into the LDS
+  }  // vocabulary tiles of this workgroup
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -1516,11 +1521,10 @@ int launch_tiles(K kfn, int threads, int lds_bytes, int blocks, const A& args, h
 #define PRL_LAUNCH_DUAL(KERNEL, blocks, args, s, name) \
   launch_tiles(KERNEL, CfgDual::NT, CfgDual::LDS_BYTES, blocks, args, s, name)
 
-// the d-logits kernel also stages a whole output tile in LDS (its epilogue): [BN][BM * 2 + 8] or [BM][BN * 2 + 8] bytes
+// the d-logits kernel also stages both planes of HALF an output tile in LDS (its epilogue): 2 x [BN / 2][BM * 2 + 8] bytes
 template <class C>
 constexpr int dl_lds_bytes() {
-  constexpr int r = C::BN * (C::BM * 2 + 8), t = C::BM * (C::BN * 2 + 8);
-  constexpr int e = r > t ? r : t;
+  constexpr int e = 2 * (C::BN / 2) * (C::BM * 2 + 8);
   return e > C::LDS_BYTES ? e : C::LDS_BYTES;
 }
 #define PRL_LAUNCH_DL(shape, blocks, args, s, name)                                                                                  \
@@ -1562,7 +1566,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdLayout {
   int chunk_pad;
-  size_t hT, dl_hi, dl_lo, dlT_hi, dlT_lo, dh_partial, h16, h8, maxbits, total;
+  size_t hT, dl_hi, dl_lo, dh_partial, h16, h8, maxbits, total;
 };
 
 // Split-K factor of the d hidden product: its grid (chunk rows / 256 x hidden / 256 = 224 tiles at the 7B shape)
@@ -1588,10 +1592,6 @@ int pick_ksplit(int tiles, int ksteps_total) {
   return best;
 }
 
-// PRL_TUNE_LMHEAD_BWD bit 1: 1 = the round-2 structure of d W (the recompute also writes TRANSPOSED d-logits planes, d W
-// runs on the plain dual-plane core); 0 = d W gathers its fragments from the row-major planes with ds_read_b64_tr_b16
-bool dw_from_row_major() { return (prl::tuning(PRL_TUNE_LMHEAD_BWD, 0) & 2) == 0; }
-
 BwdLayout bwd_layout(int64_t hidden, int64_t vocab, int64_t chunk_rows) {
   BwdLayout L;
   L.chunk_pad = ceil_div(chunk_rows, 128) * 128;
@@ -1603,10 +1603,6 @@ BwdLayout bwd_layout(int64_t hidden, int64_t vocab, int64_t chunk_rows) {
   o += plane;
   L.dl_lo = o;
   o += plane;
-  L.dlT_hi = o;
-  if (!dw_from_row_major()) o += plane;
-  L.dlT_lo = o;
-  if (!dw_from_row_major()) o += plane;
   L.dh_partial = o;
   o += align256((size_t)kMaxKSplit * L.chunk_pad * hidden * 4);
   // the mixed-precision recompute reads the chunk's hidden states as f16 + fp8
@@ -1801,8 +1797,6 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
   uint16_t* hT = reinterpret_cast<uint16_t*>(ws + L.hT);
   uint16_t* dl_hi = reinterpret_cast<uint16_t*>(ws + L.dl_hi);
   uint16_t* dl_lo = reinterpret_cast<uint16_t*>(ws + L.dl_lo);
-  uint16_t* dlT_hi = reinterpret_cast<uint16_t*>(ws + L.dlT_hi);
-  uint16_t* dlT_lo = reinterpret_cast<uint16_t*>(ws + L.dlT_lo);
   hipStream_t s = static_cast<hipStream_t>(stream);
 
   for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
@@ -1830,10 +1824,8 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
       d.chunk_pad = L.chunk_pad;
       d.dl_hi = dl_hi;
       d.dl_lo = dl_lo;
-      const bool tr = dw_from_row_major() && vocab % 8 == 0;
-      d.dlT_hi = tr ? nullptr : dlT_hi;
-      d.dlT_lo = tr ? nullptr : dlT_lo;
       d.scales = nullptr;
+      d.ablate = (int)((prl::tuning(PRL_TUNE_LMHEAD_BWD, 0) >> 2) & 3);
       if (mx.w16) {  // recompute on the mixed-precision core: the logits are those of prl_lm_head_logprob_fwd_mx
         uint16_t* h16 = reinterpret_cast<uint16_t*>(ws + L.h16);
         uint8_t* h8 = mx.w8lo ? reinterpret_cast<uint8_t*>(ws + L.h8) : nullptr;
@@ -1846,9 +1838,10 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
         d.scales = mx.scales;
         d.vt = ceil_div(vocab, CfgMx::BM);
         d.tt = ceil_div(m_pad, CfgMx::BN);
+        d.nsplit = fwd_nsplit(d.tt, d.vt, true);
         if (mx.w8lo) {
-          if (int rc = launch_tiles(lmhead_dlogits_kernel<CfgMx, 2>, CfgMx::NT, dl_lds_bytes<CfgMx>(), d.vt * d.tt, d, s, "lmhead_dlogits_kernel(mx)")) return rc;
-        } else if (int rc = launch_tiles(lmhead_dlogits_kernel<CfgMx, 3>, CfgMx::NT, dl_lds_bytes<CfgMx>(), d.vt * d.tt, d, s, "lmhead_dlogits_kernel(mx, f16-exact weight)")) {
+          if (int rc = launch_tiles(lmhead_dlogits_kernel<CfgMx, 2>, CfgMx::NT, dl_lds_bytes<CfgMx>(), d.tt * d.nsplit, d, s, "lmhead_dlogits_kernel(mx)")) return rc;
+        } else if (int rc = launch_tiles(lmhead_dlogits_kernel<CfgMx, 3>, CfgMx::NT, dl_lds_bytes<CfgMx>(), d.tt * d.nsplit, d, s, "lmhead_dlogits_kernel(mx, f16-exact weight)")) {
           return rc;
         }
       } else {
@@ -1857,10 +1850,11 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
       // token tiles of THIS chunk: its rows rounded up to 128 (the pad rows are written as zeros and are what the
       // d W contraction below runs over); a short last chunk does not pay for the whole buffer
       d.tt = ceil_div(m_pad, shape_bn(shape));
+      d.nsplit = fwd_nsplit(d.tt, d.vt, shape != kSmall);
       if (use_dual(shape, d.terms)) {
-        if (int rc = launch_tiles(lmhead_dlogits_kernel<CfgDual, 1>, CfgDual::NT, dl_lds_bytes<CfgDual>(), d.vt * d.tt, d, s,
+        if (int rc = launch_tiles(lmhead_dlogits_kernel<CfgDual, 1>, CfgDual::NT, dl_lds_bytes<CfgDual>(), d.tt * d.nsplit, d, s,
                                   "lmhead_dlogits_kernel(dual)")) return rc;
-      } else if (int rc = PRL_LAUNCH_DL(shape, d.vt * d.tt, d, s, "lmhead_dlogits_kernel")) {
+      } else if (int rc = PRL_LAUNCH_DL(shape, d.tt * d.nsplit, d, s, "lmhead_dlogits_kernel")) {
         return rc;
       }
       }
@@ -1922,42 +1916,30 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
       hipLaunchKernelGGL((split_transpose_kernel<uint16_t>), tg, dim3(256), 0, s, m, hidden, hidden_bf16 + r0 * hidden,
                          (uint16_t*)nullptr, (uint16_t*)nullptr, hT, (uint16_t*)nullptr, (int64_t)L.chunk_pad);
       PRL_LAUNCH_CHECK("split_transpose_kernel(hidden)");
+      // d W gathers its MFMA fragments from the ROW-MAJOR planes with transposing LDS reads (round 2 had the recompute write
+      // transposed copies of both planes for this product: 5 GB more per micro-batch, profiles/r03f_*)
       GemmArgs g;
       g.terms.n = 2;
-      g.terms.a[0] = dlT_hi;
-      g.terms.a[1] = dlT_lo;
-      g.terms.a[2] = dlT_lo;
+      g.terms.a[0] = dl_hi;
+      g.terms.a[1] = g.terms.a[2] = dl_lo;
       g.terms.b[0] = g.terms.b[1] = g.terms.b[2] = hT;
-      g.geo = Geom{(int)vocab, (int)hidden, m_pad, L.chunk_pad, L.chunk_pad};  // contraction over the chunk's (padded) rows
-      const Shape shape = pick_shape(vocab, hidden);
-      g.mt = ceil_div(vocab, shape_bm(shape));
-      g.nt = ceil_div(hidden, shape_bn(shape));
+      g.geo = Geom{(int)vocab, (int)hidden, m_pad, vocab, L.chunk_pad};  // A: [tokens, vocab] row-major, its contraction index is the row
+      g.mt = ceil_div(vocab, CfgDual::BM);
+      g.nt = ceil_div(hidden, CfgDual::BN);
       g.ldc = hidden;
       g.out_bf16 = 0;
       g.accumulate = (r0 == 0 && (flags & PRL_LM_HEAD_DW_OVERWRITE)) ? 0 : 1;  // later chunks add to the first
       g.out = grad_weight;
       g.ksplit = 1;
-      g.ksteps = 0;
       g.partial = nullptr;
-      if (dw_from_row_major()) {
-        g.terms.a[0] = dl_hi;
-        g.terms.a[1] = dl_lo;
-        g.geo = Geom{(int)vocab, (int)hidden, m_pad, vocab, L.chunk_pad};  // A: [tokens, vocab] row-major, its contraction index is the row
-        g.mt = ceil_div(vocab, CfgDual::BM);
-        g.nt = ceil_div(hidden, CfgDual::BN);
-        {  // raster group: ONE vocabulary tile with all its hidden tiles when there are many of those (measured at the 7B
-          // shape, 14 hidden tiles: groups of 1 / 2 / 3 / 4 / 8 vocabulary tiles -> 53.1 / 53.3 / 53.7 / 53.8 / 54.0 ms for the
-          // whole backward, profiles/r03h_dw_raster.txt); a narrow head takes as many as fill 16 CUs
-          const int64_t forced = prl::tuning(PRL_TUNE_LMHEAD_DW_GROUP, 0);
-          int gm = forced > 0 ? (int)forced : 16 / g.nt;
-          g.ksteps = gm < 1 ? 1 : gm;
-        }
-        if (int rc = PRL_LAUNCH_DUAL(gemm_dw_tr_kernel, g.mt * g.nt, g, s, "gemm_dw_tr_kernel(d weight)")) return rc;
-      } else if (use_dual(shape, g.terms)) {
-        if (int rc = PRL_LAUNCH_DUAL((gemm_nt_kernel<CfgDual, true>), g.mt * g.nt, g, s, "gemm_nt_kernel(d weight, dual)")) return rc;
-      } else if (int rc = PRL_LAUNCH_CFG(shape, gemm_nt_kernel, g.mt * g.nt, g, s, "gemm_nt_kernel(d weight)")) {
-        return rc;
+      {  // raster group: ONE vocabulary tile with all its hidden tiles when there are many of those (measured at the 7B
+        // shape, 14 hidden tiles: groups of 1 / 2 / 3 / 4 / 8 vocabulary tiles -> 53.1 / 53.3 / 53.7 / 53.8 / 54.0 ms for the
+        // whole backward, profiles/r03h_dw_raster.txt); a narrow head takes as many as fill 16 CUs
+        const int64_t forced = prl::tuning(PRL_TUNE_LMHEAD_DW_GROUP, 0);
+        const int gm = forced > 0 ? (int)forced : 16 / g.nt;
+        g.ksteps = gm < 1 ? 1 : gm;  // (the raster's group size travels in the otherwise unused split-K field)
       }
+      if (int rc = PRL_LAUNCH_DUAL(gemm_dw_tr_kernel, g.mt * g.nt, g, s, "gemm_dw_tr_kernel(d weight)")) return rc;
     }
   }
   return PRL_OK;
