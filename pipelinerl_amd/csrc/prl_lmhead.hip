@@ -1040,7 +1040,13 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
   const float up = a.upstream ? *a.upstream : 1.0f;
   const float k2 = a.scales ? a.k2 / (a.scales[0] * a.scales[1]) : a.k2;  // power-of-two operand scales: exact to undo
   const int64_t V = a.geo.M;
-  // per-token quantities of this lane's NJ token rows
+  f32x16 acc[2][NJ];
+  for (int tv = vt0; tv < vt1; ++tv) {
+  const int m0 = tv * C::BM;
+  zero_acc<NJ>(acc);
+  run_core<C, CORE>(acc, a.terms, a.geo, m0, n0, lds);
+  // per-token quantities of this lane's NJ token rows - re-read for every vocabulary tile (five cached scalars per row):
+  // kept in registers across the main loop they and the loop's own state exceed the register file (98 spilled)
   float t_gi[NJ], t_nhi[NJ], t_l2[NJ], t_H[NJ];
   int t_id[NJ];
 #pragma unroll
@@ -1063,11 +1069,6 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
     t_gi[j] = g * a.inv_temp;
     t_nhi[j] = -gH * a.inv_temp;
   }
-  f32x16 acc[2][NJ];
-  for (int tv = vt0; tv < vt1; ++tv) {
-  const int m0 = tv * C::BM;
-  zero_acc<NJ>(acc);
-  run_core<C, CORE>(acc, a.terms, a.geo, m0, n0, lds);
   const int vbase = m0 + acc_row(lane, wrow0, 0, 0);
   // ---- d logits -> two bf16 planes (hi + lo = value), ROW-MAJOR [token row][vocabulary], through LDS images of the tile so
   // that every global store is 16 bytes per lane and a wave writes whole 512-byte row segments (storing straight from the
@@ -1087,55 +1088,47 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
   const int wn = (tid_here >> 6) & 1;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    // the two halves are independent register work: without a fence the scheduler starts the second half's exponentials
-    // above the first half's stores and both sets of pairs are alive next to the accumulators (111 registers spilled)
-    __builtin_amdgcn_sched_barrier(0);
-    uint32_t pk[2][JH][16];  // (hi | lo << 16)
+    __syncthreads();  // every wave is done with the LDS: the main loop's tiles (h = 0) / the previous half's images
+    // 16 accumulator values at a time -> (hi, lo) pairs -> straight into the two plane images: no array of pairs is ever alive
+    // next to the 128 accumulators (a whole half of pairs first: 111 registers spilled, some of them inside the main loop)
 #pragma unroll
     for (int jj = 0; jj < JH; ++jj) {
       const int j = h * JH + jj;
       const float gi = t_gi[j], ngi = -t_gi[j], nhi = t_nhi[j], l2 = t_l2[j], H = t_H[j];
       const int id = t_id[j];
       const bool live = (gi != 0.0f) || (nhi != 0.0f);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float val = 0.0f;
-          if (live) {
-            const float d2 = __builtin_fmaf(acc[i][j][r], k2, -l2);  // log2 p
-            const float p = fast_exp2(d2);
-            val = ngi * p;
-            if (nhi != 0.0f) val = __builtin_fmaf(nhi * p, __builtin_fmaf(d2, kLn2, H), val);
-            if (vbase + i * 32 + (r & 3) + 8 * (r >> 2) == id) val += gi;
-          }
-          uint16_t hi, lo;
-          split2(val, hi, lo);
-          pk[i][jj][r] = (uint32_t)hi | ((uint32_t)lo << 16);
-        }
-    }
-    if (a.ablate & 2) {  // timing ablation: keep the values alive, skip the plane epilogue
-#pragma unroll
-      for (int jj = 0; jj < JH; ++jj)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(pk[i][jj][r]));
-      continue;
-    }
-    __syncthreads();  // every wave is done with the LDS: the main loop's tiles (h = 0) / the previous half's images
-    // lane writes its 4 consecutive vocabulary entries (registers 4 rg .. 4 rg + 3) of a token row as 8 bytes per plane
-#pragma unroll
-    for (int jj = 0; jj < JH; ++jj)
+      const int local = wn * (JH * 32) + jj * 32 + l31;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int local = wn * (JH * 32) + jj * 32 + l31, vloc = (tid_here >> 7) * 64 + i * 32 + 8 * rg + 4 * lhalf;
-          const uint32_t p0 = pk[i][jj][rg * 4 + 0], p1 = pk[i][jj][rg * 4 + 1], p2 = pk[i][jj][rg * 4 + 2], p3 = pk[i][jj][rg * 4 + 3];
-          *reinterpret_cast<uint2*>(img + local * RS + vloc * 2) = uint2{(p0 & 0xffffu) | (p1 << 16), (p2 & 0xffffu) | (p3 << 16)};
-          *reinterpret_cast<uint2*>(img + IMG + local * RS + vloc * 2) = uint2{(p0 >> 16) | (p1 & 0xffff0000u), (p2 >> 16) | (p3 & 0xffff0000u)};
+          uint32_t p[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = rg * 4 + e;
+            float val = 0.0f;
+            if (live) {
+              const float d2 = __builtin_fmaf(acc[i][j][r], k2, -l2);  // log2 p
+              const float pr = fast_exp2(d2);
+              val = ngi * pr;
+              if (nhi != 0.0f) val = __builtin_fmaf(nhi * pr, __builtin_fmaf(d2, kLn2, H), val);
+              if (vbase + i * 32 + (r & 3) + 8 * (r >> 2) == id) val += gi;
+            }
+            uint16_t hi, lo;
+            split2(val, hi, lo);
+            p[e] = (uint32_t)hi | ((uint32_t)lo << 16);
+          }
+          if (a.ablate & 2) {  // timing ablation: keep the values alive, skip the images
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(p[e]));
+            continue;
+          }
+          // the lane's 4 consecutive vocabulary entries (registers 4 rg .. 4 rg + 3) of a token row: 8 bytes per plane
+          const int vloc = (tid_here >> 7) * 64 + i * 32 + 8 * rg + 4 * lhalf;
+          *reinterpret_cast<uint2*>(img + local * RS + vloc * 2) = uint2{(p[0] & 0xffffu) | (p[1] << 16), (p[2] & 0xffffu) | (p[3] << 16)};
+          *reinterpret_cast<uint2*>(img + IMG + local * RS + vloc * 2) = uint2{(p[0] >> 16) | (p[1] & 0xffff0000u), (p[2] >> 16) | (p[3] & 0xffff0000u)};
         }
+    }
     __syncthreads();
     for (int c = tid_here; c < (BN / 2) * (BM / 8); c += C::NT) {
       const int local = c / (BM / 8), k = c % (BM / 8);
