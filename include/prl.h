@@ -85,7 +85,8 @@ enum prl_tune_key {
   PRL_TUNE_PACK_TPL = 10,           /* tokens per lane of the pack kernel: 2 | 4 */
   PRL_TUNE_LMHEAD_BWD = 11,         /* backward structure of the fused head, see prl_lmhead.hip */
   PRL_TUNE_LMHEAD_DW_GROUP = 12,    /* vocabulary tiles per raster group of the d W product */
-  PRL_TUNE_COUNT = 13
+  PRL_TUNE_LMHEAD_SEG = 13,         /* 32-deep stages per contraction segment of the d hidden product */
+  PRL_TUNE_COUNT = 14
 };
 #define PRL_TUNE_UNSET INT64_MIN
 int prl_set_tuning(int32_t key, int64_t value);

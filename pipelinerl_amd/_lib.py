@@ -214,12 +214,12 @@ def load() -> ctypes.CDLL:
 # measurement scripts and tests use are mapped onto it HERE, on the Python side of the entry points they
 # influence: a dictionary lookup per call in the host language, nothing on the C launch path.
 TUNE_KEYS = {"fused_variant": 0, "lmhead_tile": 1, "lmhead_dual": 2, "lmhead_nsplit": 3, "lmhead_ksplit": 4, "lmhead_exp": 5,
-             "loss_fast_stats": 6, "loss_tpl": 7, "loss_blocks_per_cu": 8, "pack_nt": 9, "pack_tpl": 10, "lmhead_bwd": 11, "lmhead_dw_group": 12}
+             "loss_fast_stats": 6, "loss_tpl": 7, "loss_blocks_per_cu": 8, "pack_nt": 9, "pack_tpl": 10, "lmhead_bwd": 11, "lmhead_dw_group": 12, "lmhead_seg": 13}
 PRL_TUNE_UNSET = -(1 << 63)
 _ENV_OF_KEY = {"fused_variant": "PRL_FUSED_VARIANT", "lmhead_tile": "PRL_LMHEAD_TILE", "lmhead_dual": "PRL_LMHEAD_DUAL",
                "lmhead_nsplit": "PRL_LMHEAD_NSPLIT", "lmhead_ksplit": "PRL_LMHEAD_KSPLIT", "lmhead_exp": "PRL_LMHEAD_EXP",
                "loss_fast_stats": "PRL_LOSS_FAST_STATS", "loss_tpl": "PRL_LOSS_TPL", "loss_blocks_per_cu": "PRL_LOSS_BLOCKS_PER_CU",
-               "pack_nt": "PRL_PACK_NT", "pack_tpl": "PRL_PACK_TPL", "lmhead_bwd": "PRL_LMHEAD_BWD", "lmhead_dw_group": "PRL_LMHEAD_DW_GROUP"}
+               "pack_nt": "PRL_PACK_NT", "pack_tpl": "PRL_PACK_TPL", "lmhead_bwd": "PRL_LMHEAD_BWD", "lmhead_dw_group": "PRL_LMHEAD_DW_GROUP", "lmhead_seg": "PRL_LMHEAD_SEG"}
 _ENV_TUNED_ENTRY_POINTS = ("prl_fused_logits_loss", "prl_lm_head_logprob_fwd", "prl_lm_head_logprob_bwd", "prl_lm_head_workspace_bytes",
                            "prl_lm_head_logprob_fwd_mx", "prl_lm_head_mx_workspace_bytes", "prl_lm_head_logprob_bwd_mx",
                            "prl_grpo_loss_fwd_bwd", "prl_pack_collate")

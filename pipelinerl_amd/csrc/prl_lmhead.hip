@@ -1220,12 +1220,13 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_nt_kernel(GemmArgs a) {
 // d hidden on the triple-plane core.  Work item = (output tile, contraction slice kz).  With 8 slices every XCD works on
 // ONE slice (block b runs on XCD b % 8): the 32 workgroups an XCD runs at a time are an 8 x 4 patch of output tiles that
 // all walk the same 1/8 of the vocabulary, so each staged d-logits tile is wanted by 4 of them and each weight tile by 8,
-// out of the XCD's own L2 - provided they stay together.  One tile is ~600 stages long; workgroups that never wait for
-// each other drift apart and every one of them misses L2 on its own (the generic kernel: L2 hit 64 %, HBM fetch 7 x the
-// operands, profiles/r02aj).  So the contraction runs in SEGMENTS of kSegSteps stages with an empty pipeline in between
-// (the forward's per-tile refill, which is what keeps its workgroups in step): whoever is ahead waits for the first
-// loads of the next segment, which are misses for the leader and hits for the rest.
-constexpr int kSegSteps = 64;  // 32-deep stages per segment (2048 of contraction)
+// out of the XCD's own L2.  The generic kernel spread the slices of a tile over the XCDs and ran the three products one
+// after the other: L2 hit 64 %, HBM fetch 7 x the operands (profiles/r02aj); here 89.5 % (profiles/r03g).
+// The contraction can run in SEGMENTS with an empty pipeline in between (the forward's per-tile refill, which keeps ITS
+// workgroups in step); measured here it buys nothing - segments of 16 / 32 / 64 / 128 / 256 stages and none at all:
+// 53.0 / 52.1 / 52.0-52.2 / 51.9 / 51.7 / 51.7 ms for the whole backward (profiles/r03p_dh_segments.txt) - the shared
+// slice alone keeps the patch together.  Default: one segment per slice; PRL_TUNE_LMHEAD_SEG sets a length.
+constexpr int kSegSteps = 1 << 20;
 
 struct Dh3Args {
   const uint16_t *a1, *a2, *b1, *b2;  // d logits hi / lo [M, K], W^T hi / lo [N, K]
@@ -1233,6 +1234,7 @@ struct Dh3Args {
   int mt, nt;
   int ksplit, ksteps;                  // stages (of 32) per slice
   float* partial;                      // [ksplit][M][N] (ksplit > 1) or the fp32 output itself (ksplit == 1)
+  int seg;                             // stages per segment
 };
 
 __global__ __launch_bounds__(CfgTriple::NT, 2) void gemm_dh3_kernel(Dh3Args a) {
@@ -1263,8 +1265,8 @@ __global__ __launch_bounds__(CfgTriple::NT, 2) void gemm_dh3_kernel(Dh3Args a) {
   const int s0 = kz * a.ksteps;
   int s1 = s0 + a.ksteps;
   s1 = s1 < total_steps ? s1 : total_steps;
-  for (int s = s0; s < s1; s += kSegSteps) {
-    const int n = (s1 - s) < kSegSteps ? (s1 - s) : kSegSteps;
+  for (int s = s0; s < s1; s += a.seg) {
+    const int n = (s1 - s) < a.seg ? (s1 - s) : a.seg;
     Geom g = a.geo;
     g.Kc = n * BK32;
     const int64_t k0 = (int64_t)s * BK32;
@@ -1877,11 +1879,12 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
       const bool triple = g.terms.n == 3 && (prl::tuning(PRL_TUNE_LMHEAD_BWD, 0) & 1) == 0;
       int slices = 1;       // fp32 slices in g.partial to be added (and converted) into g.out; 0: the kernel wrote g.out itself
       if (triple) {
-        Dh3Args d3{dl_hi, dl_lo, wt_hi, wt_lo, g.geo, ceil_div(m, CfgTriple::BM), ceil_div(hidden, CfgTriple::BN), 1, 0, nullptr};
+        Dh3Args d3{dl_hi, dl_lo, wt_hi, wt_lo, g.geo, ceil_div(m, CfgTriple::BM), ceil_div(hidden, CfgTriple::BN), 1, 0, nullptr, kSegSteps};
+        if (const int64_t seg = prl::tuning(PRL_TUNE_LMHEAD_SEG, 0); seg > 0) d3.seg = (int)seg;
         const int steps32 = (int)(vocab / BK32);
         d3.ksplit = pick_ksplit(d3.mt * d3.nt, steps32 / 2);
-        // one slice per XCD whenever the grid then still fills whole rounds and a slice keeps at least two segments
-        if (prl::tuning(PRL_TUNE_LMHEAD_KSPLIT, 0) == 0 && ((int64_t)d3.mt * d3.nt * 8) % 256 == 0 && steps32 / 8 >= 2 * kSegSteps) d3.ksplit = 8;
+        // one slice per XCD whenever the grid then still fills whole rounds and a slice keeps at least 128 stages
+        if (prl::tuning(PRL_TUNE_LMHEAD_KSPLIT, 0) == 0 && ((int64_t)d3.mt * d3.nt * 8) % 256 == 0 && steps32 / 8 >= 128) d3.ksplit = 8;
         d3.ksteps = ceil_div(steps32, d3.ksplit);
         d3.ksplit = ceil_div(steps32, d3.ksteps);  // no empty slice
         const bool direct = d3.ksplit == 1 && !g.out_bf16;  // a single fp32 slice IS the output
