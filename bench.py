@@ -408,7 +408,7 @@ def fused_head_probe(dev: torch.device, seq_length: int, vocab: int, hidden: int
         "flops_per_launch": 2 * gemm, "ms_per_launch": fwd_ms,
         "config": {"tokens": T, "hidden": H, "vocab": V, "weight": "fp32 as two bf16 planes (fp32-GEMM accuracy)", "logits_materialised_bytes": 0},
         "backward": {"ms": bwd_ms, "executed_tflops": 7 * gemm / (bwd_ms * 1e-3) / 1e12, "chunk_rows": chunk_rows,
-                     "what": "recompute (2 plane products, d logits as two ROW-MAJOR bf16 planes of one row chunk) + d hidden (3 products on the "
+                     "what": "recompute (2 plane products, a workgroup walks a range of vocabulary tiles; d logits as two ROW-MAJOR bf16 planes of one row chunk) + d hidden (3 products on the "
                              "triple-plane core, one contraction slice per XCD) + d W (2 products, fragments gathered from the row-major planes by "
                              "ds_read_b64_tr_b16)"},
         "forward_mixed_precision": mixed,

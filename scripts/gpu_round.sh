@@ -1,52 +1,31 @@
 #!/bin/bash
-# One GPU-box session: tests, smoke, bench, rocprof.  Everything is logged under gpurun_out/.
-# usage: scripts/gpu_round.sh [tag]
+# One GPU-box session: the whole -m gpu suite, smoke, the default bench line (live 7B model-in-the-loop step included),
+# rocprofv3 kernel stats of the same command.  Everything is logged under gpurun_out/<tag>/.
+# usage: /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash scripts/gpu_round.sh r03z'
 set -u
-TAG=${1:-r01}
+TAG=${1:-round}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-echo "== env" | tee $OUT/env.log
-(rocminfo | grep -E "Marketing Name|gfx" | head -4; nproc; grep -m1 "model name" /proc/cpuinfo; free -g | head -2; python -c "import torch;print(torch.__version__, torch.cuda.is_available(), torch.cuda.get_device_name(0))") >> $OUT/env.log 2>&1
-echo "== build check" | tee -a $OUT/env.log
-python -c "from pipelinerl_amd import _lib; l=_lib.load(); print('libprl abi', l.prl_abi_version())" >> $OUT/env.log 2>&1
-
-echo "== pytest -m gpu"
-timeout 900 python -m pytest tests -m gpu -q --maxfail=30 --timeout 300 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
+(rocminfo | grep -E "Marketing Name|gfx" | head -4; nproc; grep -m1 "model name" /proc/cpuinfo; free -g | head -2) > $OUT/env.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 --timeout 600 -p no:cacheprovider --durations=8 > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit $?" | tee -a $OUT/pytest_gpu.log
-tail -5 $OUT/pytest_gpu.log
-
-echo "== smoke"
+tail -6 $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
-echo "smoke exit $?" | tee -a $OUT/smoke.log
-tail -3 $OUT/smoke.log
-
-echo "== bench tiny"
-timeout 300 python bench.py --workload tiny --steps 2 --warmup 1 > $OUT/bench_tiny.log 2>&1
-echo "bench tiny exit $?" | tee -a $OUT/bench_tiny.log
-tail -2 $OUT/bench_tiny.log | cut -c1-600
-
-echo "== kernel sweep"
-timeout 600 python scripts/kernel_sweep.py > $OUT/sweep.log 2>&1
-echo "sweep exit $?" | tee -a $OUT/sweep.log
-tail -40 $OUT/sweep.log
-
-echo "== bench full"
-timeout 900 python bench.py --steps 2 --warmup 1 > $OUT/bench_full.log 2>&1
-echo "bench full exit $?" | tee -a $OUT/bench_full.log
-tail -2 $OUT/bench_full.log | cut -c1-1500
-
-echo "== rocprof stats of the default bench command"
-cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_stats -o stats -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-weight-sync > $GRAFT_REPO_ROOT/$OUT/rocprof_stats.log 2>&1
-echo "rocprof exit $?" | tee -a $GRAFT_REPO_ROOT/$OUT/rocprof_stats.log
-cd $GRAFT_REPO_ROOT
-find $OUT/prof_stats -name "*kernel_stats*" | head; for f in $(find $OUT/prof_stats -name "*kernel_stats.csv" | head -1); do head -12 $f; done
-# keep the merge-back small: the raw kernel trace can be large
-find $OUT/prof_stats -name "*kernel_trace.csv" -size +2M -delete
-tail -3 $OUT/rocprof_stats.log | cut -c1-1200
-echo "== pmc passes (separate runs, kernel-trace only)"
-for C in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o pmc -- python $GRAFT_REPO_ROOT/scripts/kernel_sweep.py --quick > $GRAFT_REPO_ROOT/$OUT/pmc_$C.log 2>&1; echo "pmc $C exit $?")
-done
-find $OUT -name "*counter_collection.csv" | head
-echo "== done"
+echo "smoke exit $?" | tee -a $OUT/smoke.log; tail -2 $OUT/smoke.log
+( time timeout 1500 python bench.py --steps 5 --warmup 2 ) > $OUT/bench_full.log 2> $OUT/bench_full.err
+echo "bench exit $?" | tee -a $OUT/bench_full.log
+python - "$OUT" <<'PY'
+import json, sys
+out = sys.argv[1]
+d = json.loads([l for l in open(out + "/bench_full.log") if l.startswith("{")][0])
+print({k: d[k] for k in ("value", "ms_per_step")}, "roofline", round(d["roofline"]["frac"], 4))
+m = d["roofline_mfma"]
+print("head fwd ms", round(m["ms_per_launch"], 2), "bwd ms", round(m["backward"]["ms"], 2), "mixed fwd", m.get("forward_mixed_precision", {}).get("ms"))
+e = d["e2e"]
+print({k: e.get(k) for k in ("s_per_step", "samples_per_s", "peak_memory_GB", "source", "error")})
+print({k: round(v["avg_us"], 1) for k, v in d["kernels"].items()})
+PY
+cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-weight-sync --no-e2e --no-transport > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
+cd $GRAFT_REPO_ROOT; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do cut -c1-260 $f > $OUT/bench_kernel_stats.csv; cut -c1-150 $f | head -10; done
+find $OUT/prof -name "*kernel_trace.csv" -delete
