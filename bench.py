@@ -62,6 +62,7 @@ def parse_args():
                    help="N > 1: bytes of data-parallel gradients all-reduced per step (default: Qwen2.5-7B in bf16)")
     p.add_argument("--e2e", action="store_true", help="(default at N = 1 on the 7B workload) run scripts/e2e_learner_bench.py live")
     p.add_argument("--no-e2e", action="store_true", help="N = 1: quote the committed model-in-the-loop step from profiles/ instead of running it (source: committed)")
+    p.add_argument("--no-live-pmc", action="store_true", help="quote the committed PMC traffic figure instead of measuring it with two rocprofv3 --pmc sub-runs")
     p.add_argument("--no-transport", action="store_true", help="skip the host-side transport probe (shm log / files backend round trips)")
     p.add_argument("--cpu-baseline-threads", default=None,
                    help="comma-separated thread counts: time ONLY the cpu_baseline loss leg at each count and exit (no GPU work)")
@@ -340,6 +341,47 @@ def _committed_json(rel: str, note: str) -> dict | None:
     d["source"] = rel
     d["note"] = note
     return d
+
+
+def live_pmc_traffic(kernel_substr: str = "fused_logits_loss_keep_kernel") -> dict | None:
+    """HBM-side bytes per launch of the dominant kernel, MEASURED IN THIS RUN: two separate `rocprofv3 --pmc` passes
+    (FETCH_SIZE, then WRITE_SIZE; kernel trace only, as the CDNA guide prescribes) over `scripts/kernel_sweep.py --quick` (the
+    same kernel on the same [8192, 152 064] fp32 micro-batch), in subprocesses.  FETCH_SIZE is doubled (gfx950 tallies the 128-byte
+    requests of a 16 B/lane stream at 64 bytes; calibrated on a 1 GiB copy in round 1), WRITE_SIZE taken as is, both in KB.
+    Returns None when rocprofv3 is unavailable or a pass fails (the committed figure is quoted instead, labelled)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not Path(exe).exists():
+        return None
+    got = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = Path(tmp) / counter
+            try:
+                r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", str(out), "-o", "pmc", "--",
+                                    sys.executable, str(ROOT / "scripts" / "kernel_sweep.py"), "--quick"],
+                                   cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True,
+                                   timeout=float(os.environ.get("PRL_BENCH_PMC_TIMEOUT", 240)))
+            except Exception:  # noqa: BLE001
+                return None
+            files = glob.glob(str(out / "**" / "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            per_dispatch: dict[str, float] = {}
+            for row in csv.DictReader(open(files[0])):
+                if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    per_dispatch[row["Dispatch_Id"]] = per_dispatch.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per_dispatch:
+                return None
+            got[counter] = (sum(per_dispatch.values()) / len(per_dispatch), len(per_dispatch))
+    fetch_kb, n = got["FETCH_SIZE"]
+    write_kb, _ = got["WRITE_SIZE"]
+    return {"hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0, "fetch_kb": fetch_kb, "write_kb": write_kb, "launches": n}
 
 
 def fused_head_probe(dev: torch.device, seq_length: int, vocab: int, hidden: int) -> dict:
@@ -690,6 +732,17 @@ def main():
                 kernels["preprocess_K5_K6"]["pack_write_traffic"] = table["pack_collate"]["write_kb"] * 1024 / table["pack_collate"]["tokens"] * tokens_per_rank
         except Exception:
             traffic = None
+    if (rank == 0 and world == 1 and dom == "fused_logits_loss" and (seq_length, vocab) == (8192, 152064) and not args.no_live_pmc
+            and os.environ.get("PRL_BENCH_LIVE_PMC", "1") != "0"):
+        try:
+            live = live_pmc_traffic()
+        except Exception:  # noqa: BLE001 - must never take the benchmark line down
+            live = None
+        if live is not None:
+            traffic = live["hbm_bytes_per_launch"]
+            traffic_source = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) over "
+                              f"scripts/kernel_sweep.py --quick, {live['launches']} launches of the same kernel on the same micro-batch shape with every "
+                              f"row labelled; FETCH_SIZE {live['fetch_kb']:.0f} KB doubled per MI355X_MICROARCH.md + WRITE_SIZE {live['write_kb']:.0f} KB")
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": kernels[dom]["hbm_frac"], "traffic": traffic, "traffic_source": traffic_source,
