@@ -422,10 +422,14 @@ def fused_head_probe(dev: torch.device, seq_length: int, vocab: int, hidden: int
         return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     fwd_ms = timed(lambda: head.logprob_entropy(h, ids, 1.0), 5)
-    nlp, ent, lse2, hb = head.logprob_entropy(h, ids, 1.0)
+    keep_ms = timed(lambda: head.logprob_entropy(h, ids, 1.0, keep=True), 5)  # the training forward: also leaves the logits behind
+    nlp, ent, lse2, hb, kept = head.logprob_entropy(h, ids, 1.0, keep=True)
     _, _, g_nlp, _ = grpo_loss_from_logprobs(cfg, batch, nlp, ent)
     gw = torch.zeros(V, H, device=dev)
-    bwd_ms = timed(lambda: head.backward_from_token_grads(hb, ids, 1.0, lse2, ent, g_nlp, None, None, grad_weight=gw), 2)
+    bwd_ms = timed(lambda: head.backward_from_token_grads(hb, ids, 1.0, lse2, ent, g_nlp, None, None, grad_weight=gw, kept_logits=kept), 2)
+    del kept
+    torch.cuda.empty_cache()
+    rec_ms = timed(lambda: head.backward_from_token_grads(hb, ids, 1.0, lse2, ent, g_nlp, None, None, grad_weight=gw), 2)
     gemm = 2.0 * T * V * H
     fwd_tf = 2 * gemm / (fwd_ms * 1e-3) / 1e12
     chunk_rows = head.chunk_rows
@@ -449,10 +453,16 @@ def fused_head_probe(dev: torch.device, seq_length: int, vocab: int, hidden: int
         "unit": "TFLOP/s", "frac": fwd_tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
         "flops_per_launch": 2 * gemm, "ms_per_launch": fwd_ms,
         "config": {"tokens": T, "hidden": H, "vocab": V, "weight": "fp32 as two bf16 planes (fp32-GEMM accuracy)", "logits_materialised_bytes": 0},
-        "backward": {"ms": bwd_ms, "executed_tflops": 7 * gemm / (bwd_ms * 1e-3) / 1e12, "chunk_rows": chunk_rows,
-                     "what": "recompute (2 plane products, a workgroup walks a range of vocabulary tiles; d logits as two ROW-MAJOR bf16 planes of one row chunk) + d hidden (3 products on the "
+        "forward_keeping_logits": {"ms": keep_ms, "executed_tflops": 2 * gemm / (keep_ms * 1e-3) / 1e12, "kept_bytes": 4 * T * V,
+                                   "what": "the same launch, each accumulator tile also stored as fp32 logits (16-byte stores from the accumulator "
+                                           "layout): the forward of a training step (FusedLmHead(keep_logits=True), the default)"},
+        "backward": {"ms": bwd_ms, "executed_tflops": 5 * gemm / (bwd_ms * 1e-3) / 1e12, "chunk_rows": chunk_rows,
+                     "what": "from the kept logits: one elementwise pass (fp32 logits -> d logits as two ROW-MAJOR bf16 planes) + d hidden (3 products on the "
                              "triple-plane core, one contraction slice per XCD) + d W (2 products, fragments gathered from the row-major planes by "
                              "ds_read_b64_tr_b16)"},
+        "backward_recompute": {"ms": rec_ms, "executed_tflops": 7 * gemm / (rec_ms * 1e-3) / 1e12,
+                               "what": "FusedLmHead(keep_logits=False): no logits anywhere, the d-logits planes come from recomputing both plane products "
+                                       "(a workgroup walks a range of vocabulary tiles) - 7 products instead of 5"},
         "forward_mixed_precision": mixed,
         "fp32_equivalent_tflops": gemm / (fwd_ms * 1e-3) / 1e12,
         "note": "second roofline object for the MFMA-bound fused output head (hidden -> log-prob/entropy, logits never in HBM); "
@@ -795,6 +805,20 @@ def main():
             if "error" not in e2e:
                 e2e["source"] = "measured in this run (scripts/e2e_learner_bench.py in a subprocess of bench.py)"
                 e2e["wall_s_including_model_init"] = time.perf_counter() - t_e2e
+                # the same step with every layer's activations KEPT (no recompute in the backward): what the 288 GB of one MI355X
+                # allow for 7B x 8192 tokens; the entry above keeps the reference's gradient checkpointing for comparability
+                try:
+                    out.unlink()
+                    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "e2e_learner_bench.py"), "--model", "7b", "--batch-size", "16", "--seq-len", "8192",
+                                        "--micro-batch", "1", "--fused", "--fused-head", "--no-checkpointing", "--steps", "1", "--warmup", "1", "--out", str(out)],
+                                       capture_output=True, text=True, timeout=float(os.environ.get("PRL_BENCH_E2E_TIMEOUT", 900)))
+                    if r.returncode == 0 and out.exists():
+                        k = json.loads(out.read_text().splitlines()[0])
+                        e2e["without_activation_recompute"] = {key: k[key] for key in ("s_per_step", "samples_per_s", "tokens_per_s", "peak_memory_GB", "loss")}
+                    else:
+                        e2e["without_activation_recompute"] = {"error": (r.stderr or r.stdout)[-300:]}
+                except Exception as e:  # noqa: BLE001
+                    e2e["without_activation_recompute"] = {"error": f"{type(e).__name__}: {e}"}
             elif committed is not None:
                 committed["source"] = "committed (profiles/r02_e2e_learner_7b_fused_head.json) - the live run failed: " + e2e["error"][-200:]
                 e2e = committed

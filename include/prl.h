@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 6
+#define PRL_ABI_VERSION 7
 
 #define PRL_OK 0
 #define PRL_EINVAL (-22)   /* bad argument                                  */
@@ -618,6 +618,36 @@ int prl_lm_head_logprob_bwd_mx(int64_t rows, int64_t cols, int64_t hidden, int64
                                int32_t grad_hidden_dtype, float* grad_weight, int64_t chunk_rows,
                                int32_t flags, void* workspace, size_t workspace_bytes,
                                prl_stream_t stream);
+
+/*
+ * The same head with the logits KEPT between forward and backward (reference lines as above: rl/__init__.py:204-233 reads the
+ * [T, V] fp32 logits of checkpoints.py:87-103's lm_head, autograd keeps them for the backward).  The *_keep forwards compute
+ * exactly what prl_lm_head_logprob_fwd / _fwd_mx compute and also write `logits2` [rows * cols, vocab] fp32 = the logits in
+ * base-2 units (logit * log2(e) / temperature) straight from the accumulators (vocab must be a multiple of 8).
+ * prl_lm_head_logprob_bwd_kept then forms the d-logits planes in one pass over them instead of recomputing the two plane
+ * products: 5 products instead of 7 per micro-batch at the price of rows * cols * vocab * 4 bytes that live from the head's
+ * forward to its backward (4.98 GB for 8192 x 152 064).  Workspaces: prl_lm_head_workspace_bytes /
+ * prl_lm_head_mx_workspace_bytes as for the recomputing forms.  Neither the weight planes nor the mixed-precision operands are
+ * read by the backward (d hidden runs on wt_hi / wt_lo, d W on the hidden states).
+ */
+int prl_lm_head_logprob_fwd_keep(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
+                                 const uint16_t* hidden_bf16, const uint16_t* w_hi, const uint16_t* w_lo,
+                                 const int64_t* input_ids, float temperature, float* new_logprobs,
+                                 float* entropy, float* lse2, float* logits2, void* workspace,
+                                 size_t workspace_bytes, prl_stream_t stream);
+int prl_lm_head_logprob_fwd_mx_keep(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
+                                    const uint16_t* hidden_bf16, const uint16_t* w16, const uint8_t* w8lo,
+                                    float* scales, const int64_t* input_ids, float temperature,
+                                    float* new_logprobs, float* entropy, float* lse2, float* logits2,
+                                    void* workspace, size_t workspace_bytes, prl_stream_t stream);
+int prl_lm_head_logprob_bwd_kept(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
+                                 const uint16_t* hidden_bf16, const float* logits2, const uint16_t* wt_hi,
+                                 const uint16_t* wt_lo, const int64_t* input_ids, float temperature,
+                                 const float* lse2, const float* entropy, const float* grad_new_logprobs,
+                                 const float* grad_entropy, const float* upstream, void* grad_hidden,
+                                 int32_t grad_hidden_dtype, float* grad_weight, int64_t chunk_rows,
+                                 int32_t flags, void* workspace, size_t workspace_bytes,
+                                 prl_stream_t stream);
 
 #ifdef __cplusplus
 }

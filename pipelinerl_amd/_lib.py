@@ -13,7 +13,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl.so"
 
-PRL_ABI_VERSION = 6
+PRL_ABI_VERSION = 7
 PRL_OK = 0
 PRL_EINVAL = -22
 PRL_ENOMEM = -12
@@ -176,6 +176,10 @@ PROTOTYPES: dict[str, tuple] = {
                                              c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
     "prl_lm_head_logprob_bwd": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P,
                                           c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
+    "prl_lm_head_logprob_fwd_keep": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "prl_lm_head_logprob_fwd_mx_keep": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "prl_lm_head_logprob_bwd_kept": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P,
+                                               c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
 }
 
 _lib: ctypes.CDLL | None = None
@@ -222,6 +226,7 @@ _ENV_OF_KEY = {"fused_variant": "PRL_FUSED_VARIANT", "lmhead_tile": "PRL_LMHEAD_
                "pack_nt": "PRL_PACK_NT", "pack_tpl": "PRL_PACK_TPL", "lmhead_bwd": "PRL_LMHEAD_BWD", "lmhead_dw_group": "PRL_LMHEAD_DW_GROUP", "lmhead_seg": "PRL_LMHEAD_SEG"}
 _ENV_TUNED_ENTRY_POINTS = ("prl_fused_logits_loss", "prl_lm_head_logprob_fwd", "prl_lm_head_logprob_bwd", "prl_lm_head_workspace_bytes",
                            "prl_lm_head_logprob_fwd_mx", "prl_lm_head_mx_workspace_bytes", "prl_lm_head_logprob_bwd_mx",
+                           "prl_lm_head_logprob_fwd_keep", "prl_lm_head_logprob_fwd_mx_keep", "prl_lm_head_logprob_bwd_kept",
                            "prl_grpo_loss_fwd_bwd", "prl_pack_collate")
 _env_seen: tuple | None = None
 

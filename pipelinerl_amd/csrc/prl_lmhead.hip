@@ -55,6 +55,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MAX_TERMS = 3;
 
@@ -874,6 +875,7 @@ struct FwdArgs {
   float* part;          // [nsplit][padded][4]  (M, S, W, -)
   float* ysel;          // [padded] selected logit (base-2 units), written by whichever split owns the row
   const float* scales;  // mixed-precision cores: device floats {S_w, S_h} the operands were multiplied by; nullptr otherwise
+  float* logits2;       // nullable [n, vocab]: the logits in base-2 units (logit * log2(e) / temperature), kept for the backward
 };
 
 template <class C, int EXP = 0, int CORE = 0>
@@ -918,6 +920,21 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_fwd_kernel(FwdArgs a) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[i * 16 + r] = acc[i][j][r] * k2;
+      if (a.logits2) {
+        // kept logits: registers 4 rg .. 4 rg + 3 are four consecutive vocabulary entries of one token row - one 16-byte store;
+        // the two half-waves complete a 32-byte aligned piece of the row (V is a multiple of 8)
+        const int64_t q = n0 + acc_col(lane, wcol0, j);
+        if (q < a.geo.N) {
+          float* dst = a.logits2 + q * (int64_t)V + vbase;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+              if (vbase + i * 32 + 8 * rg + 3 < V)
+                *reinterpret_cast<float4*>(dst + i * 32 + 8 * rg) =
+                    float4{y[i * 16 + 4 * rg], y[i * 16 + 4 * rg + 1], y[i * 16 + 4 * rg + 2], y[i * 16 + 4 * rg + 3]};
+        }
+      }
       const int d = tgt[j] - vbase;
       if (d >= 0 && d < 64 && (d & 7) < 4) {  // the target row is one of this lane's 32
         float sel = 0.0f;
@@ -1145,6 +1162,69 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
   }
   __syncthreads();  // the images are read: the next vocabulary tile may stage into the LDS
   }  // vocabulary tiles of this workgroup
+}
+
+// backward, step 1 when the forward KEPT its logits (FwdArgs.logits2): no recompute - one pass over the chunk's rows of the kept
+// fp32 logits (base-2 units) writes the same two d-logits planes.  One workgroup per token row of the chunk buffers (the pad
+// rows and the rows without a gradient are written as zeros without reading anything); a thread owns 8 consecutive entries.
+struct KeptArgs {
+  const float* logits2;  // [n_total, vocab]
+  int64_t vocab, row_base, cols;
+  int rows;              // rows of this chunk (the buffers have gridDim.x >= rows: the rest is padding)
+  const int64_t* ids;
+  const float* lse2;
+  const float* ent;
+  const float* g_nlp;
+  const float* g_ent;     // nullable
+  const float* upstream;  // nullable device scalar
+  float inv_temp;
+  uint16_t* dl_hi;        // [gridDim.x, vocab]
+  uint16_t* dl_lo;
+};
+
+__global__ __launch_bounds__(256) void dlogits_from_kept_kernel(KeptArgs a) {
+  const int lrow = (int)blockIdx.x;
+  const int64_t q = a.row_base + lrow;
+  const int64_t V = a.vocab;
+  float gi = 0.0f, nhi = 0.0f, l2 = 0.0f, H = 0.0f;
+  int id = -1;
+  if (lrow < a.rows && (q % a.cols) != a.cols - 1) {
+    const float up = a.upstream ? *a.upstream : 1.0f;
+    const int64_t u = q + 1;
+    gi = a.g_nlp[u] * up * a.inv_temp;
+    nhi = a.g_ent ? -(a.g_ent[u] * up) * a.inv_temp : 0.0f;
+    l2 = a.lse2[u];
+    H = a.ent[u];
+    const int64_t v = a.ids[u];
+    if (v >= 0 && v < V) id = (int)v;
+  }
+  const bool live = (gi != 0.0f) || (nhi != 0.0f);
+  const float ngi = -gi;
+  const f32x4* src = reinterpret_cast<const f32x4*>(a.logits2 + q * V);
+  uint4* hi = reinterpret_cast<uint4*>(a.dl_hi + (int64_t)lrow * V);
+  uint4* lo = reinterpret_cast<uint4*>(a.dl_lo + (int64_t)lrow * V);
+  const int groups = (int)(V / 8);
+  for (int g = threadIdx.x; g < groups; g += 256) {
+    uint32_t oh[4] = {0, 0, 0, 0}, ol[4] = {0, 0, 0, 0};
+    if (live) {
+      const f32x4 x0 = __builtin_nontemporal_load(src + 2 * g), x1 = __builtin_nontemporal_load(src + 2 * g + 1);
+      const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d2 = x[e] - l2;  // log2 p
+        const float pr = fast_exp2(d2);
+        float val = ngi * pr;
+        if (nhi != 0.0f) val = __builtin_fmaf(nhi * pr, __builtin_fmaf(d2, kLn2, H), val);
+        if (g * 8 + e == id) val += gi;
+        uint16_t h16, l16;
+        split2(val, h16, l16);
+        oh[e >> 1] |= (uint32_t)h16 << (16 * (e & 1));
+        ol[e >> 1] |= (uint32_t)l16 << (16 * (e & 1));
+      }
+    }
+    hi[g] = uint4{oh[0], oh[1], oh[2], oh[3]};
+    lo[g] = uint4{ol[0], ol[1], ol[2], ol[3]};
+  }
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -1651,11 +1731,12 @@ extern "C" int prl_lm_head_workspace_bytes(int64_t rows, int64_t cols, int64_t h
   return PRL_OK;
 }
 
-extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
-                                       const uint16_t* w_hi, const uint16_t* w_lo, const int64_t* input_ids,
-                                       float temperature, float* new_logprobs, float* entropy, float* lse2,
-                                       void* workspace, size_t workspace_bytes, prl_stream_t stream) {
+static int lm_head_fwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
+                           const uint16_t* w_hi, const uint16_t* w_lo, const int64_t* input_ids,
+                           float temperature, float* new_logprobs, float* entropy, float* lse2, float* logits2,
+                           void* workspace, size_t workspace_bytes, prl_stream_t stream) {
   PRL_CHECK_ARG(rows >= 1 && cols >= 1, "rows and cols must be >= 1");
+  PRL_CHECK_ARG(!logits2 || (vocab % 8 == 0 && prl::aligned16(logits2)), "kept logits need a vocabulary that is a multiple of 8 and a 16-byte aligned buffer");
   PRL_CHECK_ARG(hidden >= BK && hidden % BK == 0, "hidden size %lld must be a multiple of %d", (long long)hidden, BK);
   PRL_CHECK_ARG(vocab >= 1 && vocab < ((int64_t)1 << 31) - 256, "vocab out of range");
   PRL_CHECK_ARG(rows * cols < ((int64_t)1 << 31) - 256, "too many rows");
@@ -1684,6 +1765,7 @@ extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidde
   a.part = static_cast<float*>(workspace);
   a.ysel = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_bytes);
   a.scales = nullptr;
+  a.logits2 = logits2;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int exp_bits = (int)prl::tuning(PRL_TUNE_LMHEAD_EXP, 0);
   if (shape == kWide && exp_bits && exp_bits != 256) {  // timing ablations, generic 256 x 256 forward only
@@ -1713,6 +1795,23 @@ extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidde
                      a.padded, a.part, a.ysel, input_ids, new_logprobs, entropy, lse2);
   PRL_LAUNCH_CHECK("lmhead_fwd_finish_kernel");
   return PRL_OK;
+}
+
+extern "C" int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
+                                       const uint16_t* w_hi, const uint16_t* w_lo, const int64_t* input_ids,
+                                       float temperature, float* new_logprobs, float* entropy, float* lse2,
+                                       void* workspace, size_t workspace_bytes, prl_stream_t stream) {
+  return lm_head_fwd_impl(rows, cols, hidden, vocab, hidden_bf16, w_hi, w_lo, input_ids, temperature, new_logprobs, entropy, lse2, nullptr,
+                          workspace, workspace_bytes, stream);
+}
+
+extern "C" int prl_lm_head_logprob_fwd_keep(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
+                                            const uint16_t* w_hi, const uint16_t* w_lo, const int64_t* input_ids,
+                                            float temperature, float* new_logprobs, float* entropy, float* lse2, float* logits2,
+                                            void* workspace, size_t workspace_bytes, prl_stream_t stream) {
+  PRL_CHECK_ARG(logits2, "null pointer");
+  return lm_head_fwd_impl(rows, cols, hidden, vocab, hidden_bf16, w_hi, w_lo, input_ids, temperature, new_logprobs, entropy, lse2, logits2,
+                          workspace, workspace_bytes, stream);
 }
 
 namespace {
@@ -1772,14 +1871,15 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
                             const float* lse2, const float* entropy, const float* grad_new_logprobs,
                             const float* grad_entropy, const float* upstream, void* grad_hidden,
                             int32_t grad_hidden_dtype, float* grad_weight, int64_t chunk_rows, int32_t flags,
-                            void* workspace, size_t workspace_bytes, prl_stream_t stream, const MxRecompute& mx) {
+                            void* workspace, size_t workspace_bytes, prl_stream_t stream, const MxRecompute& mx,
+                            const float* kept_logits2 = nullptr) {
   PRL_CHECK_ARG(rows >= 1 && cols >= 1, "rows and cols must be >= 1");
   PRL_CHECK_ARG(hidden >= BK && hidden % BK == 0, "hidden size %lld must be a multiple of %d", (long long)hidden, BK);
   PRL_CHECK_ARG(vocab >= BK && vocab % BK == 0 && vocab < ((int64_t)1 << 31) - 256,
                 "the fused backward contracts over the vocabulary: vocab %lld must be a multiple of %d", (long long)vocab, BK);
   PRL_CHECK_ARG(rows * cols < ((int64_t)1 << 31) - 256, "too many rows");
-  PRL_CHECK_ARG(hidden_bf16 && w_hi && wt_hi && input_ids && lse2 && entropy && grad_new_logprobs && workspace, "null pointer");
-  PRL_CHECK_ARG((w_lo == nullptr) == (wt_lo == nullptr), "w_lo and wt_lo go together");
+  PRL_CHECK_ARG(hidden_bf16 && (w_hi || kept_logits2) && wt_hi && input_ids && lse2 && entropy && grad_new_logprobs && workspace, "null pointer");
+  PRL_CHECK_ARG(kept_logits2 || (w_lo == nullptr) == (wt_lo == nullptr), "w_lo and wt_lo go together");
   PRL_CHECK_ARG(grad_hidden || grad_weight, "nothing to compute");
   PRL_CHECK_ARG(grad_hidden_dtype == PRL_DTYPE_F32 || grad_hidden_dtype == PRL_DTYPE_BF16, "unsupported grad_hidden dtype");
   PRL_CHECK_ARG(temperature > 0.0f, "temperature must be > 0");
@@ -1797,8 +1897,13 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
   for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
     const int64_t m = (n - r0) < chunk_rows ? (n - r0) : chunk_rows;
     const int m_pad = ceil_div(m, 128) * 128;  // <= L.chunk_pad
-    // ---- 1. d logits planes of this chunk (recompute the logits tile by tile)
-    {
+    // ---- 1. d logits planes of this chunk: from the logits the forward kept, or by recomputing them tile by tile
+    if (kept_logits2) {
+      KeptArgs k{kept_logits2, vocab, r0, cols, (int)m, input_ids, lse2, entropy, grad_new_logprobs, grad_entropy, upstream,
+                 1.0f / temperature, dl_hi, dl_lo};
+      hipLaunchKernelGGL(dlogits_from_kept_kernel, dim3((unsigned)m_pad), dim3(256), 0, s, k);
+      PRL_LAUNCH_CHECK("dlogits_from_kept_kernel");
+    } else {
       DlArgs d;
       d.terms.n = w_lo ? 2 : 1;
       for (int k = 0; k < MAX_TERMS; ++k) {
@@ -1859,7 +1964,7 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
       GemmArgs g;
       // PRL_LM_HEAD_DH_LEADING_TERM: only d logits_hi x W_hi.  The two dropped products are 2^-9 relative
       // corrections - the size of the rounding d hidden receives anyway when it is delivered in bf16.
-      g.terms.n = (flags & PRL_LM_HEAD_DH_LEADING_TERM) ? 1 : (w_lo ? 3 : 2);
+      g.terms.n = (flags & PRL_LM_HEAD_DH_LEADING_TERM) ? 1 : (wt_lo ? 3 : 2);
       g.terms.a[0] = dl_hi;
       g.terms.b[0] = wt_hi;
       g.terms.a[1] = dl_lo;
@@ -1972,6 +2077,18 @@ extern "C" int prl_lm_head_logprob_bwd_mx(int64_t rows, int64_t cols, int64_t hi
                           workspace, workspace_bytes, stream, mx);
 }
 
+extern "C" int prl_lm_head_logprob_bwd_kept(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
+                                            const float* logits2, const uint16_t* wt_hi, const uint16_t* wt_lo,
+                                            const int64_t* input_ids, float temperature, const float* lse2, const float* entropy,
+                                            const float* grad_new_logprobs, const float* grad_entropy, const float* upstream,
+                                            void* grad_hidden, int32_t grad_hidden_dtype, float* grad_weight, int64_t chunk_rows,
+                                            int32_t flags, void* workspace, size_t workspace_bytes, prl_stream_t stream) {
+  PRL_CHECK_ARG(logits2 && prl::aligned16(logits2), "the kept logits must be a 16-byte aligned device buffer");
+  return lm_head_bwd_impl(rows, cols, hidden, vocab, hidden_bf16, nullptr, nullptr, wt_hi, wt_lo, input_ids, temperature, lse2, entropy,
+                          grad_new_logprobs, grad_entropy, upstream, grad_hidden, grad_hidden_dtype, grad_weight, chunk_rows, flags,
+                          workspace, workspace_bytes, stream, MxRecompute{}, logits2);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // mixed-precision head (f16 + MX fp8 residual plane): operand preparation and forward
 // ---------------------------------------------------------------------------------------------------
@@ -1992,11 +2109,12 @@ extern "C" int prl_lm_head_prepare_mx(int64_t vocab, int64_t hidden, const void*
   return mx_convert<uint16_t, true>(vocab, hidden, static_cast<const uint16_t*>(weight), max_bits, scales, w16, w8lo, s);
 }
 
-extern "C" int prl_lm_head_logprob_fwd_mx(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
-                                          const uint16_t* w16, const uint8_t* w8lo, float* scales, const int64_t* input_ids,
-                                          float temperature, float* new_logprobs, float* entropy, float* lse2, void* workspace,
-                                          size_t workspace_bytes, prl_stream_t stream) {
+static int lm_head_fwd_mx_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
+                              const uint16_t* w16, const uint8_t* w8lo, float* scales, const int64_t* input_ids,
+                              float temperature, float* new_logprobs, float* entropy, float* lse2, float* logits2, void* workspace,
+                              size_t workspace_bytes, prl_stream_t stream) {
   PRL_CHECK_ARG(rows >= 1 && cols >= 1, "rows and cols must be >= 1");
+  PRL_CHECK_ARG(!logits2 || (vocab % 8 == 0 && prl::aligned16(logits2)), "kept logits need a vocabulary that is a multiple of 8 and a 16-byte aligned buffer");
   PRL_CHECK_ARG(hidden >= 64 && hidden % 64 == 0, "hidden size %lld must be a multiple of 64", (long long)hidden);
   PRL_CHECK_ARG(vocab >= 1 && vocab < ((int64_t)1 << 31) - 256 && rows * cols < ((int64_t)1 << 31) - 256, "shape out of range");
   PRL_CHECK_ARG(hidden_bf16 && w16 && scales && input_ids && new_logprobs && entropy && lse2 && workspace, "null pointer");
@@ -2027,6 +2145,7 @@ extern "C" int prl_lm_head_logprob_fwd_mx(int64_t rows, int64_t cols, int64_t hi
   a.part = reinterpret_cast<float*>(ws + L.part);
   a.ysel = reinterpret_cast<float*>(ws + L.ysel);
   a.scales = scales;
+  a.logits2 = logits2;
   if (w8lo) {
     if (int rc = launch_tiles(lmhead_fwd_kernel<CfgMx, 0, 2>, CfgMx::NT, CfgMx::LDS_BYTES, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(mx)")) return rc;
   } else if (int rc = launch_tiles(lmhead_fwd_kernel<CfgMx, 0, 3>, CfgMx::NT, CfgMx::LDS_BYTES, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(mx, f16-exact weight)")) {
@@ -2036,4 +2155,21 @@ extern "C" int prl_lm_head_logprob_fwd_mx(int64_t rows, int64_t cols, int64_t hi
                      a.padded, a.part, a.ysel, input_ids, new_logprobs, entropy, lse2);
   PRL_LAUNCH_CHECK("lmhead_fwd_finish_kernel");
   return PRL_OK;
+}
+
+extern "C" int prl_lm_head_logprob_fwd_mx(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
+                                          const uint16_t* w16, const uint8_t* w8lo, float* scales, const int64_t* input_ids,
+                                          float temperature, float* new_logprobs, float* entropy, float* lse2, void* workspace,
+                                          size_t workspace_bytes, prl_stream_t stream) {
+  return lm_head_fwd_mx_impl(rows, cols, hidden, vocab, hidden_bf16, w16, w8lo, scales, input_ids, temperature, new_logprobs, entropy, lse2,
+                             nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int prl_lm_head_logprob_fwd_mx_keep(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, const uint16_t* hidden_bf16,
+                                               const uint16_t* w16, const uint8_t* w8lo, float* scales, const int64_t* input_ids,
+                                               float temperature, float* new_logprobs, float* entropy, float* lse2, float* logits2,
+                                               void* workspace, size_t workspace_bytes, prl_stream_t stream) {
+  PRL_CHECK_ARG(logits2, "null pointer");
+  return lm_head_fwd_mx_impl(rows, cols, hidden, vocab, hidden_bf16, w16, w8lo, scales, input_ids, temperature, new_logprobs, entropy, lse2,
+                             logits2, workspace, workspace_bytes, stream);
 }

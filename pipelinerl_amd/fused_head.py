@@ -12,8 +12,10 @@ hands them, with the head's weight, to the MFMA kernels of csrc/prl_lmhead.hip:
       --prl_lm_head_logprob_bwd-->  d hidden, d W  (logits recomputed per row chunk, d logits live as bf16
                                     planes of ONE chunk only)
 
-Memory: no logits (4.98 GB) and no d logits (4.98 GB) per micro-batch; the backward workspace is
-`chunk_rows / T` of that.  Numerics: bf16 x bf16 products are exact in fp32 and accumulate in fp32; the
+Memory: no d logits in fp32 and no autograd copies of the logits; the backward workspace holds the two bf16 d-logits
+planes of one row chunk.  By default (`keep_logits`) the forward leaves the fp32 logits of the micro-batch behind for the
+backward (4.98 GB from the head's forward to its backward, two plane products less); with `keep_logits=False` there are
+no logits at all and the backward recomputes them chunk by chunk.  Numerics: bf16 x bf16 products are exact in fp32 and accumulate in fp32; the
 two-plane split reproduces the fp32 head to ~2^-17 relative.
 """
 
@@ -41,14 +43,19 @@ class FusedLmHead:
     `.data.copy_()` must call `invalidate()` - same contract as lm_head.SplitBf16LmHead."""
 
     def __init__(self, weight: torch.Tensor, backward: bool = True, chunk_rows: int = 8192, hidden_grad_terms: int = 3,
-                 skip_unlabelled: bool = True, precision: str | None = None):
+                 skip_unlabelled: bool = True, precision: str | None = None, keep_logits: bool | None = None):
         """`chunk_rows`: logits rows whose d logits planes live in the workspace at a time (2 x chunk x V x 2 bytes: 5 GB for
         8192 rows of a 152 064-entry vocabulary; one chunk per 8192-token micro-batch halves the d W epilogues).
         `hidden_grad_terms`: 3 = d hidden from every bf16 product (fp32-GEMM accuracy before the final rounding),
         1 = leading product only (2^-9 relative, the size of the bf16 rounding of d hidden; two GEMM passes less).
         `skip_unlabelled` (loss path only, `fused_head_loss`): rows whose next token carries no label (prompt and
         observation tokens, sequence starts, padding) enter neither the loss nor any statistic - the head runs,
-        forward and backward, on the labelled rows only; see `_FusedHeadLossFn`."""
+        forward and backward, on the labelled rows only; see `_FusedHeadLossFn`.
+        `keep_logits` (default on, PRL_LMHEAD_KEEP_LOGITS=0 turns it off): a forward that will be followed by a backward also
+        writes its logits (fp32, rows x vocab x 4 bytes - they live from the head's forward to the end of its backward, where the
+        d-logits planes of the recomputing form live anyway) and the backward forms d logits in one pass over them instead of
+        recomputing both plane products: 5 products per micro-batch instead of 7.  Off: no logits anywhere, the backward
+        recomputes them chunk by chunk (workspace only)."""
         if weight.dim() != 2:
             raise ValueError("lm_head weight must be [vocab, hidden]")
         if weight.dtype not in (torch.float32, torch.bfloat16):
@@ -63,6 +70,7 @@ class FusedLmHead:
         self.precision = precision or os.environ.get("PRL_LMHEAD_PRECISION", "bf16x2")
         if self.precision not in ("bf16x2", "f16_fp8"):
             raise ValueError(f"unknown precision {self.precision!r}")
+        self.keep_logits = bool(int(os.environ.get("PRL_LMHEAD_KEEP_LOGITS", "1"))) if keep_logits is None else bool(keep_logits)
         self.w16 = self.w8lo = self.mx_scales = None
         self._key = None
         self.w_hi = self.w_lo = self.wt_hi = self.wt_lo = None
@@ -129,8 +137,9 @@ class FusedLmHead:
         return ws
 
     # -- forward ------------------------------------------------------------------------------------
-    def logprob_entropy(self, hidden: torch.Tensor, input_ids: torch.Tensor, temperature: float):
-        """hidden [B, L, H] -> token-aligned (new_logprobs, entropy, lse2), each fp32 [B, L]; no graph."""
+    def logprob_entropy(self, hidden: torch.Tensor, input_ids: torch.Tensor, temperature: float, keep: bool = False):
+        """hidden [B, L, H] -> token-aligned (new_logprobs, entropy, lse2), each fp32 [B, L], and the bf16 hidden states the
+        kernels read; no graph.  `keep`: a fifth value, the [B * L, V] fp32 logits in base-2 units for `backward_from_token_grads`."""
         lib = _lib.load()
         _lib.require_device(hidden, input_ids)
         self.refresh()
@@ -147,6 +156,9 @@ class FusedLmHead:
         nlp = torch.empty((B, L), dtype=torch.float32, device=dev)
         ent = torch.empty_like(nlp)
         lse2 = torch.empty_like(nlp)
+        if keep and self.vocab % 8:
+            raise ValueError("kept logits need a vocabulary that is a multiple of 8")
+        kept = torch.empty((B * L, self.vocab), dtype=torch.float32, device=dev) if keep else None
         if self.precision == "f16_fp8":
             need = ctypes.c_size_t(0)
             _lib.check(lib.prl_lm_head_mx_workspace_bytes(B, L, H, self.vocab, ctypes.byref(need)))
@@ -154,26 +166,35 @@ class FusedLmHead:
             ws = self._ws.get(key)
             if ws is None or ws.numel() < need.value:
                 ws = self._ws[key] = torch.empty(need.value, dtype=torch.uint8, device=dev)
+            head = (B, L, H, self.vocab, h.data_ptr(), self.w16.data_ptr(), _lib.ptr(self.w8lo), self.mx_scales.data_ptr(), ids.data_ptr(),
+                    float(temperature), nlp.data_ptr(), ent.data_ptr(), lse2.data_ptr())
+            tail = (ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev))
             with torch.cuda.device(dev):
-                _lib.check(lib.prl_lm_head_logprob_fwd_mx(B, L, H, self.vocab, h.data_ptr(), self.w16.data_ptr(), _lib.ptr(self.w8lo),
-                                                          self.mx_scales.data_ptr(), ids.data_ptr(), float(temperature), nlp.data_ptr(),
-                                                          ent.data_ptr(), lse2.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev)))
-            return nlp, ent, lse2, h
+                if keep:
+                    _lib.check(lib.prl_lm_head_logprob_fwd_mx_keep(*head, kept.data_ptr(), *tail))
+                else:
+                    _lib.check(lib.prl_lm_head_logprob_fwd_mx(*head, *tail))
+            return (nlp, ent, lse2, h, kept) if keep else (nlp, ent, lse2, h)
         ws = self._workspace("fwd", B, L, dev, self.chunk_rows)
+        head = (B, L, H, self.vocab, h.data_ptr(), self.w_hi.data_ptr(), _lib.ptr(self.w_lo), ids.data_ptr(), float(temperature),
+                nlp.data_ptr(), ent.data_ptr(), lse2.data_ptr())
+        tail = (ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev))
         with torch.cuda.device(dev):
-            _lib.check(lib.prl_lm_head_logprob_fwd(B, L, H, self.vocab, h.data_ptr(), self.w_hi.data_ptr(), _lib.ptr(self.w_lo),
-                                                   ids.data_ptr(), float(temperature), nlp.data_ptr(), ent.data_ptr(), lse2.data_ptr(),
-                                                   ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev)))
-        return nlp, ent, lse2, h
+            if keep:
+                _lib.check(lib.prl_lm_head_logprob_fwd_keep(*head, kept.data_ptr(), *tail))
+            else:
+                _lib.check(lib.prl_lm_head_logprob_fwd(*head, *tail))
+        return (nlp, ent, lse2, h, kept) if keep else (nlp, ent, lse2, h)
 
     # -- backward -----------------------------------------------------------------------------------
     def backward_from_token_grads(self, h: torch.Tensor, input_ids: torch.Tensor, temperature: float, lse2: torch.Tensor,
                                   ent: torch.Tensor, g_nlp: torch.Tensor, g_ent: torch.Tensor | None, upstream: torch.Tensor | None,
                                   want_hidden: bool = True, grad_weight: torch.Tensor | None = None,
                                   grad_hidden_dtype: torch.dtype = torch.bfloat16, chunk_rows: int | None = None,
-                                  overwrite_weight_grad: bool = False):
+                                  overwrite_weight_grad: bool = False, kept_logits: torch.Tensor | None = None):
         """d hidden (returned) and d W (ACCUMULATED into `grad_weight`, fp32 [V, H]; with `overwrite_weight_grad`
-        the buffer may be uninitialised and is overwritten) from the token-aligned gradients of new_logprobs / entropy."""
+        the buffer may be uninitialised and is overwritten) from the token-aligned gradients of new_logprobs / entropy.
+        `kept_logits`: the fifth value of `logprob_entropy(..., keep=True)` for the same hidden states - no recompute."""
         if not self.backward:
             raise RuntimeError("this FusedLmHead was built with backward=False")
         lib = _lib.load()
@@ -191,7 +212,12 @@ class FusedLmHead:
                 _lib.ptr(gh), 0 if grad_hidden_dtype == torch.float32 else 1, _lib.ptr(grad_weight), chunk, flags, ws.data_ptr(), ws.numel(),
                 _lib.current_stream_ptr(dev))
         with torch.cuda.device(dev):
-            if self.precision == "f16_fp8":  # the recompute runs on the core the forward ran on
+            if kept_logits is not None:
+                if kept_logits.dtype != torch.float32 or not kept_logits.is_contiguous() or tuple(kept_logits.shape) != (B * L, self.vocab):
+                    raise ValueError("kept_logits must be the contiguous float32 [rows, vocab] tensor of the forward")
+                _lib.check(lib.prl_lm_head_logprob_bwd_kept(B, L, H, self.vocab, h.data_ptr(), kept_logits.data_ptr(), self.wt_hi.data_ptr(),
+                                                            _lib.ptr(self.wt_lo), *tail))
+            elif self.precision == "f16_fp8":  # the recompute runs on the core the forward ran on
                 _lib.check(lib.prl_lm_head_logprob_bwd_mx(B, L, H, self.vocab, h.data_ptr(), self.w16.data_ptr(), _lib.ptr(self.w8lo),
                                                           self.mx_scales.data_ptr(), self.wt_hi.data_ptr(), _lib.ptr(self.wt_lo), *tail))
             else:
@@ -242,8 +268,11 @@ class _FusedHeadLossFn(torch.autograd.Function):
         need_grad = hidden.requires_grad or weight.requires_grad
         B, L, H = hidden.shape
         idx = rows if (rows is not None and rows.numel() <= (1.0 - _MIN_SKIP_FRACTION) * B * L) else None
+        keep = need_grad and head.keep_logits and head.vocab % 8 == 0
+        kept = None
         if idx is None:
-            nlp, ent, lse2, h = head.logprob_entropy(hidden, batch.input_ids, temperature)
+            nlp, ent, lse2, h, *rest = head.logprob_entropy(hidden, batch.input_ids, temperature, keep=keep)
+            kept = rest[0] if rest else None
             ids = batch.input_ids
         else:
             n = idx.numel()
@@ -252,7 +281,8 @@ class _FusedHeadLossFn(torch.autograd.Function):
             hc[0, :n] = hidden.detach().reshape(B * L, H).index_select(0, idx)
             ids = torch.zeros((1, n + 1), dtype=torch.int64, device=dev)
             ids[0, 1:] = batch.input_ids.reshape(-1).index_select(0, idx + 1)  # row j predicts ids[j + 1]
-            nlp_c, ent_c, lse2, h = head.logprob_entropy(hc, ids, temperature)
+            nlp_c, ent_c, lse2, h, *rest = head.logprob_entropy(hc, ids, temperature, keep=keep)
+            kept = rest[0] if rest else None
             nlp = torch.zeros((B, L), dtype=torch.float32, device=dev)
             ent = torch.zeros_like(nlp)
             nlp.view(-1).index_copy_(0, idx + 1, nlp_c[0, 1:])  # token-aligned: the value for token u = q + 1
@@ -273,7 +303,8 @@ class _FusedHeadLossFn(torch.autograd.Function):
 
                 g_nlp, g_ent, ent = compact(g_nlp), (compact(g_ent) if g_ent is not None else None), ent_c
             ctx.save_for_backward(h, ids, lse2, ent, g_nlp, g_ent if g_ent is not None else torch.empty(0, device=h.device),
-                                  idx if idx is not None else torch.empty(0, dtype=torch.int64, device=h.device))
+                                  idx if idx is not None else torch.empty(0, dtype=torch.int64, device=h.device),
+                                  kept if kept is not None else torch.empty(0, device=h.device))
         ctx.has_g_ent = g_ent is not None
         ctx.compact = idx is not None
         ctx.hidden_shape = tuple(hidden.shape)
@@ -289,7 +320,7 @@ class _FusedHeadLossFn(torch.autograd.Function):
             gh = torch.zeros(hs, dtype=hd, device=dev) if ctx.needs_input_grad[0] else None
             gw = torch.zeros(ws_, dtype=wd, device=dev) if ctx.needs_input_grad[1] else None
             return gh, gw, None, None, None, None, None
-        h, ids, lse2, ent, g_nlp, g_ent, idx = ctx.saved_tensors
+        h, ids, lse2, ent, g_nlp, g_ent, idx, kept = ctx.saved_tensors
         head: FusedLmHead = ctx.head
         want_h, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gw = torch.empty((head.vocab, head.hidden), dtype=torch.float32, device=h.device) if want_w else None
@@ -297,7 +328,8 @@ class _FusedHeadLossFn(torch.autograd.Function):
         gh = head.backward_from_token_grads(h, ids, ctx.temperature, lse2, ent, g_nlp, g_ent if ctx.has_g_ent else None, up,
                                             want_hidden=want_h, grad_weight=gw, overwrite_weight_grad=True,
                                             grad_hidden_dtype=torch.float32 if ctx.hidden_dtype == torch.float32 else torch.bfloat16,
-                                            chunk_rows=ctx.chunk_rows)
+                                            chunk_rows=ctx.chunk_rows, kept_logits=kept if kept.numel() else None)
+        del kept
         if gh is not None and ctx.compact:  # rows without a label have no gradient
             B, L, H = ctx.hidden_shape
             full = torch.zeros((B * L, H), dtype=gh.dtype, device=gh.device)

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--model", default="0p5b", choices=["0p5b", "7b"], help="Qwen2.5 shape (random init)")
     ap.add_argument("--split-head", action="store_true", help="fp32 lm_head evaluated as bf16 MFMA GEMMs (pipelinerl_amd.lm_head)")
     ap.add_argument("--fused-head", action="store_true", help="fused head: hidden states -> loss without materialising the logits (pipelinerl_amd.fused_head)")
+    ap.add_argument("--no-checkpointing", action="store_true",
+                    help="keep every layer's activations instead of recomputing them in the backward (fits the 288 GB of one MI355X for 7B x 8192 tokens)")
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     args = ap.parse_args()
 
@@ -64,7 +66,8 @@ def main():
         model.lm_head = SplitBf16LmHead.from_linear(model.lm_head)  # same fp32 parameter, bf16 MFMA GEMMs
     else:
         model.lm_head.register_forward_pre_hook(lambda m, a: (a[0].float(),))
-    model.gradient_checkpointing_enable()
+    if not args.no_checkpointing:
+        model.gradient_checkpointing_enable()
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-6, fused=True)
     n_params = sum(p.numel() for p in model.parameters())
@@ -131,7 +134,8 @@ def main():
         "head": "fused (logits never written)" if args.fused_head else ("split-bf16 GEMMs" if args.split_head else "fp32 nn.Linear"),
         "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9,
         "model": f"Qwen2.5-{args.model} shape, random init, {n_params / 1e6:.0f}M params, {args.layers} layers, bf16 + fp32 lm_head"
-                 f"{' on bf16 matrix cores (2-term split)' if args.split_head else ''}, grad checkpointing, sdpa",
+                 f"{' on bf16 matrix cores (2-term split)' if args.split_head else ''}, {'activations kept' if args.no_checkpointing else 'grad checkpointing'}, sdpa",
+        "activation_recompute": not args.no_checkpointing,
         "global_batch": bs, "seq_len": L, "micro_batch": mb, "logits_mode": "fused" if args.fused else "two_pass",
         "samples_per_s": bs / dt, "s_per_step": dt, "tokens_per_s": bs * L / dt,
         "loss_forward_path_ms_per_step": loss_fwd_ms, "loss_forward_fraction": loss_fwd_ms / 1e3 / dt,

@@ -21,11 +21,12 @@ out = sys.argv[1]
 d = json.loads([l for l in open(out + "/bench_full.log") if l.startswith("{")][0])
 print({k: d[k] for k in ("value", "ms_per_step")}, "roofline", round(d["roofline"]["frac"], 4))
 m = d["roofline_mfma"]
-print("head fwd ms", round(m["ms_per_launch"], 2), "bwd ms", round(m["backward"]["ms"], 2), "mixed fwd", m.get("forward_mixed_precision", {}).get("ms"))
+print("head fwd ms", round(m["ms_per_launch"], 2), "keeping fwd ms", m.get("forward_keeping_logits", {}).get("ms"), "bwd ms", round(m["backward"]["ms"], 2),
+      "recomputing bwd ms", m.get("backward_recompute", {}).get("ms"), "mixed fwd", m.get("forward_mixed_precision", {}).get("ms"))
 e = d["e2e"]
 print({k: e.get(k) for k in ("s_per_step", "samples_per_s", "peak_memory_GB", "source", "error")})
 print({k: round(v["avg_us"], 1) for k, v in d["kernels"].items()})
 PY
-cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-weight-sync --no-e2e --no-transport > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
+cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-weight-sync --no-e2e --no-transport --no-live-pmc > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
 cd $GRAFT_REPO_ROOT; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do cut -c1-260 $f > $OUT/bench_kernel_stats.csv; cut -c1-150 $f | head -10; done
 find $OUT/prof -name "*kernel_trace.csv" -delete

@@ -3,7 +3,8 @@
 (bit pattern 1, pinned to the oracle by tests/test_gpu_lmhead_fused.py), then the variants are timed interleaved over several
 rounds (HIP events), whole backward and d-hidden-only / d-W-only.  One JSON line per variant.
 
-A third field selects the precision of forward + recompute ("bf16x2" default, "f16_fp8" = mixed precision on the MX core).
+A third field selects the precision of forward + recompute ("bf16x2" default, "f16_fp8" = mixed precision on the MX core); a
+fourth field "keep" runs the backward from the logits the forward kept (no recompute); --fwd then also times the keeping forward.
 
 usage: python scripts/lmhead_ab.py [--variants 1:4096,0:4096,0:8192,0:8192:f16_fp8] [--rounds 3] [--tokens 8192] [--fwd]"""
 import argparse
@@ -33,19 +34,23 @@ g_nlp = torch.randn(1, T, device=dev) * 1e-4
 variants = []
 for v in args.variants.split(","):
     f = v.split(":")
-    variants.append((int(f[0]), int(f[1]), f[2] if len(f) > 2 else "bf16x2"))
-heads, fwd = {}, {}
+    variants.append((int(f[0]), int(f[1]), (f[2] or "bf16x2") if len(f) > 2 else "bf16x2", len(f) > 3 and f[3] == "keep"))
+heads, fwd, kept = {}, {}, {}
 for prec in sorted({v[2] for v in variants} | {"bf16x2"}):
     heads[prec] = FusedLmHead(W, precision=prec)
-    fwd[prec] = heads[prec].logprob_entropy(hidden, ids, 1.0)  # (nlp, ent, lse2, h): each precision's own saved statistics
+    if any(v[2] == prec and v[3] for v in variants):
+        *fwd[prec], kept[prec] = heads[prec].logprob_entropy(hidden, ids, 1.0, keep=True)
+    else:
+        fwd[prec] = heads[prec].logprob_entropy(hidden, ids, 1.0)  # (nlp, ent, lse2, h): each precision's own saved statistics
 
 
-def run(bits, chunk, prec="bf16x2", want_hidden=True, want_weight=True, gw=None):
+def run(bits, chunk, prec="bf16x2", keep=False, want_hidden=True, want_weight=True, gw=None):
     _lib.set_tuning("lmhead_bwd", bits)
     gw = gw if gw is not None else (torch.zeros(V, H, device=dev) if want_weight else None)
     _, ent, lse2, h = fwd[prec]
     gh = heads[prec].backward_from_token_grads(h, ids, 1.0, lse2, ent, g_nlp, None, None, want_hidden=want_hidden, grad_weight=gw,
-                                               grad_hidden_dtype=torch.float32, chunk_rows=chunk, overwrite_weight_grad=True)
+                                               grad_hidden_dtype=torch.float32, chunk_rows=chunk, overwrite_weight_grad=True,
+                                               kept_logits=kept[prec] if keep else None)
     return gh, gw
 
 
@@ -57,10 +62,10 @@ ref_h, ref_w = run(1, 4096)
 torch.cuda.synchronize()
 gw_buf = torch.zeros(V, H, device=dev)
 report = {}
-for bits, chunk, prec in variants:
-    gh, gw = run(bits, chunk, prec, gw=gw_buf)
+for bits, chunk, prec, keep in variants:
+    gh, gw = run(bits, chunk, prec, keep, gw=gw_buf)
     torch.cuda.synchronize()
-    report[(bits, chunk, prec)] = {"bits": bits, "chunk_rows": chunk, "precision": prec, "d_hidden_vs_round2": rel(gh, ref_h), "d_weight_vs_round2": rel(gw, ref_w),
+    report[(bits, chunk, prec, keep)] = {"bits": bits, "chunk_rows": chunk, "precision": prec, "kept_logits": keep, "d_hidden_vs_round2": rel(gh, ref_h), "d_weight_vs_round2": rel(gw, ref_w),
                              "ms": [], "ms_dh_only": [], "ms_dw_only": []}
     del gh
 del ref_h, ref_w
@@ -76,15 +81,19 @@ def timed(fn):
 
 
 for _ in range(args.rounds):
-    for bits, chunk, prec in variants:
-        r = report[(bits, chunk, prec)]
-        r["ms"].append(timed(lambda: run(bits, chunk, prec, gw=gw_buf)))
-        r["ms_dh_only"].append(timed(lambda: run(bits, chunk, prec, want_weight=False)))
-        r["ms_dw_only"].append(timed(lambda: run(bits, chunk, prec, want_hidden=False, gw=gw_buf)))
+    for bits, chunk, prec, keep in variants:
+        r = report[(bits, chunk, prec, keep)]
+        r["ms"].append(timed(lambda: run(bits, chunk, prec, keep, gw=gw_buf)))
+        r["ms_dh_only"].append(timed(lambda: run(bits, chunk, prec, keep, want_weight=False)))
+        r["ms_dw_only"].append(timed(lambda: run(bits, chunk, prec, keep, want_hidden=False, gw=gw_buf)))
 if args.fwd:
     for prec, head in heads.items():
         f = [round(timed(lambda: head.logprob_entropy(hidden, ids, 1.0)), 3) for _ in range(5)]
         print(json.dumps({"forward_ms": f, "precision": prec}))
+        if prec in kept:
+            del kept[prec]
+            f = [round(timed(lambda: head.logprob_entropy(hidden, ids, 1.0, keep=True)), 3) for _ in range(5)]
+            print(json.dumps({"forward_keeping_logits_ms": f, "precision": prec}))
 for r in report.values():
     for k in ("ms", "ms_dh_only", "ms_dw_only"):
         r[k + "_min"] = min(r[k])

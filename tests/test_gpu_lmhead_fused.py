@@ -62,7 +62,7 @@ def _oracle(hidden, W, batch, logits64):
     return want
 
 
-def _run(hidden, W, batch, chunk_rows=None, grad_scale=1.0):
+def _run(hidden, W, batch, chunk_rows=None, grad_scale=1.0, keep_logits=None):
     from pipelinerl_amd.finetune.rl import RLConfig
     from pipelinerl_amd.finetune.types import PipelineBatchEncoding
     from pipelinerl_amd.fused_head import FusedLmHead, fused_head_loss
@@ -71,7 +71,7 @@ def _run(hidden, W, batch, chunk_rows=None, grad_scale=1.0):
     pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(dev)
     h = hidden.clone().requires_grad_(True)
     w = W.clone().requires_grad_(True)
-    head = FusedLmHead(w, chunk_rows=chunk_rows or 4096)
+    head = FusedLmHead(w, chunk_rows=chunk_rows or 4096, keep_logits=keep_logits)  # None: the default (kept logits)
     loss, stats = fused_head_loss(h, w, head, pb, RLConfig(**CFG), 2, 10, chunk_rows=chunk_rows)
     (loss * grad_scale).backward()
     torch.cuda.synchronize()
@@ -88,15 +88,17 @@ def _compare(loss, stats, gh, gw, want, scale=1.0):
     assert rel_err(gh[0].float().cpu().numpy(), want["d_hidden"] * scale) <= tol_h
 
 
+@pytest.mark.parametrize("keep", [True, False], ids=["kept_logits", "recompute"])
 @pytest.mark.parametrize("tile", ["256x256", "256", "128"], ids=["tile256x256", "tile256x128_ring3", "tile128x128"])
 @pytest.mark.parametrize("T,H,V", [(130, 64, 192), (257, 128, 320), (64, 192, 4160), (300, 64, 1088)])
-def test_small_ragged_shapes(libprl, cuda_device, monkeypatch, tile, T, H, V):
+def test_small_ragged_shapes(libprl, cuda_device, monkeypatch, tile, T, H, V, keep):
     """Tile edges everywhere: rows not a multiple of 128, a partly masked last vocabulary tile, one K step
-    (fewer tiles than pipeline stages), both workgroup shapes."""
+    (fewer tiles than pipeline stages), both workgroup shapes; the backward from the logits the forward kept and the
+    backward that recomputes them."""
     monkeypatch.setenv("PRL_LMHEAD_TILE", tile)
     hidden, W, batch, logits64 = _problem(T, H, V, cuda_device, seed=T)
     want = _oracle(hidden, W, batch, logits64)
-    loss, stats, gh, gw, _ = _run(hidden, W, batch)
+    loss, stats, gh, gw, _ = _run(hidden, W, batch, keep_logits=keep)
     _compare(loss, stats, gh, gw, want)
 
 
@@ -128,16 +130,19 @@ def test_forward_values_and_split_count_independence(libprl, cuda_device, monkey
         assert torch.allclose(ent[0, 1:].double(), w_ent[:-1], rtol=FP_TOL, atol=2e-5), ns
 
 
-@pytest.mark.parametrize("tile", ["256x256", "256", "128", None], ids=["tile256x256", "tile256x128_ring3", "tile128x128", "default_dispatch"])
+@pytest.mark.parametrize("tile", ["256x256", "256", "128", None, "recompute"],
+                         ids=["tile256x256", "tile256x128_ring3", "tile128x128", "default_dispatch", "default_dispatch_recompute"])
 def test_qwen7b_head_shape_vs_oracle(libprl, cuda_device, monkeypatch, tile):
     """H = 3584, V = 152 064, fp32 weight (two bf16 planes): loss, statistics, d hidden, d W."""
+    keep = tile != "recompute"  # the default keeps the logits for the backward; "recompute": no logits anywhere
+    tile = None if tile == "recompute" else tile
     if tile is None:
         monkeypatch.delenv("PRL_LMHEAD_TILE", raising=False)
     else:
         monkeypatch.setenv("PRL_LMHEAD_TILE", tile)
     hidden, W, batch, logits64 = _problem(160, 3584, 152064, cuda_device, seed=3)
     want = _oracle(hidden, W, batch, logits64)
-    loss, stats, gh, gw, head = _run(hidden, W, batch)
+    loss, stats, gh, gw, head = _run(hidden, W, batch, keep_logits=keep)
     _compare(loss, stats, gh, gw, want)
     # fp32 d hidden straight from the C ABI: the 1e-4 bar without the bf16 rounding of the autograd path
     from pipelinerl_amd.finetune.rl import RLConfig, grpo_loss_from_logprobs, make_loss_config
@@ -173,8 +178,9 @@ def test_chunked_backward_and_upstream_scale(libprl, cuda_device, monkeypatch, t
     hidden, W, batch, logits64 = _problem(300, 128, 1024, cuda_device, seed=21)
     want = _oracle(hidden, W, batch, logits64)
     for chunk, scale in ((None, 1.0), (128, 1.0), (100, 0.25), (299, 3.0)):
-        loss, stats, gh, gw, _ = _run(hidden, W, batch, chunk_rows=chunk, grad_scale=scale)
-        _compare(loss, stats, gh, gw, want, scale)
+        for keep in (True, False):
+            loss, stats, gh, gw, _ = _run(hidden, W, batch, chunk_rows=chunk, grad_scale=scale, keep_logits=keep)
+            _compare(loss, stats, gh, gw, want, scale)
 
 
 @pytest.mark.parametrize("tile", ["256x256", "256", "128"], ids=["tile256x256", "tile256x128_ring3", "tile128x128"])
@@ -205,6 +211,44 @@ def test_split_k_hidden_gradient(libprl, cuda_device, monkeypatch, tile, ksplit)
     # the slices are added in a fixed order: run to run the split result is bitwise stable
     gh = head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, grad_hidden_dtype=torch.float32)
     assert np.array_equal(gh[0].cpu().numpy(), out[ksplit, torch.float32])
+
+
+@pytest.mark.parametrize("T,H,V,wdt,prec", [(300, 128, 4160, torch.float32, "bf16x2"), (257, 64, 1088, torch.bfloat16, "bf16x2"),
+                                             (300, 128, 1088, torch.float32, "f16_fp8")])
+def test_kept_logits_are_the_logits_and_give_the_recomputed_gradients(libprl, cuda_device, T, H, V, wdt, prec):
+    """`logprob_entropy(keep=True)` leaves [T, V] fp32 logits in base-2 units (logit * log2(e) / temperature) next to the same
+    three outputs; the backward from them equals the recomputing backward up to one fp32 rounding of the logit (the recompute
+    fuses the scale into a multiply-add) - including vocabularies whose last tile is partial and rows without a gradient."""
+    import math
+
+    from pipelinerl_amd.finetune.rl import RLConfig, grpo_loss_from_logprobs, make_loss_config
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.fused_head import FusedLmHead
+
+    hidden, W, batch, logits64 = _problem(T, H, V, cuda_device, weight_dtype=wdt, seed=V)
+    pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(cuda_device)
+    head = FusedLmHead(W, chunk_rows=128, precision=prec)
+    plain = head.logprob_entropy(hidden, pb.input_ids, CFG["temperature"])
+    nlp, ent, lse2, h, kept = head.logprob_entropy(hidden, pb.input_ids, CFG["temperature"], keep=True)
+    for a, b in zip(plain[:3], (nlp, ent, lse2)):
+        assert torch.equal(a, b)
+    assert kept.shape == (T, V) and kept.dtype == torch.float32
+    want2 = logits64 * (math.log2(math.e) / CFG["temperature"])
+    tol = 2e-5 if prec == "bf16x2" else 2e-4  # of the largest logit: the plane split / the mixed-precision core
+    assert float((kept.double() - want2).abs().max()) <= tol * float(want2.abs().max())
+    c_cfg, _, _ = make_loss_config(RLConfig(**CFG), 2, 10)
+    _, _, g_nlp, g_ent = grpo_loss_from_logprobs(c_cfg, pb, nlp, ent)
+    out = {}
+    for name, kw in (("recompute", {}), ("kept", {"kept_logits": kept})):
+        gw = torch.full((V, H), float("nan"), device=cuda_device)
+        gh = head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, grad_weight=gw,
+                                            overwrite_weight_grad=True, grad_hidden_dtype=torch.float32, **kw)
+        torch.cuda.synchronize()
+        out[name] = (gh[0].cpu().numpy(), gw.cpu().numpy())
+    for a, b in zip(out["kept"], out["recompute"]):
+        assert np.isfinite(a).all() and rel_err(a, b) <= 5e-6
+    with pytest.raises(ValueError):
+        head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, kept_logits=kept[:, :-8])
 
 
 def test_leading_term_hidden_gradient(libprl, cuda_device):
