@@ -565,6 +565,9 @@ int prl_lm_head_logprob_fwd(int64_t rows, int64_t cols, int64_t hidden, int64_t 
                                          a zero fill and the first chunk a read of the [vocab, hidden] fp32 buffer */
 #define PRL_LM_HEAD_DH_LEADING_TERM 1 /* flags: d hidden from the leading bf16 product only (d logits_hi x W_hi):
                                          2^-9 relative error, the size of a bf16 rounding - meant for bf16 grad_hidden */
+#define PRL_LM_HEAD_DH_NO_WEIGHT_LO 4 /* flags: d hidden = (d logits_hi + d logits_lo) x W_hi: only the fp32 weight's low plane is
+                                         dropped (2^-9 of each weight, i.e. a bf16 weight) - two products on the dual-plane core
+                                         instead of three; no effect on a bf16 weight, whose d hidden is these two products */
 
 /*
  * Backward of the above for token-aligned upstream gradients grad_new_logprobs /

@@ -36,6 +36,7 @@ PRL_WSYNC_UID_BYTES = 128
 PRL_IPC_HANDLE_BYTES = 64
 PRL_LM_HEAD_DH_LEADING_TERM = 1
 PRL_LM_HEAD_DW_OVERWRITE = 2
+PRL_LM_HEAD_DH_NO_WEIGHT_LO = 4
 PRL_LOG_CREATE, PRL_LOG_TRUNCATE, PRL_LOG_READER, PRL_LOG_TRIM = 1, 2, 4, 8
 
 # index of every public statistic in the device stats vector (enum in include/prl.h)

@@ -1317,9 +1317,13 @@ struct Dh3Args {
   int seg;                             // stages per segment
 };
 
-__global__ __launch_bounds__(CfgTriple::NT, 2) void gemm_dh3_kernel(Dh3Args a) {
+// TRIPLE false: two products that share W^T_hi - (dl_hi + dl_lo) W^T_hi, the whole d hidden of a bf16 weight (b2 unused) - on the
+// dual-plane core of the forward: same work items, same raster, three staged tiles per stage instead of four.
+template <bool TRIPLE>
+__global__ __launch_bounds__(CfgTriple::NT, 2) void gemm_dh_kernel(Dh3Args a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  using C = CfgTriple;
+  using C = CfgTriple;  // (the tile geometry of CfgDual is the same)
+  static_assert(CfgTriple::BM == CfgDual::BM && CfgTriple::BN == CfgDual::BN && CfgTriple::NT == CfgDual::NT && CfgTriple::WCOLS == CfgDual::WCOLS, "");
   const int tiles = a.mt * a.nt;
   int kz, L;
   if (a.ksplit == 8) {  // slice = XCD; the tile list of a slice is walked in groups of 8 row tiles, row-fastest
@@ -1350,7 +1354,11 @@ __global__ __launch_bounds__(CfgTriple::NT, 2) void gemm_dh3_kernel(Dh3Args a) {
     Geom g = a.geo;
     g.Kc = n * BK32;
     const int64_t k0 = (int64_t)s * BK32;
-    gemm_mainloop_triple(acc, a.a1 + k0, a.a2 + k0, a.b1 + k0, a.b2 + k0, g, m0, n0, lds);
+    if constexpr (TRIPLE) {
+      gemm_mainloop_triple(acc, a.a1 + k0, a.a2 + k0, a.b1 + k0, a.b2 + k0, g, m0, n0, lds);
+    } else {
+      gemm_mainloop_dual<1>(acc, a.a1 + k0, a.a2 + k0, a.b1 + k0, g, m0, n0, lds);
+    }
   }
   float* out = a.partial + (a.ksplit > 1 ? (int64_t)kz * a.geo.M * a.geo.N : 0);
 #pragma unroll
@@ -1964,7 +1972,8 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
       GemmArgs g;
       // PRL_LM_HEAD_DH_LEADING_TERM: only d logits_hi x W_hi.  The two dropped products are 2^-9 relative
       // corrections - the size of the rounding d hidden receives anyway when it is delivered in bf16.
-      g.terms.n = (flags & PRL_LM_HEAD_DH_LEADING_TERM) ? 1 : (wt_lo ? 3 : 2);
+      // PRL_LM_HEAD_DH_NO_WEIGHT_LO: (d logits_hi + d logits_lo) x W_hi - only the weight's low plane is dropped.
+      g.terms.n = (flags & PRL_LM_HEAD_DH_LEADING_TERM) ? 1 : ((wt_lo && !(flags & PRL_LM_HEAD_DH_NO_WEIGHT_LO)) ? 3 : 2);
       g.terms.a[0] = dl_hi;
       g.terms.b[0] = wt_hi;
       g.terms.a[1] = dl_lo;
@@ -1981,9 +1990,10 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
       g.out = static_cast<char*>(grad_hidden) + (size_t)r0 * hidden * (g.out_bf16 ? 2 : 4);
       g.partial = reinterpret_cast<float*>(ws + L.dh_partial);
       // PRL_TUNE_LMHEAD_BWD bit 0: 1 = the round-2 structure (generic core, the three products one after the other)
-      const bool triple = g.terms.n == 3 && (prl::tuning(PRL_TUNE_LMHEAD_BWD, 0) & 1) == 0;
+      const bool new_core = g.terms.n >= 2 && (prl::tuning(PRL_TUNE_LMHEAD_BWD, 0) & 1) == 0;
+      const bool triple = g.terms.n == 3;
       int slices = 1;       // fp32 slices in g.partial to be added (and converted) into g.out; 0: the kernel wrote g.out itself
-      if (triple) {
+      if (new_core) {
         Dh3Args d3{dl_hi, dl_lo, wt_hi, wt_lo, g.geo, ceil_div(m, CfgTriple::BM), ceil_div(hidden, CfgTriple::BN), 1, 0, nullptr, kSegSteps};
         if (const int64_t seg = prl::tuning(PRL_TUNE_LMHEAD_SEG, 0); seg > 0) d3.seg = (int)seg;
         const int steps32 = (int)(vocab / BK32);
@@ -1994,7 +2004,11 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
         d3.ksplit = ceil_div(steps32, d3.ksteps);  // no empty slice
         const bool direct = d3.ksplit == 1 && !g.out_bf16;  // a single fp32 slice IS the output
         d3.partial = direct ? static_cast<float*>(g.out) : g.partial;
-        if (int rc = launch_tiles(gemm_dh3_kernel, CfgTriple::NT, CfgTriple::LDS_BYTES, d3.mt * d3.nt * d3.ksplit, d3, s, "gemm_dh3_kernel(d hidden)")) return rc;
+        if (triple) {
+          if (int rc = launch_tiles(gemm_dh_kernel<true>, CfgTriple::NT, CfgTriple::LDS_BYTES, d3.mt * d3.nt * d3.ksplit, d3, s, "gemm_dh_kernel(d hidden, 3 products)")) return rc;
+        } else if (int rc = launch_tiles(gemm_dh_kernel<false>, CfgDual::NT, CfgDual::LDS_BYTES, d3.mt * d3.nt * d3.ksplit, d3, s, "gemm_dh_kernel(d hidden, 2 products)")) {
+          return rc;
+        }
         slices = direct ? 0 : d3.ksplit;
       } else {
         const int steps = (int)(vocab / BK);

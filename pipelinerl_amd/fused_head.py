@@ -47,7 +47,9 @@ class FusedLmHead:
         """`chunk_rows`: logits rows whose d logits planes live in the workspace at a time (2 x chunk x V x 2 bytes: 5 GB for
         8192 rows of a 152 064-entry vocabulary; one chunk per 8192-token micro-batch halves the d W epilogues).
         `hidden_grad_terms`: 3 = d hidden from every bf16 product (fp32-GEMM accuracy before the final rounding),
-        1 = leading product only (2^-9 relative, the size of the bf16 rounding of d hidden; two GEMM passes less).
+        2 = (d logits_hi + d logits_lo) x W_hi: the fp32 weight rounded to bf16 for this product only, the d logits in full (2^-9 of
+        each weight; one product less, on the forward's dual-plane core), 1 = leading product only (2^-9 relative in both operands,
+        the size of the bf16 rounding of d hidden; two products less).
         `skip_unlabelled` (loss path only, `fused_head_loss`): rows whose next token carries no label (prompt and
         observation tokens, sequence starts, padding) enter neither the loss nor any statistic - the head runs,
         forward and backward, on the labelled rows only; see `_FusedHeadLossFn`.
@@ -64,6 +66,8 @@ class FusedLmHead:
         self.backward = backward
         self.chunk_rows = int(chunk_rows)
         self.hidden_grad_terms = int(hidden_grad_terms)
+        if self.hidden_grad_terms not in (1, 2, 3):
+            raise ValueError("hidden_grad_terms must be 1, 2 or 3")
         self.skip_unlabelled = bool(skip_unlabelled)
         # "bf16x2": the fp32 weight as two bf16 planes (~4e-6 relative); "f16_fp8": an f16 plane + an fp8 residual plane on the
         # MX instruction (~1e-5 relative, 3/4 of the matrix-pipe time) - forward only so far, the backward keeps the bf16 planes
@@ -207,7 +211,8 @@ class FusedLmHead:
             raise ValueError("grad_weight must be a contiguous float32 [vocab, hidden] tensor")
         ws = self._workspace("bwd", B, L, dev, chunk)
         ids = input_ids if input_ids.is_contiguous() else input_ids.contiguous()
-        flags = (_lib.PRL_LM_HEAD_DH_LEADING_TERM if self.hidden_grad_terms == 1 else 0) | (_lib.PRL_LM_HEAD_DW_OVERWRITE if overwrite_weight_grad else 0)
+        flags = ({1: _lib.PRL_LM_HEAD_DH_LEADING_TERM, 2: _lib.PRL_LM_HEAD_DH_NO_WEIGHT_LO}.get(self.hidden_grad_terms, 0)
+                 | (_lib.PRL_LM_HEAD_DW_OVERWRITE if overwrite_weight_grad else 0))
         tail = (ids.data_ptr(), float(temperature), lse2.data_ptr(), ent.data_ptr(), g_nlp.data_ptr(), _lib.ptr(g_ent), _lib.ptr(upstream),
                 _lib.ptr(gh), 0 if grad_hidden_dtype == torch.float32 else 1, _lib.ptr(grad_weight), chunk, flags, ws.data_ptr(), ws.numel(),
                 _lib.current_stream_ptr(dev))

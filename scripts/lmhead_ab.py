@@ -23,12 +23,16 @@ ap.add_argument("--variants", default="1:4096,0:4096,0:8192")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--tokens", type=int, default=8192)
 ap.add_argument("--fwd", action="store_true")
+ap.add_argument("--hidden", type=int, default=3584)
+ap.add_argument("--vocab", type=int, default=152064)
+ap.add_argument("--weight-dtype", default="float32", choices=["float32", "bfloat16"])
+ap.add_argument("--terms", type=int, default=3, help="hidden_grad_terms of every variant's head")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
-T, H, V = args.tokens, 3584, 152064
+T, H, V = args.tokens, args.hidden, args.vocab
 torch.manual_seed(0)
 hidden = torch.randn(1, T, H, device=dev).to(torch.bfloat16)
-W = torch.randn(V, H, device=dev) * 0.02
+W = (torch.randn(V, H, device=dev) * 0.02).to(getattr(torch, args.weight_dtype))
 ids = torch.randint(3, V, (1, T), device=dev)
 g_nlp = torch.randn(1, T, device=dev) * 1e-4
 variants = []
@@ -37,7 +41,7 @@ for v in args.variants.split(","):
     variants.append((int(f[0]), int(f[1]), (f[2] or "bf16x2") if len(f) > 2 else "bf16x2", len(f) > 3 and f[3] == "keep"))
 heads, fwd, kept = {}, {}, {}
 for prec in sorted({v[2] for v in variants} | {"bf16x2"}):
-    heads[prec] = FusedLmHead(W, precision=prec)
+    heads[prec] = FusedLmHead(W, precision=prec, hidden_grad_terms=args.terms)
     if any(v[2] == prec and v[3] for v in variants):
         *fwd[prec], kept[prec] = heads[prec].logprob_entropy(hidden, ids, 1.0, keep=True)
     else:
@@ -46,7 +50,7 @@ for prec in sorted({v[2] for v in variants} | {"bf16x2"}):
 
 def run(bits, chunk, prec="bf16x2", keep=False, want_hidden=True, want_weight=True, gw=None):
     _lib.set_tuning("lmhead_bwd", bits)
-    gw = gw if gw is not None else (torch.zeros(V, H, device=dev) if want_weight else None)
+    gw = gw if gw is not None else (torch.zeros(V, H, device=dev) if want_weight else None)  # d W is always fp32
     _, ent, lse2, h = fwd[prec]
     gh = heads[prec].backward_from_token_grads(h, ids, 1.0, lse2, ent, g_nlp, None, None, want_hidden=want_hidden, grad_weight=gw,
                                                grad_hidden_dtype=torch.float32, chunk_rows=chunk, overwrite_weight_grad=True,

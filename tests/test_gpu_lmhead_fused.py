@@ -418,6 +418,36 @@ def test_unlabelled_rows_are_skipped_without_changing_the_result(libprl, cuda_de
     assert rel_err(a[3], (dl.t() @ hidden.reshape(-1, H).double()).cpu().numpy()) <= FP_TOL
 
 
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16], ids=["fp32_weight_opt_in", "bf16_weight_exact"])
+def test_two_product_hidden_gradient_on_the_dual_plane_core(libprl, cuda_device, wdt):
+    """hidden_grad_terms = 2: (d logits_hi + d logits_lo) x W_hi.  For a bf16 weight that IS d hidden (the default path of a tied
+    head: 1e-4 of the fp64 product, split-K slices of uneven length included); for an fp32 weight it drops the weight's low plane
+    only - a bf16 rounding of each weight, between the full and the leading-term form."""
+    from pipelinerl_amd.finetune.rl import RLConfig, grpo_loss_from_logprobs, make_loss_config
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.fused_head import FusedLmHead
+
+    hidden, W, batch, logits64 = _problem(300, 256, 4160, cuda_device, weight_dtype=wdt, seed=17)
+    want = _oracle(hidden, W, batch, logits64)
+    pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(cuda_device)
+    c_cfg, _, _ = make_loss_config(RLConfig(**CFG), 2, 10)
+    err = {}
+    for terms in (3, 2, 1):
+        head = FusedLmHead(W, hidden_grad_terms=terms)
+        nlp, ent, lse2, h = head.logprob_entropy(hidden, pb.input_ids, CFG["temperature"])
+        _, _, g_nlp, g_ent = grpo_loss_from_logprobs(c_cfg, pb, nlp, ent)
+        gh = head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, grad_hidden_dtype=torch.float32)
+        torch.cuda.synchronize()
+        err[terms] = rel_err(gh[0].cpu().numpy(), want["d_hidden"])
+    assert err[3] <= FP_TOL
+    if wdt == torch.bfloat16:
+        assert err[2] <= FP_TOL  # nothing was dropped: the weight has no low plane
+    else:
+        assert err[3] < err[2] <= 4e-3 and err[2] < err[1], err  # measured 1.4e-5 / 2.1e-3 / 2.8e-3: the weight's low plane is most of it
+    with pytest.raises(ValueError):
+        FusedLmHead(W, hidden_grad_terms=4)
+
+
 def test_weight_gradient_accumulates_or_overwrites(libprl, cuda_device):
     """`grad_weight` is `+=` by contract (gradient accumulation over micro-batches); PRL_LM_HEAD_DW_OVERWRITE stores
     instead, into memory that may hold anything - with several row chunks (the later chunks still add)."""
