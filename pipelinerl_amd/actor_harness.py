@@ -159,6 +159,8 @@ class ActorHarness:
     async def run_async(self, problems: Sequence[dict], n_groups: int | None = None, first_group_id: int = 0,
                         concurrent_groups: int = 4) -> int:
         """Roll out `n_groups` problems (default: each problem once, in order), publishing every group as it completes."""
+        if not problems:
+            raise ValueError("no problems to roll out (the dataset loader returned an empty list)")
         todo = list(problems if n_groups is None else [problems[i % len(problems)] for i in range(n_groups)])
         start = self.published_samples
         with write_to_streams(self.data_stream) as writer:

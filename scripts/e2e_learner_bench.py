@@ -131,7 +131,7 @@ def main():
     loss_fwd_ms = sum(a.elapsed_time(b) for a, b in timers["pairs"]) / args.steps
     line = json.dumps({
         "what": "end-to-end learner step incl. model fwd/bwd + AdamW (stock PyTorch-ROCm) + HIP loss path",
-        "head": "fused (logits never written)" if args.fused_head else ("split-bf16 GEMMs" if args.split_head else "fp32 nn.Linear"),
+        "head": "fused (log-prob / entropy in the GEMM epilogue, hand-written backward; the training forward keeps its fp32 logits for that backward)" if args.fused_head else ("split-bf16 GEMMs" if args.split_head else "fp32 nn.Linear"),
         "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9,
         "model": f"Qwen2.5-{args.model} shape, random init, {n_params / 1e6:.0f}M params, {args.layers} layers, bf16 + fp32 lm_head"
                  f"{' on bf16 matrix cores (2-term split)' if args.split_head else ''}, {'activations kept' if args.no_checkpointing else 'grad checkpointing'}, sdpa",
