@@ -283,18 +283,55 @@ __global__ __launch_bounds__(kBlock) void pack_collate_kernel(PackArgs a) {
     }
     Tok tk[TPL];
     const int cnt = (a.total - t0) < TPL ? (int)(a.total - t0) : TPL;
-#pragma unroll
-    for (int k = 0; k < TPL; ++k) {
-      if (k < cnt) {
-        const int64_t t = t0 + k;
-        while (t >= c.dst_e) {  // also skips zero-length sequences
-          ++j;
-          load_seq(a, j, c);
-          cj = j;
-        }
-        make_token(a, c, t, tk[k]);
+    // The lane's TPL tokens inside ONE sequence with scalar columns (all but a few groups at sequence ends): their ids, labels and
+    // log-probs are TPL consecutive 4-byte words each - one load per column instead of TPL (the ragged offsets are only 4-byte
+    // aligned; global loads of 8 / 16 bytes need no more than that on gfx950)
+    if (VEC && a.per_token == 0 && c.src_b >= 0 && t0 + TPL <= c.dst_e) {
+      typedef int iv __attribute__((ext_vector_type(TPL), aligned(4)));
+      typedef float fv __attribute__((ext_vector_type(TPL), aligned(4)));
+      const int64_t i0 = t0 - c.dst_b;
+      const iv ids = *reinterpret_cast<const iv*>(a.tokens + c.src_b + i0);
+      const iv labs = *reinterpret_cast<const iv*>(a.labels + c.src_b + i0);
+      const int64_t k0 = i0 - c.lp_skip;
+      fv old, ref;
+      if (k0 >= 0) {
+        old = *reinterpret_cast<const fv*>(a.lp + c.lp_b + k0);
+        ref = a.ref_lp ? *reinterpret_cast<const fv*>(a.ref_lp + c.lp_b + k0) : old;
       } else {
-        tk[k] = tk[0];
+#pragma unroll
+        for (int k = 0; k < TPL; ++k) {
+          old[k] = k0 + k >= 0 ? a.lp[c.lp_b + k0 + k] : 0.0f;
+          ref[k] = k0 + k >= 0 ? (a.ref_lp ? a.ref_lp[c.lp_b + k0 + k] : old[k]) : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < TPL; ++k) {
+        tk[k].id = ids[k];
+        tk[k].label = (i0 + k == 0 && c.seg > 0) ? -100 : (int64_t)labs[k];  // data.py:264-265
+        tk[k].pos = i0 + k;
+        tk[k].seg = c.seg;
+        tk[k].reward = c.reward;
+        tk[k].adv = c.adv;
+        tk[k].gt = c.gt;
+        tk[k].nl = c.nl;
+        tk[k].ovf = c.ovf;
+        tk[k].old = old[k];
+        tk[k].ref = ref[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < TPL; ++k) {
+        if (k < cnt) {
+          const int64_t t = t0 + k;
+          while (t >= c.dst_e) {  // also skips zero-length sequences
+            ++j;
+            load_seq(a, j, c);
+            cj = j;
+          }
+          make_token(a, c, t, tk[k]);
+        } else {
+          tk[k] = tk[0];
+        }
       }
     }
     if (VEC && cnt == TPL) {
