@@ -1,5 +1,7 @@
-// Fused output head: hidden states -> log-prob / entropy of the next token WITHOUT ever writing the
-// [T, V] logits to HBM, and its backward.
+// Fused output head: hidden states -> log-prob / entropy of the next token with the soft-max inside the GEMM epilogue, and its
+// backward.  Two forms: the logits are never written (recomputing backward, 7 plane products per micro-batch),
+// or the TRAINING forward also leaves them behind as fp32 for a backward of 5 products (prl_lm_head_logprob_fwd_keep /
+// _bwd_kept, the default of fused_head.FusedLmHead); no fp32 d logits and no autograd copies in either.
 //
 // The reference computes  logits = lm_head(hidden)  with the head forced to fp32
 // (pipelinerl/finetune/checkpoints.py:87-103), hands the [1, T, V] fp32 tensor (4.98 GB for a
@@ -20,12 +22,16 @@
 //   * forward: each workgroup owns 128 tokens and a range of vocabulary tiles; the logits never leave
 //     the registers.  Partial states per (token, vocabulary split) are merged by a small second kernel
 //     that also writes the token-aligned new_logprobs / entropy / lse2.
-//   * backward: per chunk of rows the logits tile is recomputed by the same main loop, turned into
-//     d logits with the saved lse2 / entropy and the per-token loss gradients, split into bf16
-//     (hi, lo) planes and written in both layouts to a workspace sized for the chunk only; two more
-//     passes of the same NT GEMM core produce  d hidden = d logits W  and  d W += d logits^T hidden.
+//   * backward: per chunk of rows the logits are recomputed by the same main loop (or read back from the kept fp32 logits in
+//     one elementwise pass), turned into d logits with the saved lse2 / entropy and the per-token loss gradients, split into
+//     bf16 (hi, lo) planes and written ROW-MAJOR to a workspace sized for the chunk only;  d hidden = d logits W  runs on a
+//     three-product core (gemm_mainloop_triple, one contraction slice per XCD) and  d W += d logits^T hidden  gathers its
+//     fragments from the same row-major planes with transposing LDS reads (gemm_mainloop_dual_tr).
+//   * opt-in mixed precision (f16 plane + fp8 residual plane on the MX-scaled MFMA): gemm_mainloop_mx.
 //
-// GEMM core: C[M, N] = sum_terms A_t[M, Kc] B_t[N, Kc]^T, both operands contraction-contiguous bf16.
+// Generic GEMM core (small shapes, A/B reference): C[M, N] = sum_terms A_t[M, Kc] B_t[N, Kc]^T, both operands
+// contraction-contiguous bf16; the large shapes run on the dual- / triple-plane cores below (256 x 256 x 32, planes share
+// the staged partner tile).
 //   tile     BM x 128 x 64 with BM = 256 (512 threads, 8 waves as 4 x 2) or 128 (256 threads, 2 x 2);
 //            every wave computes 64 x 64 as 2 x 2 tiles of v_mfma_f32_32x32x16_bf16
 //   staging  HBM/L2 -> LDS by global_load_lds (16 B per lane, no VGPR round trip), 16-byte chunks
