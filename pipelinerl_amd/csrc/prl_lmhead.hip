@@ -1391,7 +1391,19 @@ __global__ __launch_bounds__(CfgDual::NT, 2) void gemm_dw_tr_kernel(GemmArgs a) 
   // row-tile groups of a.ksteps (reused as the raster's group size here): the workgroups an XCD runs at a time should cover
   // FEW vocabulary tiles and ALL hidden tiles - the d-logits planes (5 GB per micro-batch) then stream from HBM once instead of
   // once per quartet of hidden tiles, while the re-read operand is the 58 MB of hidden^T that the Infinity Cache holds
-  tile_coords_g((int)blockIdx.x, a.mt, a.nt, a.ksteps > 0 ? a.ksteps : 8, tm, tn);
+  if (a.ksteps < 0) {
+    // XCD-local patches (measurement, PRL_TUNE_LMHEAD_DW_GROUP = -PA): block b runs on XCD b % 8; an XCD owns the vocabulary tiles
+    // x, x + 8, ... and walks them in patches of PA tiles x all hidden tiles, vocabulary-fastest
+    const int PA = -a.ksteps;
+    const int x = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int per_patch = PA * a.nt;
+    const int p = slot / per_patch, in = slot - p * per_patch;
+    tm = x + 8 * (p * PA + in % PA);
+    tn = in / PA;
+    if (tm >= a.mt) return;  // the whole workgroup: before any barrier
+  } else {
+    tile_coords_g((int)blockIdx.x, a.mt, a.nt, a.ksteps > 0 ? a.ksteps : 8, tm, tn);
+  }
   const int m0 = tm * C::BM, n0 = tn * C::BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
@@ -2060,8 +2072,14 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
         const int64_t forced = prl::tuning(PRL_TUNE_LMHEAD_DW_GROUP, 0);
         const int gm = forced > 0 ? (int)forced : 16 / g.nt;
         g.ksteps = gm < 1 ? 1 : gm;  // (the raster's group size travels in the otherwise unused split-K field)
+        if (forced < 0) g.ksteps = (int)forced;
       }
-      if (int rc = PRL_LAUNCH_DUAL(gemm_dw_tr_kernel, g.mt * g.nt, g, s, "gemm_dw_tr_kernel(d weight)")) return rc;
+      int dw_blocks = g.mt * g.nt;
+      if (g.ksteps < 0) {
+        const int pa = -g.ksteps, per_xcd = ceil_div(ceil_div(g.mt, 8), pa) * pa;
+        dw_blocks = 8 * per_xcd * g.nt;
+      }
+      if (int rc = PRL_LAUNCH_DUAL(gemm_dw_tr_kernel, dw_blocks, g, s, "gemm_dw_tr_kernel(d weight)")) return rc;
     }
   }
   return PRL_OK;
