@@ -77,7 +77,7 @@ enum prl_tune_key {
   PRL_TUNE_LMHEAD_DUAL = 2,         /* 0: generic core where the dual-plane core would be taken */
   PRL_TUNE_LMHEAD_NSPLIT = 3,       /* vocabulary splits of the forward */
   PRL_TUNE_LMHEAD_KSPLIT = 4,       /* split-K factor of the d hidden product */
-  PRL_TUNE_LMHEAD_EXP = 5,          /* timing ablations of the forward (wrong results), see prl_lmhead.hip */
+  PRL_TUNE_LMHEAD_EXP = 5,          /* 256: the dual-plane forward with its DMA pieces interleaved with the MFMA groups (A/B reference) */
   PRL_TUNE_LOSS_FAST_STATS = 6,     /* 0: always-nan_to_num statistics path */
   PRL_TUNE_LOSS_TPL = 7,            /* tokens per lane of the loss kernel: 2 | 4 */
   PRL_TUNE_LOSS_BLOCKS_PER_CU = 8,

@@ -146,8 +146,8 @@ __device__ __forceinline__ void wait_tile_then_barrier() {
 // -----------------------------------------------------------------------------------------------
 // main loop: acc[i][j] (32 x 32 tiles of this wave's 64 x 64) += sum over terms and K
 // -----------------------------------------------------------------------------------------------
-// EXP (experiment bits; 0 = the shipped schedule; only 16 / 32 / 48 are instantiated, for the 256 x 256 forward,
-// selected with PRL_LMHEAD_EXP - the timing ablations behind profiles/r02h_lmhead_fwd_ablation.txt):
+// EXP (experiment bits of round 2; 0 = the shipped schedule and the only value instantiated for this loop - the ablation
+// launches behind profiles/r02h_lmhead_fwd_ablation.txt produced wrong results by design and are no longer built):
 //   1  all LDS-DMA pieces right after the first MFMA group instead of spread over three   } measured: +-1 %
 //   2  s_setprio(1) around every MFMA group                                                } -5 %
 //   4  LDS-DMA loads with the sc0 cache-policy bit                                         } 0
@@ -575,7 +575,7 @@ __device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const
 // dual-plane core).
 struct CfgTriple {
   static constexpr int BM = 256, BN = 256, NT = 512, STAGES = 2;
-  static constexpr int NJ = 4, WCOLS = 128;
+  static constexpr int WCOLS = 128;
   static constexpr int Q = 2;                       // 16-byte chunks per thread, tile and stage
   static constexpr int LOADS = 4 * Q;
   static constexpr int TILE_BYTES = 256 * ROW_BYTES32;  // 16 KB
@@ -1045,7 +1045,6 @@ struct DlArgs {
   uint16_t* dl_hi;      // [chunk_pad, vocab]
   uint16_t* dl_lo;
   const float* scales;  // mixed-precision recompute: device floats {S_w, S_h}; nullptr otherwise
-  int ablate;           // timing ablations (wrong results), PRL_TUNE_LMHEAD_BWD bits 2 / 3: 1 = no global stores, 2 = no plane epilogue at all
 };
 
 template <class C, int CORE = 0>
@@ -1142,11 +1141,6 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
             split2(val, hi, lo);
             p[e] = (uint32_t)hi | ((uint32_t)lo << 16);
           }
-          if (a.ablate & 2) {  // timing ablation: keep the values alive, skip the images
-#pragma unroll
-            for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(p[e]));
-            continue;
-          }
           // the lane's 4 consecutive vocabulary entries (registers 4 rg .. 4 rg + 3) of a token row: 8 bytes per plane
           const int vloc = (tid_here >> 7) * 64 + i * 32 + 8 * rg + 4 * lhalf;
           *reinterpret_cast<uint2*>(img + local * RS + vloc * 2) = uint2{(p[0] & 0xffffu) | (p[1] << 16), (p[2] & 0xffffu) | (p[3] << 16)};
@@ -1158,7 +1152,7 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
       const int local = c / (BM / 8), k = c % (BM / 8);
       const int row = (local / (JH * 32)) * C::WCOLS + h * (JH * 32) + local % (JH * 32);  // token row inside the tile
       const int lrow = n0 + row, v = m0 + k * 8;
-      if (lrow < a.chunk_pad && v + 7 < V && !(a.ablate & 1)) {  // V and chunk_pad are multiples of 8: a group of eight is inside or outside as a whole
+      if (lrow < a.chunk_pad && v + 7 < V) {  // V and chunk_pad are multiples of 8: a group of eight is inside or outside as a whole
         const unsigned char* src = img + local * RS + k * 16;
         const uint2 x0 = *reinterpret_cast<const uint2*>(src), x1 = *reinterpret_cast<const uint2*>(src + 8);
         const uint2 y0 = *reinterpret_cast<const uint2*>(src + IMG), y1 = *reinterpret_cast<const uint2*>(src + IMG + 8);
@@ -1795,21 +1789,7 @@ static int lm_head_fwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
   a.logits2 = logits2;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int exp_bits = (int)prl::tuning(PRL_TUNE_LMHEAD_EXP, 0);
-  if (shape == kWide && exp_bits && exp_bits != 256) {  // timing ablations, generic 256 x 256 forward only
-    int rc = PRL_EINVAL;
-#define PRL_EXP_CASE(E)                                                                                                  \
-  case E:                                                                                                                \
-    rc = launch_tiles(lmhead_fwd_kernel<CfgWide, E>, CfgWide::NT, CfgWide::LDS_BYTES, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel"); \
-    break;
-    switch (exp_bits) {
-      PRL_EXP_CASE(16)
-      PRL_EXP_CASE(32)
-      PRL_EXP_CASE(48)
-      default: return prl::set_error(PRL_EINVAL, "PRL_LMHEAD_EXP=%d is not built", exp_bits);
-    }
-#undef PRL_EXP_CASE
-    if (rc) return rc;
-  } else if (use_dual(shape, a.terms)) {
+  if (use_dual(shape, a.terms)) {
     if (exp_bits == 256) {  // A/B reference: DMA pieces interleaved with the MFMA groups, all waves alike
       if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 256, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual, interleaved)")) return rc;
     } else if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 0, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual)")) {
@@ -1952,7 +1932,6 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
       d.dl_hi = dl_hi;
       d.dl_lo = dl_lo;
       d.scales = nullptr;
-      d.ablate = (int)((prl::tuning(PRL_TUNE_LMHEAD_BWD, 0) >> 2) & 3);
       if (mx.w16) {  // recompute on the mixed-precision core: the logits are those of prl_lm_head_logprob_fwd_mx
         uint16_t* h16 = reinterpret_cast<uint16_t*>(ws + L.h16);
         uint8_t* h8 = mx.w8lo ? reinterpret_cast<uint8_t*>(ws + L.h8) : nullptr;
