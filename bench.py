@@ -373,9 +373,10 @@ def live_pmc_traffic(kernel_substr: str = "fused_logits_loss_keep_kernel") -> di
             if r.returncode != 0 or not files:
                 return None
             per_dispatch: dict[str, float] = {}
-            for row in csv.DictReader(open(files[0])):
-                if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                    per_dispatch[row["Dispatch_Id"]] = per_dispatch.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            with open(files[0], newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        per_dispatch[row["Dispatch_Id"]] = per_dispatch.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
             if not per_dispatch:
                 return None
             got[counter] = (sum(per_dispatch.values()) / len(per_dispatch), len(per_dispatch))
