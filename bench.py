@@ -358,6 +358,9 @@ def live_pmc_traffic(kernel_substr: str = "fused_logits_loss_keep_kernel") -> di
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not Path(exe).exists():
         return None
+    # this process is itself being profiled (rocprofv3 -- python bench.py): no profiler inside a profiler
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
     got = {}
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -61,3 +61,9 @@ def test_any_failure_falls_back_to_none(bench, monkeypatch, mode):
 
     monkeypatch.setattr(subprocess, "run", run)
     assert bench.live_pmc_traffic() is None
+
+
+def test_no_profiler_inside_a_profiler(bench, monkeypatch):
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: pytest.fail("rocprofv3 must not be started under rocprofv3"))
+    monkeypatch.setenv("ROCPROFILER_LIBRARY_CTOR", "1")
+    assert bench.live_pmc_traffic() is None
