@@ -41,9 +41,17 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, same guide (AMD's 5 PF f
 
 WORKLOADS = {
     # name: (global batch, seq_length, vocab, attempts)
-    "7b_grpo_bs4096_seq8192": (4096, 8192, 152064, 8),
-    "0p5b_grpo_bs512_seq2048": (512, 2048, 151936, 8),
+    "7b_grpo_bs4096_seq8192": (4096, 8192, 152064, 8),        # BASELINE.json configs[2] / [3] (the headline)
+    "0p5b_grpo_bs512_seq2048": (512, 2048, 151936, 8),        # configs[1]
+    "32b_grpo_kl_bs4096_seq8192": (4096, 8192, 152064, 8),    # configs[4]: KL-to-reference on, TP = 2 receivers
     "tiny": (64, 512, 4096, 8),
+}
+# name: (parameter set of weight_sync_probe.qwen25_shapes, hidden size of the output head, kl_coef, bf16 gradient bytes of a DP learner)
+WORKLOAD_MODEL = {
+    "7b_grpo_bs4096_seq8192": ("7b", 3584, 0.0, 15_231_233_024),
+    "0p5b_grpo_bs512_seq2048": ("0p5b", 896, 0.0, 988_065_536),
+    "32b_grpo_kl_bs4096_seq8192": ("32b", 5120, 0.001, 65_527_752_704),  # kl_coef: conf/deepscaler15b.yaml:34, SURVEY §8(d)
+    "tiny": ("0p5b", 256, 0.0, 1 << 20),
 }
 
 
@@ -58,12 +66,14 @@ def parse_args():
     p.add_argument("--no-weight-sync", action="store_true")
     p.add_argument("--no-fused-head", action="store_true", help="skip the MFMA fused-head measurement (roofline_mfma)")
     p.add_argument("--no-grad-allreduce", action="store_true", help="N > 1: leave the gradient-sized all-reduce out of the step")
-    p.add_argument("--grad-bytes", type=int, default=int(os.environ.get("PRL_BENCH_GRAD_BYTES", 15_231_233_024)),
-                   help="N > 1: bytes of data-parallel gradients all-reduced per step (default: Qwen2.5-7B in bf16)")
+    p.add_argument("--grad-bytes", type=int, default=int(os.environ.get("PRL_BENCH_GRAD_BYTES", 0)),
+                   help="N > 1: bytes of data-parallel gradients all-reduced per step (default: the workload's model in bf16)")
     p.add_argument("--e2e", action="store_true", help="(default at N = 1 on the 7B workload) run scripts/e2e_learner_bench.py live")
     p.add_argument("--no-e2e", action="store_true", help="N = 1: quote the committed model-in-the-loop step from profiles/ instead of running it (source: committed)")
     p.add_argument("--no-live-pmc", action="store_true", help="quote the committed PMC traffic figure instead of measuring it with two rocprofv3 --pmc sub-runs")
     p.add_argument("--no-transport", action="store_true", help="skip the host-side transport probe (shm log / files backend round trips)")
+    p.add_argument("--no-preprocess-loop", action="store_true", help="skip the actor-record -> published micro-batch measurement (preprocess_loop)")
+    p.add_argument("--no-ref-logprob", action="store_true", help="skip the reference-policy head measurement (ref_logprob)")
     p.add_argument("--cpu-baseline-threads", default=None,
                    help="comma-separated thread counts: time ONLY the cpu_baseline loss leg at each count and exit (no GPU work)")
     p.add_argument("--backend", default=os.environ.get("PRL_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
@@ -248,11 +258,12 @@ def cpu_baseline(seq_length: int, vocab: int) -> dict:
         if "logprob_fwd" in ref["legs"] and "logprob_bwd" in ref["legs"]:
             legs["logprob_fwd_bwd_closed_form"]["reference_us_per_token"] = ref["legs"]["logprob_fwd"]["us_per_token"] + ref["legs"]["logprob_bwd"]["us_per_token"]
             legs["logprob_fwd_bwd_closed_form"]["reference_note"] = "reference = forward + AUTOGRAD backward"
-    return {
+    port = {
         "value": 1.0 / per_sample,
         "unit": "samples/s",
         "cores": cores,
         "kind": "port",
+        "measured_in_this_run": True,
         "sample": f"oracle (port of the reference, pinned to it by golden vectors): preprocess+collate of {n_seq} x {seq_length}-token "
                   f"sequences, single process ({t_pre * 1e3:.1f} ms/seq) + logits->loss->dlogits on {t_logits} tokens x V={vocab} with vectorised "
                   f"fp32 torch CPU kernels (closed-form gradient) on {cores} threads, median of 3 ({t_loss_tok * 1e6:.0f} us/token), "
@@ -263,8 +274,24 @@ def cpu_baseline(seq_length: int, vocab: int) -> dict:
         "scalar_port": {"value": 1.0 / (t_pre + t_np_tok * seq_length), "cores": 1,
                         "sample": f"same path, single-thread numpy on {t_np} tokens ({t_np_tok * 1e6:.0f} us/token)"},
         "host": {"nproc": os.cpu_count(), "cgroup_cpu_quota": cores},
-        "reference": ref,
     }
+    if ref and ref.get("samples_per_s_extrapolated") and (seq_length, vocab) == (ref.get("workload", {}).get("seq_length"), ref.get("workload", {}).get("vocab")):
+        # Lead with the REFERENCE's own functions (kind "reference"): they cannot travel to the GPU box (/root/reference exists in the build
+        # container only), so this is a stated constant from that container's cores; the port timed on THIS box follows as the second witness.
+        return {
+            "value": ref["samples_per_s_extrapolated"], "unit": "samples/s", "cores": ref.get("threads", 8), "kind": "reference",
+            "measured_in_this_run": False,
+            "host": ref.get("host"),
+            "sample": f"the reference's own preprocess_fn + populate_rl_data + collate_packed on {ref['workload']['sequences']} x {ref['workload']['seq_length']}-token "
+                      f"sequences and rl_step forward + autograd backward on {ref['workload']['loss_tokens']} tokens x V={ref['workload']['vocab']}, "
+                      f"{ref.get('threads', 8)} threads of the build container ({(ref.get('host') or {}).get('model', '?')}), extrapolated to {seq_length}-token samples; "
+                      "committed constant (profiles/r03_reference_cpu_legs.json, scripts/reference_cpu_legs.py), NOT re-measured on this box",
+            "legs": ref.get("legs"),
+            "port": port,
+            "reference": ref,
+        }
+    port["reference"] = ref
+    return port
 
 
 def transport_probe(seq_length: int, vocab: int) -> dict:
@@ -474,6 +501,163 @@ def fused_head_probe(dev: torch.device, seq_length: int, vocab: int, hidden: int
     }
 
 
+def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attempts: int) -> dict:
+    """The preprocessor LOOP at the reference's granularity (preprocess.py:370-704, `chunk_n_groups` = 2): groups of
+    `attempts` x `seq_length`-token rollouts are written to the `actor` stream first - as PRLROL01 records on the shm log
+    and as the reference's JSONL list-of-dicts records on the files backend - then `PreprocessorLoop.run` consumes them:
+    reader thread -> decode -> one H2D per chunk -> K5 -> scheduler -> K6 per drain -> one D2H -> encode -> per-trainer
+    `training_data` partitions.  Timed: `run()` from its first line to the last published micro-batch (wall clock; stream
+    read + decode run concurrently in the loader thread, as in the reference).  Host phases come from `perf_counter`
+    pairs inside the loop, K5 / K6 device time from HIP event pairs on the loop's stream.  Extra object, never `value`."""
+    import shutil
+    import tempfile
+
+    from pipelinerl_amd import streams
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.preprocess import PreprocessorConfig, PreprocessorLoop
+    from pipelinerl_amd.synthetic import make_ragged, ragged_to_entries
+
+    shm_free = shutil.disk_usage("/dev/shm").free if Path("/dev/shm").exists() else 0
+    tok_per_group = attempts * seq_length
+    # shm: the actor records (12 B/token) and the published batches (68 B/token) of one case live in /dev/shm together
+    n_fast = int(max(4, min(int(os.environ.get("PRL_BENCH_PREPROCESS_GROUPS", 32)), shm_free // 4 // (tok_per_group * 80)))) // 2 * 2
+    n_text = 4
+    rl = RLConfig(policy_loss="ppo", epsilon_low=0.02, epsilon_high=0.02, kl_coef=0.0, final_kl_coef=0.0, clamp_log_ratio_ref_new_value=5,
+                  temperature=1.0, divide_advantage_by_std=False, group_normalization=False, batch_size=4096)
+    groups = [make_ragged(1, attempts=attempts, seq_length=seq_length, vocab=vocab, seed=4000 + g, dense=True) for g in range(n_fast)]
+    was = (streams._backend, dict(streams._backend_options))
+    out: dict = {"what": f"actor stream -> PreprocessorLoop (chunk_n_groups = 2, packed, seq_length {seq_length}) -> training_data; groups of "
+                         f"{attempts} x {seq_length}-token rollouts; wall clock of run() incl. stream read + decode (loader thread)", "cases": {}}
+
+    def one_case(backend: str, binary: bool, trainers: int, n_groups: int, batched: bool):
+        tmp = tempfile.mkdtemp(prefix="prl_bench_pre_")
+        try:
+            streams.reset_streams_backend()
+            streams.set_streams_backend(backend, **({"segment_bytes": 256 << 20, "trim_topics": (), "owner": True} if backend == "shm" else {}))
+            spec = streams.SingleStreamSpec(exp_path=Path(tmp), topic="actor")
+            with streams.write_to_streams(spec) as w:
+                for rag, reasons in groups[:n_groups]:
+                    w.write(rag if binary else ragged_to_entries(rag, reasons))
+            cfg = PreprocessorConfig(exp_path=Path(tmp), num_trainers=trainers, train_batch_size=1, gradient_accumulation_passes=4096,
+                                     seq_length=seq_length, attempts=attempts, rl=rl, eos_token_id=2, chunk_n_groups=2)
+            loop = PreprocessorLoop(cfg, dev, batched_transfers=batched, profile=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            # the packer flushes a micro-batch when the NEXT sample no longer fits (preprocess.py:610-625): the very last
+            # sample of the stream stays pending, so the target is one short of what was written
+            target = n_groups * attempts - 1
+            n = loop.run(max_published_samples=target, idle_timeout=5.0)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            tokens = n * seq_length  # dense rollouts: every sample is seq_length tokens
+            chunks = n_groups // 2
+            prof = dict(loop.prof)
+            kern = loop.kernel_seconds()
+            planning = sum(prof.get(k, 0.0) for k in ("ingest_flatten", "k5_plan", "k5_launch", "schedule", "k6_plan_launch"))
+            res = {"published_samples": n, "tokens": tokens, "chunks": chunks, "wall_s": dt, "tokens_per_s": tokens / dt, "us_per_token": 1e6 * dt / tokens,
+                   "host_phase_us_per_chunk": {k: 1e6 * v / chunks for k, v in sorted(prof.items())},
+                   "kernel_us_per_chunk": {k: 1e6 * v / chunks for k, v in kern.items()},
+                   "host_planning_frac": planning / dt,
+                   "host_planning_is": "ingest_flatten + k5_plan + k5_launch + schedule + k6_plan_launch (plan AND launch calls; transfers, codec, publish, waiting for input excluded)"}
+            if loop.stager is not None:
+                res["transfers_per_chunk"] = {"h2d": loop.stager.uploads / chunks, "d2h": loop.stager.downloads / chunks,
+                                              "h2d_bytes": loop.stager.bytes_up / chunks, "d2h_bytes": loop.stager.bytes_down / chunks}
+            assert n == target, f"published {n} of {target} samples"
+            return res
+        finally:
+            if backend == "shm":
+                streams.clean_shm_streams(tmp)
+            shutil.rmtree(tmp, ignore_errors=True)
+
+    try:
+        one_case("shm", True, 1, 2, True)  # warm-up: library, page-locked ring, allocator
+        out["cases"]["PRLROL01_to_shm_1_trainer"] = one_case("shm", True, 1, n_fast, True)
+        out["cases"]["PRLROL01_to_shm_4_trainers"] = one_case("shm", True, 4, n_fast, True)
+        out["cases"]["PRLROL01_to_shm_1_trainer_one_copy_per_array"] = one_case("shm", True, 1, n_fast, False)
+        out["cases"]["JSONL_to_files_1_trainer"] = one_case("files", False, 1, n_text, True)
+    finally:
+        streams.reset_streams_backend()
+        if was[0] is not None:
+            streams.set_streams_backend(was[0], **was[1])
+    ref = (_committed_json("profiles/r03_reference_cpu_legs.json", note="") or {}).get("legs", {})
+    if ref:
+        r_pre, r_col, r_wire = (ref.get(k, {}).get("us_per_token") for k in ("preprocess", "collate_packed", "wire"))
+        out["reference_us_per_token"] = {"preprocess_fn+populate_rl_data": r_pre, "collate_packed": r_col, "jsonl_wire_round_trip": r_wire,
+                                         "source": "profiles/r03_reference_cpu_legs.json (the reference's own functions, 8 cores of the build container)"}
+        best = out["cases"]["PRLROL01_to_shm_1_trainer"]["us_per_token"]
+        if r_pre and r_col:
+            out["speedup_vs_reference_preprocess_plus_collate"] = (r_pre + r_col) / best
+        if r_pre and r_col and r_wire:
+            out["speedup_vs_reference_incl_wire"] = (r_pre + r_col + r_wire) / best
+    return out
+
+
+def ref_logprob_probe(dev: torch.device, seq_length: int, vocab: int, hidden: int) -> dict:
+    """The reference-policy forward of a KL-enabled config (reference: a second inference server asked over
+    HTTP, preprocess.py:86-104, llm.py:606-648): last hidden states [T, H] -> log p_ref of the labelled tokens.
+    OLD: stock lm_head GEMM writing `[T, V]` logits + the K1 kernel reading them back (round 3's `annotate_ref_logprobs`).
+    FUSED: `FusedLmHead(backward=False)` - the product on the MFMA head, online softmax in its epilogue, no logits.
+    Both for an fp32 head (two bf16 planes; the fp32 `F.linear` of finetune/checkpoints.py:87-103 on the old path) and a
+    bf16 head (one plane; a bf16 GEMM writing bf16 logits on the old path).  One micro-batch of `seq_length` tokens."""
+    from pipelinerl_amd.finetune.rl import logprob_entropy
+    from pipelinerl_amd.fused_head import FusedLmHead, token_logprobs_from_hidden
+
+    T, H, V = seq_length, hidden, vocab
+    g = torch.Generator(device=dev).manual_seed(11)
+    h = torch.empty(1, T, H, device=dev).normal_(generator=g).to(torch.bfloat16)
+    ids = torch.randint(3, V, (1, T), device=dev, generator=g)
+    labels = ids.clone()
+    labels[:, : T // 28] = -100  # the benchmark's prompt share (~3.5 %): below the 1/32 compaction threshold, every row runs
+
+    def timed(fn, iters=5):
+        fn()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    out: dict = {"what": f"log p_ref of one {T}-token micro-batch from the reference policy's last hidden states, H = {H}, V = {V}", "heads": {}}
+    for name, wdt in (("fp32_head", torch.float32), ("bf16_head", torch.bfloat16)):
+        W = torch.empty(V, H, device=dev).normal_(0.0, 0.02, generator=g).to(wdt)
+        head = FusedLmHead(W, backward=False, keep_logits=False)
+        head.refresh()
+
+        def old_path():
+            logits = torch.nn.functional.linear(h.float() if wdt == torch.float32 else h, W)
+            nlp = logprob_entropy(logits, ids, 1.0)[0]
+            return torch.where(labels != -100, nlp, torch.zeros_like(nlp))
+
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        a = old_path()
+        old_peak = torch.cuda.max_memory_allocated() - base
+        old_ms = timed(old_path)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        b = token_logprobs_from_hidden(head, h, ids, labels, 1.0)
+        new_peak = torch.cuda.max_memory_allocated() - base
+        new_ms = timed(lambda: token_logprobs_from_hidden(head, h, ids, labels, 1.0))
+        planes = 2 if wdt == torch.float32 else 1
+        itemsize = 4 if wdt == torch.float32 else 2
+        out["heads"][name] = {
+            "old_ms": old_ms, "fused_ms": new_ms, "speedup": old_ms / new_ms,
+            "old_what": ("fp32 F.linear (library GEMM)" if wdt == torch.float32 else "bf16 F.linear (library GEMM)") + f" writing [T, V] {str(wdt).replace('torch.', '')} logits + K1",
+            "fused_what": f"{planes} bf16 plane product(s) on v_mfma_f32_32x32x16_bf16, online softmax in the epilogue",
+            "fused_executed_tflops": planes * 2.0 * T * V * H / (new_ms * 1e-3) / 1e12,
+            "logits_bytes_not_written": T * V * itemsize, "hbm_bytes_saved": 2 * T * V * itemsize,
+            "peak_extra_memory_bytes": {"old": old_peak, "fused": new_peak},
+            "max_abs_difference": float((a - b).abs().max().item()),
+        }
+        del W, head, a, b
+        torch.cuda.empty_cache()
+    return out
+
+
 def weight_sync_probe(rank: int, world: int, dev: torch.device, out: dict) -> dict:
     """Trainer -> actor weight update (rank 0 -> all others) over RCCL, Qwen2.5-7B sized (bf16):
       (1) the wire alone: 15 x 1 GiB buckets, plain broadcast vs scatter + all-gather;
@@ -483,7 +667,7 @@ def weight_sync_probe(rank: int, world: int, dev: torch.device, out: dict) -> di
     Extra field, never `value`."""
     import torch.distributed as dist
 
-    total_bytes = int(os.environ.get("PRL_BENCH_WSYNC_BYTES", 15_231_233_024))  # 7.6B params bf16
+    total_bytes = int(os.environ.get("PRL_BENCH_WSYNC_BYTES", out.get("param_bytes", 15_231_233_024)))  # default: 7.6B params bf16
     bucket_bytes = 1 << 30
     grp = None
     try:
@@ -521,7 +705,7 @@ def weight_sync_probe(rank: int, world: int, dev: torch.device, out: dict) -> di
         from pipelinerl_amd.weight_sync_probe import qwen25_shapes
 
         out["stage"] = "full_update"
-        shapes = qwen25_shapes("7b")
+        shapes = qwen25_shapes(out.get("params", "7b"))
         gen = torch.Generator(device=dev).manual_seed(77)  # same values on every rank: receivers can verify
         probe_name = "model.norm.weight"
         if rank == 0:
@@ -597,15 +781,18 @@ def main():
 
     _lib.load()
     bs, seq_length, vocab, attempts = WORKLOADS[args.workload]
+    param_set, hidden, kl_coef, grad_bytes_default = WORKLOAD_MODEL[args.workload]
+    if not args.grad_bytes:
+        args.grad_bytes = grad_bytes_default
     assert bs % (attempts * world) == 0, "global batch must split into whole groups per rank"
     groups_per_rank = bs // attempts // world
-    cfg = RLConfig(policy_loss="ppo", epsilon_low=0.02, epsilon_high=0.02, kl_coef=0.0, final_kl_coef=0.0,
+    cfg = RLConfig(policy_loss="ppo", epsilon_low=0.02, epsilon_high=0.02, kl_coef=kl_coef, final_kl_coef=kl_coef,
                    clamp_log_ratio_ref_new_value=5, temperature=1.0, divide_advantage_by_std=False,
                    group_normalization=False, batch_size=bs)
 
     # synthetic rollouts of this rank's shard, resident in HBM before the timed region (§8d: dense)
     rag_h, _ = make_ragged(groups_per_rank, attempts=attempts, seq_length=seq_length, vocab=vocab,
-                           seed=1234 + 2 + 1000 * rank, dense=True)
+                           seed=1234 + 2 + 1000 * rank, dense=True, with_ref=kl_coef > 0)
     torch.cuda.synchronize()
     t_h2d = time.perf_counter()
     rag = rag_h.to(dev)
@@ -618,7 +805,8 @@ def main():
     torch.cuda.synchronize()
     t_h2d_pinned = time.perf_counter() - t_h2d_pinned
     del rag_pinned
-    h2d_bytes = sum(t.numel() * t.element_size() for t in (rag.tokens, rag.labels, rag.logprobs, rag.seq_off, rag.lp_off, rag.reward))
+    h2d_bytes = sum(t.numel() * t.element_size() for t in (rag.tokens, rag.labels, rag.logprobs, rag.seq_off, rag.lp_off, rag.reward)
+                    + ((rag.ref_logprobs,) if rag.ref_logprobs is not None else ()))
     n_seq = rag.n_seqs
     micro_batches = [[i] for i in range(n_seq)]  # dense: every sequence fills one seq_length budget
     tokens_per_rank = int(rag_h.host_seq_off[-1])
@@ -645,6 +833,8 @@ def main():
         c = int(lo[j + 1] - lo[j])
         noise = torch.empty(c, device=dev).normal_(0.0, sigma, generator=gen)
         rag.logprobs[int(lo[j]) : int(lo[j + 1])] = nlp[0, seq_length - c :] + noise
+        if rag.ref_logprobs is not None:  # KL-to-reference on: ref = old + N(0, 0.05) per SURVEY §8(d), a DIFFERENT column
+            rag.ref_logprobs[int(lo[j]) : int(lo[j + 1])] = rag.logprobs[int(lo[j]) : int(lo[j + 1])] + torch.empty(c, device=dev).normal_(0.0, 0.05, generator=gen)
     del setup, setup_batches
     torch.cuda.synchronize()
 
@@ -760,6 +950,10 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": kernels[dom]["hbm_frac"], "traffic": traffic, "traffic_source": traffic_source,
+        # what `achieved` is made of, so that the trimmed line is self-sufficient: algorithmic bytes per launch / average launch duration
+        "avg_us": kernels[dom]["avg_us"], "min_us": kernels[dom]["min_us"], "launches": kernels[dom]["launches"],
+        "algorithmic_bytes_per_launch": kernels[dom].get("algorithmic_bytes"),
+        "timing": "HIP events on torch's current stream (the stream the kernel is launched on), every launch of the timed region",
     }
     if grad_buckets and "grad_allreduce" in kernels:
         k = kernels["grad_allreduce"]
@@ -770,7 +964,6 @@ def main():
     cpu_base = None if (args.no_cpu_baseline or world != 1) else cpu_baseline(seq_length, vocab)
 
     # ---- secondary objects (never part of `value`) ----
-    hidden = {152064: 3584, 151936: 896}.get(vocab, 256)
     roofline_mfma = None
     if world == 1 and not args.no_fused_head:
         try:
@@ -781,7 +974,7 @@ def main():
             roofline_mfma = {"error": f"{type(e).__name__}: {e}"}
         logits = grad_logits = None
     e2e = None
-    if world == 1 and args.workload.startswith("7b"):
+    if world == 1 and param_set == "7b" and vocab == 152064:
         committed = _committed_json("profiles/r02_e2e_learner_7b_fused_head.json",
                                     note="MODEL-IN-THE-LOOP step (random-init Qwen2.5-7B shape, stock PyTorch-ROCm forward/backward + AdamW on ONE MI355X, "
                                          "bs 16 x 8192) measured separately with scripts/e2e_learner_bench.py and committed; `value` above is the post-model "
@@ -830,6 +1023,20 @@ def main():
             e2e = committed
             if e2e is not None:
                 e2e["source"] = "committed (profiles/r02_e2e_learner_7b_fused_head.json), NOT measured in this run"
+    ref_logprob = None
+    if world == 1 and not args.no_ref_logprob and not args.no_fused_head:
+        try:
+            logits = grad_logits = None
+            torch.cuda.empty_cache()
+            ref_logprob = ref_logprob_probe(dev, seq_length, vocab, hidden)
+        except Exception as e:  # noqa: BLE001
+            ref_logprob = {"error": f"{type(e).__name__}: {e}"}
+    preprocess_loop = None
+    if world == 1 and not args.no_preprocess_loop:
+        try:
+            preprocess_loop = preprocess_loop_probe(dev, seq_length, vocab, attempts)
+        except Exception as e:  # noqa: BLE001
+            preprocess_loop = {"error": f"{type(e).__name__}: {e}"}
     transport = None
     if rank == 0 and not args.no_transport:
         try:
@@ -837,7 +1044,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             transport = {"error": f"{type(e).__name__}: {e}"}
 
-    label = {"7b_grpo_bs4096_seq8192": "7B GRPO bs=4096", "0p5b_grpo_bs512_seq2048": "0.5B GRPO bs=512 seq=2048"}.get(args.workload, args.workload)
+    label = {"7b_grpo_bs4096_seq8192": "7B GRPO bs=4096", "0p5b_grpo_bs512_seq2048": "0.5B GRPO bs=512 seq=2048",
+             "32b_grpo_kl_bs4096_seq8192": "32B GRPO bs=4096, KL-to-ref on"}.get(args.workload, args.workload)
 
     def emit(wsync):
         if rank != 0:
@@ -857,7 +1065,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "global_batch": bs, "seq_len": seq_length, "vocab": vocab,
                        "tokens_per_step": bs * seq_length, "parallelism": f"dp{world}", "logits_mode": args.logits_mode,
-                       "policy_loss": "ppo", "kl_coef": 0.0, "old_logprob_sigma": sigma, "labelled_token_fraction": live_frac,
+                       "policy_loss": "ppo", "kl_coef": kl_coef, "ref_logprobs": ("old + N(0, 0.05)" if kl_coef > 0 else "== old (KL off)"),
+                       "model": param_set, "head_hidden": hidden, "old_logprob_sigma": sigma, "labelled_token_fraction": live_frac,
                        "grad_allreduce_bytes_per_step": sum(b.numel() * 2 for b in grad_buckets) if grad_buckets else 0,
                        "torch_distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices_visible": torch.cuda.device_count()}
                                              if world > 1 else None),
@@ -865,6 +1074,8 @@ def main():
                                             "note": "one step's ragged rollouts, pageable vs page-locked host memory; not part of value"}},
             "roofline": roofline,
             "roofline_mfma": roofline_mfma,
+            "ref_logprob": ref_logprob,
+            "preprocess_loop": preprocess_loop,
             "e2e": e2e,
             "transport": transport,
             "kernels": kernels,
@@ -885,7 +1096,7 @@ def main():
         try:
             from pipelinerl_amd.weight_sync_probe import colocated_probe
 
-            wsync = colocated_probe("7b" if args.workload.startswith("7b") else "0p5b", iters=5, rehome=True, ready_timeout=240.0)
+            wsync = colocated_probe(param_set, iters=5, rehome=True, ready_timeout=240.0 if param_set != "32b" else 600.0)
         except Exception as e:  # noqa: BLE001 - the probe must never take the benchmark line down
             wsync = {"error": f"{type(e).__name__}: {e}"}
     force = os.environ.get("PRL_BENCH_FORCE_WSYNC") == "1"  # dry runs: exercise the probe's error handling under gloo
@@ -893,7 +1104,7 @@ def main():
         import threading
 
         done = threading.Event()
-        wsync = {}
+        wsync = {"params": param_set, "param_bytes": grad_bytes_default}
 
         def watchdog():
             if not done.wait(float(os.environ.get("PRL_BENCH_WSYNC_TIMEOUT", 90))):

@@ -244,12 +244,18 @@ def _parse_tuning(key: str, text: str) -> int:
 
 
 def _sync_env_tuning(lib) -> None:
+    """Map the PRL_* variables onto the library's tuning table - ONLY the keys whose variable changed since the last look
+    (first look: only the variables that are set).  A key the environment does not mention is never written, so values
+    placed with `set_tuning()` / `prl_set_tuning` survive (an A/B that calls `set_tuning` before its first launch used to
+    be silently reset to the defaults); a variable that DISAPPEARS restores the library's own choice for its key."""
     global _env_seen
-    now = tuple(os.environ.get(v) for v in _ENV_OF_KEY.values())
+    now = tuple(os.environ.get(v) or None for v in _ENV_OF_KEY.values())
     if now == _env_seen:
         return
-    for (key, _), text in zip(_ENV_OF_KEY.items(), now):
-        lib.prl_set_tuning(TUNE_KEYS[key], PRL_TUNE_UNSET if text is None or text == "" else _parse_tuning(key, text))
+    before = _env_seen or (None,) * len(now)
+    for (key, _), text, old in zip(_ENV_OF_KEY.items(), now, before):
+        if text != old:
+            lib.prl_set_tuning(TUNE_KEYS[key], PRL_TUNE_UNSET if text is None else _parse_tuning(key, text))
     _env_seen = now
 
 

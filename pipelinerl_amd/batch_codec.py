@@ -30,7 +30,8 @@ MAGIC_JSON = b"PRLJSON1"
 MAGIC_BATCH = b"PRLBAT01"
 MAGIC_ROLLOUTS = b"PRLROL01"
 _ALIGN = 16
-_TORCH = {"int64": torch.int64, "float32": torch.float32, "int32": torch.int32, "float64": torch.float64, "uint8": torch.uint8}
+_TORCH = {"int64": torch.int64, "float32": torch.float32, "int32": torch.int32, "float64": torch.float64, "uint8": torch.uint8,
+          "bool": torch.bool, "bfloat16": torch.bfloat16, "float16": torch.float16}
 
 
 def encode_json(text: str) -> bytes:
@@ -44,6 +45,8 @@ def _frame(magic: bytes, scalars: dict, named_tensors) -> bytearray:
     offset = 0
     for name, t in named_tensors:
         t = t.detach()
+        if str(t.dtype).replace("torch.", "") not in _TORCH:  # fail at the PRODUCER, not with a KeyError in the consumer process
+            raise TypeError(f"stream record field {name!r} has dtype {t.dtype}; the binary record carries {sorted(_TORCH)}")
         offset += (-offset) % _ALIGN
         nbytes = t.numel() * t.element_size()
         layout.append((name, t, offset, nbytes))
@@ -62,7 +65,7 @@ def _frame(magic: bytes, scalars: dict, named_tensors) -> bytearray:
         if t.device.type == "cpu" and t.is_contiguous():
             # plain memcpy: torch's copy_ hands anything above 32 K elements to its intra-op thread pool, whose wake-up
             # costs more than the copy (measured 70 ms per 256 KB column under a CPU quota)
-            np.frombuffer(buf, dtype=np.uint8, count=nb, offset=base + off)[:] = t.view(torch.uint8).reshape(-1).numpy()
+            np.frombuffer(buf, dtype=np.uint8, count=nb, offset=base + off)[:] = t.reshape(-1).view(torch.uint8).numpy()  # reshape first: 0-dim tensors have no byte view
         else:
             torch.frombuffer(buf, dtype=t.dtype, count=t.numel(), offset=base + off).view(t.shape).copy_(t)
     return buf

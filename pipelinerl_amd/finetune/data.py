@@ -40,11 +40,33 @@ _PER_TOKEN_BITS = {"rewards": 1, "advantages": 2, "group_tokens": 4, "num_labels
 # ---------------------------------------------------------------------------------------------
 
 
-def _alloc_outputs(total: int, dev: torch.device, packed: bool) -> dict[str, torch.Tensor]:
+_F32_COLUMNS = ("rewards", "advantages", "ref_logprobs", "old_logprobs", "group_tokens", "num_labels", "overflow")
+
+
+def _column_stride(total: int) -> int:
+    """Elements between two columns of a block: `total` rounded up to 64, so that every column starts on a 256-byte
+    boundary whatever the token count (the pack kernels store 16 bytes per lane)."""
+    return (total + 63) // 64 * 64
+
+
+def _column_views(block: torch.Tensor, total: int, packed: bool) -> dict[str, torch.Tensor]:
+    """The batch columns as views into one uint8 block: the int64 columns first, then the fp32 ones, each `total` long."""
     names_i64 = ["input_ids", "labels", "attention_mask"] + (["position_ids", "segment_ids"] if packed else [])
-    out = {k: torch.empty(total, dtype=torch.int64, device=dev) for k in names_i64}
-    for k in ("rewards", "advantages", "ref_logprobs", "old_logprobs", "group_tokens", "num_labels", "overflow"):
-        out[k] = torch.empty(total, dtype=torch.float32, device=dev)
+    n64, stride = len(names_i64), _column_stride(total)
+    i64 = block[: n64 * stride * 8].view(torch.int64).view(n64, stride)
+    f32 = block[n64 * stride * 8:].view(torch.float32).view(len(_F32_COLUMNS), stride)
+    out = {k: i64[i, :total] for i, k in enumerate(names_i64)}
+    out.update({k: f32[i, :total] for i, k in enumerate(_F32_COLUMNS)})
+    return out
+
+
+def _alloc_outputs(total: int, dev: torch.device, packed: bool) -> dict[str, torch.Tensor]:
+    """ONE allocation for the 12 (packed) / 10 (padded) output columns - 68 / 52 bytes per token - so that a whole launch's
+    output can leave the device in one copy (`PackedStep.to_host`); `out["__block__"]` is that allocation."""
+    n64 = 5 if packed else 3
+    block = torch.empty(_column_stride(total) * (n64 * 8 + len(_F32_COLUMNS) * 4), dtype=torch.uint8, device=dev)
+    out = _column_views(block, total, packed)
+    out["__block__"] = block
     return out
 
 
@@ -55,6 +77,8 @@ class PackedStep(Sequence):
 
     def __init__(self, flat: dict[str, torch.Tensor], pk_dst: np.ndarray, mb_off: np.ndarray,
                  model_versions: np.ndarray, pads: np.ndarray | None):
+        flat = dict(flat)
+        self.block = flat.pop("__block__", None)  # the one allocation behind every column (None: separate tensors)
         self.flat = flat
         self.pk_dst = pk_dst          # int64 [m + 1] token offset of every packed sequence
         self.mb_off = mb_off          # int64 [n_mb + 1] index into pk_dst of every micro-batch
@@ -89,6 +113,16 @@ class PackedStep(Sequence):
             )
             self._cache[j] = got
         return got
+
+    def to_host(self, stager) -> "PackedStep":
+        """The same micro-batches over HOST memory: the whole block leaves the device in ONE copy into a page-locked
+        buffer of `stager` (a `staging.PinnedStager`); the columns are views of that buffer - consume them (encode them
+        into stream records) before the stager's ring comes round."""
+        if self.block is None:
+            raise RuntimeError("this PackedStep was not allocated as one block")
+        host = stager.download(self.block)
+        flat = _column_views(host, self.total_tokens, packed=True)
+        return PackedStep(flat, self.pk_dst, self.mb_off, self.model_versions, self.pads)
 
     def step_batch(self) -> PipelineBatchEncoding:
         """The whole launch as ONE [1, T_step] batch over the same buffers (no copy)."""
@@ -135,6 +169,7 @@ def pack_prepared(
     sentinel_pad: Sequence[int] | None = None,
     per_token_columns: int = 0,
     timer: Any = None,
+    stager: Any = None,
 ) -> PackedStep:
     """Pack `micro_batches[j]` (lists of sequence indices into `prep`) into packed batches with a
     single K6 launch.  `sentinel_pad[j]` > 0 appends that many filler tokens to micro-batch j
@@ -148,9 +183,12 @@ def pack_prepared(
     m = len(pk_src)
     total = int(pk_dst[-1])
     out = _alloc_outputs(total, dev, packed=True)
-    d_src = torch.from_numpy(pk_src).to(dev, non_blocking=True)
-    d_dst = torch.from_numpy(pk_dst).to(dev, non_blocking=True)
-    d_seg = torch.from_numpy(pk_seg).to(dev, non_blocking=True)
+    if stager is not None:  # the three plan arrays in one page-locked copy
+        d_src, d_dst, d_seg = stager.upload([pk_src, pk_dst, pk_seg])
+    else:
+        d_src = torch.from_numpy(pk_src).to(dev, non_blocking=True)
+        d_dst = torch.from_numpy(pk_dst).to(dev, non_blocking=True)
+        d_seg = torch.from_numpy(pk_seg).to(dev, non_blocking=True)
     if m and total:
         # `timer` (bench.py's EventTimer): HIP events around the kernel alone, so that the host planning
         # above (O(#sequences) numpy + three small uploads) is not charged to the kernel's bandwidth
@@ -215,7 +253,7 @@ def pad_prepared(
                 _lib.ptr(out["overflow"]), _lib.current_stream_ptr(dev),
             )
         )
-    fields = {k: v.view(B, longest) for k, v in out.items()}
+    fields = {k: v.view(B, longest) for k, v in out.items() if k != "__block__"}
     mv = r.host_model_version
     return PipelineBatchEncoding(**fields, model_version=int(min(mv[list(rows)])), is_packed=False)
 

@@ -74,6 +74,11 @@ class RLConfig(BaseModel):
                                        "and gradient are zeros and every labelled value is bit-identical, but the reference's assert over "
                                        "ALL positions (rl/__init__.py:213) can then no longer see a non-finite value in such a row - so the "
                                        "drop-in default is False; the native loops (HotPathStep, NativeLearnerStep, fused_head_loss) turn it on")
+    fused_head_keep_logits: bool | None = Field(default=None, description="`rl_step_fused_head` on a bare model: None = keep the forward's fp32 "
+                                                "logits for the backward while two copies of them fit in free device memory (2 plane products less), "
+                                                "False = never (no logits anywhere), True = as None")
+    fused_head_chunk_rows: int = Field(default=8192, description="`rl_step_fused_head` on a bare model: rows of d-logits planes the backward holds at a "
+                                       "time (2 x rows x vocab x 2 bytes of workspace)")
 
 
 def make_rl_data_callback(args: Any, current_dir: Any, rl_config: "RLConfig | None", model: Any):
@@ -304,12 +309,23 @@ def gspo_segment_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, new_log
     return loss, ext_g, ext_c
 
 
-def annotate_ref_logprobs(ref_model: Any, batch: PipelineBatchEncoding, temperature: float = 1.0) -> PipelineBatchEncoding:
+def annotate_ref_logprobs(ref_model: Any, batch: PipelineBatchEncoding, temperature: float = 1.0, fused_head: bool = True) -> PipelineBatchEncoding:
     """Fill `batch.ref_logprobs` with a no-grad forward of a frozen reference model that lives on
     the learner GPU.  The reference pipeline instead asks a second vLLM server
     for `prompt_logprobs` over HTTP per chunk (preprocess.py:86-104, llm.py:606-648) and stores
-    the completion-token logprobs left-zero-padded; here the same values come out of the K1 kernel:
-    ref_logprobs[u] = log p_ref(token u | prefix) on labelled tokens, 0 elsewhere."""
+    the completion-token logprobs left-zero-padded:
+    ref_logprobs[u] = log p_ref(token u | prefix) on labelled tokens, 0 elsewhere.
+
+    A model in the Hugging Face layout (`.model` body + bias-free `.lm_head`) is asked for its last HIDDEN STATES and
+    the output head runs on the MFMA kernels of csrc/prl_lmhead.hip (`fused_head.token_logprobs_from_hidden`): the
+    `[T, V]` reference logits - 4.98 GB fp32 per 8192-token micro-batch at V = 152 064 - are never written, and only the
+    rows that predict a labelled token enter the product.  Anything else (a callable that only returns `.logits`), or
+    `fused_head=False`, goes through the logits and the K1 kernel."""
+    if fused_head:
+        from ..fused_head import annotate_ref_logprobs_fused
+
+        if annotate_ref_logprobs_fused(ref_model, batch, temperature):
+            return batch
     model_inputs = {"input_ids": batch.input_ids, "attention_mask": batch.attention_mask}
     if batch.is_packed:
         model_inputs["position_ids"] = batch.position_ids
@@ -541,24 +557,25 @@ def plan_groups(group_index: np.ndarray, step_index: np.ndarray, rollout_index: 
     return key_off, key_members, group_off, group_members, counts.astype(np.int32)
 
 
-def populate_rl_data_ragged(rollouts: RaggedRollouts, eos_token_id: int, config: RLConfig) -> PreparedRollouts:
+def populate_rl_data_ragged(rollouts: RaggedRollouts, eos_token_id: int, config: RLConfig, plan: Sequence[torch.Tensor] | None = None) -> PreparedRollouts:
     """K5 on device: num_labels / overflow per sequence, leave-one-out advantages per
-    (group_id, step_index), mean rollout tokens per group (reference rl/__init__.py:453-570)."""
+    (group_id, step_index), mean rollout tokens per group (reference rl/__init__.py:453-570).
+    `plan`: the five arrays of `plan_groups` already on the device (they rode along with the rollouts' upload,
+    `RaggedRollouts.to(device, stager, extra=plan_groups(...))`); None = planned and uploaded here."""
     lib = _lib.load()
     r = rollouts
     _lib.require_device(r.tokens)
     dev = r.device
     S = r.n_seqs
-    key_off, key_members, group_off, group_members, n_roll = plan_groups(
-        r.host_group_index, r.host_step_index, r.host_rollout_index
-    )
-    plan = [torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True) for a in (key_off, key_members, group_off, group_members, n_roll)]
-    num_labels = torch.empty(S, dtype=torch.float32, device=dev)
-    overflow = torch.empty(S, dtype=torch.float32, device=dev)
-    adv64 = torch.empty(S, dtype=torch.float64, device=dev)
-    gt64 = torch.empty(S, dtype=torch.float64, device=dev)
-    adv32 = torch.empty(S, dtype=torch.float32, device=dev)
-    gt32 = torch.empty(S, dtype=torch.float32, device=dev)
+    if plan is None:
+        plan = [torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
+                for a in plan_groups(r.host_group_index, r.host_step_index, r.host_rollout_index)]
+    key_off, group_off = plan[0], plan[2]
+    # the six per-sequence outputs live in one allocation (8-byte columns first)
+    out64 = torch.empty((2, S), dtype=torch.float64, device=dev)
+    out32 = torch.empty((4, S), dtype=torch.float32, device=dev)
+    adv64, gt64 = out64[0], out64[1]
+    num_labels, overflow, adv32, gt32 = out32[0], out32[1], out32[2], out32[3]
     with torch.cuda.device(dev):
         stream = _lib.current_stream_ptr(dev)
         _lib.check(

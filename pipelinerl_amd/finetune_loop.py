@@ -676,10 +676,13 @@ class NativeLearnerStep:
                  ref_model: torch.nn.Module | None = None, training_metrics: TrainingMetrics | None = None,
                  weight_update_manager: WeightUpdateManager | None = None, weight_update_interval: int = 1,
                  send_weight_updates: bool = True, trainer_stream: SingleStreamSpec | None = None,
-                 equalize_micro_batches: bool = True):
+                 equalize_micro_batches: bool = True, fused_ref_head: bool = True):
         """`ref_model`: a frozen reference policy on this GPU.  When given, the KL-to-reference term
         uses ITS log-probabilities, computed per micro-batch right before the policy forward (SURVEY
         §8f-3: replaces the HTTP round trip to a second inference server for KL-enabled configs).
+        With `fused_ref_head` (default) a model in the Hugging Face layout (`.model` + bias-free `.lm_head`) is asked for
+        its hidden states and the head runs on the MFMA kernels (no `[T, V]` reference logits); other models, or
+        `fused_ref_head=False`, go through their logits and K1.
         `samples_per_step`: the GLOBAL number of samples per optimizer step (the loss normaliser).
         `equalize_micro_batches`: pad with sentinel micro-batches up to the largest count over the ranks
         (needed by ZeRO / FSDP; plain DDP only needs every rank to run at least one)."""
@@ -687,6 +690,7 @@ class NativeLearnerStep:
 
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
         self.ref_model = ref_model
+        self.fused_ref_head = bool(fused_ref_head)
         self.rl_config = rl_config.model_copy()
         self.rl_config.batch_size = samples_per_step
         self.samples_per_step = samples_per_step
@@ -751,7 +755,15 @@ class NativeLearnerStep:
                     self._sentinel_pass(rollouts.device)
                 continue
             b = batches[j]
-            if self.ref_model is not None:
+            fused_ref = None
+            if self.ref_model is not None and self.fused_ref_head:
+                from .fused_head import _hidden_states, ref_head_for
+
+                fused_ref = ref_head_for(self.ref_model)
+            if fused_ref is not None:  # hidden states -> MFMA head: the [T, V] reference logits are never written
+                with torch.no_grad():
+                    hp.annotate_ref_logprobs_from_hidden(j, fused_ref[1], _hidden_states(fused_ref[0], b))
+            elif self.ref_model is not None:
                 with torch.no_grad():
                     ref_logits = self.ref_model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits
                     if ref_logits.dtype not in (torch.float32, torch.bfloat16) or not ref_logits.is_contiguous():

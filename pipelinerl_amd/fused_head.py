@@ -140,6 +140,22 @@ class FusedLmHead:
             self._ws[key] = ws
         return ws
 
+    def can_keep_logits(self, rows: int, device: torch.device) -> bool:
+        """Whether `rows` x vocab fp32 logits (+ the same again for the backward's two bf16 d-logits planes, which live
+        while the kept logits still do) fit comfortably in what the device has free right now - the allocator's cached
+        blocks included.  The kept form trades 4.98 GB per 8192 x 152 064 micro-batch for two plane products; on a GPU
+        that is nearly full (longer micro-batches, a co-located inference engine) the recomputing form is the right one,
+        and `_FusedHeadLossFn` falls back to it instead of running out of memory."""
+        if not self.keep_logits or self.vocab % 8:
+            return False
+        need = 2 * rows * self.vocab * 4
+        try:
+            free, _ = torch.cuda.mem_get_info(device)
+            cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        except Exception:  # noqa: BLE001 - no way to ask: keep the configured behaviour
+            return True
+        return need <= 0.9 * (free + max(cached, 0))
+
     # -- forward ------------------------------------------------------------------------------------
     def logprob_entropy(self, hidden: torch.Tensor, input_ids: torch.Tensor, temperature: float, keep: bool = False):
         """hidden [B, L, H] -> token-aligned (new_logprobs, entropy, lse2), each fp32 [B, L], and the bf16 hidden states the
@@ -273,10 +289,21 @@ class _FusedHeadLossFn(torch.autograd.Function):
         need_grad = hidden.requires_grad or weight.requires_grad
         B, L, H = hidden.shape
         idx = rows if (rows is not None and rows.numel() <= (1.0 - _MIN_SKIP_FRACTION) * B * L) else None
-        keep = need_grad and head.keep_logits and head.vocab % 8 == 0
+        n_rows = B * L if idx is None else idx.numel() + 1
+        keep = need_grad and head.can_keep_logits(n_rows, hidden.device)
         kept = None
+
+        def forward_head(h_in, ids_in):
+            """The head's forward; a kept-logits allocation that does not fit after all falls back to the recomputing form."""
+            if keep:
+                try:
+                    return head.logprob_entropy(h_in, ids_in, temperature, keep=True)
+                except torch.cuda.OutOfMemoryError:
+                    torch.cuda.empty_cache()
+            return head.logprob_entropy(h_in, ids_in, temperature, keep=False)
+
         if idx is None:
-            nlp, ent, lse2, h, *rest = head.logprob_entropy(hidden, batch.input_ids, temperature, keep=keep)
+            nlp, ent, lse2, h, *rest = forward_head(hidden, batch.input_ids)
             kept = rest[0] if rest else None
             ids = batch.input_ids
         else:
@@ -286,7 +313,7 @@ class _FusedHeadLossFn(torch.autograd.Function):
             hc[0, :n] = hidden.detach().reshape(B * L, H).index_select(0, idx)
             ids = torch.zeros((1, n + 1), dtype=torch.int64, device=dev)
             ids[0, 1:] = batch.input_ids.reshape(-1).index_select(0, idx + 1)  # row j predicts ids[j + 1]
-            nlp_c, ent_c, lse2, h, *rest = head.logprob_entropy(hc, ids, temperature, keep=keep)
+            nlp_c, ent_c, lse2, h, *rest = forward_head(hc, ids)
             kept = rest[0] if rest else None
             nlp = torch.zeros((B, L), dtype=torch.float32, device=dev)
             ent = torch.zeros_like(nlp)
@@ -383,15 +410,15 @@ def _hidden_states(body: Any, batch: PipelineBatchEncoding) -> torch.Tensor:
     return out[0] if isinstance(out, (tuple, list)) else getattr(out, "last_hidden_state", out)
 
 
-def _head_for(owner: Any, weight: torch.Tensor, chunk_rows: int, hidden_grad_terms: int = 3) -> FusedLmHead:
+def _head_for(owner: Any, weight: torch.Tensor, chunk_rows: int, hidden_grad_terms: int = 3, keep_logits: bool | None = None) -> FusedLmHead:
     """The FusedLmHead of `owner` (the lm_head module).  It lives ON the module - one per head, gone with the model - and is
     re-bound when the module hands out a new tensor object for its weight (FSDP with use_orig_params=False and re-created
     models do, on every forward): the planes and workspaces are reused, only the split is redone."""
     head = getattr(owner, "_prl_fused_lm_head", None)
     stale = head is None or tuple(head.weight.shape) != tuple(weight.shape) or head.weight.dtype != weight.dtype \
         or head.weight.device != weight.device or head.hidden_grad_terms != hidden_grad_terms
-    if stale:
-        head = FusedLmHead(weight, backward=True, chunk_rows=chunk_rows, hidden_grad_terms=hidden_grad_terms)
+    if stale or (keep_logits is not None and head.keep_logits != bool(keep_logits)) or head.chunk_rows != int(chunk_rows):
+        head = FusedLmHead(weight, backward=True, chunk_rows=chunk_rows, hidden_grad_terms=hidden_grad_terms, keep_logits=keep_logits)
         object.__setattr__(owner, "_prl_fused_lm_head", head)
     elif head.weight is not weight:
         head.weight = weight
@@ -399,7 +426,7 @@ def _head_for(owner: Any, weight: torch.Tensor, chunk_rows: int, hidden_grad_ter
     return head
 
 
-def install_fused_head(model: Any, chunk_rows: int = 8192, hidden_grad_terms: int = 3) -> Any:
+def install_fused_head(model: Any, chunk_rows: int = 8192, hidden_grad_terms: int = 3, keep_logits: bool | None = None) -> Any:
     """Teach a causal LM (`.model` body + bias-free `.lm_head`, the Hugging Face layout) to compute the RL loss
     INSIDE its own forward: `model(rl_batch=batch, rl_config=config, current_step=s, max_step=m)` returns
     `(loss, stats_device)`; every other call is the model's original forward.  Call this BEFORE wrapping the
@@ -429,16 +456,19 @@ def install_fused_head(model: Any, chunk_rows: int = 8192, hidden_grad_terms: in
         w = lm_head.weight
         cfg, _, _ = make_loss_config(rl_config, current_step, max_step)
         opts = model._prl_fused_head
-        return _FusedHeadLossFn.apply(hidden, w, _head_for(lm_head, w, opts["chunk_rows"], opts["hidden_grad_terms"]), rl_batch, cfg,
+        return _FusedHeadLossFn.apply(hidden, w, _head_for(lm_head, w, opts["chunk_rows"], opts["hidden_grad_terms"], opts["keep_logits"]), rl_batch, cfg,
                                       rl_config.temperature, opts["chunk_rows"])
 
-    model._prl_fused_head = {"chunk_rows": int(chunk_rows), "hidden_grad_terms": int(hidden_grad_terms)}
+    # `keep_logits`: None = the default (on, unless PRL_LMHEAD_KEEP_LOGITS=0, and only while two copies of the micro-batch's logits
+    # fit in free device memory); False = never (no logits anywhere, 2 more plane products in the backward); `chunk_rows`: rows of
+    # d-logits planes in the backward workspace at a time (2 x chunk_rows x vocab x 2 bytes)
+    model._prl_fused_head = {"chunk_rows": int(chunk_rows), "hidden_grad_terms": int(hidden_grad_terms), "keep_logits": keep_logits}
     model.forward = forward
     return model
 
 
 def rl_step_fused_head(model: Any, batch: PipelineBatchEncoding, current_step: int, max_step: int, config: RLConfig,
-                       seq_parallel_group=None, chunk_rows: int = 8192):
+                       seq_parallel_group=None, chunk_rows: int | None = None, keep_logits: bool | None = None):
     """`rl_step` (reference rl/__init__.py:136-143, same signature and return value) for a causal LM
     that exposes its body and head separately, as Hugging Face models do (`model.model`,
     `model.lm_head`): the body runs as usual, the head never produces logits.
@@ -456,4 +486,76 @@ def rl_step_fused_head(model: Any, batch: PipelineBatchEncoding, current_step: i
     body, lm_head = _body_and_head(model)
     hidden = _hidden_states(body, batch)
     w = lm_head.weight
-    return fused_head_loss(hidden, w, _head_for(lm_head, w, chunk_rows), batch, config, current_step, max_step, chunk_rows)
+    # a bare model: the two memory knobs come from the call or from the RLConfig (`fused_head_chunk_rows`, `fused_head_keep_logits`)
+    chunk_rows = int(chunk_rows or getattr(config, "fused_head_chunk_rows", 8192) or 8192)
+    keep = keep_logits if keep_logits is not None else getattr(config, "fused_head_keep_logits", None)
+    return fused_head_loss(hidden, w, _head_for(lm_head, w, chunk_rows, keep_logits=keep), batch, config, current_step, max_step, chunk_rows)
+
+
+# -- reference log-probabilities ---------------------------------------------------------
+def token_logprobs_from_hidden(head: FusedLmHead, hidden: torch.Tensor, input_ids: torch.Tensor, labels: torch.Tensor | None,
+                               temperature: float = 1.0) -> torch.Tensor:
+    """log p(token u | prefix) of the LABELLED tokens, 0 elsewhere, fp32 [B, L], from last hidden states - no graph, no
+    `[T, V]` tensor: the no-grad forward of the fused head (1 plane product for a bf16 weight, 2 for an fp32 one).
+
+    This is the dense contraction of the reference-policy forward: the reference asks a second inference server for
+    `prompt_logprobs` of prompt + completion and keeps the completion tokens' values (preprocess.py:86-104,
+    llm.py:606-648), later left-zero-padded to the sequence (rl/__init__.py:573-594).  `labels` marks those tokens
+    (labels != -100); only the rows that PREDICT one are handed to the kernels (a compact problem, as in the loss
+    path), so prompt tokens cost nothing.  `labels=None`: every token (the first of each row has no prediction: 0)."""
+    _lib.require_device(hidden, input_ids)
+    B, L, H = hidden.shape
+    dev = hidden.device
+    with torch.no_grad():
+        if labels is None:
+            return head.logprob_entropy(hidden, input_ids, temperature)[0]
+        idx = _labelled_rows(labels)
+        n = idx.numel()
+        out = torch.zeros((B, L), dtype=torch.float32, device=dev)
+        if n == 0:
+            return out
+        if n > (1.0 - _MIN_SKIP_FRACTION) * B * L:
+            nlp = head.logprob_entropy(hidden, input_ids, temperature)[0]
+            return torch.where(labels != -100, nlp, out)
+        hc = torch.zeros((1, n + 1, H), dtype=torch.bfloat16, device=dev)  # + one closing row (predicts nothing)
+        hc[0, :n] = hidden.detach().reshape(B * L, H).index_select(0, idx)
+        ids = torch.zeros((1, n + 1), dtype=torch.int64, device=dev)
+        ids[0, 1:] = input_ids.reshape(-1).index_select(0, idx + 1)  # row j predicts ids[j + 1]
+        nlp_c = head.logprob_entropy(hc, ids, temperature)[0]
+        out.view(-1).index_copy_(0, idx + 1, nlp_c[0, 1:])
+        return out
+
+
+def ref_head_for(ref_model: Any) -> tuple[Any, FusedLmHead] | None:
+    """(body, no-grad FusedLmHead) of a frozen causal LM in the Hugging Face layout (`.model` + bias-free `.lm_head`),
+    None for anything else (a bare callable that only returns logits).  The head lives on the lm_head module and
+    follows its weight like the training head does (`_head_for`); it holds the row-major planes only (`backward=False`:
+    no transposed copies, half the memory of a training head)."""
+    body = getattr(ref_model, "model", None)
+    lm_head = getattr(ref_model, "lm_head", None)
+    w = getattr(lm_head, "weight", None)
+    if body is None or w is None or getattr(lm_head, "bias", None) is not None or not callable(body):
+        return None
+    if w.dim() != 2 or w.dtype not in (torch.float32, torch.bfloat16) or not w.is_cuda:
+        return None
+    head = getattr(lm_head, "_prl_ref_lm_head", None)
+    if head is None or tuple(head.weight.shape) != tuple(w.shape) or head.weight.dtype != w.dtype or head.weight.device != w.device:
+        head = FusedLmHead(w, backward=False, keep_logits=False)
+        object.__setattr__(lm_head, "_prl_ref_lm_head", head)
+    elif head.weight is not w:
+        head.weight = w
+        head.invalidate()
+    return body, head
+
+
+def annotate_ref_logprobs_fused(ref_model: Any, batch: PipelineBatchEncoding, temperature: float = 1.0) -> bool:
+    """Fill `batch.ref_logprobs` from the reference model's HIDDEN STATES through the MFMA head.  Returns False (and
+    leaves the batch alone) when `ref_model` does not expose body and head separately."""
+    found = ref_head_for(ref_model)
+    if found is None:
+        return False
+    body, head = found
+    with torch.no_grad():
+        hidden = _hidden_states(body, batch)
+        batch.ref_logprobs = token_logprobs_from_hidden(head, hidden, batch.input_ids, batch.labels, temperature)
+    return True

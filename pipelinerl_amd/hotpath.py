@@ -121,6 +121,16 @@ class HotPathStep:
             nlp, _, _, _ = logprob_entropy(ref_logits, b.input_ids, temp)
             b.ref_logprobs.copy_(torch.where(b.labels != -100, nlp, torch.zeros_like(nlp)))
 
+    def annotate_ref_logprobs_from_hidden(self, j: int, head, ref_hidden: torch.Tensor, temperature: float | None = None) -> None:
+        """The same column from the reference model's last HIDDEN STATES [1, T_j, H] through the MFMA head
+        (`fused_head.FusedLmHead(weight, backward=False)`): no `[T, V]` reference logits, only the rows that predict a
+        labelled token enter the product.  Writes in place like `annotate_ref_logprobs`."""
+        from .fused_head import token_logprobs_from_hidden
+
+        b = self.batches[j]
+        temp = float(self.config.temperature if temperature is None else temperature)
+        b.ref_logprobs.copy_(token_logprobs_from_hidden(head, ref_hidden, b.input_ids, b.labels, temp))
+
     def logits_two_pass(self, j: int, logits: torch.Tensor, grad_out: torch.Tensor | None = None) -> torch.Tensor:
         """Unfused alternative: K1 forward, K2+K3 on the micro-batch, K1 backward (three launches)."""
         lib = _lib.load()

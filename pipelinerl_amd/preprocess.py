@@ -285,6 +285,38 @@ class SlidingWindowAggregator:
                 "tokens_per_second": sum(sum(t) for t in self.tokens_window) / span}
 
 
+class _TrackedDeque(deque):
+    """`deque(maxlen)` of samples that keeps their lengths and model versions in two parallel deques, so that the
+    per-admission bookkeeping of `ProcessedRing.admit` (the reference recomputes both lists over the whole ring for
+    every admitted sample, :572-585) is two C-level passes instead of two Python loops.  Only the operations the loop
+    and the scheduler use are tracked: append, popleft, extend, clear."""
+
+    def __init__(self, maxlen: int, length_of, version_of):
+        super().__init__(maxlen=maxlen)
+        self.lengths: deque = deque(maxlen=maxlen)
+        self.versions: deque = deque(maxlen=maxlen)
+        self._length_of, self._version_of = length_of, version_of
+
+    def append(self, x) -> None:
+        super().append(x)
+        self.lengths.append(self._length_of(x))
+        self.versions.append(self._version_of(x))
+
+    def extend(self, xs) -> None:
+        for x in xs:
+            self.append(x)
+
+    def popleft(self):
+        self.lengths.popleft()
+        self.versions.popleft()
+        return super().popleft()
+
+    def clear(self) -> None:
+        super().clear()
+        self.lengths.clear()
+        self.versions.clear()
+
+
 class ProcessedRing:
     """The ring of preprocessed samples the scheduler draws from (`processed_entries_queue`, a
     `deque(maxlen=ring_buffer_size)`, reference :455, :572-585).  `admit` moves samples from the arrival
@@ -295,7 +327,7 @@ class ProcessedRing:
 
     def __init__(self, maxlen: int, pop_old_data: bool, stats: SlidingWindowAggregator | None = None,
                  length_of=lambda s: s.length, version_of=lambda s: s.model_version):
-        self.entries: deque = deque(maxlen=maxlen)
+        self.entries: deque = _TrackedDeque(maxlen, length_of, version_of)
         self.pop_old_data = pop_old_data
         self.popped = 0
         self.max_model_version: int | None = None
@@ -313,8 +345,8 @@ class ProcessedRing:
                     logger.warning(f"Popped {self.popped} old entries from processed entries queue")
             q.append(buffer.popleft())  # a full deque(maxlen) drops from the left
             if self.stats is not None:
-                self.stats.update([self._length_of(e) for e in q])
-            self.max_model_version = max((self._version_of(e) for e in q), default=0)
+                self.stats.update(q.lengths)
+            self.max_model_version = max(q.versions, default=0)
 
 
 def preprocessor_stats_record(published_samples: int, max_model_version: Any, raw_queue_chunks: int, output_queue_chunks: int,
@@ -447,15 +479,29 @@ class PreprocessorLoop:
     Back-pressure as in the reference (:587-592): publishing pauses while
     published - trainer_state.samples_processed exceeds max_ready_samples_per_lead * num_trainers."""
 
-    def __init__(self, cfg: PreprocessorConfig, device, trainer_state=None, ref_model=None, oov_patcher: OovPatcher | None = None):
+    def __init__(self, cfg: PreprocessorConfig, device, trainer_state=None, ref_model=None, oov_patcher: OovPatcher | None = None,
+                 batched_transfers: bool = True, profile: bool = False):
         """`ref_model`: a frozen reference policy on the preprocessor's GPU.  When given, every real
-        micro-batch gets its `ref_logprobs` from a no-grad forward of that model (K1 on its logits)
+        micro-batch gets its `ref_logprobs` from a no-grad forward of that model (hidden states -> MFMA head for a
+        model in the Hugging Face layout, K1 on its logits otherwise)
         before it is published - the device-side replacement of the reference's HTTP round trip to a
-        second inference server (preprocess.py:86-104, llm.py:606-648)."""
+        second inference server (preprocess.py:86-104, llm.py:606-648).
+        `batched_transfers` (default): a chunk crosses the bus in ONE host -> device copy (13 ragged arrays + the K5 plan
+        through a page-locked ring, `staging.PinnedStager`), the K6 plan in one more, and a drain's packed micro-batches
+        come back in ONE device -> host copy before they are encoded into stream records; off = one copy per array
+        (the round-3 form, kept for A/B).
+        `profile`: accumulate host wall time per phase in `self.prof` (seconds; `perf_counter` pairs, no device sync)."""
         from .streams import SingleStreamSpec, StreamRangeSpec
 
         self.cfg = cfg
         self.device = device
+        self.stager = None
+        if batched_transfers and torch.device(device).type == "cuda":
+            from .staging import PinnedStager
+
+            self.stager = PinnedStager(device, slots=4)
+        self.prof: dict[str, float] | None = {} if profile else None
+        self._kernel_events: list = []
         self.trainer_state = trainer_state
         self.ref_model = ref_model
         self.oov_patcher = oov_patcher
@@ -483,16 +529,65 @@ class PreprocessorLoop:
     def max_model_version(self) -> int:
         return self.ring.max_model_version or 0
 
+    def _kernels(self, name: str):
+        """Profiling only: a HIP event pair around the launches of one kernel family (K5 / K6), on the current stream."""
+        import contextlib
+
+        if self.prof is None or torch.device(self.device).type != "cuda":
+            return contextlib.nullcontext()
+        loop = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self.a.record()
+
+            def __exit__(self, *exc):
+                self.b.record()
+                loop._kernel_events.append((name, self.a, self.b))
+
+        return _Ctx()
+
+    def kernel_seconds(self) -> dict[str, float]:
+        """Device time per kernel family from the event pairs collected while profiling (synchronises)."""
+        if torch.device(self.device).type == "cuda":
+            torch.cuda.synchronize(self.device)
+        out: dict[str, float] = {}
+        for name, a, b in self._kernel_events:
+            out[name] = out.get(name, 0.0) + a.elapsed_time(b) * 1e-3
+        return out
+
+    def _tick(self, name: str, t0: float) -> float:
+        """Charge the time since `t0` to phase `name` (profiling only); returns now."""
+        now = time.perf_counter()
+        if self.prof is not None:
+            self.prof[name] = self.prof.get(name, 0.0) + (now - t0)
+        return now
+
     def _ingest(self, groups: list) -> None:
         """`groups`: stream records, each either a list of TrainingText dicts (the reference's text
         record) or a `RaggedRollouts` (binary record of the shm backend)."""
+        from .finetune.rl import plan_groups
+
+        t = time.perf_counter()
         if all(isinstance(g, RaggedRollouts) for g in groups):
-            rag = concat_ragged(groups).to(self.device)
+            host = concat_ragged(groups)
         else:
-            rag = RaggedRollouts.from_entries([e for g in groups for e in g]).to(self.device)
+            host = RaggedRollouts.from_entries([e for g in groups for e in g])
+        t = self._tick("ingest_flatten", t)
+        if self.stager is not None and not host.tokens.is_cuda:
+            plan = plan_groups(host.host_group_index, host.host_step_index, host.host_rollout_index)
+            t = self._tick("k5_plan", t)
+            rag, plan_dev = host.to(self.device, stager=self.stager, extra=plan)
+            t = self._tick("h2d", t)
+        else:
+            rag, plan_dev = host.to(self.device), None
+            t = self._tick("h2d", t)
         if self.oov_patcher is not None:
             self.oov_patcher.apply(rag)
-        prep = populate_rl_data_ragged(rag, self.cfg.eos_token_id, self.cfg.rl)
+        with self._kernels("K5"):
+            prep = populate_rl_data_ragged(rag, self.cfg.eos_token_id, self.cfg.rl, plan=plan_dev)
+        t = self._tick("k5_launch", t)
         keep = np.ones(prep.rollouts.n_seqs, dtype=bool)
         self.filtered_out = 0
         if self.cfg.rl.filter_zero_advantage_groups:
@@ -505,15 +600,18 @@ class PreprocessorLoop:
         lens = prep.rollouts.seq_lengths()
         versions = prep.rollouts.host_model_version
         self.buffer.extend(_Sample(cid, i, int(lens[i]), int(versions[i])) for i in range(len(lens)) if keep[i])
+        self._tick("schedule", t)
 
     def _publish(self, writer) -> bool:
         """Drain the scheduler once and write what it emitted.  Returns batch_done."""
         from .finetune.data import pack_prepared, pad_prepared
         from .finetune.utils import create_sentinel_batch
 
+        t = time.perf_counter()
         sp = self.cfg.seq_parallel
         mbs, done = self.sched.drain()
         real = [mb for mb in mbs if not mb.sentinel]
+        t = self._tick("schedule", t)
         packed: Any = None
         merged = base = None
         if real:
@@ -526,8 +624,22 @@ class PreprocessorLoop:
             if self.cfg.seq_packing:
                 # sequence-parallel filler: the packed length must divide by seq_parallel (data.py:222-230)
                 pads = [(-sum(s.length for s in mb.samples)) % sp for mb in real] if sp > 1 else None
-                packed = pack_prepared(merged, [[base[s.chunk] + s.index for s in mb.samples] for mb in real], self.cfg.eos_token_id,
-                                       sentinel_pad=pads)
+                with self._kernels("K6"):  # incl. the plan upload
+                    packed = pack_prepared(merged, [[base[s.chunk] + s.index for s in mb.samples] for mb in real], self.cfg.eos_token_id,
+                                           sentinel_pad=pads, stager=self.stager)
+                t = self._tick("k6_plan_launch", t)
+                if self.ref_model is not None:
+                    from .finetune.rl import annotate_ref_logprobs
+
+                    for k in range(len(packed)):  # on the device, written back into the packed block
+                        b = packed[k]
+                        annotate_ref_logprobs(self.ref_model, b, self.cfg.rl.temperature)
+                        t0_, t1_ = int(packed.token_off[k]), int(packed.token_off[k + 1])
+                        packed.flat["ref_logprobs"][t0_:t1_].copy_(b.ref_logprobs.reshape(-1))
+                    t = self._tick("ref_logprobs", t)
+                if self.stager is not None and packed.block is not None:
+                    packed = packed.to_host(self.stager)  # ONE device -> host copy for every micro-batch of this drain
+                    t = self._tick("d2h", t)
         k = 0
         for mb in mbs:
             if mb.sentinel:
@@ -537,14 +649,16 @@ class PreprocessorLoop:
                 k += 1
             else:  # unpacked: fixed train_batch_size rows padded to a common length (reference `collate`, :639-648)
                 batch = pad_prepared(merged, [base[s.chunk] + s.index for s in mb.samples], padding_side=self.cfg.padding_side)
-            if not mb.sentinel and self.ref_model is not None:
-                from .finetune.rl import annotate_ref_logprobs
+                if self.ref_model is not None:
+                    from .finetune.rl import annotate_ref_logprobs
 
-                annotate_ref_logprobs(self.ref_model, batch, self.cfg.rl.temperature)
+                    annotate_ref_logprobs(self.ref_model, batch, self.cfg.rl.temperature)
             slices = batch.make_slices(sp) if sp > 1 else [batch]
             for off, piece in enumerate(slices):
                 writer.write(piece, partition=mb.trainer_id + off)
+        t = self._tick("encode_publish", t)
         self._prune_chunks()
+        self._tick("schedule", t)
         return done
 
     def _prune_chunks(self) -> None:
@@ -586,19 +700,24 @@ class PreprocessorLoop:
                 if cfg.samples_target is not None and ts is not None and ts.samples_processed is not None and ts.samples_processed >= cfg.samples_target:
                     logger.info("Trainer signalled completion; stopping preprocessor loop")
                     break
+                t = time.perf_counter()
                 try:
                     chunk = raw_q.get(timeout=0.01)
+                    t = self._tick("input_wait", t)
                     if isinstance(chunk, Exception):
                         raise chunk
                     self._ingest(chunk)
                     last_data = time.time()
                 except queue.Empty:
+                    self._tick("input_wait", t)
                     if time.time() - last_data > idle_timeout and not self.ring.entries and not self.buffer:
                         break
                 if len(self.buffer) < cfg.dataset_buffer_size:
                     continue
+                t = time.perf_counter()
                 self.ring.admit(self.buffer)
                 self._prune_chunks()
+                self._tick("schedule", t)
                 if ts is not None and ts.samples_processed is not None:
                     if self.sched.published_samples - ts.samples_processed > cfg.max_ready_samples_per_lead * cfg.num_trainers:
                         continue  # wait for the finetune loop to catch up

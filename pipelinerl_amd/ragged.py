@@ -76,9 +76,19 @@ class RaggedRollouts:
     def seq_lengths(self) -> np.ndarray:
         return np.diff(self.host_seq_off)
 
-    def to(self, device: str | torch.device) -> "RaggedRollouts":
+    def to(self, device: str | torch.device, stager=None, extra=None):
         """Copies are enqueued `non_blocking` on the current stream: with `pin_memory()`ed sources
-        they are true asynchronous DMAs that overlap the previous step's kernels."""
+        they are true asynchronous DMAs that overlap the previous step's kernels.
+
+        `stager` (a `staging.PinnedStager` of that device): the 13 arrays - and the host arrays in `extra`, e.g. the K5
+        plan - are laid out back to back in one page-locked buffer and travel in ONE copy; the device tensors are views
+        into one allocation.  Returns `(rollouts, device tensors of extra)` in that form."""
+        if stager is not None:
+            names = [f.name for f in fields(self) if isinstance(getattr(self, f.name), torch.Tensor)]
+            up = stager.upload([getattr(self, n) for n in names] + list(extra or ()))
+            kw = {f.name: getattr(self, f.name) for f in fields(self)}
+            kw.update(zip(names, up[:len(names)]))
+            return RaggedRollouts(**kw), up[len(names):]
         kw = {}
         for f in fields(self):
             v = getattr(self, f.name)

@@ -121,7 +121,7 @@ class Log:
             | (_lib.PRL_LOG_READER if reader else 0) | (_lib.PRL_LOG_TRIM if trim else 0)
         h = ctypes.c_void_p()
         deadline = None if wait is None else time.time() + wait
-        stuck_since, warned = None, 0.0
+        stuck_since, stuck_ident, warned = None, None, 0.0
         while True:
             rc = lib.prl_log_open(name.encode(), segment_bytes, flags, ctypes.byref(h))
             if rc == _lib.PRL_OK:
@@ -133,12 +133,16 @@ class Log:
                     _lib.check(rc)
                 flags &= ~_lib.PRL_LOG_TRUNCATE  # never truncate twice
                 if rc == _lib.PRL_EAGAIN and create and takeover_after is not None:
-                    stuck_since = stuck_since or now
-                    if now - stuck_since > takeover_after:
-                        logger.warning(f"shm log {name}: control block uninitialised for {now - stuck_since:.1f} s, its creator "
-                                       "is gone - removing it and creating the log again")
-                        lib.prl_log_unlink(name.encode())
-                        stuck_since = None
+                    # the timer belongs to ONE object: when the control block disappears or is replaced (another waiter took
+                    # it over, or a live creator finally re-created it) the wait starts again
+                    ident = self._shm_identity(name)
+                    if ident != stuck_ident:
+                        stuck_since, stuck_ident = now, ident
+                    if ident is not None and now - stuck_since > takeover_after:
+                        if self._take_over(lib, name, ident, segment_bytes, flags):
+                            logger.warning(f"shm log {name}: control block uninitialised for {now - stuck_since:.1f} s, its creator "
+                                           "is gone - removed it, creating the log again")
+                        stuck_since, stuck_ident = None, None
                     elif now - warned > 1.0:
                         logger.info(f"shm log {name} is being created by another process, waiting")
                         warned = now
@@ -146,6 +150,49 @@ class Log:
                 continue
             _lib.check(rc)
         self._h = h
+
+    @staticmethod
+    def _shm_identity(name: str):
+        """(inode, creation-ish time) of the log's control block, None when it does not exist."""
+        try:
+            st = os.stat("/dev/shm/" + name.lstrip("/"))
+            return (st.st_ino, st.st_ctime_ns)
+        except OSError:
+            return None
+
+    @classmethod
+    def _take_over(cls, lib, name: str, ident, segment_bytes: int, flags: int) -> bool:
+        """Remove a control block that stayed uninitialised - serialised between the waiters by an exclusive flock on a
+        sidecar, and only if, under that lock, the object is STILL the one this waiter timed (same inode) and STILL answers
+        "being created".  Without the re-check a waiter whose timer expires a moment after another one already replaced
+        the object would unlink the live replacement (round-3 advisor finding), and its creator would write into an
+        orphan.  Returns True when this call removed it."""
+        import fcntl
+
+        lock_path = "/dev/shm/" + name.lstrip("/") + ".takeover"
+        try:
+            fd = os.open(lock_path, os.O_CREAT | os.O_RDWR, 0o600)
+        except OSError:
+            return False
+        try:
+            fcntl.flock(fd, fcntl.LOCK_EX)
+            if cls._shm_identity(name) != ident:
+                return False  # somebody else dealt with it while we waited for the lock
+            h = ctypes.c_void_p()
+            rc = lib.prl_log_open(name.encode(), segment_bytes, flags & ~_lib.PRL_LOG_TRUNCATE & ~_lib.PRL_LOG_CREATE, ctypes.byref(h))
+            if rc == _lib.PRL_OK:  # it came up after all: a slow creator, not a dead one
+                lib.prl_log_close(h)
+                return False
+            if rc != _lib.PRL_EAGAIN:
+                return False
+            lib.prl_log_unlink(name.encode())
+            return True
+        finally:
+            try:
+                os.unlink(lock_path)
+            except OSError:
+                pass
+            os.close(fd)
 
     def append(self, data: bytes | bytearray | memoryview) -> None:
         if isinstance(data, bytes):

@@ -76,6 +76,7 @@ def reset_streams_backend() -> None:
     """Testing hook: forget the configured backend."""
     global _backend, _backend_options
     _backend, _backend_options = None, {}
+    _checked_experiments.clear()
 
 
 def unlink_shm_stream(stream: "SingleStreamSpec") -> None:
@@ -106,6 +107,46 @@ def clean_shm_streams(exp_path: "str | Path") -> int:
             except OSError:
                 pass
     return n
+
+
+def begin_run(exp_path: "str | Path") -> int:
+    """Call ONCE from the process that owns a run - the launcher, where the reference's `clean_up` removes
+    `<exp_path>/streams` (launch.py:462-470) - BEFORE any stage opens a stream: every shared-memory log a previous run
+    of this `exp_path` left behind is removed (writers never unlink their logs, so a finished or killed run leaves all of
+    them in /dev/shm, and a new run appending to them would replay the old run's `TrainingDone`, `SamplesProcessed`,
+    `WeightUpdateSuccess` from record 0), and this process removes the new run's logs again when it exits.
+    Returns the number of stale shm objects removed.  A no-op for the other backends (their storage is the launcher's)."""
+    if _backend not in (None, "shm"):
+        return 0
+    n = clean_shm_streams(exp_path)
+    if n:
+        logger.info(f"begin_run: removed {n} shared-memory log objects of an earlier run of {exp_path}")
+    _own_experiment(exp_path)
+    _checked_experiments.add(str(Path(exp_path).resolve()))
+    return n
+
+
+_checked_experiments: set[str] = set()
+
+
+def _warn_if_logs_predate_this_process(exp_path: "str | Path") -> None:
+    """First stream of an experiment opened by this process, no owner declared: if logs of that experiment already
+    exist, say so once.  That is normal for a stage that joins a live run - and exactly what a forgotten
+    `begin_run` / `clean_shm_streams` after a finished or killed run looks like, which is why it is worth a line."""
+    key = str(Path(exp_path).resolve())
+    if key in _checked_experiments or key in _owned_experiments or _backend_options.get("owner", False):
+        return
+    _checked_experiments.add(key)
+    prefix = _exp_prefix(exp_path)
+    try:
+        stale = [f for f in os.listdir("/dev/shm") if f.startswith(prefix)]
+    except OSError:
+        return
+    if stale:
+        logger.warning(f"shm streams: {len(stale)} shared-memory log objects of {exp_path} exist already.  Fine if this process joins a "
+                       "live run; if they are left from an EARLIER run (writers never unlink their logs), its records will be replayed "
+                       "from record 0 - the process that owns a run must call pipelinerl_amd.streams.begin_run(exp_path) first "
+                       "(or set_streams_backend('shm', owner=True)); see INTEGRATION.md 'launcher'.")
 
 
 def raise_if_backend_not_set() -> None:
@@ -340,6 +381,7 @@ class ShmStreamWriter(StreamWriter):
 
         name = ring_name(self.stream)
         seg, trim = _shm_options(self.stream.topic)
+        _warn_if_logs_predate_this_process(self.stream.exp_path)
         self._log = Log(name, create=True, truncate=self.mode == "w", trim=trim, segment_bytes=seg,
                         takeover_after=float(_backend_options.get("creator_timeout", 5.0)))
         if _backend_options.get("owner", False):
@@ -378,6 +420,7 @@ class ShmStreamReader(StreamReader):
         from .ring import Log
 
         warned = 0.0
+        _warn_if_logs_predate_this_process(self.stream.exp_path)
         while True:
             try:
                 self._log = Log(ring_name(self.stream), reader=True, wait=_RECHECK_DELAY)

@@ -16,7 +16,10 @@ import torch
 
 
 def qwen25_shapes(which: str):
-    H, I, V, L, KV, tied = {"7b": (3584, 18944, 152064, 28, 512, False), "0p5b": (896, 4864, 151936, 24, 128, True)}[which]
+    # (hidden, intermediate, vocab, layers, kv_heads * head_dim, tied embeddings) of the BASELINE.json model sizes; "32b" =
+    # configs[4]: 771 tensors, 32.76 G parameters = 65.5 GB in bf16 (finetune_loop.py:205-292 broadcasts each of them)
+    H, I, V, L, KV, tied = {"7b": (3584, 18944, 152064, 28, 512, False), "0p5b": (896, 4864, 151936, 24, 128, True),
+                            "32b": (5120, 27648, 152064, 64, 1024, False)}[which]
     out = [("model.embed_tokens.weight", (V, H))]
     for i in range(L):
         p = f"model.layers.{i}."

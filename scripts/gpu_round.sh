@@ -28,5 +28,6 @@ print({k: e.get(k) for k in ("s_per_step", "samples_per_s", "peak_memory_GB", "s
 print({k: round(v["avg_us"], 1) for k, v in d["kernels"].items()})
 PY
 cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-weight-sync --no-e2e --no-transport --no-live-pmc > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
-cd $GRAFT_REPO_ROOT; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do cut -c1-260 $f > $OUT/bench_kernel_stats.csv; cut -c1-150 $f | head -10; done
+# the summary for profiles/: names shortened, ALL numeric columns kept (a width cut lost the dominant kernel's numbers in round 3)
+cd $GRAFT_REPO_ROOT; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do python scripts/kernel_stats_summary.py $f $OUT/bench_kernel_stats.csv; head -8 $OUT/bench_kernel_stats.csv; done
 find $OUT/prof -name "*kernel_trace.csv" -delete

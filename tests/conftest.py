@@ -13,6 +13,7 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a full BASELINE-size case checked against the CPU oracle (tens of seconds; still part of -m gpu)")
 
 
 @pytest.fixture(scope="session", autouse=True)

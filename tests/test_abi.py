@@ -55,6 +55,10 @@ def test_abi_version_and_error_string(libprl):
     from pipelinerl_amd import _lib
 
     assert libprl.prl_abi_version() == _lib.PRL_ABI_VERSION
+    # header, host bindings and INTEGRATION.md state the same number (round 3 shipped a document that was one behind)
+    header = int(re.search(r"#define PRL_ABI_VERSION (\d+)", (ROOT / "include" / "prl.h").read_text()).group(1))
+    doc = re.search(r"`prl_abi_version` \(= `PRL_ABI_VERSION` of `include/prl.h`, (\d+) today", (ROOT / "INTEGRATION.md").read_text())
+    assert header == _lib.PRL_ABI_VERSION and doc is not None and int(doc.group(1)) == header
     # argument validation happens before any device work, so it is checkable without a GPU
     rc = libprl.prl_grpo_loss_workspace_bytes(1, 1, None)
     assert rc == _lib.PRL_EINVAL
@@ -119,6 +123,16 @@ def test_tuning_table_and_environment_mapping(libprl, monkeypatch):
     monkeypatch.delenv("PRL_FUSED_VARIANT")
     _lib.check(libprl.prl_lm_head_workspace_bytes(1, 512, 64, 1024, 256, c.byref(fwd), c.byref(bwd)))
     assert get("lmhead_tile") == _lib.PRL_TUNE_UNSET and get("fused_variant") == _lib.PRL_TUNE_UNSET
+    # a value placed programmatically survives the environment sync of the next wrapped call (round-3 advisor finding: the sync
+    # used to rewrite all keys, so an A/B that called set_tuning before its first launch compared two identical configurations) ...
+    _lib.set_tuning("lmhead_ksplit", 8)
+    monkeypatch.setenv("PRL_LMHEAD_NSPLIT", "3")  # ... even when ANOTHER variable changes
+    _lib.check(libprl.prl_lm_head_workspace_bytes(1, 512, 64, 1024, 256, c.byref(fwd), c.byref(bwd)))
+    assert get("lmhead_ksplit") == 8 and get("lmhead_nsplit") == 3
+    monkeypatch.delenv("PRL_LMHEAD_NSPLIT")
+    _lib.check(libprl.prl_lm_head_workspace_bytes(1, 512, 64, 1024, 256, c.byref(fwd), c.byref(bwd)))
+    assert get("lmhead_ksplit") == 8 and get("lmhead_nsplit") == _lib.PRL_TUNE_UNSET
+    _lib.set_tuning("lmhead_ksplit", None)
     import subprocess
     src = "\n".join(p.read_text() for p in (ROOT / "pipelinerl_amd" / "csrc").glob("*.hip"))
     assert "getenv(" not in src, "no environment reads in the kernel launch sources"

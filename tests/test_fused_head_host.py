@@ -51,7 +51,7 @@ def test_install_keeps_forward_and_names():
     names = [n for n, _ in lm.named_parameters()]
     assert install_fused_head(lm, chunk_rows=256, hidden_grad_terms=1) is lm
     assert install_fused_head(lm) is lm  # idempotent: the first options stay
-    assert lm._prl_fused_head == {"chunk_rows": 256, "hidden_grad_terms": 1}
+    assert lm._prl_fused_head == {"chunk_rows": 256, "hidden_grad_terms": 1, "keep_logits": None}
     assert torch.equal(lm(input_ids=ids).logits, before)
     assert [n for n, _ in lm.named_parameters()] == names
     assert set(lm.state_dict()) == set(names)

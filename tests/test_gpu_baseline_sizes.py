@@ -136,15 +136,19 @@ def _big_case(T, V, cfg, device):
     return logits, batch
 
 
-@pytest.mark.parametrize("cfg_name", ["grpo_clip", "kl_ent_temp"])
-def test_fused_logits_loss_at_2048_rows_vs_oracle(libprl, cuda_device, monkeypatch, cfg_name):
+@pytest.mark.parametrize("cfg_name,T", [("grpo_clip", 2048), ("kl_ent_temp", 2048), pytest.param("grpo_clip", 8192, marks=pytest.mark.slow)],
+                         ids=["grpo_clip_2048_rows", "kl_ent_temp_2048_rows", "grpo_clip_8192_rows_the_benchmarked_launch"])
+def test_fused_logits_loss_at_2048_rows_vs_oracle(libprl, cuda_device, monkeypatch, cfg_name, T):
+    """The row-resident fused kernel vs `oracle.rl_loss_torch.rl_step_closed_form`, in and out of place.  T = 8192 x
+    V = 152 064 is EXACTLY the launch bench.py times (one row per workgroup, 8191 workgroups = 32 rounds per CU); the
+    oracle needs ~15 GB of host memory and a few seconds of torch CPU kernels for it (slow, still part of -m gpu)."""
     from test_gpu_fullvocab import CONFIGS
 
     from pipelinerl_amd import _lib
     from pipelinerl_amd.finetune.rl import RLConfig, make_loss_config
 
     monkeypatch.delenv("PRL_FUSED_VARIANT", raising=False)
-    T, V = 2048, 152064
+    V = 152064
     cfg = CONFIGS[cfg_name]
     logits, batch = _big_case(T, V, cfg, cuda_device)
     want = orlt.rl_step_closed_form(logits, batch, cfg, 2, 10, True)

@@ -29,6 +29,9 @@ def test_bench_json_contract(libprl, cuda_device):
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    # the line alone reproduces `achieved`: algorithmic bytes per launch / average launch duration (HIP events)
+    assert r["launches"] == d["steps"] * d["config"]["global_batch"] and r["avg_us"] >= r["min_us"] > 0
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9) <= 1e-9 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert "traffic_source" in r  # the counter traffic is a committed figure, labelled as such
@@ -49,6 +52,17 @@ def test_bench_json_contract(libprl, cuda_device):
     assert "error" not in t, t
     assert 0 < t["shm_us_per_token"] < t["files_us_per_token"] and 60 < t["shm_bytes_per_token"] < 80 < t["files_bytes_per_token"]
     assert t["rollout_record"]["PRLROL01_bytes_per_token"] < t["rollout_record"]["jsonl_bytes_per_token"]
+    p = d["preprocess_loop"]  # actor records -> PreprocessorLoop -> published micro-batches, at chunk_n_groups = 2
+    assert "error" not in p, p
+    fast, slow, text = (p["cases"][k] for k in ("PRLROL01_to_shm_1_trainer", "PRLROL01_to_shm_1_trainer_one_copy_per_array", "JSONL_to_files_1_trainer"))
+    assert fast["tokens_per_s"] > text["tokens_per_s"] > 0 and fast["published_samples"] == slow["published_samples"]
+    assert fast["transfers_per_chunk"]["h2d"] <= 2.5 and fast["transfers_per_chunk"]["d2h"] <= 1.5  # one upload per chunk + one K6 plan, one download
+    assert {"K5", "K6"} <= set(fast["kernel_us_per_chunk"]) and 0 < fast["host_planning_frac"] < 1
+    q = d["ref_logprob"]  # reference-policy head: stock GEMM + [T, V] logits + K1 vs the MFMA head
+    assert "error" not in q, q
+    for name, h in q["heads"].items():
+        # the old bf16 path rounds the LOGITS to bf16 (2^-9 of |logit|): its log-probs are the less exact ones
+        assert h["fused_ms"] > 0 and h["old_ms"] > 0 and h["max_abs_difference"] < (1e-3 if name == "fp32_head" else 0.1) and h["hbm_bytes_saved"] > 0
     w = d["weight_sync"]  # N = 1: colocated hand-off over HIP IPC
     assert "error" not in w, w
     assert w["metric"] == "trainer_to_actor_weight_sync_ms" and w["median_ms"] > 0 and w["gbytes"] > 0.9

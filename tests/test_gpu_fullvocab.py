@@ -313,14 +313,16 @@ def test_logits_backward_full_vocab_vs_fp64(libprl, cuda_device, vocab, dtype):
         assert torch.allclose(ent[:, 1:].double(), H[..., 0], rtol=1e-4, atol=2e-5)
 
 
-def test_step_scale_loss_launch_vs_oracle(libprl, cuda_device):
-    """K2+K3 as bench.py launches it - ONE launch over a flat [1, 64 x 8192] step batch
+@pytest.mark.parametrize("n_mb", [64, pytest.param(4096, marks=pytest.mark.slow)], ids=["64_micro_batches", "whole_step_4096_micro_batches"])
+def test_step_scale_loss_launch_vs_oracle(libprl, cuda_device, n_mb):
+    """K2+K3 as bench.py launches it - ONE launch over a flat [1, n_mb x 8192] step batch
     (flat_micro_batches = 1, statistics only) - against the oracle evaluated per micro-batch and
-    combined the way the reference aggregates (sums add, max/min combine)."""
+    combined the way the reference aggregates (sums add in fp64, max/min combine).  4096 micro-batches = the
+    33 554 432 tokens of one BASELINE step (bs 4096 x seq 8192): the exact launch the benchmark times."""
     from pipelinerl_amd.finetune.rl import RLConfig, grpo_loss_from_logprobs, make_loss_config
     from pipelinerl_amd.finetune.types import PipelineBatchEncoding
 
-    n_mb, T = 64, 8192
+    T = 8192
     cfg_d = dict(CONFIGS["grpo_clip"], kl_coef=0.001, final_kl_coef=0.001)
     rng = np.random.default_rng(11)
     cols: dict[str, list] = {}

@@ -26,6 +26,52 @@ class TinyLM(torch.nn.Module):
         return types.SimpleNamespace(logits=self.head(self.emb(input_ids)).float())
 
 
+class TinyHFLM(torch.nn.Module):
+    """The Hugging Face causal-LM layout: `.model` returns the last hidden states, `.lm_head` is a bias-free Linear.
+    A reference policy of this shape goes through the MFMA head (`fused_head.annotate_ref_logprobs_fused`)."""
+
+    class Body(torch.nn.Module):
+        def __init__(self, vocab, dim):
+            super().__init__()
+            self.emb = torch.nn.Embedding(vocab, dim)
+            self.calls = 0
+
+        def forward(self, input_ids=None, **kw):
+            self.calls += 1
+            return types.SimpleNamespace(last_hidden_state=torch.tanh(self.emb(input_ids)).to(torch.bfloat16))
+
+    def __init__(self, vocab=64, dim=64):
+        super().__init__()
+        self.model = TinyHFLM.Body(vocab, dim)
+        self.lm_head = torch.nn.Linear(dim, vocab, bias=False)
+        self.logits_calls = 0
+
+    def forward(self, input_ids=None, **kw):
+        self.logits_calls += 1
+        return types.SimpleNamespace(logits=self.lm_head(self.model(input_ids=input_ids).last_hidden_state.float()))
+
+
+def _oracle_ref_logprobs(ref_model, b, temperature=1.0):
+    """log p_ref of the labelled tokens, 0 elsewhere, from `oracle.rl_loss.logprob_entropy` (the restatement of reference
+    rl/__init__.py:207-213) fed the reference model's fp32 logits - the CPU oracle, not a second device computation."""
+    import numpy as np
+
+    from oracle import rl_loss as orl
+
+    with torch.no_grad():
+        if hasattr(ref_model, "lm_head"):  # fp64 product of the bf16 hidden states and the fp32 weight, rounded once
+            h = ref_model.model(input_ids=b.input_ids).last_hidden_state
+            logits = (h.double() @ ref_model.lm_head.weight.double().t()).float()
+            ref_model.model.calls -= 1
+        else:
+            logits = ref_model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits.float()
+    nlp = orl.logprob_entropy(logits.cpu().numpy(), b.input_ids.cpu().numpy(), temperature)[0]
+    want = np.zeros(tuple(b.input_ids.shape), dtype=np.float64)
+    want[:, 1:] = nlp
+    want[b.labels.cpu().numpy() == -100] = 0.0
+    return torch.from_numpy(want).to(b.input_ids.device)
+
+
 @pytest.mark.parametrize("backend", ["files", "shm"])
 def test_replay_actor_stream_through_preprocessor_and_learner(libprl, cuda_device, tmp_path, backend):
     from pipelinerl_amd import streams
@@ -213,10 +259,13 @@ def test_rl_step_drives_a_huggingface_causal_lm(libprl, cuda_device):
     assert stats["num_output_tokens_sum"] == int(m.sum().item()) and stats["input_size"] == batch.input_ids.numel()
 
 
-def test_native_step_with_reference_model_on_the_learner(libprl, cuda_device):
+@pytest.mark.parametrize("layout", ["logits_model", "hf_layout_fused_head"])
+def test_native_step_with_reference_model_on_the_learner(libprl, cuda_device, layout):
     """KL-to-reference with the reference policy living on the learner GPU: NativeLearnerStep(ref_model=...)
     must equal the drop-in loop in which every batch was annotated by `annotate_ref_logprobs`, and the
-    annotated column must equal a plain torch log_softmax of the reference model's logits."""
+    annotated column must equal the ORACLE's log-probs of the reference model's logits.  `hf_layout_fused_head`: the
+    reference policy exposes body and head separately and its head runs on the MFMA kernels (no logits, its
+    `forward` is never called)."""
     import copy
 
     from pipelinerl_amd.finetune.rl import RLConfig, annotate_ref_logprobs, rl_step
@@ -234,7 +283,8 @@ def test_native_step_with_reference_model_on_the_learner(libprl, cuda_device):
     model_a = TinyLM(V).to(cuda_device)
     model_b = copy.deepcopy(model_a)
     torch.manual_seed(2)
-    ref_model = TinyLM(V).to(cuda_device).eval()  # a DIFFERENT policy: the KL term is not zero
+    fused = layout == "hf_layout_fused_head"
+    ref_model = (TinyHFLM(V) if fused else TinyLM(V)).to(cuda_device).eval()  # a DIFFERENT policy: the KL term is not zero
 
     captured = {}
     opt_a = torch.optim.SGD(model_a.parameters(), lr=0.0)
@@ -244,6 +294,8 @@ def test_native_step_with_reference_model_on_the_learner(libprl, cuda_device):
     res = native.step(rag, mbs)
     stats_a = native.stats_dict(res["stats"])
     assert stats_a["kl"] > 1e-4  # the reference policy really differs
+    if fused:
+        assert ref_model.logits_calls == 0 and ref_model.model.calls == len(mbs)
 
     cfg_b = rl.model_copy()
     cfg_b.batch_size = 12
@@ -252,12 +304,8 @@ def test_native_step_with_reference_model_on_the_learner(libprl, cuda_device):
     agg = {}
     for b in batches:
         annotate_ref_logprobs(ref_model, b, cfg_b.temperature)
-        with torch.no_grad():
-            lp = torch.log_softmax(ref_model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits.float(), -1)
-            want = torch.zeros_like(b.ref_logprobs)
-            want[:, 1:] = lp[:, :-1].gather(-1, b.input_ids[:, 1:, None])[..., 0]
-            want = torch.where(b.labels != -100, want, torch.zeros_like(want))
-        assert torch.allclose(b.ref_logprobs, want, rtol=1e-5, atol=1e-5)
+        want = _oracle_ref_logprobs(ref_model, b, cfg_b.temperature)
+        assert torch.allclose(b.ref_logprobs.double(), want, rtol=1e-4, atol=2e-5)
         loss, st = rl_step(model_b, b, 0, 10, cfg_b)
         loss.backward()
         for k, v in st.items():
@@ -268,9 +316,10 @@ def test_native_step_with_reference_model_on_the_learner(libprl, cuda_device):
         assert abs(stats_a[k] - sum(agg[k])) <= 1e-4 * max(1.0, abs(sum(agg[k]))), k
 
 
-def test_preprocessor_fills_ref_logprobs_from_a_model_on_its_gpu(libprl, cuda_device, tmp_path):
+@pytest.mark.parametrize("layout", ["logits_model", "hf_layout_fused_head"])
+def test_preprocessor_fills_ref_logprobs_from_a_model_on_its_gpu(libprl, cuda_device, tmp_path, layout):
     """PreprocessorLoop(ref_model=...): the published batches carry log p_ref of every labelled token
-    (what the reference fetches over HTTP, preprocess.py:86-104), equal to a torch log_softmax."""
+    (what the reference fetches over HTTP, preprocess.py:86-104), equal to the oracle's log-probs."""
     from pipelinerl_amd import streams
     from pipelinerl_amd.finetune.rl import RLConfig
     from pipelinerl_amd.finetune.types import PipelineBatchEncoding
@@ -286,7 +335,7 @@ def test_preprocessor_fills_ref_logprobs_from_a_model_on_its_gpu(libprl, cuda_de
         cfg = PreprocessorConfig(exp_path=tmp_path, num_trainers=1, train_batch_size=1, gradient_accumulation_passes=8,
                                  seq_length=80, attempts=attempts, rl=rl, eos_token_id=2, chunk_n_groups=2)
         torch.manual_seed(5)
-        ref_model = TinyLM(V).to(cuda_device).eval()
+        ref_model = (TinyHFLM(V) if layout == "hf_layout_fused_head" else TinyLM(V)).to(cuda_device).eval()
         with streams.write_to_streams(streams.SingleStreamSpec(exp_path=tmp_path, topic="actor")) as w:
             for g in range(4):
                 w.write(raw[g * attempts:(g + 1) * attempts])
@@ -298,12 +347,8 @@ def test_preprocessor_fills_ref_logprobs_from_a_model_on_its_gpu(libprl, cuda_de
                 b = PipelineBatchEncoding(**rec).to_device(cuda_device)
                 if b.sentinel:
                     continue
-                with torch.no_grad():
-                    lp = torch.log_softmax(ref_model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits.float(), -1)
-                want = torch.zeros_like(b.ref_logprobs)
-                want[:, 1:] = lp[:, :-1].gather(-1, b.input_ids[:, 1:, None])[..., 0]
-                want = torch.where(b.labels != -100, want, torch.zeros_like(want))
-                assert torch.allclose(b.ref_logprobs, want, rtol=1e-5, atol=1e-5)
+                want = _oracle_ref_logprobs(ref_model, b)
+                assert torch.allclose(b.ref_logprobs.double(), want, rtol=1e-4, atol=2e-5)
                 assert not torch.equal(b.ref_logprobs, b.old_logprobs)
                 seen += int(b.seq_boundaries.shape[0]) - 1
                 if seen >= 8:

@@ -258,7 +258,8 @@ def test_rlconfig_accepts_the_reference_keys_with_the_reference_defaults():
     want = json.loads((GOLDEN / "rlconfig_fields.json").read_text())
     got = json.loads(json.dumps(field_table(RLConfig)))
     assert {k: got[k] for k in want} == want
-    assert set(got) - set(want) == {"fused_logits_grad", "inplace_logits_grad", "expected_loss_scale", "skip_unlabelled_rows"}  # MI355X extensions
+    assert set(got) - set(want) == {"fused_logits_grad", "inplace_logits_grad", "expected_loss_scale", "skip_unlabelled_rows",
+                                    "fused_head_keep_logits", "fused_head_chunk_rows"}  # MI355X extensions
 
 
 def test_split_bf16_host_formulation():

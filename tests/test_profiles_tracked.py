@@ -1,0 +1,63 @@
+"""`profiles/` must reproduce the numbers the documents quote: every tracked rocprofv3 kernel-stats summary parses row by
+row to a name + 7 numeric fields (round 3's width-cut summaries had lost Calls / TotalDurationNs / AverageNs of the
+dominant kernel - files in that state are kept as `*.truncated.txt`, never as `.csv`), and the condenser that writes them
+(`scripts/kernel_stats_summary.py`) keeps every numeric column whatever the length of the kernel's signature."""
+
+import csv
+import importlib.util
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+FILES = sorted((ROOT / "profiles").glob("*kernel_stats*.csv"))
+COLUMNS = ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"]
+
+
+@pytest.mark.parametrize("path", FILES, ids=[f.name for f in FILES])
+def test_tracked_kernel_stats_rows_are_complete(path):
+    with open(path, newline="") as fh:
+        rows = list(csv.reader(fh))
+    assert rows[0] == COLUMNS
+    assert len(rows) > 1
+    for row in rows[1:]:
+        assert len(row) == 8, row[0][:80]
+        calls, total, avg = int(float(row[1])), float(row[2]), float(row[3])
+        assert calls >= 1 and total > 0 and abs(avg - total / calls) <= 1e-6 * avg + 1e-3, row[0][:80]
+        for x in row[4:]:
+            float(x)
+
+
+def test_at_least_one_bench_summary_names_the_dominant_kernel_with_its_duration():
+    found = False
+    for path in FILES:
+        if "bench" not in path.name:
+            continue
+        with open(path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if "fused_logits_loss" in row["Name"] and float(row["AverageNs"]) > 1e5 and int(float(row["Calls"])) >= 1000:
+                    found = True
+    assert found
+
+
+def test_condenser_keeps_the_numbers_of_a_400_character_signature(tmp_path):
+    spec = importlib.util.spec_from_file_location("kss", ROOT / "scripts" / "kernel_stats_summary.py")
+    kss = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kss)
+    long_name = ("void (anonymous namespace)::fused_logits_loss_keep_kernel<(anonymous namespace)::F32, 1024, 2, 16, 9, true, "
+                 "(anonymous namespace)::DenseOut<(anonymous namespace)::F32> >((anonymous namespace)::RowGeom, (anonymous namespace)::FusedArgs, "
+                 "(anonymous namespace)::F32::scalar const*, float, float, (anonymous namespace)::DenseOut<(anonymous namespace)::F32>)")
+    assert len(long_name) > 300
+    src = tmp_path / "raw.csv"
+    with open(src, "w", newline="") as fh:
+        w = csv.writer(fh, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(COLUMNS)
+        w.writerow(["small_kernel(int)", 10, 1000, 100.0, 0.01, 90, 110, 5.0])
+        w.writerow([long_name, 28672, 51520195033, 1796881.802211, 93.24, 1747019, 2657158, 1791479.099093])
+    dst = tmp_path / "out.csv"
+    assert kss.condense(str(src), str(dst)) == 2
+    with open(dst, newline="") as fh:
+        rows = list(csv.DictReader(fh))
+    assert rows[0]["Name"] == "fused_logits_loss_keep_kernel<F32, 1024, 2, 16, 9, true, DenseOut<F32> >"  # sorted by total time
+    assert (int(rows[0]["Calls"]), float(rows[0]["AverageNs"]), int(rows[0]["MaxNs"])) == (28672, 1796881.802211, 2657158)
+    assert rows[1]["Name"] == "small_kernel"

@@ -383,6 +383,46 @@ def test_clean_at_start_hides_a_killed_run(tmp_path):
         streams.reset_streams_backend()
 
 
+def test_begin_run_removes_an_earlier_runs_logs_and_a_forgotten_one_is_warned_about(tmp_path, caplog):
+    """Round-3 advisor finding: writers never unlink, so the NEXT run on the same exp_path replays the old run's
+    `TrainingDone` from record 0 unless the run's owner cleans first.  `begin_run(exp_path)` is that call (the shm
+    counterpart of launch.py:462-470); a process that attaches without any owner having done it gets ONE warning."""
+    import logging
+    import os
+
+    from pipelinerl_amd import streams
+
+    streams.reset_streams_backend()
+    streams.set_streams_backend("shm", segment_bytes=1 << 16)
+    try:
+        spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="stats")
+        with streams.write_to_streams(spec) as w:  # the "earlier run": finishes, leaves its log behind
+            w.write({"kind": "training_done", "run": "old"})
+        prefix = streams._exp_prefix(tmp_path)
+        assert any(f.startswith(prefix) for f in os.listdir("/dev/shm"))
+        # a new process (simulated: the per-process bookkeeping is forgotten) attaches without an owner: warned, once
+        streams.reset_streams_backend()
+        streams.set_streams_backend("shm", segment_bytes=1 << 16)
+        with caplog.at_level(logging.WARNING, logger="pipelinerl_amd.streams"):
+            assert _take(streams.read_stream(spec), 1)[0]["run"] == "old"
+            assert _take(streams.read_stream(spec), 1)[0]["run"] == "old"
+        assert sum("begin_run" in r.getMessage() for r in caplog.records) == 1
+        # the owner of the next run calls begin_run first: nothing of the old run is left, no warning afterwards
+        streams.reset_streams_backend()
+        streams.set_streams_backend("shm", segment_bytes=1 << 16)
+        caplog.clear()
+        assert streams.begin_run(tmp_path) == 2
+        with caplog.at_level(logging.WARNING, logger="pipelinerl_amd.streams"):
+            with streams.write_to_streams(spec) as w:
+                w.write({"kind": "samples_processed", "run": "new"})
+            assert _take(streams.read_stream(spec), 1)[0]["run"] == "new"
+        assert not [r for r in caplog.records if "begin_run" in r.getMessage()]
+        assert str(tmp_path.resolve()) in streams._owned_experiments  # removed again when this process exits
+    finally:
+        streams.clean_shm_streams(tmp_path)
+        streams.reset_streams_backend()
+
+
 def test_writer_takes_over_a_control_block_whose_creator_died(tmp_path):
     """A creator killed between shm_open and publishing the magic word leaves a control block that answers EAGAIN
     forever.  A later writer waits `takeover_after`, removes it and creates the log; a reader that was already waiting

@@ -156,6 +156,25 @@ def test_batch_codec_is_compact(libprl):
     _same(batch_codec.decode(blob), want)
 
 
+def test_batch_codec_scalars_and_dtypes(libprl):
+    """Round-3 advisor finding: a 0-dim CPU tensor has no byte view (`t.view(torch.uint8)` raises) and bool / bf16 / f16
+    fields were encoded but not decodable - the failure surfaced in the CONSUMER.  Now: 0-dim tensors travel, the three
+    dtypes are part of the format, anything else is refused at the producer."""
+    import torch
+
+    from pipelinerl_amd import batch_codec
+
+    fields = [("scalar", torch.tensor(7, dtype=torch.int64)), ("flag", torch.tensor([True, False, True])),
+              ("half", torch.arange(5, dtype=torch.float32).to(torch.bfloat16)), ("h16", torch.arange(3, dtype=torch.float16)),
+              ("empty", torch.empty(0, dtype=torch.float32))]
+    rec = batch_codec._frame(batch_codec.MAGIC_BATCH, {"model_version": 0}, fields)
+    got = batch_codec.decode(rec)
+    for name, t in fields:
+        assert got[name].dtype == t.dtype and got[name].shape == t.shape and torch.equal(got[name], t), name
+    with pytest.raises(TypeError, match="complex64"):
+        batch_codec._frame(batch_codec.MAGIC_BATCH, {}, [("z", torch.zeros(2, dtype=torch.complex64))])
+
+
 def test_rollouts_binary_record_roundtrip(streams, tmp_path, libprl):
     """The `actor` hop in binary: RaggedRollouts -> shm ring -> RaggedRollouts, field for field; and
     the text form written by the files backend is the reference's list-of-dicts group record."""
