@@ -539,7 +539,8 @@ def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attemp
                 for rag, reasons in groups[:n_groups]:
                     w.write(rag if binary else ragged_to_entries(rag, reasons))
             cfg = PreprocessorConfig(exp_path=Path(tmp), num_trainers=trainers, train_batch_size=1, gradient_accumulation_passes=4096,
-                                     seq_length=seq_length, attempts=attempts, rl=rl, eos_token_id=2, chunk_n_groups=2)
+                                     seq_length=seq_length, attempts=attempts, rl=rl, eos_token_id=2, chunk_n_groups=2,
+                                     pop_old_data=False)  # lossless: with the default the loader DROPS old chunks when the loop is the slower side
             loop = PreprocessorLoop(cfg, dev, batched_transfers=batched, profile=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -570,7 +571,7 @@ def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attemp
             shutil.rmtree(tmp, ignore_errors=True)
 
     try:
-        one_case("shm", True, 1, 2, True)  # warm-up: library, page-locked ring, allocator
+        one_case("shm", True, 1, min(8, n_fast), True)  # warm-up: library, page-locked ring, the allocator's block cache (several chunks are alive at once)
         out["cases"]["PRLROL01_to_shm_1_trainer"] = one_case("shm", True, 1, n_fast, True)
         out["cases"]["PRLROL01_to_shm_4_trainers"] = one_case("shm", True, 4, n_fast, True)
         out["cases"]["PRLROL01_to_shm_1_trainer_one_copy_per_array"] = one_case("shm", True, 1, n_fast, False)
@@ -762,6 +763,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # host-side torch ops (stream decode, codec, the CPU baseline) use the cores this process was GRANTED: the GPU boxes show 256
+    # CPUs behind a 16-core quota, and an intra-op pool sized for 256 spends the quota on its own wake-ups
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_host_cores())))
     if os.environ.get("PRL_BENCH_SHARE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -1066,7 +1070,7 @@ def main():
             "config": {"workload": args.workload, "global_batch": bs, "seq_len": seq_length, "vocab": vocab,
                        "tokens_per_step": bs * seq_length, "parallelism": f"dp{world}", "logits_mode": args.logits_mode,
                        "policy_loss": "ppo", "kl_coef": kl_coef, "ref_logprobs": ("old + N(0, 0.05)" if kl_coef > 0 else "== old (KL off)"),
-                       "model": param_set, "head_hidden": hidden, "old_logprob_sigma": sigma, "labelled_token_fraction": live_frac,
+                       "param_set": param_set, "head_hidden": hidden, "old_logprob_sigma": sigma, "labelled_token_fraction": live_frac,
                        "grad_allreduce_bytes_per_step": sum(b.numel() * 2 for b in grad_buckets) if grad_buckets else 0,
                        "torch_distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices_visible": torch.cuda.device_count()}
                                              if world > 1 else None),

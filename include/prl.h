@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 7
+#define PRL_ABI_VERSION 8
 
 #define PRL_OK 0
 #define PRL_EINVAL (-22)   /* bad argument                                  */
@@ -437,6 +437,16 @@ typedef struct prl_log prl_log;
 /* PRL_EAGAIN: the log is being created by another process right now (retry); PRL_EFAULT: absent. */
 int prl_log_open(const char* name, uint64_t segment_bytes, int32_t flags, prl_log** out);
 int prl_log_append(prl_log* l, const void* data, uint64_t nbytes);
+/* One record gathered from several source ranges - the header and the columns of a PipelineBatchEncoding
+ * (pipelinerl/streams.py:262-270 serialises them into one JSON line) - copied straight into the segment, no
+ * intermediate record buffer.  Pieces in ascending, non-overlapping `offset` order inside a record of `nbytes`;
+ * bytes no piece covers (alignment gaps) are zero. */
+typedef struct prl_log_iov {
+  const void* ptr;
+  uint64_t offset;
+  uint64_t nbytes;
+} prl_log_iov;
+int prl_log_appendv(prl_log* l, const prl_log_iov* iov, int32_t n_iov, uint64_t nbytes);
 /* Next record of this handle's cursor (starts at the first retained record): *ptr points INTO
  * the mapping, valid until the next read / close.  timeout_ms < 0 blocks, 0 returns PRL_EAGAIN
  * at the tail, > 0 PRL_ETIMEDOUT. */

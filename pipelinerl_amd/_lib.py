@@ -13,7 +13,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl.so"
 
-PRL_ABI_VERSION = 7
+PRL_ABI_VERSION = 8
 PRL_OK = 0
 PRL_EINVAL = -22
 PRL_ENOMEM = -12
@@ -74,6 +74,12 @@ STAT_INDEX = {
     "nonfinite_kl": 30,
     "bad_group_tokens": 31,
 }
+
+
+class PrlLogIov(ctypes.Structure):
+    """`prl_log_iov` of include/prl.h: one source range of a gathered record."""
+
+    _fields_ = [("ptr", ctypes.c_void_p), ("offset", ctypes.c_uint64), ("nbytes", ctypes.c_uint64)]
 
 
 class PrlLossConfig(ctypes.Structure):
@@ -149,6 +155,7 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_ring_unlink": (c_int32, [c_char_p]),
     "prl_log_open": (c_int32, [c_char_p, c_uint64, c_int32, POINTER(c_void_p)]),
     "prl_log_append": (c_int32, [c_void_p, c_void_p, c_uint64]),
+    "prl_log_appendv": (c_int32, [c_void_p, c_void_p, c_int32, c_uint64]),
     "prl_log_read": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_uint64), c_int64]),
     "prl_log_stats": (c_int32, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
     "prl_log_close": (c_int32, [c_void_p]),

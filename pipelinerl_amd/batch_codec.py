@@ -17,6 +17,7 @@ Record = 8-byte magic/kind + payload.
 
 from __future__ import annotations
 
+import ctypes
 import json
 import struct
 from typing import Any
@@ -69,6 +70,49 @@ def _frame(magic: bytes, scalars: dict, named_tensors) -> bytearray:
         else:
             torch.frombuffer(buf, dtype=t.dtype, count=t.numel(), offset=base + off).view(t.shape).copy_(t)
     return buf
+
+
+def append_framed(log, magic: bytes, scalars: dict, named_tensors) -> int:
+    """The record `_frame` would build, written by `log.appendv` STRAIGHT into the shared-memory segment: the 12-byte
+    prefix + header JSON from a small host buffer, every contiguous CPU tensor from where it lies (one copy per byte,
+    source -> segment; `_frame` + `append` make it source -> record buffer -> segment, plus the buffer's zero fill).
+    Tensors that are not contiguous CPU tensors (device tensors, strided views) go through `_frame`.  Returns the
+    record size."""
+    tensors = [(name, t.detach()) for name, t in named_tensors]
+    if any(t.device.type != "cpu" or not t.is_contiguous() for _, t in tensors):
+        buf = _frame(magic, scalars, tensors)
+        log.append(buf)
+        return len(buf)
+    layout, offset = [], 0
+    for name, t in tensors:
+        if str(t.dtype).replace("torch.", "") not in _TORCH:
+            raise TypeError(f"stream record field {name!r} has dtype {t.dtype}; the binary record carries {sorted(_TORCH)}")
+        offset += (-offset) % _ALIGN
+        nbytes = t.numel() * t.element_size()
+        layout.append((name, t, offset, nbytes))
+        offset += nbytes
+    header = json.dumps({"scalars": scalars,
+                         "tensors": [[name, str(t.dtype).replace("torch.", ""), list(t.shape), off, nb] for name, t, off, nb in layout]}).encode("utf-8")
+    head = bytearray(12 + len(header))
+    head[:8] = magic
+    struct.pack_into("<I", head, 8, len(header))
+    head[12:] = header
+    base = len(head) + (-len(head)) % _ALIGN
+    head_c = (ctypes.c_char * len(head)).from_buffer(head)
+    pieces = [(ctypes.addressof(head_c), 0, len(head))]
+    pieces += [(t.data_ptr(), base + off, nb) for _, t, off, nb in layout if nb]
+    log.appendv(pieces, base + offset, keep_alive=(head, tensors))
+    return base + offset
+
+
+def append_batch(log, batch: PipelineBatchEncoding) -> int:
+    scalars = {"model_version": batch.model_version, "sentinel": batch.sentinel, "padding": batch.padding, "is_packed": batch.is_packed}
+    return append_framed(log, MAGIC_BATCH, scalars, list(batch.tensors()))
+
+
+def append_rollouts(log, rollouts) -> int:
+    tensors = [(name, getattr(rollouts, name)) for name in _ROLLOUT_FIELDS if getattr(rollouts, name) is not None]
+    return append_framed(log, MAGIC_ROLLOUTS, {"group_ids": list(rollouts.group_ids)}, tensors)
 
 
 _ROLLOUT_FIELDS = ("tokens", "labels", "logprobs", "ref_logprobs", "seq_off", "lp_off", "reward", "group_index", "step_index",

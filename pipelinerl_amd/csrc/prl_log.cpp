@@ -21,11 +21,20 @@
 // start at the first retained segment, and park on the commit futex when they reach the tail - no
 // polling.  Records are returned as pointers into the mapping (zero copy) valid until the next read.
 //
+// First touch: a fresh tmpfs page costs the writer a fault + allocation + zeroing (~3 us per 4 KiB measured: 8 ms for the
+// 8.9 MB a preprocessor chunk publishes, against 1.2 ms for the copy itself).  A writer handle therefore owns a helper
+// thread that populates the segment AHEAD of the append position (madvise(MADV_POPULATE_WRITE), a window of 32 MiB): the
+// kernel work happens on another core, the appending thread copies into mapped pages.  `prl_log_appendv` gathers a record
+// from several source ranges (header + the columns of a batch) straight into the segment - no intermediate record buffer.
+//
 // Retention: by default nothing is ever dropped (like a file on disk; control topics are tiny).  A log
 // created with PRL_LOG_TRIM unlinks segments that every REGISTERED reader has left behind - the
 // bulk topics (`training_data`, `actor`) use it, their single consumer is the trainer / preprocessor.
 #include <atomic>
 #include <cerrno>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <climits>
 #include <csignal>
 #include <cstdint>
@@ -135,6 +144,74 @@ int map_object(const std::string& name, size_t create_bytes, bool may_create, Ma
 
 }  // namespace
 
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23  // Linux >= 5.14
+#endif
+
+// Populates the pages of the writer's current segment ahead of the append position, on its own thread.
+struct Prefaulter {
+  static constexpr uint64_t kWindow = 32ull << 20;  // stay this far ahead of `committed`
+  static constexpr uint64_t kSlice = 2ull << 20;    // one madvise call
+  std::mutex m;
+  std::condition_variable cv;
+  std::thread th;
+  pid_t owner = 0;
+  bool stop = false, disabled = false;
+  uint8_t* base = nullptr;  // payload start of the segment being written
+  uint64_t capacity = 0, want = 0, done = 0, gen = 0;
+
+  void run() {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv.wait(lk, [&] { return stop || (!disabled && base && done < want); });
+      if (stop) return;
+      const uint64_t g = gen, from = done, n = (want - done < kSlice) ? want - done : kSlice;
+      uint8_t* p = base + from;
+      lk.unlock();
+      // page-align inwards: the first partial page was touched by the header / previous record already
+      const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
+      const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + n) & ~uintptr_t(4095);
+      int rc = 0;
+      if (e > a) rc = madvise(reinterpret_cast<void*>(a), e - a, MADV_POPULATE_WRITE);
+      lk.lock();
+      if (rc != 0 && errno == EINVAL) disabled = true;  // kernel without MADV_POPULATE_WRITE: appends fault their pages themselves
+      if (g == gen) done = from + n;  // a segment change in between restarts from its own offset
+    }
+  }
+  // called by the appending thread (under the log's writer lock): the segment now being written and how far it is filled
+  void target(uint8_t* payload, uint64_t cap, uint64_t committed, bool new_segment) {
+    std::lock_guard<std::mutex> lk(m);
+    if (new_segment || payload != base) {
+      base = payload;
+      capacity = cap;
+      done = committed;
+      ++gen;
+    }
+    if (done < committed) done = committed;
+    const uint64_t w = committed + kWindow < cap ? committed + kWindow : cap;
+    if (w > want || new_segment) want = w;
+    if (want > cap) want = cap;
+    if (done < want) cv.notify_one();
+  }
+  void start() {
+    owner = getpid();
+    th = std::thread([this] { run(); });
+  }
+  void shutdown() {
+    if (!th.joinable()) return;
+    if (getpid() != owner) {  // a forked child inherited the object, not the thread: nothing to join
+      th.detach();
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv.notify_all();
+    th.join();
+  }
+};
+
 struct prl_log {
   std::string name;
   Mapping ctl_map;
@@ -142,6 +219,7 @@ struct prl_log {
   // writer side: the segment being appended to
   Mapping wseg;
   uint64_t wseg_index = kFree;
+  Prefaulter* prefault = nullptr;  // created by the first append of this handle
   // reader side
   Mapping rseg;
   uint64_t rseg_index = kFree;
@@ -300,20 +378,25 @@ extern "C" int prl_log_open(const char* name, uint64_t segment_bytes, int32_t fl
   return PRL_OK;
 }
 
-extern "C" int prl_log_append(prl_log* l, const void* data, uint64_t nbytes) {
-  PRL_CHECK_ARG(l && (data || nbytes == 0), "null argument");
+namespace {
+
+// Reserve room for a record of `nbytes` in the last segment (rolling over when it does not fit).  Called with the writer
+// lock held; on PRL_OK *dst points at the record's length word and the caller fills [dst + 8, dst + 8 + nbytes), then
+// calls publish_record.
+int reserve_record(prl_log* l, uint64_t nbytes, uint8_t** dst, SegHeader** hdr, uint64_t* off_out) {
   LogCtl* c = l->ctl;
   const uint64_t need = 8 + pad8(nbytes);
-  lock_ctl(c);
   int rc = PRL_OK;
   SegHeader* h = nullptr;
   uint64_t off = 0;
+  bool new_segment = false;
   for (;;) {  // find (or open) the segment this record goes to
     const uint64_t last = c->n_segments.load(std::memory_order_acquire) - 1;
     if (l->wseg_index != last) {
       rc = open_segment(l->name, last, &l->wseg);
       if (rc != PRL_OK) break;
       l->wseg_index = last;
+      new_segment = true;
     }
     h = seg_hdr(l->wseg);
     if (h->sealed.load(std::memory_order_acquire)) {
@@ -326,6 +409,7 @@ extern "C" int prl_log_append(prl_log* l, const void* data, uint64_t nbytes) {
       l->wseg.reset();
       l->wseg = next;
       l->wseg_index = last + 1;
+      new_segment = true;
       continue;
     }
     off = h->committed.load(std::memory_order_relaxed);
@@ -342,17 +426,76 @@ extern "C" int prl_log_append(prl_log* l, const void* data, uint64_t nbytes) {
     l->wseg.reset();
     l->wseg = next;
     l->wseg_index = last + 1;
+    new_segment = true;
     trim(l);
   }
+  if (rc != PRL_OK) return rc;
+  if (!l->prefault && (c->segment_bytes >= (4ull << 20))) {  // bulk topics only: control topics have tiny segments
+    l->prefault = new (std::nothrow) Prefaulter();
+    if (l->prefault) l->prefault->start();
+    new_segment = true;
+  }
+  if (l->prefault) l->prefault->target(seg_data(l->wseg), h->capacity, off + need, new_segment);
+  *dst = seg_data(l->wseg) + off;
+  *hdr = h;
+  *off_out = off;
+  return PRL_OK;
+}
+
+void publish_record(prl_log* l, SegHeader* h, uint64_t off, uint64_t nbytes) {
+  LogCtl* c = l->ctl;
+  h->committed.store(off + 8 + pad8(nbytes), std::memory_order_release);
+  c->n_records.fetch_add(1, std::memory_order_relaxed);
+  c->n_bytes.fetch_add(nbytes, std::memory_order_relaxed);
+  c->commits.fetch_add(1, std::memory_order_release);
+  futex_wake_all(&c->commits);
+}
+
+}  // namespace
+
+extern "C" int prl_log_append(prl_log* l, const void* data, uint64_t nbytes) {
+  PRL_CHECK_ARG(l && (data || nbytes == 0), "null argument");
+  LogCtl* c = l->ctl;
+  lock_ctl(c);
+  uint8_t* p = nullptr;
+  SegHeader* h = nullptr;
+  uint64_t off = 0;
+  const int rc = reserve_record(l, nbytes, &p, &h, &off);
   if (rc == PRL_OK) {
-    uint8_t* p = seg_data(l->wseg) + off;
     memcpy(p, &nbytes, 8);
     if (nbytes) memcpy(p + 8, data, nbytes);
-    h->committed.store(off + need, std::memory_order_release);
-    c->n_records.fetch_add(1, std::memory_order_relaxed);
-    c->n_bytes.fetch_add(nbytes, std::memory_order_relaxed);
-    c->commits.fetch_add(1, std::memory_order_release);
-    futex_wake_all(&c->commits);
+    publish_record(l, h, off, nbytes);
+  }
+  unlock_ctl(c);
+  return rc;
+}
+
+extern "C" int prl_log_appendv(prl_log* l, const prl_log_iov* iov, int32_t n_iov, uint64_t nbytes) {
+  PRL_CHECK_ARG(l && (iov || n_iov == 0) && n_iov >= 0, "null argument");
+  uint64_t at = 0;
+  for (int i = 0; i < n_iov; ++i) {  // ascending, non-overlapping, inside the record
+    PRL_CHECK_ARG(iov[i].offset >= at && iov[i].offset + iov[i].nbytes <= nbytes && (iov[i].ptr || iov[i].nbytes == 0),
+                  "iov[%d] (offset %llu, %llu bytes) does not fit a record of %llu bytes after the previous piece", i,
+                  (unsigned long long)iov[i].offset, (unsigned long long)iov[i].nbytes, (unsigned long long)nbytes);
+    at = iov[i].offset + iov[i].nbytes;
+  }
+  LogCtl* c = l->ctl;
+  lock_ctl(c);
+  uint8_t* p = nullptr;
+  SegHeader* h = nullptr;
+  uint64_t off = 0;
+  const int rc = reserve_record(l, nbytes, &p, &h, &off);
+  if (rc == PRL_OK) {
+    memcpy(p, &nbytes, 8);
+    uint8_t* rec = p + 8;
+    at = 0;
+    for (int i = 0; i < n_iov; ++i) {
+      if (iov[i].offset > at) memset(rec + at, 0, iov[i].offset - at);  // alignment gaps are zeros, whatever the page held
+      if (iov[i].nbytes) memcpy(rec + iov[i].offset, iov[i].ptr, iov[i].nbytes);
+      at = iov[i].offset + iov[i].nbytes;
+    }
+    if (nbytes > at) memset(rec + at, 0, nbytes - at);
+    publish_record(l, h, off, nbytes);
   }
   unlock_ctl(c);
   return rc;
@@ -423,6 +566,11 @@ extern "C" int prl_log_stats(prl_log* l, uint64_t* n_records, uint64_t* n_bytes,
 extern "C" int prl_log_close(prl_log* l) {
   if (!l) return PRL_OK;
   if (l->reader_slot >= 0) l->ctl->reader_segment[l->reader_slot].store(kFree, std::memory_order_release);
+  if (l->prefault) {  // before the segment is unmapped
+    l->prefault->shutdown();
+    delete l->prefault;
+    l->prefault = nullptr;
+  }
   l->wseg.reset();
   l->rseg.reset();
   l->ctl_map.reset();

@@ -322,7 +322,7 @@ def annotate_ref_logprobs(ref_model: Any, batch: PipelineBatchEncoding, temperat
     rows that predict a labelled token enter the product.  Anything else (a callable that only returns `.logits`), or
     `fused_head=False`, goes through the logits and the K1 kernel."""
     if fused_head:
-        from ..fused_head import annotate_ref_logprobs_fused
+        from ...fused_head import annotate_ref_logprobs_fused
 
         if annotate_ref_logprobs_fused(ref_model, batch, temperature):
             return batch

@@ -203,6 +203,14 @@ class Log:
             buf = (ctypes.c_char * len(data)).from_buffer_copy(data)
         _lib.check(_lib.load().prl_log_append(self._h, buf, len(data)))
 
+    def appendv(self, pieces: "list[tuple[int, int, int]]", nbytes: int, keep_alive=None) -> None:
+        """One record of `nbytes` gathered from `pieces` = (source address, offset in the record, length), ascending and
+        non-overlapping - copied straight into the shared-memory segment (`prl_log_appendv`), no record buffer in between.
+        `keep_alive`: whatever owns the source memory (held until the call returns)."""
+        iov = (_lib.PrlLogIov * len(pieces))(*pieces)
+        _lib.check(_lib.load().prl_log_appendv(self._h, iov, len(pieces), nbytes))
+        del keep_alive
+
     def read(self, block: bool = True, timeout: float | None = None) -> bytearray:
         """Next record of this handle's cursor: ONE copy out of the shared-memory segment into a `bytearray` the caller
         owns (the reader's mapping of a segment is released when it moves on to the next one, so a view into the

@@ -399,12 +399,11 @@ class ShmStreamWriter(StreamWriter):
         if partition is not None:
             raise ValueError()
         if isinstance(data, PipelineBatchEncoding):
-            payload = batch_codec.encode_batch(data)
+            batch_codec.append_batch(self._log, data)  # host columns go straight into the segment (one copy)
         elif isinstance(data, RaggedRollouts):
-            payload = batch_codec.encode_rollouts(data)
+            batch_codec.append_rollouts(self._log, data)
         else:
-            payload = batch_codec.encode_json(_dumps(data))
-        self._log.append(payload)
+            self._log.append(batch_codec.encode_json(_dumps(data)))
         if self._mirror is not None:
             self._mirror.write(data.to_entries() if isinstance(data, RaggedRollouts) else data)
 

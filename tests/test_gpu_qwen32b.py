@@ -182,6 +182,9 @@ def test_reference_logprobs_through_the_mfma_head_vs_oracle(libprl, cuda_device,
 
     ref = RefLM().eval()
     pb = _to_device(batch, cuda_device)
+    from pipelinerl_amd.fused_head import ref_head_for
+
+    ref_head_for(ref)[1].refresh()  # the weight's bf16 planes (3.1 GB for two) are built once per weight, not per micro-batch
     before = torch.cuda.max_memory_allocated()
     torch.cuda.reset_peak_memory_stats()
     base = torch.cuda.memory_allocated()
