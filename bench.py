@@ -1028,7 +1028,7 @@ def main():
             if e2e is not None:
                 e2e["source"] = "committed (profiles/r02_e2e_learner_7b_fused_head.json), NOT measured in this run"
     ref_logprob = None
-    if world == 1 and not args.no_ref_logprob and not args.no_fused_head:
+    if not args.no_ref_logprob and not args.no_fused_head:  # every rank runs it (no collective inside), rank 0 reports
         try:
             logits = grad_logits = None
             torch.cuda.empty_cache()
@@ -1111,7 +1111,7 @@ def main():
         wsync = {"params": param_set, "param_bytes": grad_bytes_default}
 
         def watchdog():
-            if not done.wait(float(os.environ.get("PRL_BENCH_WSYNC_TIMEOUT", 90))):
+            if not done.wait(float(os.environ.get("PRL_BENCH_WSYNC_TIMEOUT", 90 if param_set != "32b" else 300))):
                 emit({**wsync, "error": f"weight-sync probe timed out in stage {wsync.get('stage')}"})
                 os._exit(0)
 

@@ -246,7 +246,7 @@ def set_tuning(key: str, value: int | None) -> None:
 
 def _parse_tuning(key: str, text: str) -> int:
     if key == "lmhead_tile":  # "128" | "256" | "256x256"
-        return {"128": 128, "256": 256, "256x256": 512}.get(text.strip(), 0)
+        return {"128": 128, "256": 256, "256x256": 512, "256x384": 384, "256x320": 320}.get(text.strip(), 0)
     return int(text)
 
 

@@ -455,6 +455,193 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
 }
 
 // -----------------------------------------------------------------------------------------------
+// ONE WAVE PER SIMD: 256 x BN tile (BN = 384 | 320) on four waves with up to 512 registers each
+// -----------------------------------------------------------------------------------------------
+// The 8-wave shapes above hold 128 accumulator registers per lane, which caps the workgroup tile at 256 x 256 - and at
+// that tile the dual-plane forward STAGES more than it can hide: 48 KB per 32-deep step at the ~21-24 B/clk/CU the LDS DMA
+// path sustains is ~2300 clocks against 2048 clocks of MFMA per SIMD (profiles/r02c, r03ai: matrix pipes 66 % busy, waves
+// issue-stalled 50-65 %).  Staged bytes per flop only fall with a larger tile, i.e. more accumulators per lane than two
+// waves per SIMD can have.  Here a wave is ALONE on its SIMD (4 waves, __launch_bounds__(256): 512 registers, the
+// accumulators spill over into the AGPR half of the file) and owns 128 vocabulary rows x BN / 2 tokens:
+//   BN = 384: 4 x 6 tiles = 384 accumulator registers, 56 KB per step (2 x 16 KB planes + 24 KB of hidden states) for
+//             96 MFMAs per wave = 3072 clocks: 220 flop / staged byte (256 x 256: 175), staging ~0.87 of the MFMA time;
+//             2 stages (112 KB)
+//   BN = 320: 4 x 5 tiles = 320 registers, 52 KB per step for 80 MFMAs = 2560 clocks (201 flop/B), 3 stages (156 KB)
+// Fragment reads per MFMA fall from 0.5 to 0.29 (8 + 6 reads feed 48 MFMAs).  No partner wave hides this wave's LDS
+// latency, so the reads of the NEXT plane / sub-step are issued before the MFMA group that precedes their use.
+template <int BN_>
+struct CfgOne {
+  static constexpr int BM = 256, BN = BN_, NT = 256;
+  static constexpr int MI = 4, NJ = BN_ / 64, WROWS = 128, WCOLS = BN_ / 2;
+  static constexpr int QA = 4, QB = BN_ / 64;           // 16-byte chunks per thread: a 256-row plane, the BN-row hidden tile
+  static constexpr int LOADS = 2 * QA + QB;
+  static constexpr int A_BYTES = 256 * ROW_BYTES32, B_BYTES = BN_ * ROW_BYTES32;
+  static constexpr int STAGE_BYTES = 2 * A_BYTES + B_BYTES;
+  static constexpr int STAGES = (3 * STAGE_BYTES <= 160 * 1024) ? 3 : 2;
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+};
+
+// Where an accumulator tile lives is decided HERE, not by the register allocator: handed 320-384 accumulator registers
+// and `__builtin_amdgcn_mfma_*`, hipcc selects the VGPR form of the instruction for all of them and uses the AGPR half of
+// the file as spill space - 18 v_accvgpr_read / _write per MFMA in the main loop and 850 dwords of scratch (measured on
+// the first version of this kernel).  Tiles t < 16 are bound to AGPRs ("+a", 256 registers), the rest to VGPRs ("+v").
+// The MFMAs are volatile asm, so the compiler's hazard recogniser does not see them: `mfma_settle()` supplies the wait
+// states an MFMA result needs before anything but another MFMA touches it.
+template <bool IN_AGPR>
+__device__ __forceinline__ void mfma_bf16_asm(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  if constexpr (IN_AGPR) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  } else {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  }
+}
+__device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
+// acc[i][j] += (A1 + A2)[m0 + 128 wm + 32 i .., :] B[n0 + WCOLS wn + 32 j .., :]^T over Kc.  HAS_LO = false: one plane (A2 unused).
+// MODE 0: the next stage's DMA pieces ride between the MFMA groups.  MODE 1: all of them right after the barrier (the whole
+// step to land - with two stages the step ends on vmcnt(0)) and the first group's fragment reads in the order the MFMAs
+// consume them (a0, b0 .. b5, a1 .. a3: the first MFMA waits for two reads, not fourteen).
+template <int BN_, bool HAS_LO, int MODE = 0>
+__device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
+                                                  const Geom& g, int m0, int n0, char* lds) {
+  using C = CfgOne<BN_>;
+  constexpr int NJ = C::NJ;
+  constexpr int PLANES = HAS_LO ? 2 : 1;
+  constexpr int LOADS = PLANES * C::QA + C::QB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kcol = stage_kcol32(tid);
+  int64_t offA[C::QA], offB[C::QB];
+#pragma unroll
+  for (int q = 0; q < C::QA; ++q) {
+    int ra = m0 + stage_row32(tid, q, C::NT);
+    ra = ra < g.M ? ra : g.M - 1;
+    offA[q] = (int64_t)ra * g.lda + kcol;
+  }
+#pragma unroll
+  for (int q = 0; q < C::QB; ++q) {
+    int rb = n0 + stage_row32(tid, q, C::NT);
+    rb = rb < g.N ? rb : g.N - 1;
+    offB[q] = (int64_t)rb * g.ldb + kcol;
+  }
+  int rdA[2], rdB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    rdA[ks] = frag_lds_byte32(lane, wm * C::WROWS, 0, ks);
+    rdB[ks] = 2 * C::A_BYTES + frag_lds_byte32(lane, wn * C::WCOLS, 0, ks);
+  }
+  const int total = g.Kc / BK32;
+  int st_k = 0;
+  // piece idx: A1 q0..3, [A2 q0..3,] B q0..QB-1
+  auto stage_piece = [&](int buf, int idx) {
+    const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
+    const uint16_t* src;
+    unsigned off;
+    if (idx < C::QA) {
+      src = A1 + offA[idx];
+      off = idx * C::NT * 16;
+    } else if (HAS_LO && idx < 2 * C::QA) {
+      src = A2 + offA[idx - C::QA];
+      off = C::A_BYTES + (idx - C::QA) * C::NT * 16;
+    } else {
+      const int q = idx - PLANES * C::QA;
+      src = B + offB[q];
+      off = 2 * C::A_BYTES + q * C::NT * 16;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + st_k),
+                                     (__attribute__((address_space(3))) void*)(lds + dst + off), 16, 0, 0);
+  };
+  // the DMA pieces of the next stage ride between the MFMA groups of this one: GROUPS = 2 * PLANES groups per step
+  constexpr int GROUPS = 2 * PLANES;
+  constexpr int PER = (LOADS + GROUPS - 1) / GROUPS;
+  auto compute = [&](int buf, int sbuf) {
+    const char* base = lds + buf * C::STAGE_BYTES;
+    bf16x8 bfr[2][NJ], af[2][4];  // bfr[ks]; af ping-pongs between consecutive MFMA groups
+    if (MODE == 1 && sbuf >= 0) {
+#pragma unroll
+      for (int k = 0; k < LOADS; ++k) stage_piece(sbuf, k);
+    }
+    if constexpr (MODE == 1) {
+      af[0][0] = *reinterpret_cast<const bf16x8*>(base + rdA[0]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(base + rdB[0] + j * 32 * ROW_BYTES32);
+#pragma unroll
+      for (int i = 1; i < 4; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(base + rdA[0] + i * 32 * ROW_BYTES32);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(base + rdB[0] + j * 32 * ROW_BYTES32);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(base + rdA[0] + i * 32 * ROW_BYTES32);
+    }
+    int grp = 0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int pl = 0; pl < PLANES; ++pl) {
+        const int cur = grp & 1, nxt = cur ^ 1;
+        // reads the NEXT group needs, issued before this group's MFMAs
+        if (pl + 1 < PLANES) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[nxt][i] = *reinterpret_cast<const bf16x8*>(base + C::A_BYTES + rdA[ks] + i * 32 * ROW_BYTES32);
+        } else if (ks == 0) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) bfr[1][j] = *reinterpret_cast<const bf16x8*>(base + rdB[1] + j * 32 * ROW_BYTES32);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[nxt][i] = *reinterpret_cast<const bf16x8*>(base + rdA[1] + i * 32 * ROW_BYTES32);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            if (i * NJ + j < 16) {
+              mfma_bf16_asm<true>(acc[i][j], af[cur][i], bfr[ks][j]);
+            } else {
+              mfma_bf16_asm<false>(acc[i][j], af[cur][i], bfr[ks][j]);
+            }
+          }
+        if (MODE == 0 && sbuf >= 0) {
+#pragma unroll
+          for (int k = 0; k < PER; ++k)
+            if (grp * PER + k < LOADS) stage_piece(sbuf, grp * PER + k);
+        }
+        ++grp;
+      }
+    }
+  };
+
+  constexpr int D = C::STAGES - 1;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < D; ++p)
+    if (p < total) {
+#pragma unroll
+      for (int idx = 0; idx < LOADS; ++idx) stage_piece(p, idx);
+      st_k += BK32;
+    }
+  int cur = 0, nxt = D % C::STAGES;
+  int s = 0;
+  for (; s + D < total; ++s) {
+    wait_tile_then_barrier<(D - 1) * LOADS>();
+    compute(cur, nxt);
+    st_k += BK32;
+    cur = cur + 1 == C::STAGES ? 0 : cur + 1;
+    nxt = nxt + 1 == C::STAGES ? 0 : nxt + 1;
+  }
+  for (; s < total; ++s) {
+    if (s + D - 1 < total) {
+      wait_tile_then_barrier<(D - 1) * LOADS>();
+    } else {
+      wait_tile_then_barrier<0>();
+    }
+    compute(cur, -1);
+    cur = cur + 1 == C::STAGES ? 0 : cur + 1;
+  }
+  mfma_settle();
+}
+
+// -----------------------------------------------------------------------------------------------
 // dual-plane main loop with a TRANSPOSED A operand (d W from the row-major d-logits planes)
 // -----------------------------------------------------------------------------------------------
 // acc[v][n] += sum over t of (A1 + A2)[t][m0 + v] B[n0 + n][t]: A1 / A2 are [K, lda] row-major with the contraction index
@@ -993,6 +1180,106 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_fwd_kernel(FwdArgs a) {
       m = osm_merge(m, Osm{x.x, x.y, x.z});
     }
     reinterpret_cast<float4*>(a.part)[(int64_t)split * a.padded + n0 + tid] = float4{m.M, m.S, m.W, 0.0f};
+  }
+}
+
+// The forward on the one-wave-per-SIMD core: same arguments, outputs and split / merge scheme as lmhead_fwd_kernel; a wave
+// owns 128 vocabulary rows (4 MFMA tiles) x BN / 2 tokens (NJ tiles), a lane one token per tile column and 64 of its rows.
+template <int BN_, bool HAS_LO, int MODE = 0>
+__global__ __launch_bounds__(256) void lmhead_fwd1_kernel(FwdArgs a) {
+  using C = CfgOne<BN_>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int tok_tile, split;
+  tile_coords(blockIdx.x, a.tt, a.nsplit, tok_tile, split);
+  constexpr int BN = C::BN, NJ = C::NJ;
+  const int n0 = tok_tile * BN;
+  const int vt0 = (int)((int64_t)a.vt * split / a.nsplit), vt1 = (int)((int64_t)a.vt * (split + 1) / a.nsplit);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow0 = (wave >> 1) * C::WROWS, wcol0 = (wave & 1) * C::WCOLS;
+  const int V = a.geo.M;
+  const float k2 = a.k2;
+  Osm st[NJ];
+  int tgt[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    osm_init(st[j]);
+    const int64_t q = n0 + acc_col(lane, wcol0, j);
+    int id = -1;
+    if (q < a.geo.N && (q % a.cols) != a.cols - 1) {
+      const int64_t v = a.ids[q + 1];
+      if (v >= 0 && v < V) id = (int)v;
+    }
+    tgt[j] = id;
+  }
+  f32x16 acc[4][NJ];
+  for (int tv = vt0; tv < vt1; ++tv) {
+    const int m0 = tv * C::BM;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    gemm_mainloop_one<BN_, HAS_LO, MODE>(acc, a.terms.a[0], a.terms.a[1], a.terms.b[0], a.geo, m0, n0, lds);
+    const int vbase = m0 + acc_row(lane, wrow0, 0, 0);  // vocabulary row of acc[0][j][0]; + 32 i + (reg & 3) + 8 (reg >> 2)
+    const bool full = m0 + C::BM <= V;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int64_t q = n0 + acc_col(lane, wcol0, j);
+      const int d = tgt[j] - vbase;
+      const bool mine = d >= 0 && d < 128 && (d & 7) < 4;  // the target row is one of this lane's 64
+      float sel = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // one MFMA tile (16 rows of this lane) at a time: 16 live values, not 64
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = acc[i][j][r] * k2;
+        if (a.logits2 && q < a.geo.N) {
+          float* dst = a.logits2 + q * (int64_t)V + vbase + i * 32;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            if (vbase + i * 32 + 8 * rg + 3 < V)
+              *reinterpret_cast<float4*>(dst + 8 * rg) = float4{y[4 * rg], y[4 * rg + 1], y[4 * rg + 2], y[4 * rg + 3]};
+        }
+        if (mine) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (d == i * 32 + (r & 3) + 8 * (r >> 2)) sel = y[r];
+        }
+        if (full) {
+          osm_push<16>(st[j], y);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (vbase + i * 32 + (r & 3) + 8 * (r >> 2) < V) {
+              float one[1] = {y[r]};
+              osm_push<1>(st[j], one);
+            }
+        }
+      }
+      if (mine) a.ysel[q] = sel;
+    }
+  }
+  // the two half-waves (lane, lane ^ 32) hold the same tokens; then the two waves (wm = 0, 1) that share them
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    Osm o;
+    o.M = __shfl_xor(st[j].M, 32, 64);
+    o.S = __shfl_xor(st[j].S, 32, 64);
+    o.W = __shfl_xor(st[j].W, 32, 64);
+    st[j] = osm_merge(st[j], o);
+  }
+  __syncthreads();
+  float4* red = reinterpret_cast<float4*>(lds);  // [2][BN]
+  if (lane < 32) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) red[(wave >> 1) * BN + acc_col(lane, wcol0, j)] = float4{st[j].M, st[j].S, st[j].W, 0.0f};
+  }
+  __syncthreads();
+  for (int c = tid; c < BN; c += C::NT) {
+    const float4 x = red[c], z = red[BN + c];
+    const Osm m = osm_merge(Osm{x.x, x.y, x.z}, Osm{z.x, z.y, z.z});
+    reinterpret_cast<float4*>(a.part)[(int64_t)split * a.padded + n0 + c] = float4{m.M, m.S, m.W, 0.0f};
   }
 }
 
@@ -1592,12 +1879,17 @@ bool use_dual(Shape shape, const Terms& t) {
   if (shape != kWide || t.n != 2 || t.b[0] != t.b[1]) return false;
   return prl::tuning(PRL_TUNE_LMHEAD_DUAL, 1) != 0;
 }
+// 384 | 320: run the forward on the one-wave-per-SIMD core with that token tile (a table read; 0: not selected)
+int one_wave_bn() {
+  const int64_t v = prl::tuning(PRL_TUNE_LMHEAD_TILE, 0);
+  return (v == 384 || v == 320) ? (int)v : 0;
+}
 int shape_bm(Shape s) { return s == kSmall ? 128 : 256; }
 int shape_bn(Shape s) { return s == kWide ? 256 : 128; }
 
 template <class K, class A>
 int launch_tiles(K kfn, int threads, int lds_bytes, int blocks, const A& args, hipStream_t s, const char* name) {
-  static thread_local const void* configured[8] = {nullptr};
+  static thread_local const void* configured[32] = {nullptr};
   const void* key = reinterpret_cast<const void*>(kfn);
   bool seen = false;
   for (auto c : configured) seen = seen || c == key;
@@ -1744,7 +2036,14 @@ extern "C" int prl_lm_head_workspace_bytes(int64_t rows, int64_t cols, int64_t h
     const int k = fwd_nsplit(ceil_div(n, shape_bn(shp)), ceil_div(vocab, shape_bm(shp)), shp != kSmall);
     ns = k > ns ? k : ns;
   }
-  if (fwd_bytes) *fwd_bytes = align256((size_t)ns * padded * 16) + align256((size_t)padded * 4);
+  int64_t padded_max = padded;
+  for (int bn : {384, 320}) {  // the one-wave-per-SIMD forward pads the tokens to its own tile and picks its own split count
+    const int tt1 = ceil_div(n, bn);
+    const int k = fwd_nsplit(tt1, ceil_div(vocab, 256), true);
+    ns = k > ns ? k : ns;
+    padded_max = (int64_t)tt1 * bn > padded_max ? (int64_t)tt1 * bn : padded_max;
+  }
+  if (fwd_bytes) *fwd_bytes = align256((size_t)ns * padded_max * 16) + align256((size_t)padded_max * 4);
   if (bwd_bytes) {
     PRL_CHECK_ARG(chunk_rows >= 1, "chunk_rows must be >= 1");
     *bwd_bytes = bwd_layout(hidden, vocab, chunk_rows < n ? chunk_rows : n).total;
@@ -1776,10 +2075,11 @@ static int lm_head_fwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
   a.ids = input_ids;
   a.k2 = kLog2e / temperature;
   const Shape shape = pick_shape(vocab, n);
-  a.tt = ceil_div(n, shape_bn(shape));
-  a.vt = ceil_div(vocab, shape_bm(shape));
-  a.nsplit = fwd_nsplit(a.tt, a.vt, shape != kSmall);
-  a.padded = (int64_t)a.tt * shape_bn(shape);
+  const int one_bn = one_wave_bn();  // 384 | 320: the one-wave-per-SIMD core (PRL_TUNE_LMHEAD_TILE), 0: the 8-wave shapes
+  a.tt = ceil_div(n, one_bn ? one_bn : shape_bn(shape));
+  a.vt = ceil_div(vocab, one_bn ? 256 : shape_bm(shape));
+  a.nsplit = fwd_nsplit(a.tt, a.vt, one_bn || shape != kSmall);
+  a.padded = (int64_t)a.tt * (one_bn ? one_bn : shape_bn(shape));
   const size_t part_bytes = align256((size_t)a.nsplit * a.padded * 16);
   const size_t need = part_bytes + align256((size_t)a.padded * 4);
   if (workspace_bytes < need) return prl::set_error(PRL_ENOMEM, "lm_head forward workspace: %zu bytes given, %zu needed", workspace_bytes, need);
@@ -1789,7 +2089,24 @@ static int lm_head_fwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
   a.logits2 = logits2;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int exp_bits = (int)prl::tuning(PRL_TUNE_LMHEAD_EXP, 0);
-  if (use_dual(shape, a.terms)) {
+  if (one_bn) {
+    const int blocks = a.tt * a.nsplit;
+    int rc;
+    if (one_bn == 384 && exp_bits == 1) {  // PRL_TUNE_LMHEAD_EXP = 1: DMA-first issue + consumption-ordered reads
+      rc = w_lo ? launch_tiles(lmhead_fwd1_kernel<384, true, 1>, 256, CfgOne<384>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<384,dma first>")
+                : launch_tiles(lmhead_fwd1_kernel<384, false, 1>, 256, CfgOne<384>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<384,one plane,dma first>");
+    } else if (one_bn == 320 && exp_bits == 1) {
+      rc = w_lo ? launch_tiles(lmhead_fwd1_kernel<320, true, 1>, 256, CfgOne<320>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<320,dma first>")
+                : launch_tiles(lmhead_fwd1_kernel<320, false, 1>, 256, CfgOne<320>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<320,one plane,dma first>");
+    } else if (one_bn == 384) {
+      rc = w_lo ? launch_tiles(lmhead_fwd1_kernel<384, true>, 256, CfgOne<384>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<384>")
+                : launch_tiles(lmhead_fwd1_kernel<384, false>, 256, CfgOne<384>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<384,one plane>");
+    } else {
+      rc = w_lo ? launch_tiles(lmhead_fwd1_kernel<320, true>, 256, CfgOne<320>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<320>")
+                : launch_tiles(lmhead_fwd1_kernel<320, false>, 256, CfgOne<320>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<320,one plane>");
+    }
+    if (rc) return rc;
+  } else if (use_dual(shape, a.terms)) {
     if (exp_bits == 256) {  // A/B reference: DMA pieces interleaved with the MFMA groups, all waves alike
       if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 256, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual, interleaved)")) return rc;
     } else if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 0, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual)")) {

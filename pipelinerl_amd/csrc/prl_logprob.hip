@@ -484,6 +484,11 @@ __device__ __forceinline__ V load_vec(const V* p) {
 
 // NTHEAD: the chip-resident head is read exactly once -> stream it past the caches so that the
 // tail (which IS re-read) keeps its lines in L2 / Infinity Cache.
+// Measured in round 4 and NOT kept: TWO 512-thread workgroups per CU, each with the head of its own row on chip (16 + 9 or
+// 12 + 9 vectors per lane, registers capped at 128 for four waves per SIMD; one workgroup drains / reduces while the other
+// streams): 2020-2070 us against 1800-1820 us for the one 1024-thread workgroup below on the same box
+// (profiles/r04d_kernel_sweep_fused_variants.txt).  Each row keeps half as much on chip (33 % / 28 % instead of 67 %), the
+// re-read share of pass 2 doubles, and that costs more than the overlap of the two rows' phases buys.
 template <class T, int BLOCK, int UNROLL, int KREG, int KLDS, bool NTHEAD = false, class OUT = DenseOut<T>>
 __global__ __launch_bounds__(BLOCK) void fused_logits_loss_keep_kernel(
     RowGeom geo, FusedArgs a, const typename T::scalar* logits, float k2, float inv_temp,

@@ -122,7 +122,7 @@ def main():
         b0.ref_logprobs.data_ptr(), b0.advantages.data_ptr(), b0.rewards.data_ptr(), b0.group_tokens.data_ptr(), b0.overflow.data_ptr(),
         o_nlp.data_ptr(), o_ent.data_ptr(), o_lse.data_ptr(), grad.data_ptr(), stream))
     print("advantage of sequence 0:", float(b0.advantages[0, 0]))
-    for variant in (21, 6, 0, 21):  # the shapes still built (the full round-1 sweep: profiles/r01[c-f]_kernel_sweep*.txt)
+    for variant in (21, 6, 0, 21):  # the shapes still built (the full round-1 sweep: profiles/r01[c-f]_kernel_sweep*.txt; round 4: r04d_*) (the full round-1 sweep: profiles/r01[c-f]_kernel_sweep*.txt)
         os.environ["PRL_FUSED_VARIANT"] = str(variant)
         med, mn = timeit(fused, iters=8)
         report(f"fused K1+grad+K1' variant {variant} [algorithmic: read+write V*4/token]", 2 * T * V * 4, med, mn)

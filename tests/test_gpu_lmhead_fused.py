@@ -89,8 +89,9 @@ def _compare(loss, stats, gh, gw, want, scale=1.0):
 
 
 @pytest.mark.parametrize("keep", [True, False], ids=["kept_logits", "recompute"])
-@pytest.mark.parametrize("tile", ["256x256", "256", "128"], ids=["tile256x256", "tile256x128_ring3", "tile128x128"])
-@pytest.mark.parametrize("T,H,V", [(130, 64, 192), (257, 128, 320), (64, 192, 4160), (300, 64, 1088)])
+@pytest.mark.parametrize("tile", ["256x256", "256", "128", "256x384", "256x320"],
+                         ids=["tile256x256", "tile256x128_ring3", "tile128x128", "one_wave_per_simd_256x384", "one_wave_per_simd_256x320"])
+@pytest.mark.parametrize("T,H,V", [(130, 64, 192), (257, 128, 320), (64, 192, 4160), (300, 64, 1088), (900, 128, 1088)])
 def test_small_ragged_shapes(libprl, cuda_device, monkeypatch, tile, T, H, V, keep):
     """Tile edges everywhere: rows not a multiple of 128, a partly masked last vocabulary tile, one K step
     (fewer tiles than pipeline stages), both workgroup shapes; the backward from the logits the forward kept and the
@@ -121,7 +122,8 @@ def test_forward_values_and_split_count_independence(libprl, cuda_device, monkey
     w_nlp = lp[torch.arange(T - 1), ids[0, 1:]]
     w_ent = -(lp.exp() * lp).sum(-1)
     head = FusedLmHead(W, backward=False)
-    for tile, ns in (("256x256", "1"), ("256x256", "3"), ("256x256", "64"), ("256", "1"), ("256", "2"), ("256", "7"), ("256", "64"), ("128", "1"), ("128", "5"), ("128", "64")):
+    for tile, ns in (("256x256", "1"), ("256x256", "3"), ("256x256", "64"), ("256", "1"), ("256", "2"), ("256", "7"), ("256", "64"), ("128", "1"), ("128", "5"), ("128", "64"),
+                     ("256x384", "1"), ("256x384", "3"), ("256x384", "64"), ("256x320", "1"), ("256x320", "5")):
         monkeypatch.setenv("PRL_LMHEAD_NSPLIT", ns)
         monkeypatch.setenv("PRL_LMHEAD_TILE", tile)
         nlp, ent, lse2, _ = head.logprob_entropy(hidden, ids, 0.9)
@@ -130,8 +132,9 @@ def test_forward_values_and_split_count_independence(libprl, cuda_device, monkey
         assert torch.allclose(ent[0, 1:].double(), w_ent[:-1], rtol=FP_TOL, atol=2e-5), ns
 
 
-@pytest.mark.parametrize("tile", ["256x256", "256", "128", None, "recompute"],
-                         ids=["tile256x256", "tile256x128_ring3", "tile128x128", "default_dispatch", "default_dispatch_recompute"])
+@pytest.mark.parametrize("tile", ["256x256", "256", "128", None, "recompute", "256x384", "256x320"],
+                         ids=["tile256x256", "tile256x128_ring3", "tile128x128", "default_dispatch", "default_dispatch_recompute",
+                              "one_wave_per_simd_256x384", "one_wave_per_simd_256x320"])
 def test_qwen7b_head_shape_vs_oracle(libprl, cuda_device, monkeypatch, tile):
     """H = 3584, V = 152 064, fp32 weight (two bf16 planes): loss, statistics, d hidden, d W."""
     keep = tile != "recompute"  # the default keeps the logits for the backward; "recompute": no logits anywhere

@@ -37,7 +37,7 @@ def _pattern(nbytes: int, seed: int, dev) -> "torch.Tensor":
     return torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device=dev, generator=g)
 
 
-def _wsync_worker(rank: int, world: int, port: int, out_q) -> None:
+def _wsync_worker(rank: int, world: int, port: int, out_q, which: str = "7b") -> None:
     try:
         from pipelinerl_amd.weight_sync import BucketedReceiver, BucketedSender, ParamSpec, WeightSyncGroup
         from pipelinerl_amd.weight_sync_probe import qwen25_shapes
@@ -57,8 +57,9 @@ def _wsync_worker(rank: int, world: int, port: int, out_q) -> None:
                     bad = int((buf != want).sum())
                     errs.append(f"{mode} {n} bytes: {bad} bytes differ on rank {rank}")
                 del buf, want
-        # ---- the whole 7B update through the bucketed sender / receiver, every tensor verified
-        shapes = qwen25_shapes("7b")
+        # ---- the whole update (339 tensors / 15.2 GB for 7B, 771 tensors / 65.5 GB for 32B) through the bucketed sender /
+        # receiver, every tensor verified
+        shapes = qwen25_shapes(which)
         gen = torch.Generator(device=dev).manual_seed(77)
         params = [(n, torch.empty(s, dtype=torch.bfloat16, device=dev).normal_(generator=gen)) for n, s in shapes]
         if rank == 0:
@@ -82,14 +83,14 @@ def _wsync_worker(rank: int, world: int, port: int, out_q) -> None:
         out_q.put((rank, [f"{type(e).__name__}: {e}", traceback.format_exc()]))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_rccl_weight_broadcast_is_byte_exact(libprl, world):
+@pytest.mark.parametrize("world,which", [(2, "7b"), (4, "7b"), (3, "32b")], ids=["2_gpus_7b", "4_gpus_7b", "3_gpus_32b_65GB"])
+def test_rccl_weight_broadcast_is_byte_exact(libprl, world, which):
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs {world} GPUs")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_wsync_worker, args=(r, world, port, q), daemon=True) for r in range(world)]
+    procs = [ctx.Process(target=_wsync_worker, args=(r, world, port, q, which), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -103,7 +104,7 @@ def test_rccl_weight_broadcast_is_byte_exact(libprl, world):
         assert not results[r], (r, results[r])
 
 
-def _tp_shard_worker(rank: int, world: int, port: int, tp: int, out_q) -> None:
+def _tp_shard_worker(rank: int, world: int, port: int, tp: int, out_q, which: str = "7b") -> None:
     """rank 0 = trainer; ranks 1.. = TP rank (r - 1) % tp of engine (r - 1) // tp, one GPU each."""
     try:
         from pipelinerl_amd.tp_shard import plan_tp_shards, shard_view
@@ -115,8 +116,9 @@ def _tp_shard_worker(rank: int, world: int, port: int, tp: int, out_q) -> None:
         dev = torch.device("cuda", rank)
         torch.cuda.set_device(dev)
         groups = WeightSyncGroup.tp_shard_groups(f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, tp_size=tp, device=dev, timeout_s=120)
-        shapes = qwen25_shapes("7b")
-        cuts = plan_tp_shards(shapes, tp, kv_heads=4)
+        kv_heads = {"7b": 4, "32b": 8}[which]
+        shapes = qwen25_shapes(which)
+        cuts = plan_tp_shards(shapes, tp, kv_heads=kv_heads)
         gen = torch.Generator(device=dev).manual_seed(91)  # the same tensors on every rank: the workers check against them
         params = [(n, torch.empty(s, dtype=torch.bfloat16, device=dev).normal_(generator=gen)) for n, s in shapes]
         errs = []
@@ -129,7 +131,7 @@ def _tp_shard_worker(rank: int, world: int, port: int, tp: int, out_q) -> None:
                 errs.append(f"bytes per TP rank {sender.bytes_sent} of {total}")
         else:
             t = (rank - 1) % tp
-            w = StandaloneShardReceiver(shapes, lambda n: torch.bfloat16, dev, t, tp, kv_heads=4)
+            w = StandaloneShardReceiver(shapes, lambda n: torch.bfloat16, dev, t, tp, kv_heads=kv_heads)
             w.model_update_group, w.tp_rank, w.tp_size = groups[0], t, tp
             req = WeightUpdateRequest(version=1, transport="sharded", bucket_bytes=1 << 30, tp_size=tp,
                                       parameters_info=[ParameterInfo(name=n, shape=list(s), dtype="torch.bfloat16", shard_dim=cuts[n].dim,
@@ -148,17 +150,19 @@ def _tp_shard_worker(rank: int, world: int, port: int, tp: int, out_q) -> None:
         out_q.put((rank, [f"{type(e).__name__}: {e}", traceback.format_exc()]))
 
 
-@pytest.mark.parametrize("engines,tp", [(1, 2), (2, 2)])
-def test_tp_aware_update_over_rccl(libprl, engines, tp):
-    """The TP-aware update over RCCL: one communicator per TP rank, every worker receives half of the 7B parameter set
-    (its own slices), verified slice by slice."""
+@pytest.mark.parametrize("engines,tp,which", [(1, 2, "7b"), (2, 2, "7b"), (2, 2, "32b")],
+                         ids=["1_engine_tp2_7b", "2_engines_tp2_7b", "configs4_2_engines_tp2_32b"])
+def test_tp_aware_update_over_rccl(libprl, engines, tp, which):
+    """The TP-aware update over RCCL: one communicator per TP rank, every worker receives half of the parameter set
+    (its own slices), verified slice by slice.  `configs4_...`: BASELINE.json configs[4]'s receiver layout - two TP = 2
+    engines and the trainer, the 771-tensor / 65.5 GB Qwen2.5-32B set, 8 KV heads."""
     world = 1 + engines * tp
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs {world} GPUs")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_tp_shard_worker, args=(r, world, port, tp, q), daemon=True) for r in range(world)]
+    procs = [ctx.Process(target=_tp_shard_worker, args=(r, world, port, tp, q, which), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     try:
