@@ -487,10 +487,16 @@ struct CfgOne {
 // the first version of this kernel).  Tiles t < 16 are bound to AGPRs ("+a", 256 registers), the rest to VGPRs ("+v").
 // The MFMAs are volatile asm, so the compiler's hazard recogniser does not see them: `mfma_settle()` supplies the wait
 // states an MFMA result needs before anything but another MFMA touches it.
-template <bool IN_AGPR>
+// PIN: the asm also clobbers "memory", i.e. no LDS read and no LDS-DMA issue moves across it - the instruction stream
+// around the MFMAs is the one written in the source (the hand-placed interleave of MODE 2 below).
+template <bool IN_AGPR, bool PIN = false>
 __device__ __forceinline__ void mfma_bf16_asm(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  if constexpr (IN_AGPR) {
+  if constexpr (IN_AGPR && PIN) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b) : "memory");
+  } else if constexpr (IN_AGPR) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  } else if constexpr (PIN) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "memory");
   } else {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
   }
@@ -498,9 +504,11 @@ __device__ __forceinline__ void mfma_bf16_asm(f32x16& acc, const bf16x8& a, cons
 __device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
 // acc[i][j] += (A1 + A2)[m0 + 128 wm + 32 i .., :] B[n0 + WCOLS wn + 32 j .., :]^T over Kc.  HAS_LO = false: one plane (A2 unused).
-// MODE 0: the next stage's DMA pieces ride between the MFMA groups.  MODE 1: all of them right after the barrier (the whole
-// step to land - with two stages the step ends on vmcnt(0)) and the first group's fragment reads in the order the MFMAs
-// consume them (a0, b0 .. b5, a1 .. a3: the first MFMA waits for two reads, not fourteen).
+// MODE 0: the next stage's DMA pieces ride between the MFMA GROUPS (bursts of 3-4 per wave), the compiler places the reads.
+// MODE 2: a hand-placed stream - every MFMA is an order-pinning asm, ONE DMA piece after every 6th-7th MFMA, the next group's
+// fragment reads after the 4th MFMA of the current one.  Measured (7B forward, same box, interleaved;
+// profiles/r04d_lmhead_fwd_one_wave_per_simd_ab.jsonl): MODE 0 14.8 ms, all pieces in one burst after the barrier 15.95 ms,
+// MODE 2 13.46 ms against 13.85 ms for the shipped 8-wave dual-plane core (13.77 vs 13.96 on a second box).
 template <int BN_, bool HAS_LO, int MODE = 0>
 __device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
                                                   const Geom& g, int m0, int n0, char* lds) {
@@ -556,14 +564,21 @@ __device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], co
   // the DMA pieces of the next stage ride between the MFMA groups of this one: GROUPS = 2 * PLANES groups per step
   constexpr int GROUPS = 2 * PLANES;
   constexpr int PER = (LOADS + GROUPS - 1) / GROUPS;
-  auto compute = [&](int buf, int sbuf) {
+  // MODE 2: ONE piece after every SPACE-th MFMA.  A wave that is alone on its SIMD pays for every cycle a VMEM issue waits for
+  // room in the LDS-DMA path with an idle matrix pipe (no partner wave issues MFMAs meanwhile): bursts of 3-4 pieces per wave
+  // (16 KB per CU at ~21 B/clk = ~780 clocks) back the queue up, single pieces 6-7 MFMAs (~200 clocks) apart do not.
+  constexpr int MFMAS = GROUPS * 4 * NJ;
+  // (every 5th / 4th MFMA instead - the last piece issued earlier, more of the step left for it to land before the step-end
+  // vmcnt(0) of the two-stage ring - measured the same / 0.8 % slower: the landing time is not what the step waits for)
+  constexpr int SPACE = MFMAS / LOADS;
+  static_assert(MODE < 2 || (MFMAS - SPACE / 2 - 1) / SPACE + 1 >= LOADS, "not every DMA piece has an MFMA slot");
+  // NEXT (a type tag): whether a stage is issued during this step - compile-time, so the step is one straight-line block
+  auto compute = [&](int buf, int sbuf, auto next_tag) {
+    constexpr bool NEXT = decltype(next_tag)::value;
+    constexpr bool PIN = MODE >= 2;
     const char* base = lds + buf * C::STAGE_BYTES;
     bf16x8 bfr[2][NJ], af[2][4];  // bfr[ks]; af ping-pongs between consecutive MFMA groups
-    if (MODE == 1 && sbuf >= 0) {
-#pragma unroll
-      for (int k = 0; k < LOADS; ++k) stage_piece(sbuf, k);
-    }
-    if constexpr (MODE == 1) {
+    if constexpr (MODE != 0) {  // in the order the first MFMAs consume them
       af[0][0] = *reinterpret_cast<const bf16x8*>(base + rdA[0]);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(base + rdB[0] + j * 32 * ROW_BYTES32);
@@ -581,27 +596,36 @@ __device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], co
 #pragma unroll
       for (int pl = 0; pl < PLANES; ++pl) {
         const int cur = grp & 1, nxt = cur ^ 1;
-        // reads the NEXT group needs, issued before this group's MFMAs
-        if (pl + 1 < PLANES) {
+        // the reads the NEXT group needs: before this group's MFMAs (MODE 0 / 1), or after its first four (MODE 2: the pinned
+        // stream would otherwise start every group with a burst of reads in front of an idle matrix pipe)
+        auto prefetch = [&]() {
+          if (pl + 1 < PLANES) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) af[nxt][i] = *reinterpret_cast<const bf16x8*>(base + C::A_BYTES + rdA[ks] + i * 32 * ROW_BYTES32);
-        } else if (ks == 0) {
+            for (int i = 0; i < 4; ++i) af[nxt][i] = *reinterpret_cast<const bf16x8*>(base + C::A_BYTES + rdA[ks] + i * 32 * ROW_BYTES32);
+          } else if (ks == 0) {
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) bfr[1][j] = *reinterpret_cast<const bf16x8*>(base + rdB[1] + j * 32 * ROW_BYTES32);
+            for (int j = 0; j < NJ; ++j) bfr[1][j] = *reinterpret_cast<const bf16x8*>(base + rdB[1] + j * 32 * ROW_BYTES32);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) af[nxt][i] = *reinterpret_cast<const bf16x8*>(base + rdA[1] + i * 32 * ROW_BYTES32);
-        }
+            for (int i = 0; i < 4; ++i) af[nxt][i] = *reinterpret_cast<const bf16x8*>(base + rdA[1] + i * 32 * ROW_BYTES32);
+          }
+        };
+        if constexpr (MODE < 2) prefetch();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             if (i * NJ + j < 16) {
-              mfma_bf16_asm<true>(acc[i][j], af[cur][i], bfr[ks][j]);
+              mfma_bf16_asm<true, PIN>(acc[i][j], af[cur][i], bfr[ks][j]);
             } else {
-              mfma_bf16_asm<false>(acc[i][j], af[cur][i], bfr[ks][j]);
+              mfma_bf16_asm<false, PIN>(acc[i][j], af[cur][i], bfr[ks][j]);
+            }
+            if constexpr (MODE >= 2) {
+              const int m = grp * 4 * NJ + i * NJ + j;  // index of this MFMA in the step
+              if (i * NJ + j == 3) prefetch();
+              if (NEXT && m % SPACE == SPACE / 2 && m / SPACE < LOADS) stage_piece(sbuf, m / SPACE);
             }
           }
-        if (MODE == 0 && sbuf >= 0) {
+        if (MODE == 0 && NEXT) {
 #pragma unroll
           for (int k = 0; k < PER; ++k)
             if (grp * PER + k < LOADS) stage_piece(sbuf, grp * PER + k);
@@ -610,6 +634,8 @@ __device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], co
       }
     }
   };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
 
   constexpr int D = C::STAGES - 1;
   __syncthreads();
@@ -624,7 +650,7 @@ __device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], co
   int s = 0;
   for (; s + D < total; ++s) {
     wait_tile_then_barrier<(D - 1) * LOADS>();
-    compute(cur, nxt);
+    compute(cur, nxt, Yes{});
     st_k += BK32;
     cur = cur + 1 == C::STAGES ? 0 : cur + 1;
     nxt = nxt + 1 == C::STAGES ? 0 : nxt + 1;
@@ -635,7 +661,7 @@ __device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], co
     } else {
       wait_tile_then_barrier<0>();
     }
-    compute(cur, -1);
+    compute(cur, -1, No{});
     cur = cur + 1 == C::STAGES ? 0 : cur + 1;
   }
   mfma_settle();
@@ -2092,18 +2118,16 @@ static int lm_head_fwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
   if (one_bn) {
     const int blocks = a.tt * a.nsplit;
     int rc;
-    if (one_bn == 384 && exp_bits == 1) {  // PRL_TUNE_LMHEAD_EXP = 1: DMA-first issue + consumption-ordered reads
-      rc = w_lo ? launch_tiles(lmhead_fwd1_kernel<384, true, 1>, 256, CfgOne<384>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<384,dma first>")
-                : launch_tiles(lmhead_fwd1_kernel<384, false, 1>, 256, CfgOne<384>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<384,one plane,dma first>");
-    } else if (one_bn == 320 && exp_bits == 1) {
-      rc = w_lo ? launch_tiles(lmhead_fwd1_kernel<320, true, 1>, 256, CfgOne<320>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<320,dma first>")
-                : launch_tiles(lmhead_fwd1_kernel<320, false, 1>, 256, CfgOne<320>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<320,one plane,dma first>");
+    // the hand-placed stream (MODE 2) is the one-wave core; PRL_TUNE_LMHEAD_EXP = 256 selects the compiler-placed MODE 0 (A/B reference)
+    if (one_bn == 384 && exp_bits == 256) {
+      rc = w_lo ? launch_tiles(lmhead_fwd1_kernel<384, true, 0>, 256, CfgOne<384>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<384,grouped dma>")
+                : launch_tiles(lmhead_fwd1_kernel<384, false, 0>, 256, CfgOne<384>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<384,one plane,grouped dma>");
     } else if (one_bn == 384) {
-      rc = w_lo ? launch_tiles(lmhead_fwd1_kernel<384, true>, 256, CfgOne<384>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<384>")
-                : launch_tiles(lmhead_fwd1_kernel<384, false>, 256, CfgOne<384>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<384,one plane>");
+      rc = w_lo ? launch_tiles(lmhead_fwd1_kernel<384, true, 2>, 256, CfgOne<384>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<384>")
+                : launch_tiles(lmhead_fwd1_kernel<384, false, 2>, 256, CfgOne<384>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<384,one plane>");
     } else {
-      rc = w_lo ? launch_tiles(lmhead_fwd1_kernel<320, true>, 256, CfgOne<320>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<320>")
-                : launch_tiles(lmhead_fwd1_kernel<320, false>, 256, CfgOne<320>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<320,one plane>");
+      rc = w_lo ? launch_tiles(lmhead_fwd1_kernel<320, true, 2>, 256, CfgOne<320>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<320>")
+                : launch_tiles(lmhead_fwd1_kernel<320, false, 2>, 256, CfgOne<320>::LDS_BYTES, blocks, a, s, "lmhead_fwd1_kernel<320,one plane>");
     }
     if (rc) return rc;
   } else if (use_dual(shape, a.terms)) {
