@@ -26,8 +26,35 @@ print("head fwd ms", round(m["ms_per_launch"], 2), "keeping fwd ms", m.get("forw
 e = d["e2e"]
 print({k: e.get(k) for k in ("s_per_step", "samples_per_s", "peak_memory_GB", "source", "error")})
 print({k: round(v["avg_us"], 1) for k, v in d["kernels"].items()})
+p = d.get("preprocess_loop") or {}
+for k, c in (p.get("cases") or {}).items():
+    print(" pre", k, round(c["us_per_token"], 4), "us/tok planning", round(c["host_planning_frac"], 3))
+print(" pre speedup", p.get("speedup_vs_reference_preprocess_plus_collate"), "ref_logprob", {k: (round(v["old_ms"], 2), round(v["fused_ms"], 2)) for k, v in ((d.get("ref_logprob") or {}).get("heads") or {}).items()})
+print(" cpu_baseline", d["cpu_baseline"]["kind"], d["cpu_baseline"]["value"], "port", (d["cpu_baseline"].get("port") or {}).get("value"))
 PY
 cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-weight-sync --no-e2e --no-transport --no-live-pmc > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
 # the summary for profiles/: names shortened, ALL numeric columns kept (a width cut lost the dominant kernel's numbers in round 3)
 cd $GRAFT_REPO_ROOT; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do python scripts/kernel_stats_summary.py $f $OUT/bench_kernel_stats.csv; head -8 $OUT/bench_kernel_stats.csv; done
 find $OUT/prof -name "*kernel_trace.csv" -delete
+# the other two BASELINE workloads (configs[4]: 32B, KL on; configs[1]: 0.5B) and the head-tile A/B
+( time timeout 600 python bench.py --workload 32b_grpo_kl_bs4096_seq8192 --steps 2 --warmup 1 --no-preprocess-loop --no-transport ) > $OUT/bench_32b.log 2> $OUT/bench_32b.err
+echo "bench 32b exit $?"
+( time timeout 300 python bench.py --workload 0p5b_grpo_bs512_seq2048 --steps 5 --warmup 2 --no-preprocess-loop --no-transport ) > $OUT/bench_0p5b.log 2> $OUT/bench_0p5b.err
+echo "bench 0p5b exit $?"
+timeout 600 python scripts/lmhead_fwd_tile_ab.py --rounds 3 --iters 4 --tiles default,256x384,256x384:256,256x320 > $OUT/fwd_tile_ab.jsonl 2> $OUT/fwd_tile_ab.err
+timeout 300 python scripts/lmhead_fwd_tile_ab.py --rounds 3 --iters 4 --shapes 7b --keep --tiles default,256x384 >> $OUT/fwd_tile_ab.jsonl 2>> $OUT/fwd_tile_ab.err
+python - "$OUT" <<'PY'
+import json, sys
+out = sys.argv[1]
+for name in ("bench_32b", "bench_0p5b"):
+    try:
+        d = json.loads([l for l in open(f"{out}/{name}.log") if l.startswith("{")][0])
+    except Exception as e:
+        print(name, "no line", e); continue
+    m = d.get("roofline_mfma") or {}
+    print(name, round(d["value"], 1), "samples/s roofline", round(d["roofline"]["frac"], 4), "head fwd", m.get("ms_per_launch"), "bwd", (m.get("backward") or {}).get("ms"),
+          "ref_logprob", {k: (round(v["old_ms"], 2), round(v["fused_ms"], 2)) for k, v in ((d.get("ref_logprob") or {}).get("heads") or {}).items()},
+          "wsync", (d.get("weight_sync") or {}).get("median_ms"), "cpu", (d.get("cpu_baseline") or {}).get("kind"))
+for l in open(f"{out}/fwd_tile_ab.jsonl"):
+    d = json.loads(l); print(d["shape"], d["weight"], "keep" if d["keep_logits"] else "", d["ms"])
+PY
