@@ -520,7 +520,9 @@ def test_workspace_too_small_and_bad_shapes_are_refused(libprl, cuda_device):
     # 2 bf16 planes of 2048 x 152064 (row-major only: d W gathers its fragments with transposing LDS reads; round 2 wrote
     # four) + the transposed hidden chunk + 8 fp32 split-K slices of the d hidden chunk + the f16 / fp8 copies of the chunk's
     # hidden states for the mixed-precision recompute
-    assert fwd.value < 2 << 20 and 1.45e9 < bwd.value < 1.6e9
+    # forward: per-split partial softmax states, sized for whichever tile a launch may pick - the one-wave-per-SIMD tiles
+    # (256 x 320: 26 token tiles x 39 vocabulary splits) need the most, 5.3 MB
+    assert fwd.value < 8 << 20 and 1.45e9 < bwd.value < 1.6e9
 
 
 @pytest.mark.parametrize("T,H,V,wdt", [(300, 64, 1088, torch.float32), (257, 128, 320, torch.float32), (300, 128, 1088, torch.bfloat16),
