@@ -154,7 +154,7 @@ struct Prefaulter {
   static constexpr uint64_t kSlice = 2ull << 20;    // one madvise call
   std::mutex m;
   std::condition_variable cv;
-  std::thread th;
+  std::thread* th = nullptr;  // on the heap: a forked child abandons it (the thread does not exist there) instead of destroying it
   pid_t owner = 0;
   bool stop = false, disabled = false;
   uint8_t* base = nullptr;  // payload start of the segment being written
@@ -180,6 +180,7 @@ struct Prefaulter {
   }
   // called by the appending thread (under the log's writer lock): the segment now being written and how far it is filled
   void target(uint8_t* payload, uint64_t cap, uint64_t committed, bool new_segment) {
+    if (getpid() != owner) return;  // a handle inherited through fork(): no helper here, and the mutex may have been held at the fork
     std::lock_guard<std::mutex> lk(m);
     if (new_segment || payload != base) {
       base = payload;
@@ -195,20 +196,22 @@ struct Prefaulter {
   }
   void start() {
     owner = getpid();
-    th = std::thread([this] { run(); });
+    th = new (std::nothrow) std::thread([this] { run(); });
   }
-  void shutdown() {
-    if (!th.joinable()) return;
-    if (getpid() != owner) {  // a forked child inherited the object, not the thread: nothing to join
-      th.detach();
-      return;
+  // true: the helper is gone and the object may be deleted; false (a forked child): leave everything alone
+  bool shutdown() {
+    if (getpid() != owner) return false;
+    if (th) {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        stop = true;
+      }
+      cv.notify_all();
+      th->join();
+      delete th;
+      th = nullptr;
     }
-    {
-      std::lock_guard<std::mutex> lk(m);
-      stop = true;
-    }
-    cv.notify_all();
-    th.join();
+    return true;
   }
 };
 
@@ -567,8 +570,7 @@ extern "C" int prl_log_close(prl_log* l) {
   if (!l) return PRL_OK;
   if (l->reader_slot >= 0) l->ctl->reader_segment[l->reader_slot].store(kFree, std::memory_order_release);
   if (l->prefault) {  // before the segment is unmapped
-    l->prefault->shutdown();
-    delete l->prefault;
+    if (l->prefault->shutdown()) delete l->prefault;
     l->prefault = nullptr;
   }
   l->wseg.reset();

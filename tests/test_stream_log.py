@@ -445,3 +445,94 @@ def test_writer_takes_over_a_control_block_whose_creator_died(tmp_path):
         w.close()
     finally:
         Log.unlink_name(name)
+
+
+def test_appendv_gathers_a_record_in_place_and_validates_its_pieces(libprl):
+    """`prl_log_appendv`: one record gathered from several source ranges straight into the segment - the bytes equal the
+    record `append` would have been handed, alignment gaps are zeros whatever the page held before, pieces that overlap, go
+    backwards or leave the record are refused before anything is written."""
+    import ctypes
+
+    import numpy as np
+
+    from pipelinerl_amd import _lib
+    from pipelinerl_amd.ring import Log
+
+    name = f"prl_test_{time.time_ns()}"
+    w = Log(name, create=True, segment_bytes=1 << 16)
+    try:
+        head = np.frombuffer(b"HEADER-0123", dtype=np.uint8).copy()
+        a = np.arange(100, dtype=np.int64)
+        b = np.linspace(0, 1, 37, dtype=np.float32)
+        off_a, off_b = 16, 16 + 800 + 8  # 5 and 8 bytes of gap
+        total = off_b + b.nbytes + 3     # 3 trailing bytes no piece covers
+        w.append(b"\xff" * 4000)         # dirty the page the gathered record lands on... (the log is append-only: next record)
+        w.appendv([(head.ctypes.data, 0, head.nbytes), (a.ctypes.data, off_a, a.nbytes), (b.ctypes.data, off_b, b.nbytes)], total)
+        w.appendv([], 0)                 # an empty record is a record
+        want = bytearray(total)
+        want[:head.nbytes] = head.tobytes()
+        want[off_a:off_a + a.nbytes] = a.tobytes()
+        want[off_b:off_b + b.nbytes] = b.tobytes()
+        r = Log(name, reader=True, wait=2)
+        assert r.read(block=False) == b"\xff" * 4000
+        assert r.read(block=False) == want
+        assert r.read(block=False) == b""
+        r.close()
+        for bad in ([(a.ctypes.data, 8, 16), (a.ctypes.data, 16, 16)],   # overlap
+                    [(a.ctypes.data, 32, 8), (a.ctypes.data, 0, 8)],     # backwards
+                    [(a.ctypes.data, 0, 64)]):                           # past the end of a 32-byte record
+            with pytest.raises(_lib.PrlError):
+                w.appendv(bad, 32)
+        assert w.stats()["records"] == 3
+    finally:
+        w.close()
+        Log.unlink_name(name)
+
+
+def test_bulk_writer_prefaults_ahead_across_segment_rollovers_and_survives_fork(libprl):
+    """Writers of bulk topics (segments >= 4 MiB) own a helper thread that populates the segment ahead of the append position.
+    40 MB through 8 MiB segments (four rollovers; the helper's target moves with every append and segment change): every
+    record reads back intact.  A forked child that inherits the handle has no helper (threads do not survive fork): its
+    appends and its close neither hang nor touch the parent's helper."""
+    import os
+
+    import numpy as np
+
+    from pipelinerl_amd.ring import Log
+
+    name = f"prl_test_{time.time_ns()}"
+    w = Log(name, create=True, segment_bytes=8 << 20)
+    rng = np.random.default_rng(3)
+    recs = [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in rng.integers(200_000, 900_000, size=70)]
+    try:
+        for k, rec in enumerate(recs):
+            if k % 2:
+                w.append(rec)
+            else:
+                buf = np.frombuffer(rec, dtype=np.uint8)
+                half = len(rec) // 2 // 16 * 16
+                w.appendv([(buf.ctypes.data, 0, half), (buf.ctypes.data + half, half, len(rec) - half)], len(rec))
+            if k == 30:
+                pid = os.fork()
+                if pid == 0:
+                    try:
+                        w.append(b"from the child")
+                        w.close()
+                        os._exit(0)
+                    except BaseException:  # noqa: BLE001
+                        os._exit(1)
+                _, status = os.waitpid(pid, 0)
+                assert status == 0
+        assert w.stats()["segments"] >= 5
+        r = Log(name, reader=True, wait=2)
+        got = []
+        while True:
+            try:
+                got.append(bytes(r.read(block=False)))
+            except Exception:  # noqa: BLE001 - queue.Empty at the tail
+                break
+        r.close()
+        assert got[:31] == recs[:31] and got[31] == b"from the child" and got[32:] == recs[31:]
+    finally:
+        w.close()
+        Log.unlink_name(name)
