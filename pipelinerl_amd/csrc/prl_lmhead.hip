@@ -143,6 +143,26 @@ __device__ __forceinline__ void wait_tile_then_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// MFMAs as volatile asm with the accumulator bound to a register class by hand (used by the one-wave-per-SIMD core below,
+// whose 320-384 accumulators the register allocator cannot place, and by the hand-placed streams: MODE 2 of the loops).
+// The compiler's hazard recogniser does not see inside asm: `mfma_settle()` supplies the wait states an MFMA result needs
+// before anything but another MFMA touches it.
+// PIN: the asm also clobbers "memory", i.e. no LDS read and no LDS-DMA issue moves across it - the instruction stream
+// around the MFMAs is the one written in the source (the hand-placed interleave of MODE 2 below).
+template <bool IN_AGPR, bool PIN = false>
+__device__ __forceinline__ void mfma_bf16_asm(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  if constexpr (IN_AGPR && PIN) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b) : "memory");
+  } else if constexpr (IN_AGPR) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  } else if constexpr (PIN) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "memory");
+  } else {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  }
+}
+__device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
 // -----------------------------------------------------------------------------------------------
 // main loop: acc[i][j] (32 x 32 tiles of this wave's 64 x 64) += sum over terms and K
 // -----------------------------------------------------------------------------------------------
@@ -236,8 +256,46 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
   // with 64-deep stages the DMA burst of 8 pieces is long enough to delay the partner; kept behind EXP bit 512.
   constexpr bool STAGGER = C::NT == 512 && (EXP & 512) != 0;
   const bool dma_first = STAGGER && wave >= 4;
+  // HAND (EXP bit 1024, round 4): the hand-placed stream of gemm_mainloop_dual's MODE 2 on this core - order-pinning asm MFMAs,
+  // one LDS-DMA piece after every (MFMAS / LOADS)-th MFMA, the fragment reads of sub-step ks + 1 two per gap after the first
+  // MFMAs of sub-step ks
+  constexpr bool HAND = (EXP & 1024) != 0;
   auto compute = [&](int buf, int sbuf) {
     const char* base = lds + buf * C::STAGE_BYTES;
+    if constexpr (HAND) {
+      constexpr int NJ = C::NJ, PER_KS = 2 * NJ, MFMAS = 4 * PER_KS, SPACE = MFMAS / C::LOADS;
+      static_assert(SPACE >= 1 && (MFMAS - SPACE / 2 - 1) / SPACE + 1 >= C::LOADS, "not every DMA piece has an MFMA slot");
+      bf16x8 af[2][2], bfr[2][NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(base + rdA[0] + i * 32 * ROW_BYTES);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(base + rdB[0] + j * 32 * ROW_BYTES);
+      int m = 0;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            mfma_bf16_asm<false, true>(acc[i][j], af[cur][i], bfr[cur][j]);
+            const int t = i * NJ + j;  // position in this sub-step: the 2 + NJ reads of the next one go two per gap from t = 1 on
+            if (ks < 3 && t >= 1 && 2 * (t - 1) < 2 + NJ) {
+#pragma unroll
+              for (int r = 2 * (t - 1); r < 2 * t; ++r) {
+                if (r < 2) {
+                  af[nxt][r] = *reinterpret_cast<const bf16x8*>(base + rdA[ks + 1] + r * 32 * ROW_BYTES);
+                } else if (r < 2 + NJ) {
+                  bfr[nxt][r - 2] = *reinterpret_cast<const bf16x8*>(base + rdB[ks + 1] + (r - 2) * 32 * ROW_BYTES);
+                }
+              }
+            }
+            if (sbuf >= 0 && m % SPACE == SPACE / 2 && m / SPACE < C::LOADS) stage_piece(sbuf, m / SPACE);
+            ++m;
+          }
+      }
+      return;
+    }
     constexpr int GROUPS = (EXP & 1) ? 1 : (EXP & 8) ? 2 : 3;
     constexpr int PER = (C::LOADS + GROUPS - 1) / GROUPS;  // pieces after each of the first GROUPS MFMA groups
     if (STAGGER && sbuf >= 0 && dma_first) {
@@ -320,6 +378,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
     compute(cur, -1);
     cur = cur + 1 == C::STAGES ? 0 : cur + 1;
   }
+  if constexpr ((EXP & 1024) != 0) mfma_settle();
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -344,7 +403,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
 // intended (reads x 8, lgkmcnt(8), MFMA x 16, barrier, reads x 8, MFMA x 16; 248 VGPRs, no scratch) and was 3 % SLOWER:
 // forward 14.5 vs 14.0 ms, backward 60.9 vs 59.5 ms (profiles/r02w_lmhead_midstep_barrier_ab.txt).  The exposed LDS
 // latency after the barrier is not what the schedule is waiting for.
-template <int MODE = 0>
+template <int MODE = 2>
 __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
                                                    const Geom& g, int m0, int n0, char* lds) {
   using C = CfgDual;
@@ -379,8 +438,56 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
                                      (__attribute__((address_space(3))) void*)(lds + dst + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
   };
   const bool dma_first = MODE == 1 && wave >= 4;
-  auto compute = [&](int buf, int sbuf) {
+  // MODE 2 (round 4, the default): a hand-placed stream, every wave alike - order-pinning asm MFMAs, ONE LDS-DMA piece after
+  // every 5th MFMA (m = 2, 7, .. 27), the second half's fragment reads two per gap after MFMAs 3-6.  A piece costs its wave
+  // ~60 clocks of issue among bare MFMAs and 100-185 inside a burst (MI355X_MICROARCH.md): the staggered bursts of MODE 1
+  // hide that behind the partner wave's matrix cluster, single pieces between MFMAs mostly do not incur it.  7B forward, same
+  // box, interleaved, bit-identical outputs: 13.77 (MODE 1) -> 13.16 -> 12.97 ms with the spread reads (second box 13.82 -> 13.30;
+  // profiles/r04i_*, r04j_*).  NEXT (a type tag): whether a stage is issued.
+  auto compute = [&](int buf, int sbuf, auto next_tag) {
+    constexpr bool NEXT = decltype(next_tag)::value;
     const char* base = lds + buf * C::STAGE_BYTES;
+    if constexpr (MODE == 2) {
+      bf16x8 a1[2][2], a2[2][2], bfr[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a1[0][i] = *reinterpret_cast<const bf16x8*>(base + rdA[0] + i * 32 * ROW_BYTES32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(base + rdB[0] + j * 32 * ROW_BYTES32);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a2[0][i] = *reinterpret_cast<const bf16x8*>(base + C::TILE_BYTES + rdA[0] + i * 32 * ROW_BYTES32);
+      int m = 0;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              mfma_bf16_asm<false, true>(acc[i][j], pl == 0 ? a1[ks][i] : a2[ks][i], bfr[ks][j]);
+              // the eight fragment reads of the second half two per MFMA gap (after MFMAs 3, 4, 5, 6): all eight in one gap
+              // cost 1.4 % (13.16 -> 12.97 ms, profiles/r04i_*)
+              if (m == 3) {
+                a1[1][0] = *reinterpret_cast<const bf16x8*>(base + rdA[1]);
+                bfr[1][0] = *reinterpret_cast<const bf16x8*>(base + rdB[1]);
+              } else if (m == 4) {
+                bfr[1][1] = *reinterpret_cast<const bf16x8*>(base + rdB[1] + 32 * ROW_BYTES32);
+                bfr[1][2] = *reinterpret_cast<const bf16x8*>(base + rdB[1] + 2 * 32 * ROW_BYTES32);
+              } else if (m == 5) {
+                bfr[1][3] = *reinterpret_cast<const bf16x8*>(base + rdB[1] + 3 * 32 * ROW_BYTES32);
+                a1[1][1] = *reinterpret_cast<const bf16x8*>(base + rdA[1] + 32 * ROW_BYTES32);
+              } else if (m == 6) {
+                a2[1][0] = *reinterpret_cast<const bf16x8*>(base + C::TILE_BYTES + rdA[1]);
+                a2[1][1] = *reinterpret_cast<const bf16x8*>(base + C::TILE_BYTES + rdA[1] + 32 * ROW_BYTES32);
+              }
+              constexpr int PH = 2;  // the piece goes after the 3rd of each run of five MFMAs (after the 1st: +4.7 %, after the 5th: +0.3 %)
+              if (NEXT && m % 5 == PH && m / 5 < C::LOADS) stage_piece(sbuf, m / 5);
+              ++m;
+            }
+        }
+      }
+      return;
+    }
     if (MODE == 1 && sbuf >= 0 && dma_first) {
 #pragma unroll
       for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
@@ -438,7 +545,7 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
   int s = 0;
   for (; s + D < total; ++s) {
     wait_tile_then_barrier<(D - 1) * C::LOADS>();
-    compute(cur, nxt);
+    compute(cur, nxt, std::integral_constant<bool, true>{});
     st_k += BK32;
     cur = cur + 1 == C::STAGES ? 0 : cur + 1;
     nxt = nxt + 1 == C::STAGES ? 0 : nxt + 1;
@@ -449,9 +556,10 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
     } else {
       wait_tile_then_barrier<0>();
     }
-    compute(cur, -1);
+    compute(cur, -1, std::integral_constant<bool, false>{});
     cur = cur + 1 == C::STAGES ? 0 : cur + 1;
   }
+  if constexpr (MODE == 2) mfma_settle();
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -487,21 +595,6 @@ struct CfgOne {
 // the first version of this kernel).  Tiles t < 16 are bound to AGPRs ("+a", 256 registers), the rest to VGPRs ("+v").
 // The MFMAs are volatile asm, so the compiler's hazard recogniser does not see them: `mfma_settle()` supplies the wait
 // states an MFMA result needs before anything but another MFMA touches it.
-// PIN: the asm also clobbers "memory", i.e. no LDS read and no LDS-DMA issue moves across it - the instruction stream
-// around the MFMAs is the one written in the source (the hand-placed interleave of MODE 2 below).
-template <bool IN_AGPR, bool PIN = false>
-__device__ __forceinline__ void mfma_bf16_asm(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  if constexpr (IN_AGPR && PIN) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b) : "memory");
-  } else if constexpr (IN_AGPR) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-  } else if constexpr (PIN) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "memory");
-  } else {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-  }
-}
-__device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
 // acc[i][j] += (A1 + A2)[m0 + 128 wm + 32 i .., :] B[n0 + WCOLS wn + 32 j .., :]^T over Kc.  HAS_LO = false: one plane (A2 unused).
 // MODE 0: the next stage's DMA pieces ride between the MFMA GROUPS (bursts of 3-4 per wave), the compiler places the reads.
@@ -674,6 +767,13 @@ __device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], co
 // as their ROW (d logits hi / lo, [tokens, vocabulary]), B is contraction-contiguous as everywhere else.  The A tiles are
 // staged as they lie in memory (512-byte row segments) and the fragments come out of ds_read_b64_tr_b16 (layout header).
 // Same stage geometry, ring and wave roles as the dual-plane core.
+// HAND 0 (the default HERE): the round-3 schedule - staggered wave roles, the six pieces in one burst.  HAND 1: the hand-placed
+// stream of gemm_mainloop_dual's MODE 2 (order-pinning asm MFMAs, one LDS-DMA piece after every 5th MFMA, the second half's
+// fragment reads spread over the gaps after MFMAs 3-9) - measured SLOWER on this kernel: d W 19.1 ms against 16.7
+// (profiles/r04k_*).  Its A planes stream from HBM (5 GB per 8192 rows, L2 hit 80 %): the early burst of the staggered
+// schedule puts the whole stage in flight a step and a half before it is needed, the evenly spread pieces do not (a piece
+// every 4th MFMA from the 2nd on: 19.3 ms, the same).  Selectable with PRL_TUNE_LMHEAD_BWD bit 3 for A/B.
+template <int HAND = 0>
 __device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
                                                       const Geom& g, int m0, int n0, char* lds) {
   using C = CfgDual;
@@ -718,6 +818,46 @@ __device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const
   };
   auto compute = [&](int buf, int sbuf) {
     const char* base = lds + buf * C::STAGE_BYTES;
+    if constexpr (HAND != 0) {
+      bf16x8 a1[2][2], a2[2][2], bfr[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a1[0][i] = a_frag(base, i, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(base + rdB[0] + j * 32 * ROW_BYTES32);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a2[0][i] = a_frag(base + C::TILE_BYTES, i, 0);
+      int m = 0;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              mfma_bf16_asm<false, true>(acc[i][j], pl == 0 ? a1[ks][i] : a2[ks][i], bfr[ks][j]);
+              if (m == 3) {
+                a1[1][0] = a_frag(base, 0, 1);
+              } else if (m == 4) {
+                bfr[1][0] = *reinterpret_cast<const bf16x8*>(base + rdB[1]);
+                bfr[1][1] = *reinterpret_cast<const bf16x8*>(base + rdB[1] + 32 * ROW_BYTES32);
+              } else if (m == 5) {
+                bfr[1][2] = *reinterpret_cast<const bf16x8*>(base + rdB[1] + 2 * 32 * ROW_BYTES32);
+                bfr[1][3] = *reinterpret_cast<const bf16x8*>(base + rdB[1] + 3 * 32 * ROW_BYTES32);
+              } else if (m == 6) {
+                a1[1][1] = a_frag(base, 1, 1);
+              } else if (m == 8) {
+                a2[1][0] = a_frag(base + C::TILE_BYTES, 0, 1);
+              } else if (m == 9) {
+                a2[1][1] = a_frag(base + C::TILE_BYTES, 1, 1);
+              }
+              if (sbuf >= 0 && m % 5 == 2 && m / 5 < C::LOADS) stage_piece(sbuf, m / 5);
+              ++m;
+            }
+        }
+      }
+      return;
+    }
     if (sbuf >= 0 && dma_first) {
 #pragma unroll
       for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
@@ -773,6 +913,7 @@ __device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const
     compute(cur, -1);
     cur = cur + 1 == C::STAGES ? 0 : cur + 1;
   }
+  if constexpr (HAND != 0) mfma_settle();
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -796,6 +937,9 @@ struct CfgTriple {
   static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;  // 128 KB
 };
 
+// HAND (round 4, the default): hand-placed stream - order-pinning asm MFMAs, one LDS-DMA piece after every 6th MFMA (eight
+// pieces, 48 MFMAs), the second half's twelve fragment reads two per gap after MFMAs 3-8; false: the round-3 schedule.
+template <bool HAND = true>
 __device__ __forceinline__ void gemm_mainloop_triple(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B1,
                                                      const uint16_t* B2, const Geom& g, int m0, int n0, char* lds) {
   using C = CfgTriple;
@@ -832,6 +976,61 @@ __device__ __forceinline__ void gemm_mainloop_triple(f32x16 (&acc)[2][4], const 
   const bool dma_first = wave >= 4;
   auto compute = [&](int buf, int sbuf) {
     const char* base = lds + buf * C::STAGE_BYTES;
+    if constexpr (HAND) {
+      // Products of a stage, MFMA index m: ks0 a1 b1 (0-7), a2 b1 (8-15), a1 b2 (16-23); ks1 the same at 24-47.  The second half's
+      // fragments are read INTO THE REGISTERS OF FRAGMENTS THAT ARE DEAD BY THEN (a full second set next to 128 accumulators
+      // spills: 56 registers measured): after m = 15 b1 and a2 are dead -> a1', b1' (needed at 24) are read at m = 16-19; after
+      // m = 23 a1 and b2 are dead -> a2' (needed at 32) and b2' (needed at 40) are read at m = 24-28.
+      bf16x8 a1[2], a2[2], b1[4], b2[4], a1n[2], a2n[2], b1n[4], b2n[4];
+      auto rd = [&](int off) { return *reinterpret_cast<const bf16x8*>(base + off); };
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a1[i] = rd(rdA[0] + i * 32 * ROW_BYTES32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b1[j] = rd(rdB[0] + j * 32 * ROW_BYTES32);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a2[i] = rd(C::TILE_BYTES + rdA[0] + i * 32 * ROW_BYTES32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b2[j] = rd(C::TILE_BYTES + rdB[0] + j * 32 * ROW_BYTES32);
+      int m = 0;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {  // a1 b1, a2 b1, a1 b2: the MFMAs into one tile are 8 instructions apart
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (ks == 0) {
+                mfma_bf16_asm<false, true>(acc[i][j], pr == 1 ? a2[i] : a1[i], pr == 2 ? b2[j] : b1[j]);
+              } else {
+                mfma_bf16_asm<false, true>(acc[i][j], pr == 1 ? a2n[i] : a1n[i], pr == 2 ? b2n[j] : b1n[j]);
+              }
+              if (m == 16) {
+                a1n[0] = rd(rdA[1]);
+                b1n[0] = rd(rdB[1]);
+              } else if (m == 17) {
+                b1n[1] = rd(rdB[1] + 32 * ROW_BYTES32);
+                b1n[2] = rd(rdB[1] + 2 * 32 * ROW_BYTES32);
+              } else if (m == 18) {
+                b1n[3] = rd(rdB[1] + 3 * 32 * ROW_BYTES32);
+                a1n[1] = rd(rdA[1] + 32 * ROW_BYTES32);
+              } else if (m == 24) {
+                a2n[0] = rd(C::TILE_BYTES + rdA[1]);
+                a2n[1] = rd(C::TILE_BYTES + rdA[1] + 32 * ROW_BYTES32);
+              } else if (m == 25) {
+                b2n[0] = rd(C::TILE_BYTES + rdB[1]);
+                b2n[1] = rd(C::TILE_BYTES + rdB[1] + 32 * ROW_BYTES32);
+              } else if (m == 26) {
+                b2n[2] = rd(C::TILE_BYTES + rdB[1] + 2 * 32 * ROW_BYTES32);
+                b2n[3] = rd(C::TILE_BYTES + rdB[1] + 3 * 32 * ROW_BYTES32);
+              }
+              if (sbuf >= 0 && m % 6 == 2 && m / 6 < C::LOADS) stage_piece(sbuf, m / 6);
+              ++m;
+            }
+        }
+      }
+      return;
+    }
     if (sbuf >= 0 && dma_first) {
 #pragma unroll
       for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
@@ -883,6 +1082,7 @@ __device__ __forceinline__ void gemm_mainloop_triple(f32x16 (&acc)[2][4], const 
     st_k += BK32;
     cur ^= 1;
   }
+  if constexpr (HAND) mfma_settle();
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -1051,7 +1251,7 @@ __device__ __forceinline__ void gemm_mainloop_mx(f32x16 (&acc)[2][4], const uint
 template <class C, bool DUAL, int EXP = 0>
 __device__ __forceinline__ void run_mainloop(f32x16 (&acc)[2][C::NJ], const Terms& t, const Geom& g, int m0, int n0, char* lds) {
   if constexpr (DUAL) {
-    gemm_mainloop_dual<(EXP & 256) ? 0 : 1>(acc, t.a[0], t.a[1], t.b[0], g, m0, n0, lds);
+    gemm_mainloop_dual<(EXP & 256) ? 0 : (EXP & 512) ? 1 : 2>(acc, t.a[0], t.a[1], t.b[0], g, m0, n0, lds);
   } else {
     gemm_mainloop<C, EXP>(acc, t, g, m0, n0, lds);
   }
@@ -1633,7 +1833,7 @@ struct Dh3Args {
 
 // TRIPLE false: two products that share W^T_hi - (dl_hi + dl_lo) W^T_hi, the whole d hidden of a bf16 weight (b2 unused) - on the
 // dual-plane core of the forward: same work items, same raster, three staged tiles per stage instead of four.
-template <bool TRIPLE>
+template <bool TRIPLE, bool HAND = true>
 __global__ __launch_bounds__(CfgTriple::NT, 2) void gemm_dh_kernel(Dh3Args a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   using C = CfgTriple;  // (the tile geometry of CfgDual is the same)
@@ -1669,9 +1869,9 @@ __global__ __launch_bounds__(CfgTriple::NT, 2) void gemm_dh_kernel(Dh3Args a) {
     g.Kc = n * BK32;
     const int64_t k0 = (int64_t)s * BK32;
     if constexpr (TRIPLE) {
-      gemm_mainloop_triple(acc, a.a1 + k0, a.a2 + k0, a.b1 + k0, a.b2 + k0, g, m0, n0, lds);
+      gemm_mainloop_triple<HAND>(acc, a.a1 + k0, a.a2 + k0, a.b1 + k0, a.b2 + k0, g, m0, n0, lds);
     } else {
-      gemm_mainloop_dual<1>(acc, a.a1 + k0, a.a2 + k0, a.b1 + k0, g, m0, n0, lds);
+      gemm_mainloop_dual<HAND ? 2 : 1>(acc, a.a1 + k0, a.a2 + k0, a.b1 + k0, g, m0, n0, lds);
     }
   }
   float* out = a.partial + (a.ksplit > 1 ? (int64_t)kz * a.geo.M * a.geo.N : 0);
@@ -1691,6 +1891,7 @@ __global__ __launch_bounds__(CfgTriple::NT, 2) void gemm_dh_kernel(Dh3Args a) {
 
 // d W on the transposed-A dual-plane core: out[v, n] (+)= sum over the chunk's tokens t of (dl_hi + dl_lo)[t, v] hT[n, t].
 // terms.a[0] / a[1] = the ROW-MAJOR d-logits planes [Kc, lda], terms.b[0] = hidden^T [N, ldb].
+template <int HAND = 0>
 __global__ __launch_bounds__(CfgDual::NT, 2) void gemm_dw_tr_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   using C = CfgDual;
@@ -1716,7 +1917,7 @@ __global__ __launch_bounds__(CfgDual::NT, 2) void gemm_dw_tr_kernel(GemmArgs a) 
   const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
   f32x16 acc[2][4];
   zero_acc<4>(acc);
-  gemm_mainloop_dual_tr(acc, a.terms.a[0], a.terms.a[1], a.terms.b[0], a.geo, m0, n0, lds);
+  gemm_mainloop_dual_tr<HAND>(acc, a.terms.a[0], a.terms.a[1], a.terms.b[0], a.geo, m0, n0, lds);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -2131,11 +2332,17 @@ static int lm_head_fwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
     }
     if (rc) return rc;
   } else if (use_dual(shape, a.terms)) {
-    if (exp_bits == 256) {  // A/B reference: DMA pieces interleaved with the MFMA groups, all waves alike
+    if (exp_bits == 512) {  // A/B reference: the round-2 / round-3 default (staggered wave roles, DMA pieces in bursts of six)
+      if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 512, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual, staggered bursts)")) return rc;
+    } else if (exp_bits == 256) {  // A/B reference: DMA pieces interleaved with the MFMA groups, all waves alike
       if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 256, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual, interleaved)")) return rc;
     } else if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 0, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual)")) {
       return rc;
     }
+  } else if (shape == kWide && exp_bits != 512) {
+    // one plane (a bf16 weight) at the 256 x 256 shape: the generic 64-deep core as a hand-placed stream (round 4; 7B 7.88 -> 7.53 ms,
+    // 32B 11.14 -> 10.56 ms, bit-identical, profiles/r04m_*); PRL_TUNE_LMHEAD_EXP = 512 selects the compiler-placed form
+    if (int rc = launch_tiles(lmhead_fwd_kernel<CfgWide, 1024, 0>, CfgWide::NT, CfgWide::LDS_BYTES, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(generic, hand-placed)")) return rc;
   } else if (int rc = PRL_LAUNCH_CFG(shape, lmhead_fwd_kernel, a.tt * a.nsplit, a, s, "lmhead_fwd_kernel")) {
     return rc;
   }
@@ -2343,11 +2550,18 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
         d3.ksplit = ceil_div(steps32, d3.ksteps);  // no empty slice
         const bool direct = d3.ksplit == 1 && !g.out_bf16;  // a single fp32 slice IS the output
         d3.partial = direct ? static_cast<float*>(g.out) : g.partial;
+        // PRL_TUNE_LMHEAD_BWD bit 2: the round-3 schedules (staggered wave roles, DMA pieces in bursts) instead of the hand-placed streams
+        const bool old_sched = (prl::tuning(PRL_TUNE_LMHEAD_BWD, 0) & 4) != 0;
+        const int dh_blocks = d3.mt * d3.nt * d3.ksplit;
+        int rc;
         if (triple) {
-          if (int rc = launch_tiles(gemm_dh_kernel<true>, CfgTriple::NT, CfgTriple::LDS_BYTES, d3.mt * d3.nt * d3.ksplit, d3, s, "gemm_dh_kernel(d hidden, 3 products)")) return rc;
-        } else if (int rc = launch_tiles(gemm_dh_kernel<false>, CfgDual::NT, CfgDual::LDS_BYTES, d3.mt * d3.nt * d3.ksplit, d3, s, "gemm_dh_kernel(d hidden, 2 products)")) {
-          return rc;
+          rc = old_sched ? launch_tiles(gemm_dh_kernel<true, false>, CfgTriple::NT, CfgTriple::LDS_BYTES, dh_blocks, d3, s, "gemm_dh_kernel(d hidden, 3 products, round-3 schedule)")
+                         : launch_tiles(gemm_dh_kernel<true, true>, CfgTriple::NT, CfgTriple::LDS_BYTES, dh_blocks, d3, s, "gemm_dh_kernel(d hidden, 3 products)");
+        } else {
+          rc = old_sched ? launch_tiles(gemm_dh_kernel<false, false>, CfgDual::NT, CfgDual::LDS_BYTES, dh_blocks, d3, s, "gemm_dh_kernel(d hidden, 2 products, round-3 schedule)")
+                         : launch_tiles(gemm_dh_kernel<false, true>, CfgDual::NT, CfgDual::LDS_BYTES, dh_blocks, d3, s, "gemm_dh_kernel(d hidden, 2 products)");
         }
+        if (rc) return rc;
         slices = direct ? 0 : d3.ksplit;
       } else {
         const int steps = (int)(vocab / BK);
@@ -2399,7 +2613,12 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
         const int pa = -g.ksteps, per_xcd = ceil_div(ceil_div(g.mt, 8), pa) * pa;
         dw_blocks = 8 * per_xcd * g.nt;
       }
-      if (int rc = PRL_LAUNCH_DUAL(gemm_dw_tr_kernel, dw_blocks, g, s, "gemm_dw_tr_kernel(d weight)")) return rc;
+      const int64_t bwd_bits = prl::tuning(PRL_TUNE_LMHEAD_BWD, 0);
+      if (bwd_bits & 8) {  // A/B: the hand-placed stream (measured slower here, see gemm_mainloop_dual_tr)
+        if (int rc = PRL_LAUNCH_DUAL(gemm_dw_tr_kernel<1>, dw_blocks, g, s, "gemm_dw_tr_kernel(d weight, hand-placed)")) return rc;
+      } else if (int rc = PRL_LAUNCH_DUAL(gemm_dw_tr_kernel<0>, dw_blocks, g, s, "gemm_dw_tr_kernel(d weight)")) {
+        return rc;
+      }
     }
   }
   return PRL_OK;
