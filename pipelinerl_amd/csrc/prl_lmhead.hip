@@ -162,6 +162,27 @@ __device__ __forceinline__ void mfma_bf16_asm(f32x16& acc, const bf16x8& a, cons
   }
 }
 __device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+// The other direction: an accumulator register written by a VALU instruction (the caller's zero fill, a copy) needs wait
+// states before an MFMA reads it as SrcC - and hipcc, which does not see the asm MFMAs, likes to sink the zero fill of a
+// tile right in front of the first instruction that uses it (found the hard way: `v_mov_b64 v[56:57], 0` immediately
+// followed by the first MFMA into v[56:71] left ONE accumulator register of one tile with its stale contents -
+// scripts/exp/lmhead_ps_debug.py).  `mfma_pin_acc` makes every tile pass through an opaque asm AT LOOP ENTRY - the fill must
+// be complete there - and the pipeline fill that follows (LDS-DMA issue, barrier, fragment reads) puts hundreds of clocks
+// between it and the first MFMA; from then on the tiles only flow from asm to asm.
+template <int AGPR_TILES = 0, int NI, int NJ>
+__device__ __forceinline__ void mfma_pin_acc(f32x16 (&acc)[NI][NJ]) {
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (i * NJ + j < AGPR_TILES) {
+        asm volatile("" : "+a"(acc[i][j]));
+      } else {
+        asm volatile("" : "+v"(acc[i][j]));
+      }
+    }
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+}
 
 // -----------------------------------------------------------------------------------------------
 // main loop: acc[i][j] (32 x 32 tiles of this wave's 64 x 64) += sum over terms and K
@@ -348,6 +369,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
     }
   };
 
+  if constexpr ((EXP & 1024) != 0) mfma_pin_acc(acc);
   constexpr int D = C::STAGES - 1;  // tiles of loads in flight ahead of the one being computed
   __syncthreads();                  // whoever used the LDS before (previous tile, an epilogue) is done with it
 #pragma unroll
@@ -532,6 +554,7 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
     }
   };
 
+  if constexpr (MODE == 2) mfma_pin_acc(acc);
   constexpr int D = C::STAGES - 1;
   __syncthreads();
 #pragma unroll
@@ -560,6 +583,171 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
     cur = cur + 1 == C::STAGES ? 0 : cur + 1;
   }
   if constexpr (MODE == 2) mfma_settle();
+}
+
+// -----------------------------------------------------------------------------------------------
+// dual-plane main loop, PHASE-SHIFTED: the workgroup barrier sits in the MIDDLE of the step
+// -----------------------------------------------------------------------------------------------
+// In gemm_mainloop_dual every step begins behind a barrier with eight fragment reads in front of an idle matrix pipe (the
+// reads cannot be issued earlier: the barrier is what certifies the stage).  Here the ONE barrier of step s - "A(s)" - sits
+// between its two 16-MFMA halves and certifies stage s + 1: the first half's fragments of stage s + 1 are then read during
+// the SECOND half of step s (into the registers the first half just released) and step s + 1 starts with MFMAs.  Ring of 3:
+//   A(s) = s_waitcnt vmcnt(6) lgkmcnt(0); s_barrier   - every wave's pieces of stage s + 1 have landed (the six pieces of
+//          stage s + 2, issued since A(s - 1), may still be out), and every wave's reads of stage s are complete (its second
+//          half's were issued at MFMAs 3-6 of this step) -> the buffer of stage s is free
+//   pieces issued between A(s) and A(s + 1) (MFMAs 17, 22, 27 of step s; 2, 7, 12 of step s + 1) go to stage s + 3, into the
+//          buffer stage s just left; they have a whole step to land before A(s + 2) needs them
+// The stream is the hand-placed one of MODE 2 (order-pinning asm MFMAs, one piece per five MFMAs, reads two per gap).
+// Needs at least 6 stages of contraction (shorter ones take gemm_mainloop_dual).  Measured, same box, interleaved, bit-identical
+// outputs (profiles/r04p_*): 7B forward 13.87 (round-3 schedule) -> 13.25 (MODE 2) -> 12.87 ms; 32B 19.85 -> 19.02 -> 18.06 ms.
+// (Round 2 tried the mid-step barrier on the compiler-scheduled stream and lost 3 %; with every read and DMA issue pinned
+// between specific MFMAs it is the other way round.)
+template <bool P1, int BAR, bool RD, bool P2>
+struct PsFlags {
+  static constexpr bool p1 = P1, rd = RD, p2 = P2;
+  static constexpr int bar = BAR;  // -1: no barrier, else the vmcnt of A(s)
+};
+
+__device__ __forceinline__ void gemm_mainloop_dual_ps(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
+                                                      const Geom& g, int m0, int n0, char* lds) {
+  using C = CfgDual;
+  const int total = g.Kc / BK32;
+  if (total < 6) {
+    gemm_mainloop_dual<2>(acc, A1, A2, B, g, m0, n0, lds);
+    return;
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kcol = stage_kcol32(tid);
+  int64_t offA[C::Q], offB[C::Q];
+#pragma unroll
+  for (int q = 0; q < C::Q; ++q) {
+    int ra = m0 + stage_row32(tid, q, C::NT);
+    ra = ra < g.M ? ra : g.M - 1;
+    int rb = n0 + stage_row32(tid, q, C::NT);
+    rb = rb < g.N ? rb : g.N - 1;
+    offA[q] = (int64_t)ra * g.lda + kcol;
+    offB[q] = (int64_t)rb * g.ldb + kcol;
+  }
+  int rdA[2], rdB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    rdA[ks] = frag_lds_byte32(lane, wm * 64, 0, ks);
+    rdB[ks] = 2 * C::TILE_BYTES + frag_lds_byte32(lane, wn * C::WCOLS, 0, ks);
+  }
+  // piece idx (0..5: A1 q0 q1, A2 q0 q1, B q0 q1) of stage `stage` into ring buffer stage % 3
+  auto stage_piece = [&](int buf, int stage_k, int idx) {
+    const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
+    const int tile = idx / C::Q, q = idx % C::Q;
+    const uint16_t* src = tile == 0 ? A1 + offA[q] : tile == 1 ? A2 + offA[q] : B + offB[q];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + stage_k),
+                                     (__attribute__((address_space(3))) void*)(lds + dst + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
+  };
+  bf16x8 a1[2][2], a2[2][2], bfr[2][4];  // [half][tile]
+  auto rd = [&](const char* base, int off) { return *reinterpret_cast<const bf16x8*>(base + off); };
+
+  mfma_pin_acc(acc);
+  __syncthreads();  // whoever used the LDS before is done with it
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int idx = 0; idx < C::LOADS; ++idx) stage_piece(t, t * BK32, idx);
+  wait_tile_then_barrier<2 * C::LOADS>();  // stage 0 has landed
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a1[0][i] = rd(lds, rdA[0] + i * 32 * ROW_BYTES32);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bfr[0][j] = rd(lds, rdB[0] + j * 32 * ROW_BYTES32);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a2[0][i] = rd(lds, C::TILE_BYTES + rdA[0] + i * 32 * ROW_BYTES32);
+
+  // buffers: b0 = stage s, b1 = stage s + 1, b2 = stage s + 2 (= where the first-half pieces of stage s + 2 go);
+  // stage s + 3 goes into b0 after A(s)
+  auto step = [&](int s, int b0, int b1, int b2, auto flags) {
+    using F = decltype(flags);
+    const char* base = lds + b0 * C::STAGE_BYTES;
+    const char* next = lds + b1 * C::STAGE_BYTES;
+    int m = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1 && F::bar >= 0) {
+        if constexpr (F::bar == 0) {
+          wait_tile_then_barrier<0>();
+        } else {
+          wait_tile_then_barrier<C::LOADS>();
+        }
+      }
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            mfma_bf16_asm<false, true>(acc[i][j], pl == 0 ? a1[h][i] : a2[h][i], bfr[h][j]);
+            if (h == 0) {  // second half's fragments of THIS stage
+              if (m == 3) {
+                a1[1][0] = rd(base, rdA[1]);
+                bfr[1][0] = rd(base, rdB[1]);
+              } else if (m == 4) {
+                bfr[1][1] = rd(base, rdB[1] + 32 * ROW_BYTES32);
+                bfr[1][2] = rd(base, rdB[1] + 2 * 32 * ROW_BYTES32);
+              } else if (m == 5) {
+                bfr[1][3] = rd(base, rdB[1] + 3 * 32 * ROW_BYTES32);
+                a1[1][1] = rd(base, rdA[1] + 32 * ROW_BYTES32);
+              } else if (m == 6) {
+                a2[1][0] = rd(base, C::TILE_BYTES + rdA[1]);
+                a2[1][1] = rd(base, C::TILE_BYTES + rdA[1] + 32 * ROW_BYTES32);
+              }
+              if (F::p1 && m % 5 == 2) stage_piece(b2, (s + 2) * BK32, 3 + m / 5);  // m = 2, 7, 12 -> pieces 3, 4, 5 of stage s + 2
+            } else {  // first half's fragments of the NEXT stage (certified by the barrier above)
+              if (F::rd) {
+                if (m == 19) {
+                  a1[0][0] = rd(next, rdA[0]);
+                  bfr[0][0] = rd(next, rdB[0]);
+                } else if (m == 20) {
+                  bfr[0][1] = rd(next, rdB[0] + 32 * ROW_BYTES32);
+                  bfr[0][2] = rd(next, rdB[0] + 2 * 32 * ROW_BYTES32);
+                } else if (m == 21) {
+                  bfr[0][3] = rd(next, rdB[0] + 3 * 32 * ROW_BYTES32);
+                  a1[0][1] = rd(next, rdA[0] + 32 * ROW_BYTES32);
+                } else if (m == 22) {
+                  a2[0][0] = rd(next, C::TILE_BYTES + rdA[0]);
+                  a2[0][1] = rd(next, C::TILE_BYTES + rdA[0] + 32 * ROW_BYTES32);
+                }
+              }
+              if (F::p2 && m % 5 == 2) stage_piece(b0, (s + 3) * BK32, (m - 17) / 5);  // m = 17, 22, 27 -> pieces 0, 1, 2 of stage s + 3
+            }
+            ++m;
+          }
+    }
+  };
+  int b0 = 0, b1 = 1, b2 = 2;
+  auto rotate = [&]() {
+    const int t = b0;
+    b0 = b1;
+    b1 = b2;
+    b2 = t;
+  };
+  // s = 0: the prologue issued stage 2 completely
+  step(0, b0, b1, b2, PsFlags<false, C::LOADS, true, true>{});
+  rotate();
+  int s = 1;
+  for (; s + 3 < total; ++s) {  // stages s + 2 and s + 3 exist
+    step(s, b0, b1, b2, PsFlags<true, C::LOADS, true, true>{});
+    rotate();
+  }
+  // s = total - 3: stage s + 2 is the last one
+  step(s, b0, b1, b2, PsFlags<true, C::LOADS, true, false>{});
+  rotate();
+  ++s;
+  // s = total - 2: nothing left to issue; A(s) waits for the last stage (nothing younger is out)
+  step(s, b0, b1, b2, PsFlags<false, 0, true, false>{});
+  rotate();
+  ++s;
+  // s = total - 1
+  step(s, b0, b1, b2, PsFlags<false, -1, false, false>{});
+  mfma_settle();
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -730,6 +918,7 @@ __device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], co
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
 
+  mfma_pin_acc<16>(acc);
   constexpr int D = C::STAGES - 1;
   __syncthreads();
 #pragma unroll
@@ -886,6 +1075,7 @@ __device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const
       for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
     }
   };
+  if constexpr (HAND != 0) mfma_pin_acc(acc);
   constexpr int D = C::STAGES - 1;
   __syncthreads();
 #pragma unroll
@@ -1067,6 +1257,7 @@ __device__ __forceinline__ void gemm_mainloop_triple(f32x16 (&acc)[2][4], const 
       for (int k = 0; k < C::LOADS; ++k) stage_piece(sbuf, k);
     }
   };
+  if constexpr (HAND) mfma_pin_acc(acc);
   __syncthreads();  // whoever used the LDS before (previous segment, an epilogue) is done with it
   if (total > 0) {
 #pragma unroll
@@ -1251,7 +1442,13 @@ __device__ __forceinline__ void gemm_mainloop_mx(f32x16 (&acc)[2][4], const uint
 template <class C, bool DUAL, int EXP = 0>
 __device__ __forceinline__ void run_mainloop(f32x16 (&acc)[2][C::NJ], const Terms& t, const Geom& g, int m0, int n0, char* lds) {
   if constexpr (DUAL) {
-    gemm_mainloop_dual<(EXP & 256) ? 0 : (EXP & 512) ? 1 : 2>(acc, t.a[0], t.a[1], t.b[0], g, m0, n0, lds);
+    // default: the phase-shifted hand-placed stream; EXP bit 1024: hand-placed with the barrier at the step start (MODE 2),
+    // 512: the round-2 / round-3 schedule (MODE 1), 256: MODE 0 - the A/B references
+    if constexpr ((EXP & (256 | 512 | 1024)) == 0) {
+      gemm_mainloop_dual_ps(acc, t.a[0], t.a[1], t.b[0], g, m0, n0, lds);
+    } else {
+      gemm_mainloop_dual<(EXP & 256) ? 0 : (EXP & 512) ? 1 : 2>(acc, t.a[0], t.a[1], t.b[0], g, m0, n0, lds);
+    }
   } else {
     gemm_mainloop<C, EXP>(acc, t, g, m0, n0, lds);
   }
@@ -1871,7 +2068,11 @@ __global__ __launch_bounds__(CfgTriple::NT, 2) void gemm_dh_kernel(Dh3Args a) {
     if constexpr (TRIPLE) {
       gemm_mainloop_triple<HAND>(acc, a.a1 + k0, a.a2 + k0, a.b1 + k0, a.b2 + k0, g, m0, n0, lds);
     } else {
-      gemm_mainloop_dual<HAND ? 2 : 1>(acc, a.a1 + k0, a.a2 + k0, a.b1 + k0, g, m0, n0, lds);
+      if constexpr (HAND) {
+        gemm_mainloop_dual_ps(acc, a.a1 + k0, a.a2 + k0, a.b1 + k0, g, m0, n0, lds);
+      } else {
+        gemm_mainloop_dual<1>(acc, a.a1 + k0, a.a2 + k0, a.b1 + k0, g, m0, n0, lds);
+      }
     }
   }
   float* out = a.partial + (a.ksplit > 1 ? (int64_t)kz * a.geo.M * a.geo.N : 0);
@@ -2332,7 +2533,9 @@ static int lm_head_fwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
     }
     if (rc) return rc;
   } else if (use_dual(shape, a.terms)) {
-    if (exp_bits == 512) {  // A/B reference: the round-2 / round-3 default (staggered wave roles, DMA pieces in bursts of six)
+    if (exp_bits == 1024) {  // A/B reference: the hand-placed stream with the barrier at the step start (gemm_mainloop_dual MODE 2)
+      if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 1024, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual, hand-placed, barrier first)")) return rc;
+    } else if (exp_bits == 512) {  // A/B reference: the round-2 / round-3 default (staggered wave roles, DMA pieces in bursts of six)
       if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 512, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual, staggered bursts)")) return rc;
     } else if (exp_bits == 256) {  // A/B reference: DMA pieces interleaved with the MFMA groups, all waves alike
       if (int rc = PRL_LAUNCH_DUAL((lmhead_fwd_kernel<CfgDual, 256, true>), a.tt * a.nsplit, a, s, "lmhead_fwd_kernel(dual, interleaved)")) return rc;

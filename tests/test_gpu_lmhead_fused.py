@@ -132,6 +132,34 @@ def test_forward_values_and_split_count_independence(libprl, cuda_device, monkey
         assert torch.allclose(ent[0, 1:].double(), w_ent[:-1], rtol=FP_TOL, atol=2e-5), ns
 
 
+@pytest.mark.parametrize("T,H,V", [(700, 256, 1088), (520, 3584, 2048)])
+def test_schedules_of_the_dual_plane_core_agree_bit_for_bit(libprl, cuda_device, monkeypatch, T, H, V):
+    """The dual-plane forward exists as four instruction streams over the same arithmetic - the default phase-shifted
+    hand-placed stream (barrier in the middle of the step, `gemm_mainloop_dual_ps`), the hand-placed stream with the barrier at
+    the step start (PRL_LMHEAD_EXP=1024), the round-3 schedule with staggered wave roles (512) and the round-2 one (256) -
+    and every MFMA accumulates the same products in the same order: outputs are identical to the bit, kept logits included.
+    (A race or a missed hazard in one of the hand-placed streams shows up here as a difference.)"""
+    from pipelinerl_amd.fused_head import FusedLmHead
+
+    monkeypatch.setenv("PRL_LMHEAD_TILE", "256x256")
+    hidden, W, batch, _ = _problem(T, H, V, cuda_device, seed=T + H)
+    ids = torch.from_numpy(batch["input_ids"]).to(cuda_device)
+    head = FusedLmHead(W, backward=False)
+    monkeypatch.delenv("PRL_LMHEAD_EXP", raising=False)
+    want = [t.clone() for t in head.logprob_entropy(hidden, ids, 0.9, keep=True)]
+    for exp in ("1024", "512", "256"):
+        monkeypatch.setenv("PRL_LMHEAD_EXP", exp)
+        for _ in range(2):
+            got = head.logprob_entropy(hidden, ids, 0.9, keep=True)
+            torch.cuda.synchronize()
+            for a, b in zip(got[:3] + got[4:], want[:3] + want[4:]):
+                assert torch.equal(a, b), exp
+    monkeypatch.delenv("PRL_LMHEAD_EXP", raising=False)
+    for _ in range(3):  # and the default is stable run to run
+        got = head.logprob_entropy(hidden, ids, 0.9, keep=True)
+        assert all(torch.equal(a, b) for a, b in zip(got[:3] + got[4:], want[:3] + want[4:]))
+
+
 @pytest.mark.parametrize("tile", ["256x256", "256", "128", None, "recompute", "256x384", "256x320"],
                          ids=["tile256x256", "tile256x128_ring3", "tile128x128", "default_dispatch", "default_dispatch_recompute",
                               "one_wave_per_simd_256x384", "one_wave_per_simd_256x320"])
