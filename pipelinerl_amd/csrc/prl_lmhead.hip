@@ -2030,6 +2030,10 @@ struct Dh3Args {
 
 // TRIPLE false: two products that share W^T_hi - (dl_hi + dl_lo) W^T_hi, the whole d hidden of a bf16 weight (b2 unused) - on the
 // dual-plane core of the forward: same work items, same raster, three staged tiles per stage instead of four.
+// (Round 4, measured and not kept: the three products as 2 + 1 - (dl_hi + dl_lo) W_hi on the phase-shifted dual-plane core, then
+// dl_hi W_lo on the generic core as a hand-placed stream, into the same accumulators: 24.7 ms against 24.4 for the triple-plane
+// core below on the same box (profiles/r04q_*).  Unlike the forward, this product streams its A operand - 5 GB of d-logits
+// planes, each token tile re-read by 14 column tiles - and is bound by that traffic, not by the schedule.)
 template <bool TRIPLE, bool HAND = true>
 __global__ __launch_bounds__(CfgTriple::NT, 2) void gemm_dh_kernel(Dh3Args a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
