@@ -56,7 +56,8 @@ class PinnedStager:
         buf = self._bufs[k]
         if buf is None or buf.numel() < nbytes:
             size = max(self.min_bytes, 1 << (max(nbytes, 1) - 1).bit_length())
-            buf = self._bufs[k] = torch.empty(size, dtype=torch.uint8, pin_memory=True)
+            # (a CPU "device" - the layout logic under test without a GPU - takes ordinary memory)
+            buf = self._bufs[k] = torch.empty(size, dtype=torch.uint8, pin_memory=self.device.type == "cuda")
         return k, buf
 
     def upload(self, arrays: Sequence[np.ndarray | torch.Tensor | None]) -> list[torch.Tensor | None]:
@@ -72,12 +73,15 @@ class PinnedStager:
         for a, o in zip(live, offs):
             if a.nbytes:
                 host[o:o + a.nbytes] = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
-        with torch.cuda.device(self.device):
-            dev = torch.empty(total, dtype=torch.uint8, device=self.device)
-            dev.copy_(buf[:total], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-        self._events[k] = ev
+        if self.device.type == "cuda":
+            with torch.cuda.device(self.device):
+                dev = torch.empty(total, dtype=torch.uint8, device=self.device)
+                dev.copy_(buf[:total], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            self._events[k] = ev
+        else:
+            dev = buf[:total].clone()
         self.uploads += 1
         self.bytes_up += total
         out, it = [], iter(offs)
@@ -95,11 +99,14 @@ class PinnedStager:
         n = block.numel() * block.element_size()
         k, buf = self._slot(n)
         host = buf[:n].view(block.dtype).view(block.shape)
-        with torch.cuda.device(block.device):
-            host.copy_(block, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-        ev.synchronize()
+        if block.is_cuda:
+            with torch.cuda.device(block.device):
+                host.copy_(block, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            ev.synchronize()
+        else:
+            host.copy_(block)
         self.downloads += 1
         self.bytes_down += n
         return host
