@@ -26,6 +26,8 @@
  *                                 pipelinerl/finetune/rl/utils.py:26-92
  *   prl_fused_logits_loss         the two above in one pass (no reference analogue)
  *   prl_segment_sums              pipelinerl/finetune/rl/utils.py:106-208
+ *   prl_value_head_fwd_bwd        pipelinerl/finetune/rl/__init__.py:265-272, 367-381, 441-448
+ *                                 (models of pipelinerl/finetune/value_model.py)
  *   prl_seq_scan / prl_group_advantages
  *                                 pipelinerl/finetune/rl/__init__.py:453-570
  *   prl_patch_oov                 pipelinerl/preprocess.py:107-141
@@ -52,7 +54,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 8
+#define PRL_ABI_VERSION 9
 
 #define PRL_OK 0
 #define PRL_EINVAL (-22)   /* bad argument                                  */
@@ -280,6 +282,43 @@ int prl_segment_sums(int64_t cols, int32_t n_segments, const int64_t* segment_id
                      const int64_t* labels, const float* a, const float* b,
                      double* a_sum, double* b_sum, double* count,
                      prl_stream_t stream);
+
+/*
+ * Value-head (actor-critic) branch of rl_step (rl/__init__.py:162, 265-272, 367-381, 441-448) for models
+ * of finetune/value_model.py, whose forward also returns outputs.value [rows, cols].
+ * values: float32 or bfloat16 [rows, cols] (values_dtype = PRL_DTYPE_*), values[r, c] is paired with the
+ * target at column c + 1; the last column has no target.  The four RL columns are the batch's float32
+ * [rows, cols] tensors, unshifted; token weights as in prl_grpo_loss_fwd_bwd (cfg->group_normalization,
+ * token_weight, overlong_filtering).
+ * Outputs:
+ *   advantages_out float32 [rows, cols], unshifted like batch.advantages: [r, c] = rewards[r, c] -
+ *     values[r, c - 1] at EVERY column >= 1, 0 at column 0.  Passed to prl_grpo_loss_fwd_bwd /
+ *     prl_fused_logits_loss in place of the batch's advantages column.
+ *   grad_values float32 [rows, cols] (nullable) = d value_loss / d values (0 where unlabelled, non-finite,
+ *     or in the last column); the caller scales it by value_loss_coef x the upstream gradient.
+ *   stats double[PRL_NUM_VALUE_STATS] in the reference's key order; value_loss_out (device float,
+ *     nullable) = (float) stats[PRL_VSTAT_VALUE_LOSS] = sum over labelled tokens of
+ *     nan_to_num(0.5 (V - reward)^2 w).  final loss = policy loss + value_loss_coef * value_loss.
+ * Reductions are fixed-order fp64 (bitwise reproducible); no host sync.
+ */
+enum prl_value_stat_index {
+  PRL_VSTAT_VALUE_MEAN = 0, /* sum V / num_labels over labelled tokens */
+  PRL_VSTAT_VALUE_MAX = 1,  /* over labelled tokens; 0 if there are none */
+  PRL_VSTAT_VALUE_MIN = 2,
+  PRL_VSTAT_VALUE_LOSS = 3,
+  PRL_VSTAT_VALUE_MSE = 4,  /* sum (V - reward)^2 / num_labels */
+  PRL_NUM_VALUE_STATS = 5
+};
+
+int prl_value_head_workspace_bytes(int64_t rows, int64_t cols, size_t* bytes);
+
+int prl_value_head_fwd_bwd(const prl_loss_config* cfg, int64_t rows, int64_t cols,
+                           const int64_t* labels, const void* values, int values_dtype,
+                           const float* rewards, const float* group_tokens,
+                           const float* num_labels, const float* overflow,
+                           float* advantages_out, float* grad_values, float* value_loss_out,
+                           double* stats, void* workspace, size_t workspace_bytes,
+                           prl_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* K5 : group-baseline advantages (populate_rl_data)                         */

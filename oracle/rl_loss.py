@@ -79,10 +79,13 @@ def sum_sum(values: np.ndarray, mask: np.ndarray, segments) -> np.float32:
 
 
 def token_loss(batch: dict[str, np.ndarray], new_logprobs: np.ndarray, entropy: np.ndarray, config: Any,
-               current_step: int, max_step: int, is_packed: bool) -> dict[str, Any]:
-    """rl/__init__.py:238-439.  `batch` holds the unshifted [B, L] arrays of PipelineBatchEncoding.
+               current_step: int, max_step: int, is_packed: bool, value: np.ndarray | None = None) -> dict[str, Any]:
+    """rl/__init__.py:238-448.  `batch` holds the unshifted [B, L] arrays of PipelineBatchEncoding.
     Returns loss (fp32), stats dict (or the no-label dict), and the closed-form gradients
-    d loss / d new_logprobs, d loss / d entropy on the shifted axis."""
+    d loss / d new_logprobs, d loss / d entropy on the shifted axis.
+    `value`: outputs.value [B, L] of a model with a value head (:162, :265-272, :367-381, :441-448): the advantages become
+    rewards - value[:, :-1] (detached), 0.5 (V - reward)^2 w joins the loss with `value_loss_coef`, five more statistics;
+    `g_value` [B, L] = d loss / d value."""
     labels = batch["labels"]
     mask = (labels != -100)[:, 1:]
     fm = mask.astype(F32)
@@ -97,6 +100,10 @@ def token_loss(batch: dict[str, np.ndarray], new_logprobs: np.ndarray, entropy: 
         num_sequences = labels.shape[0]
 
     nlp = new_logprobs.astype(F32)
+    if value is not None:
+        vp = value[:, :-1].astype(F32)  # no target for the last token (:267)
+        with np.errstate(all="ignore"):
+            advantages = (rewards - vp).astype(F32)  # (:272)
     with np.errstate(all="ignore"):
         if _cfg(config, "group_normalization"):
             w = (np.ones_like(group_tokens) / group_tokens).astype(F32)
@@ -198,8 +205,20 @@ def token_loss(batch: dict[str, np.ndarray], new_logprobs: np.ndarray, entropy: 
             g_nlp = np.where(finite, -((dpol - F32(kl_coef) * dkl) * w) * fm, F32(0)).astype(F32)
             g_ent = (np.where(finite, -(F32(ent_coef) * w) * fm, F32(0)) if use_entropy else np.zeros_like(tok)).astype(F32)
 
+        if value is not None:
+            # (:367-381) value labels are the shifted rewards; sum_sum's nan_to_num passes gradient only where finite
+            coef = F32(_cfg(config, "value_loss_coef", 0.0))
+            diff = (vp - rewards).astype(F32)
+            vl_tok = ((F32(0.5) * (diff * diff).astype(F32)).astype(F32) * w).astype(F32)
+            value_loss = F32(sum_sum(vl_tok, mask, segments))
+            loss = F32(loss + F32(coef * value_loss))
+            g_value = np.zeros(value.shape, dtype=F32)
+            g_value[:, :-1] = np.where(np.isfinite(vl_tok * fm), (coef * (diff * w).astype(F32)).astype(F32) * fm, F32(0))
+
     out: dict[str, Any] = {"loss": loss, "g_nlp": g_nlp, "g_ent": g_ent, "num_sequences": num_sequences,
                            "finite": bool(np.isfinite(nlp).all() and np.isfinite(lrrn).all() and np.isfinite(kl).all() and np.isfinite(loss))}
+    if value is not None:
+        out["g_value"] = g_value
     input_size = int(batch["input_ids"].size)
     if int(mask.sum()) == 0:
         out["stats"] = {"input_size": float(input_size)}
@@ -225,16 +244,22 @@ def token_loss(batch: dict[str, np.ndarray], new_logprobs: np.ndarray, entropy: 
             "kl_coef": num_sequences * kl_coef, "entropy_bonus_coef": num_sequences * ent_coef,
             "num_output_tokens_sum": int(mask.sum()), "input_size": input_size,
         }
+        if value is not None:  # (:441-448)
+            stats.update({
+                "value_mean": per(vp), "value_max": float(vp[mask].max()), "value_min": float(vp[mask].min()),
+                "value_loss": float(value_loss), "value_mse": per((diff * diff).astype(F32)),
+            })
     out["stats"] = stats
     return out
 
 
 def rl_step(logits: np.ndarray, batch: dict[str, np.ndarray], config: Any, current_step: int, max_step: int,
-            is_packed: bool) -> dict[str, Any]:
-    """Full post-model path: logits -> loss, stats, d loss / d logits [B, L, V]."""
+            is_packed: bool, value: np.ndarray | None = None) -> dict[str, Any]:
+    """Full post-model path: logits (and the value head's predictions, if the model has one) -> loss, stats,
+    d loss / d logits [B, L, V] (and `g_value`)."""
     temperature = _cfg(config, "temperature", 1.0)
     nlp, ent, p, logp = logprob_entropy(logits, batch["input_ids"], temperature)
-    res = token_loss(batch, nlp, ent, config, current_step, max_step, is_packed)
+    res = token_loss(batch, nlp, ent, config, current_step, max_step, is_packed, value=value)
     g, gh = res["g_nlp"], res["g_ent"]
     B, L, V = logits.shape
     onehot = np.zeros((B, L - 1, V), dtype=F32)

@@ -30,7 +30,7 @@ def _entropy(z: torch.Tensor) -> torch.Tensor:
 
 
 def rl_step(logits: np.ndarray | torch.Tensor, batch: dict[str, np.ndarray], config: Any, current_step: int, max_step: int,
-            is_packed: bool, want_grad: bool = True) -> dict[str, Any]:
+            is_packed: bool, want_grad: bool = True, value: np.ndarray | None = None) -> dict[str, Any]:
     """Same contract as `oracle.rl_loss.rl_step`; `grad_logits` is a torch tensor [B, L, V]."""
     temperature = float(_np_oracle._cfg(config, "temperature", 1.0))
     use_entropy = _np_oracle._cfg(config, "entropy_bonus", 0.0) != 0.0 or _np_oracle._cfg(config, "final_entropy_bonus", 0.0) != 0.0
@@ -44,7 +44,7 @@ def rl_step(logits: np.ndarray | torch.Tensor, batch: dict[str, np.ndarray], con
         with torch.no_grad():
             flat = z.reshape(-1, z.shape[-1])
             ent = torch.cat([_entropy(flat[i : i + ENTROPY_CHUNK]) for i in range(0, flat.shape[0], ENTROPY_CHUNK)]).reshape(nlp.shape)
-    res = _np_oracle.token_loss(batch, nlp.detach().numpy(), ent.detach().numpy(), config, current_step, max_step, is_packed)
+    res = _np_oracle.token_loss(batch, nlp.detach().numpy(), ent.detach().numpy(), config, current_step, max_step, is_packed, value=value)
     res.update(new_logprobs=nlp.detach().numpy(), entropy=ent.detach().numpy())
     if want_grad:
         heads, seeds = [nlp], [torch.from_numpy(np.ascontiguousarray(res["g_nlp"]))]
@@ -57,7 +57,7 @@ def rl_step(logits: np.ndarray | torch.Tensor, batch: dict[str, np.ndarray], con
 
 
 def rl_step_closed_form(logits: np.ndarray | torch.Tensor, batch: dict[str, np.ndarray], config: Any, current_step: int,
-                        max_step: int, is_packed: bool) -> dict[str, Any]:
+                        max_step: int, is_packed: bool, value: np.ndarray | None = None) -> dict[str, Any]:
     """Same result without autograd: vectorised multi-threaded torch CPU kernels for the O(T*V)
     passes and the closed-form d loss / d logits of SURVEY.md App. A (what a tuned host
     implementation would run; `bench.py` times this one as the CPU baseline).
@@ -74,7 +74,7 @@ def rl_step_closed_form(logits: np.ndarray | torch.Tensor, batch: dict[str, np.n
         nlp = z.gather(-1, ids).squeeze(-1) - lse
         p = torch.softmax(z, dim=-1)
         ent = lse - (p * z).sum(dim=-1)
-        res = _np_oracle.token_loss(batch, nlp.numpy(), ent.numpy(), config, current_step, max_step, is_packed)
+        res = _np_oracle.token_loss(batch, nlp.numpy(), ent.numpy(), config, current_step, max_step, is_packed, value=value)
         g = torch.from_numpy(np.ascontiguousarray(res["g_nlp"]))
         grad = torch.zeros_like(lg)
         dz = grad[:, :-1, :]

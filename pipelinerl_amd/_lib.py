@@ -13,7 +13,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl.so"
 
-PRL_ABI_VERSION = 8
+PRL_ABI_VERSION = 9
 PRL_OK = 0
 PRL_EINVAL = -22
 PRL_ENOMEM = -12
@@ -32,6 +32,7 @@ PRL_FINISH_NONE = 0
 PRL_FINISH_LENGTH = 1
 PRL_FINISH_STOP = 2
 PRL_NUM_STATS = 32
+PRL_NUM_VALUE_STATS = 5
 PRL_WSYNC_UID_BYTES = 128
 PRL_IPC_HANDLE_BYTES = 64
 PRL_LM_HEAD_DH_LEADING_TERM = 1
@@ -134,6 +135,8 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_last_fused_kernel": (c_char_p, []),
     "prl_scale_unless": (c_int32, [_P, c_int64, c_int32, _P, c_float, _P]),
     "prl_segment_sums": (c_int32, [c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "prl_value_head_workspace_bytes": (c_int32, [c_int64, c_int64, POINTER(c_size_t)]),
+    "prl_value_head_fwd_bwd": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64, _P, _P, c_int32] + [_P] * 8 + [_P, c_size_t, _P]),
     "prl_seq_scan": (c_int32, [c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),
     "prl_patch_oov": (c_int32, [c_int64, _P, _P, c_int32, c_int32, _P, _P]),
     "prl_group_advantages": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),

@@ -36,6 +36,7 @@ SOURCES = [
     "prl_wsync.cpp",
     "prl_ipc.cpp",
     "prl_loss.hip",
+    "prl_value.hip",
     "prl_logprob.hip",
     "prl_pack.hip",
     "prl_copy.hip",

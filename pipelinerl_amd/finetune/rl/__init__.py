@@ -61,7 +61,7 @@ class RLConfig(BaseModel):
     group_normalization: bool = Field(default=False, description="weight tokens by 1/mean group tokens")
     temperature: float = Field(default=1.0, description="sampling temperature of the rollouts")
     filter_zero_advantage_groups: bool = Field(default=False, description="drop all-zero-advantage groups")
-    value_loss_coef: float = Field(default=0.0, description="value-head loss weight (value head unsupported)")
+    value_loss_coef: float = Field(default=0.0, description="weight of the value loss for models with a value head")
     # --- MI355X extensions (absent from the reference; defaults keep its behaviour) ---
     fused_logits_grad: bool = Field(default=True, description="single-pass logits kernel (gradient computed in the forward launch) "
                                     "whenever the logits require a gradient; False = K1 forward, K2+K3, K1 backward as separate launches")
@@ -457,6 +457,80 @@ def stats_to_dict(stats: Sequence[float], kl_coef: float, ent_coef: float, input
     return out
 
 
+VALUE_STAT_KEYS = ("value_mean", "value_max", "value_min", "value_loss", "value_mse")  # rl/__init__.py:441-448, in this order
+
+
+def value_head_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, values: torch.Tensor, want_grad: bool = True):
+    """The value-head branch of rl_step in one launch (csrc/prl_value.hip; reference rl/__init__.py:265-272, 367-381,
+    441-448).  `values`: outputs.value [B, L], float32 or bfloat16.  Returns (value_loss fp32 scalar, advantages fp32
+    [B, L] unshifted like batch.advantages = rewards - V one column to the left, stats double[5] in VALUE_STAT_KEYS order,
+    d value_loss / d values fp32 [B, L] or None)."""
+    lib = _lib.load()
+    rows, cols = batch.labels.shape
+    if tuple(values.shape) != (rows, cols):
+        raise ValueError(f"Values shape {tuple(values.shape)} does not match the batch shape {(rows, cols)}")
+    tensors = [batch.labels, values.detach(), batch.rewards, batch.group_tokens, batch.num_labels, batch.overflow]
+    _lib.require_device(*tensors)
+    labels, val, rew, gt, nl, ovf = [t if t.is_contiguous() else t.contiguous() for t in tensors]
+    dev = labels.device
+    adv = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+    g_val = torch.empty((rows, cols), dtype=torch.float32, device=dev) if want_grad else None
+    vstats = torch.empty(_lib.PRL_NUM_VALUE_STATS, dtype=torch.float64, device=dev)
+    vloss = torch.empty((), dtype=torch.float32, device=dev)
+    ws = _loss_workspace(dev)  # 64 KB of the K2+K3 scratch: the two launches are ordered on the stream
+    with torch.cuda.device(dev):
+        _lib.check(lib.prl_value_head_fwd_bwd(
+            ctypes.byref(cfg), rows, cols, _lib.ptr(labels), _lib.ptr(val), _logits_dtype_code(val), _lib.ptr(rew), _lib.ptr(gt),
+            _lib.ptr(nl), _lib.ptr(ovf), _lib.ptr(adv), _lib.ptr(g_val), _lib.ptr(vloss), _lib.ptr(vstats),
+            _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr(dev)))
+    return vloss, adv, vstats, g_val
+
+
+class _ValueLossFn(torch.autograd.Function):
+    """value_loss as a node of the model's graph: forward = value_head_terms, backward = its closed-form gradient."""
+
+    @staticmethod
+    def forward(ctx, values: torch.Tensor, batch: PipelineBatchEncoding, cfg: PrlLossConfig):
+        want = ctx.needs_input_grad[0]
+        vloss, adv, vstats, g_val = value_head_terms(cfg, batch, values, want_grad=want)
+        if want:
+            ctx.save_for_backward(g_val)
+        ctx.values_dtype = values.dtype
+        ctx.mark_non_differentiable(adv, vstats)
+        return vloss, adv, vstats
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_adv, _grad_stats):
+        (g_val,) = ctx.saved_tensors
+        return (g_val * grad_loss).to(ctx.values_dtype), None, None
+
+
+def _with_advantages(batch: PipelineBatchEncoding, advantages: torch.Tensor) -> PipelineBatchEncoding:
+    """A shallow copy of the batch whose `advantages` column is `advantages` (the caller's batch is left as it was)."""
+    import copy
+
+    b = copy.copy(batch)
+    object.__setattr__(b, "advantages", advantages)
+    return b
+
+
+def host_stats(stats_dev: torch.Tensor, input_size: int, kl_coef: float, ent_coef: float, value_loss_coef: float = 0.0) -> dict[str, float]:
+    """The step's device statistics -> the reference's dict, with its runtime asserts: ONE device -> host copy.  `stats_dev`:
+    double[32] of K2+K3, optionally followed by the value head's double[5] (then the reported and asserted loss is the
+    combined one, rl/__init__.py:381-386, 399-401, and the five value keys close the dict, :441-448)."""
+    stats = stats_dev.cpu().tolist()  # the single device->host sync of the step
+    vstats = stats[_lib.PRL_NUM_STATS:]
+    if vstats:
+        combined = np.float32(stats[STAT_INDEX["loss"]]) + np.float32(value_loss_coef * np.float32(vstats[VALUE_STAT_KEYS.index("value_loss")]))
+        stats[STAT_INDEX["loss"]] = float(combined)
+    check_finite(stats)
+    if int(stats[STAT_INDEX["num_output_tokens_sum"]]) == 0:
+        return {"input_size": float(input_size)}
+    out = stats_to_dict(stats, kl_coef, ent_coef, input_size)
+    out.update({k: float(np.float32(v)) for k, v in zip(VALUE_STAT_KEYS, vstats)})
+    return out
+
+
 def check_finite(stats: Sequence[float]) -> None:
     """The reference's runtime asserts (rl/__init__.py:213,247,262,291,386) from device counters."""
     assert stats[STAT_INDEX["nonfinite_new_logprobs"]] == 0, "new_logprobs is not finite"
@@ -479,8 +553,7 @@ def rl_step(
     if config.policy_loss == "gspo":
         if not batch.is_packed:
             raise ValueError("GSPO loss requires packed sequences with segments")
-    if hasattr(model, "value_head"):
-        raise NotImplementedError("value-head (actor-critic) batches are outside the GRPO hot path")
+    has_value_head = hasattr(model, "value_head")  # finetune/value_model.py; reference rl/__init__.py:162
     cfg, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
 
     model_inputs = {
@@ -497,6 +570,11 @@ def rl_step(
     outputs = model(**model_inputs)
     logits = outputs.logits
     _lib.require_device(logits)
+    value_loss = vstats_dev = None
+    if has_value_head:
+        # advantages := rewards - V (detached, :272) for the policy loss and its statistics; the value loss joins below
+        value_loss, value_advantages, vstats_dev = _ValueLossFn.apply(outputs.value, batch, cfg)
+        batch = _with_advantages(batch, value_advantages)
 
     loss, stats_dev = _GrpoLossFn.apply(
         logits, batch, cfg, config.temperature,
@@ -504,12 +582,10 @@ def rl_step(
         bool(config.inplace_logits_grad), seq_parallel_group if config.policy_loss == "gspo" else None,
         float(config.expected_loss_scale) or 1.0, bool(config.skip_unlabelled_rows),
     )
-    stats = stats_dev.cpu().tolist()  # the single device->host sync of the step
-    check_finite(stats)
-    input_size = batch.input_ids.numel()
-    if int(stats[STAT_INDEX["num_output_tokens_sum"]]) == 0:
-        return loss, {"input_size": float(input_size)}
-    return loss, stats_to_dict(stats, kl_coef, ent_coef, input_size)
+    if has_value_head:
+        loss = loss + config.value_loss_coef * value_loss  # (:381)
+        stats_dev = torch.cat([stats_dev, vstats_dev])
+    return loss, host_stats(stats_dev, batch.input_ids.numel(), kl_coef, ent_coef, config.value_loss_coef)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -28,7 +28,7 @@ from typing import Any
 import torch
 
 from . import _lib
-from .finetune.rl import RLConfig, check_finite, grpo_loss_from_logprobs, make_loss_config, stats_to_dict
+from .finetune.rl import RLConfig, _ValueLossFn, _with_advantages, grpo_loss_from_logprobs, host_stats, make_loss_config
 from .finetune.types import PipelineBatchEncoding
 from ._lib import STAT_INDEX
 
@@ -374,23 +374,25 @@ class _FusedHeadLossFn(torch.autograd.Function):
         return gh, gw, None, None, None, None, None
 
 
-def _host_stats(stats_dev: torch.Tensor, batch: PipelineBatchEncoding, kl_coef: float, ent_coef: float):
-    stats = stats_dev.cpu().tolist()
-    check_finite(stats)
-    input_size = batch.input_ids.numel()
-    if int(stats[STAT_INDEX["num_output_tokens_sum"]]) == 0:
-        return {"input_size": float(input_size)}
-    return stats_to_dict(stats, kl_coef, ent_coef, input_size)
+def _host_stats(stats_dev: torch.Tensor, batch: PipelineBatchEncoding, kl_coef: float, ent_coef: float, value_loss_coef: float = 0.0):
+    return host_stats(stats_dev, batch.input_ids.numel(), kl_coef, ent_coef, value_loss_coef)
 
 
 def fused_head_loss(hidden: torch.Tensor, weight: torch.Tensor, head: FusedLmHead, batch: PipelineBatchEncoding,
-                    config: RLConfig, current_step: int, max_step: int, chunk_rows: int | None = None):
-    """Loss + stats from last hidden states and the head weight; same return contract as `rl_step`."""
+                    config: RLConfig, current_step: int, max_step: int, chunk_rows: int | None = None, values: torch.Tensor | None = None):
+    """Loss + stats from last hidden states and the head weight; same return contract as `rl_step`.
+    `values`: the value head's predictions [B, L] for an actor-critic model (rl/__init__.py:265-272, 367-381, 441-448)."""
     if config.policy_loss == "gspo":
         raise NotImplementedError("the fused head covers ppo / reinforce; gspo goes through rl_step")
     cfg, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
+    if values is not None:
+        value_loss, value_advantages, vstats_dev = _ValueLossFn.apply(values, batch, cfg)
+        batch = _with_advantages(batch, value_advantages)
     loss, stats_dev = _FusedHeadLossFn.apply(hidden, weight, head, batch, cfg, config.temperature, chunk_rows)
-    return loss, _host_stats(stats_dev, batch, kl_coef, ent_coef)
+    if values is not None:
+        loss = loss + config.value_loss_coef * value_loss
+        stats_dev = torch.cat([stats_dev, vstats_dev])
+    return loss, _host_stats(stats_dev, batch, kl_coef, ent_coef, config.value_loss_coef)
 
 
 
@@ -483,13 +485,17 @@ def rl_step_fused_head(model: Any, batch: PipelineBatchEncoding, current_step: i
         _, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
         loss, stats_dev = model(rl_batch=batch, rl_config=config, current_step=current_step, max_step=max_step)
         return loss, _host_stats(stats_dev, batch, kl_coef, ent_coef)
-    body, lm_head = _body_and_head(model)
+    # an actor-critic wrapper (finetune/value_model.py:54-116): the LM is `.pretrained_model`, the critic reads the same hidden states
+    value_head = getattr(model, "value_head", None)
+    body, lm_head = _body_and_head(getattr(model, "pretrained_model", model) if value_head is not None else model)
     hidden = _hidden_states(body, batch)
+    values = value_head(hidden) if value_head is not None else None
     w = lm_head.weight
     # a bare model: the two memory knobs come from the call or from the RLConfig (`fused_head_chunk_rows`, `fused_head_keep_logits`)
     chunk_rows = int(chunk_rows or getattr(config, "fused_head_chunk_rows", 8192) or 8192)
     keep = keep_logits if keep_logits is not None else getattr(config, "fused_head_keep_logits", None)
-    return fused_head_loss(hidden, w, _head_for(lm_head, w, chunk_rows, keep_logits=keep), batch, config, current_step, max_step, chunk_rows)
+    return fused_head_loss(hidden, w, _head_for(lm_head, w, chunk_rows, keep_logits=keep), batch, config, current_step, max_step, chunk_rows,
+                           values=values)
 
 
 # -- reference log-probabilities ---------------------------------------------------------

@@ -173,6 +173,19 @@ class FakeModel(torch.nn.Module):
         return types.SimpleNamespace(logits=self.logits)
 
 
+class FakeValueModel(FakeModel):
+    """What rl_step sees of AutoModelForCausalLMWithValueHead (finetune/value_model.py:54-116): a `value_head`
+    attribute and `outputs.value` of shape [B, L]."""
+
+    def __init__(self, logits, value):
+        super().__init__(logits)
+        self.value_head = torch.nn.Identity()
+        self.value = torch.nn.Parameter(value)
+
+    def forward(self, **kwargs):
+        return types.SimpleNamespace(logits=self.logits, value=self.value)
+
+
 RL_CASES = {
     # name: (builder kwargs, RLConfig kwargs, (current_step, max_step))
     "c0_ppo": (dict(vocab=97), dict(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0, clamp_log_ratio_ref_new_value=5, batch_size=16, divide_advantage_by_std=False), (0, 10)),
@@ -193,6 +206,10 @@ RL_CASES = {
     "c15_unpacked_left_reinforce": (dict(vocab=97, with_ref=True, unpacked=True, padding_side="left"), dict(policy_loss="reinforce", epsilon_high=0.2, kl_coef=0.01, final_kl_coef=0.01, batch_size=16), (0, 10)),
     "c16_ppo_final_step": (dict(vocab=97, with_ref=True, seed_offset=3), dict(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.28, kl_coef=0.5, final_kl_coef=0.0, entropy_bonus=0.0, final_entropy_bonus=0.03, batch_size=16), (10, 10)),
     "c17_ppo_overlong_only": (dict(vocab=64, seed_offset=11), dict(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0, overlong_filtering=True, divide_advantage_by_std=False, batch_size=16), (0, 10)),
+    # value-head (actor-critic) branch, rl/__init__.py:265-272, 367-381, 441-448: advantages := rewards - V, + value loss, 5 more stats
+    "c18_ppo_value_head": (dict(vocab=97, with_ref=True, seed_offset=21, value_head=True), dict(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.01, final_kl_coef=0.01, value_loss_coef=0.1, batch_size=16), (0, 10)),
+    "c19_reinforce_value_head_unpacked": (dict(vocab=64, with_ref=True, unpacked=True, padding_side="left", seed_offset=22, value_head=True), dict(policy_loss="reinforce", epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0, overlong_filtering=True, value_loss_coef=0.5, entropy_bonus=0.01, final_entropy_bonus=0.01, batch_size=16), (2, 10)),
+    "c20_ppo_value_head_rewards_sp": (dict(vocab=64, seq_parallel=8, seed_offset=23, value_head=True), dict(policy_loss="ppo", epsilon_low=0.1, epsilon_high=0.1, kl_coef=0.0, final_kl_coef=0.0, use_advantages=False, relu_log_p_weights=True, value_loss_coef=1.0, temperature=0.8, batch_size=8), (0, 10)),
 }
 
 
@@ -231,10 +248,19 @@ def gen_rl_step(ref_rl, ref_data, ref_utils, only=None, index=None):
                 batch.ref_logprobs = ref
             else:
                 batch.ref_logprobs = old.clone()
-        model = FakeModel(logits.clone())
+        value = None
+        if bk.get("value_head"):
+            # V(s) near the rewards (binary here) with noise, as a partly trained critic would give; fp32 like the rewards
+            value = (0.4 + 0.3 * torch.randn(B, L)).float()
+            model = FakeValueModel(logits.clone(), value.clone())
+        else:
+            model = FakeModel(logits.clone())
         loss, stats = ref_rl.rl_step(model, batch, cur, mx, cfg)
         loss.backward()
         arrays = {f"batch/{k}": v for k, v in batch_to_np(batch).items()}
+        if value is not None:
+            arrays["value"] = value.numpy()
+            arrays["grad_value"] = model.value.grad.numpy()
         arrays["logits"] = logits.numpy()
         arrays["loss"] = np.asarray(loss.item(), dtype=np.float64)
         arrays["grad_logits"] = model.logits.grad.numpy()

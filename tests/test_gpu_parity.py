@@ -34,6 +34,18 @@ class FakeModel(torch.nn.Module):
         return types.SimpleNamespace(logits=self.logits)
 
 
+class FakeValueModel(FakeModel):
+    """What rl_step sees of the reference's AutoModelForCausalLMWithValueHead (finetune/value_model.py:54-116)."""
+
+    def __init__(self, logits, value):
+        super().__init__(logits)
+        self.value_head = torch.nn.Identity()
+        self.value = torch.nn.Parameter(value)
+
+    def forward(self, **kwargs):
+        return types.SimpleNamespace(logits=self.logits, value=self.value)
+
+
 class Tok:
     def __init__(self, eos_token_id=2, padding_side="right"):
         self.eos_token_id = eos_token_id
@@ -65,9 +77,12 @@ def test_rl_step_matches_reference(libprl, cuda_device, name, mode):
     cur, mx = case["steps"]
     cfg = RLConfig(**case["config"], fused_logits_grad=mode.startswith("fused"), inplace_logits_grad=mode.endswith("inplace"))
     batch = _batch_from_np(case["batch"], cuda_device)
-    model = FakeModel(torch.from_numpy(case["logits"]).to(cuda_device))
+    logits = torch.from_numpy(case["logits"]).to(cuda_device)
+    model = FakeValueModel(logits, torch.from_numpy(case["value"]).to(cuda_device)) if "value" in case else FakeModel(logits)
+    advantages_before = batch.advantages.clone()
     loss, stats = rl_step(model, batch, cur, mx, cfg)
     assert loss.requires_grad and loss.dim() == 0
+    assert torch.equal(batch.advantages, advantages_before)  # a value head replaces the column in a COPY of the batch
     if mode.endswith("inplace"):
         # the gradient is written over the logits storage; autograd still routes it to .grad
         pass
@@ -88,6 +103,9 @@ def test_rl_step_matches_reference(libprl, cuda_device, name, mode):
         assert np.abs(grad).max() == 0
     else:
         assert rel_err(grad, case["grad_logits"]) <= FP_TOL
+    if "value" in case:  # d loss / d outputs.value vs the reference's autograd (rl/__init__.py:367-381)
+        assert len(stats) == 37
+        np.testing.assert_allclose(model.value.grad.cpu().numpy(), case["grad_value"], rtol=FP_TOL, atol=1e-9)
 
 
 def test_rl_step_sentinel_scaled_loss_has_zero_grad(libprl, cuda_device):

@@ -276,3 +276,34 @@ def test_split_bf16_host_formulation():
         assert len(parts) == terms and all(p.dtype == torch.bfloat16 for p in parts)
         rebuilt = sum(p.double() for p in parts)
         assert ((rebuilt - w.double()).abs() <= 2.0 ** -(bits - 1) * w.double().abs() + 1e-30).all()
+
+
+def test_host_stats_with_and_without_a_value_head():
+    """`host_stats`: the step's statistics vector -> the reference's dict.  With the value head's five entries appended
+    the reported (and asserted) loss is policy + value_loss_coef * value_loss and the five keys close the dict, in the
+    reference's order (rl/__init__.py:381-386, 399-401, 441-448) - checked against the c18 golden's own numbers."""
+    from helpers import load_rl_case
+    from pipelinerl_amd._lib import PRL_NUM_STATS, STAT_INDEX
+    from pipelinerl_amd.finetune.rl import VALUE_STAT_KEYS, host_stats
+
+    case = load_rl_case("c18_ppo_value_head")
+    want = case["stats"]
+    coef = case["config"]["value_loss_coef"]
+    dev = [0.0] * PRL_NUM_STATS
+    for k, i in STAT_INDEX.items():
+        if k in want:
+            dev[i] = want[k]
+    dev[STAT_INDEX["loss"]] = want["loss"] - coef * want["value_loss"]  # what K2+K3 report: the policy part
+    dev[STAT_INDEX["num_sequences"]] = round(want["kl_coef"] / 0.01)
+    vs = [want[k] for k in VALUE_STAT_KEYS]
+    got = host_stats(torch.tensor(dev + vs, dtype=torch.float64), int(want["input_size"]), 0.01, 0.0, coef)
+    assert list(got) == list(want) and len(got) == 37
+    for k, w in want.items():
+        assert abs(got[k] - w) <= 1e-6 * max(1.0, abs(w)), k
+    plain = host_stats(torch.tensor(dev, dtype=torch.float64), int(want["input_size"]), 0.01, 0.0)
+    assert list(plain) == list(want)[:32] and abs(plain["loss"] - dev[STAT_INDEX["loss"]]) < 1e-6
+    dev[STAT_INDEX["num_output_tokens_sum"]] = 0
+    assert host_stats(torch.tensor(dev + vs, dtype=torch.float64), 7, 0.01, 0.0, coef) == {"input_size": 7.0}
+    dev[STAT_INDEX["loss"]] = float("inf")
+    with pytest.raises(AssertionError, match="Non-finite loss"):
+        host_stats(torch.tensor(dev + vs, dtype=torch.float64), 7, 0.01, 0.0, coef)

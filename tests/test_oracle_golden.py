@@ -14,8 +14,11 @@ from helpers import PREPROCESS_CASES, RL_STEP_CASES, assert_batch_equal, load_pr
 def test_rl_step_oracle_matches_reference(name):
     case = load_rl_case(name)
     cur, mx = case["steps"]
-    res = orl.rl_step(case["logits"], case["batch"], case["config"], cur, mx, bool(case["batch"]["is_packed"]))
+    res = orl.rl_step(case["logits"], case["batch"], case["config"], cur, mx, bool(case["batch"]["is_packed"]), value=case.get("value"))
     assert res["finite"]
+    if "value" in case:  # value-head branch: d loss / d outputs.value vs the reference's autograd
+        assert len(case["stats"]) == 37 and np.abs(case["grad_value"]).max() > 0
+        np.testing.assert_allclose(res["g_value"], case["grad_value"], rtol=1e-5, atol=1e-9)
     # fp: loss / stats within 1e-5 relative of the reference's fp32 torch result
     assert abs(float(res["loss"]) - case["loss"]) <= 1e-5 * max(1.0, abs(case["loss"]))
     assert list(res["stats"].keys()) == list(case["stats"].keys())
@@ -35,7 +38,7 @@ def test_rl_step_torch_legs_match_reference(name, leg):
 
     case = load_rl_case(name)
     cur, mx = case["steps"]
-    res = getattr(orlt, leg)(case["logits"], case["batch"], case["config"], cur, mx, bool(case["batch"]["is_packed"]))
+    res = getattr(orlt, leg)(case["logits"], case["batch"], case["config"], cur, mx, bool(case["batch"]["is_packed"]), value=case.get("value"))
     assert abs(float(res["loss"]) - case["loss"]) <= 1e-5 * max(1.0, abs(case["loss"]))
     for k, want in case["stats"].items():
         assert abs(float(res["stats"][k]) - want) <= 2e-5 * max(1.0, abs(want)), k

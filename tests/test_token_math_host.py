@@ -41,8 +41,12 @@ def test_device_token_math_matches_oracle(tokmath, name):
     c_cfg, kl_coef, ent_coef = make_loss_config(cfg, cur, mx)
     b = case["batch"]
     nlp, ent, _, _ = orl.logprob_entropy(case["logits"], b["input_ids"], cfg.temperature)
-    ref = orl.token_loss(b, nlp, ent, case["config"], cur, mx, bool(b["is_packed"]))
+    ref = orl.token_loss(b, nlp, ent, case["config"], cur, mx, bool(b["is_packed"]), value=case.get("value"))
     mask = (b["labels"] != -100)[:, 1:]
+    want_loss = case["loss"]
+    if "value" in case:  # value head: the advantages column is rewards - V, the value loss is a separate kernel's
+        b = dict(b, advantages=np.concatenate([np.zeros_like(b["rewards"][:, :1]), b["rewards"][:, 1:] - case["value"][:, :-1]], axis=1))
+        want_loss = case["loss"] - case["config"]["value_loss_coef"] * case["stats"]["value_loss"]
     sel = lambda a: np.ascontiguousarray(a[mask], dtype=np.float32)  # noqa: E731
     sh = lambda k: sel(b[k][:, 1:])  # noqa: E731
     ins = [sel(nlp), sel(ent), sh("old_logprobs"), sh("ref_logprobs"), sh("advantages"), sh("rewards"),
@@ -53,7 +57,7 @@ def test_device_token_math_matches_oracle(tokmath, name):
     contrib, g_nlp, g_ent, ratio_stat, kl, clamp_no = outs
     # loss = -sum(contrib) (fp64 accumulate like the kernel)
     loss = -float(contrib.astype(np.float64).sum())
-    assert abs(loss - case["loss"]) <= 1e-5 * max(1.0, abs(case["loss"]))
+    assert abs(loss - want_loss) <= 1e-5 * max(1.0, abs(want_loss))
     np.testing.assert_allclose(g_nlp, ref["g_nlp"][mask], rtol=1e-4, atol=1e-8)  # cancelling terms: fp32 op order
     np.testing.assert_allclose(g_ent, ref["g_ent"][mask], rtol=2e-6, atol=1e-9)
     want = case["stats"]
