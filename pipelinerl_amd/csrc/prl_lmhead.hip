@@ -602,18 +602,31 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
 // outputs (profiles/r04p_*): 7B forward 13.87 (round-3 schedule) -> 13.25 (MODE 2) -> 12.87 ms; 32B 19.85 -> 19.02 -> 18.06 ms.
 // (Round 2 tried the mid-step barrier on the compiler-scheduled stream and lost 3 %; with every read and DMA issue pinned
 // between specific MFMAs it is the other way round.)
+template <int HAND>
+__device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
+                                                      const Geom& g, int m0, int n0, char* lds);
+
+// TR = true: the TRANSPOSED-A form of gemm_mainloop_dual_tr (d W: A1 / A2 are [K, lda] row-major with the contraction index as
+// their ROW; tiles staged as they lie in memory, fragments out of ds_read_b64_tr_b16 - two per fragment, so the second half's
+// reads take the gaps after MFMAs 3-6, 8, 9 instead of 3-6) on the same phase-shifted step.
 template <bool P1, int BAR, bool RD, bool P2>
 struct PsFlags {
   static constexpr bool p1 = P1, rd = RD, p2 = P2;
   static constexpr int bar = BAR;  // -1: no barrier, else the vmcnt of A(s)
 };
 
+template <bool TR = false>
 __device__ __forceinline__ void gemm_mainloop_dual_ps(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
                                                       const Geom& g, int m0, int n0, char* lds) {
   using C = CfgDual;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
   const int total = g.Kc / BK32;
   if (total < 6) {
-    gemm_mainloop_dual<2>(acc, A1, A2, B, g, m0, n0, lds);
+    if constexpr (TR) {
+      gemm_mainloop_dual_tr<0>(acc, A1, A2, B, g, m0, n0, lds);
+    } else {
+      gemm_mainloop_dual<2>(acc, A1, A2, B, g, m0, n0, lds);
+    }
     return;
   }
   const int tid = threadIdx.x;
@@ -624,29 +637,82 @@ __device__ __forceinline__ void gemm_mainloop_dual_ps(f32x16 (&acc)[2][4], const
   int64_t offA[C::Q], offB[C::Q];
 #pragma unroll
   for (int q = 0; q < C::Q; ++q) {
-    int ra = m0 + stage_row32(tid, q, C::NT);
-    ra = ra < g.M ? ra : g.M - 1;
+    if constexpr (TR) {
+      int v = m0 + 8 * tr_stage_chunk(tid, q, C::NT);
+      v = v + 8 <= g.M ? v : g.M - 8;  // entries past the edge re-read the last eight; their results are discarded (M % 8 == 0)
+      offA[q] = (int64_t)tr_stage_row(tid, q, C::NT) * g.lda + v;
+    } else {
+      int ra = m0 + stage_row32(tid, q, C::NT);
+      ra = ra < g.M ? ra : g.M - 1;
+      offA[q] = (int64_t)ra * g.lda + kcol;
+    }
     int rb = n0 + stage_row32(tid, q, C::NT);
     rb = rb < g.N ? rb : g.N - 1;
-    offA[q] = (int64_t)ra * g.lda + kcol;
     offB[q] = (int64_t)rb * g.ldb + kcol;
   }
-  int rdA[2], rdB[2];
+  int rdA[2], rdB[2];  // TR: rdA[tile i] (sub-step ks: + 16 token rows); else rdA[ks] (tile i: + 32 rows)
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    rdA[ks] = frag_lds_byte32(lane, wm * 64, 0, ks);
+    rdA[ks] = TR ? tr_frag_lds_byte(lane, wm * 64, ks, 0, 0) : frag_lds_byte32(lane, wm * 64, 0, ks);
     rdB[ks] = 2 * C::TILE_BYTES + frag_lds_byte32(lane, wn * C::WCOLS, 0, ks);
   }
   // piece idx (0..5: A1 q0 q1, A2 q0 q1, B q0 q1) of stage `stage` into ring buffer stage % 3
   auto stage_piece = [&](int buf, int stage_k, int idx) {
     const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
     const int tile = idx / C::Q, q = idx % C::Q;
-    const uint16_t* src = tile == 0 ? A1 + offA[q] : tile == 1 ? A2 + offA[q] : B + offB[q];
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + stage_k),
+    const int64_t a_step = TR ? (int64_t)stage_k * g.lda : (int64_t)stage_k;
+    const uint16_t* src = tile == 0 ? A1 + offA[q] + a_step : tile == 1 ? A2 + offA[q] + a_step : B + offB[q] + stage_k;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lds + dst + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
   };
   bf16x8 a1[2][2], a2[2][2], bfr[2][4];  // [half][tile]
   auto rd = [&](const char* base, int off) { return *reinterpret_cast<const bf16x8*>(base + off); };
+  // fragment of plane `pl` (0: A1, 1: A2), row tile i, sub-step ks of the stage at `base`
+  auto ldA = [&](const char* base, int pl, int i, int ks) -> bf16x8 {
+    if constexpr (TR) {  // 8 tokens of one entry: two transposing reads (tokens 0-3, tokens 4-7: + 4 rows = 2048 bytes)
+      const char* p0 = base + pl * C::TILE_BYTES + rdA[i] + ks * (16 * 512);
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * 512));
+      return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    } else {
+      return rd(base, pl * C::TILE_BYTES + rdA[ks] + i * 32 * ROW_BYTES32);
+    }
+  };
+  auto ldB = [&](const char* base, int j, int ks) { return rd(base, rdB[ks] + j * 32 * ROW_BYTES32); };
+  // the twelve fragments of half `ks` of the stage at `base`, two LDS reads per MFMA gap, gap 0 = after the half's 4th MFMA
+  auto read_gap = [&](const char* base, int ks, int gap) {
+    if constexpr (TR) {
+      if (gap == 0) {
+        a1[ks][0] = ldA(base, 0, 0, ks);
+      } else if (gap == 1) {
+        bfr[ks][0] = ldB(base, 0, ks);
+        bfr[ks][1] = ldB(base, 1, ks);
+      } else if (gap == 2) {
+        bfr[ks][2] = ldB(base, 2, ks);
+        bfr[ks][3] = ldB(base, 3, ks);
+      } else if (gap == 3) {
+        a1[ks][1] = ldA(base, 0, 1, ks);
+      } else if (gap == 5) {
+        a2[ks][0] = ldA(base, 1, 0, ks);
+      } else if (gap == 6) {
+        a2[ks][1] = ldA(base, 1, 1, ks);
+      }
+    } else {
+      if (gap == 0) {
+        a1[ks][0] = ldA(base, 0, 0, ks);
+        bfr[ks][0] = ldB(base, 0, ks);
+      } else if (gap == 1) {
+        bfr[ks][1] = ldB(base, 1, ks);
+        bfr[ks][2] = ldB(base, 2, ks);
+      } else if (gap == 2) {
+        bfr[ks][3] = ldB(base, 3, ks);
+        a1[ks][1] = ldA(base, 0, 1, ks);
+      } else if (gap == 3) {
+        a2[ks][0] = ldA(base, 1, 0, ks);
+        a2[ks][1] = ldA(base, 1, 1, ks);
+      }
+    }
+  };
 
   mfma_pin_acc(acc);
   __syncthreads();  // whoever used the LDS before is done with it
@@ -656,11 +722,11 @@ __device__ __forceinline__ void gemm_mainloop_dual_ps(f32x16 (&acc)[2][4], const
     for (int idx = 0; idx < C::LOADS; ++idx) stage_piece(t, t * BK32, idx);
   wait_tile_then_barrier<2 * C::LOADS>();  // stage 0 has landed
 #pragma unroll
-  for (int i = 0; i < 2; ++i) a1[0][i] = rd(lds, rdA[0] + i * 32 * ROW_BYTES32);
+  for (int i = 0; i < 2; ++i) a1[0][i] = ldA(lds, 0, i, 0);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bfr[0][j] = rd(lds, rdB[0] + j * 32 * ROW_BYTES32);
+  for (int j = 0; j < 4; ++j) bfr[0][j] = ldB(lds, j, 0);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) a2[0][i] = rd(lds, C::TILE_BYTES + rdA[0] + i * 32 * ROW_BYTES32);
+  for (int i = 0; i < 2; ++i) a2[0][i] = ldA(lds, 1, i, 0);
 
   // buffers: b0 = stage s, b1 = stage s + 1, b2 = stage s + 2 (= where the first-half pieces of stage s + 2 go);
   // stage s + 3 goes into b0 after A(s)
@@ -685,37 +751,11 @@ __device__ __forceinline__ void gemm_mainloop_dual_ps(f32x16 (&acc)[2][4], const
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             mfma_bf16_asm<false, true>(acc[i][j], pl == 0 ? a1[h][i] : a2[h][i], bfr[h][j]);
-            if (h == 0) {  // second half's fragments of THIS stage
-              if (m == 3) {
-                a1[1][0] = rd(base, rdA[1]);
-                bfr[1][0] = rd(base, rdB[1]);
-              } else if (m == 4) {
-                bfr[1][1] = rd(base, rdB[1] + 32 * ROW_BYTES32);
-                bfr[1][2] = rd(base, rdB[1] + 2 * 32 * ROW_BYTES32);
-              } else if (m == 5) {
-                bfr[1][3] = rd(base, rdB[1] + 3 * 32 * ROW_BYTES32);
-                a1[1][1] = rd(base, rdA[1] + 32 * ROW_BYTES32);
-              } else if (m == 6) {
-                a2[1][0] = rd(base, C::TILE_BYTES + rdA[1]);
-                a2[1][1] = rd(base, C::TILE_BYTES + rdA[1] + 32 * ROW_BYTES32);
-              }
+            if (h == 0) {  // second half's fragments of THIS stage (gaps after MFMAs 3-6; TR: 3-6, 8, 9)
+              if (m >= 3 && m <= 9) read_gap(base, 1, m - 3);
               if (F::p1 && m % 5 == 2) stage_piece(b2, (s + 2) * BK32, 3 + m / 5);  // m = 2, 7, 12 -> pieces 3, 4, 5 of stage s + 2
             } else {  // first half's fragments of the NEXT stage (certified by the barrier above)
-              if (F::rd) {
-                if (m == 19) {
-                  a1[0][0] = rd(next, rdA[0]);
-                  bfr[0][0] = rd(next, rdB[0]);
-                } else if (m == 20) {
-                  bfr[0][1] = rd(next, rdB[0] + 32 * ROW_BYTES32);
-                  bfr[0][2] = rd(next, rdB[0] + 2 * 32 * ROW_BYTES32);
-                } else if (m == 21) {
-                  bfr[0][3] = rd(next, rdB[0] + 3 * 32 * ROW_BYTES32);
-                  a1[0][1] = rd(next, rdA[0] + 32 * ROW_BYTES32);
-                } else if (m == 22) {
-                  a2[0][0] = rd(next, C::TILE_BYTES + rdA[0]);
-                  a2[0][1] = rd(next, C::TILE_BYTES + rdA[0] + 32 * ROW_BYTES32);
-                }
-              }
+              if (F::rd && m >= 19 && m <= 25) read_gap(next, 0, m - 19);
               if (F::p2 && m % 5 == 2) stage_piece(b0, (s + 3) * BK32, (m - 17) / 5);  // m = 17, 22, 27 -> pieces 0, 1, 2 of stage s + 3
             }
             ++m;
@@ -962,7 +1002,10 @@ __device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], co
 // (profiles/r04k_*).  Its A planes stream from HBM (5 GB per 8192 rows, L2 hit 80 %): the early burst of the staggered
 // schedule puts the whole stage in flight a step and a half before it is needed, the evenly spread pieces do not (a piece
 // every 4th MFMA from the 2nd on: 19.3 ms, the same).  Selectable with PRL_TUNE_LMHEAD_BWD bit 3 for A/B.
-template <int HAND = 0>
+// The phase-shifted step (gemm_mainloop_dual_ps<true>, bit 4) - the forward's best schedule, prefetch two and a half steps deep -
+// is slower still: 21.1 ms against 16.6 and 18.9, bit-identical d W (profiles/r04t_dw_phase_shift_ab.jsonl).  What this kernel
+// rewards is the BURST: the 512-byte row segments of a stage (rows 304 KB apart in the planes) requested together.
+template <int HAND>
 __device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
                                                       const Geom& g, int m0, int n0, char* lds) {
   using C = CfgDual;
@@ -2122,7 +2165,11 @@ __global__ __launch_bounds__(CfgDual::NT, 2) void gemm_dw_tr_kernel(GemmArgs a) 
   const int wrow0 = (wave >> 1) * 64, wcol0 = (wave & 1) * C::WCOLS;
   f32x16 acc[2][4];
   zero_acc<4>(acc);
-  gemm_mainloop_dual_tr<HAND>(acc, a.terms.a[0], a.terms.a[1], a.terms.b[0], a.geo, m0, n0, lds);
+  if constexpr (HAND == 2) {  // the phase-shifted step (gemm_mainloop_dual_ps<true>)
+    gemm_mainloop_dual_ps<true>(acc, a.terms.a[0], a.terms.a[1], a.terms.b[0], a.geo, m0, n0, lds);
+  } else {
+    gemm_mainloop_dual_tr<HAND>(acc, a.terms.a[0], a.terms.a[1], a.terms.b[0], a.geo, m0, n0, lds);
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -2823,6 +2870,8 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
       const int64_t bwd_bits = prl::tuning(PRL_TUNE_LMHEAD_BWD, 0);
       if (bwd_bits & 8) {  // A/B: the hand-placed stream (measured slower here, see gemm_mainloop_dual_tr)
         if (int rc = PRL_LAUNCH_DUAL(gemm_dw_tr_kernel<1>, dw_blocks, g, s, "gemm_dw_tr_kernel(d weight, hand-placed)")) return rc;
+      } else if (bwd_bits & 16) {  // A/B: the phase-shifted step
+        if (int rc = PRL_LAUNCH_DUAL(gemm_dw_tr_kernel<2>, dw_blocks, g, s, "gemm_dw_tr_kernel(d weight, phase-shifted)")) return rc;
       } else if (int rc = PRL_LAUNCH_DUAL(gemm_dw_tr_kernel<0>, dw_blocks, g, s, "gemm_dw_tr_kernel(d weight)")) {
         return rc;
       }
