@@ -1920,7 +1920,7 @@ __global__ __launch_bounds__(C::NT, 2) void lmhead_dlogits_kernel(DlArgs a) {
 
 // backward, step 1 when the forward KEPT its logits (FwdArgs.logits2): no recompute - one pass over the chunk's rows of the kept
 // fp32 logits (base-2 units) writes the same two d-logits planes.  One workgroup per token row of the chunk buffers (the pad
-// rows and the rows without a gradient are written as zeros without reading anything); a thread owns 8 consecutive entries.
+// rows and the rows without a gradient are written as zeros without reading anything).
 struct KeptArgs {
   const float* logits2;  // [n_total, vocab]
   int64_t vocab, row_base, cols;
@@ -1936,6 +1936,11 @@ struct KeptArgs {
   uint16_t* dl_lo;
 };
 
+// Every access wave-contiguous: a lane takes FOUR consecutive entries (one 16-byte load, one 8-byte store per plane) and keeps U
+// loads in flight.  Measured against the first form (eight entries per lane: two 16-byte loads at a 32-byte lane stride, one
+// 16-byte store per plane), same box, rocprofv3 kernel trace, 8192 x 152 064: 2.022 ms -> U = 2: 1.983, 4: 1.958, 8: 1.948 ms
+// = 5.1 TB/s of 9.96 GB read + written (profiles/r04u_*); the arithmetic per entry is unchanged, outputs bit-identical.
+template <int U = 8>
 __global__ __launch_bounds__(256) void dlogits_from_kept_kernel(KeptArgs a) {
   const int lrow = (int)blockIdx.x;
   const int64_t q = a.row_base + lrow;
@@ -1955,29 +1960,39 @@ __global__ __launch_bounds__(256) void dlogits_from_kept_kernel(KeptArgs a) {
   const bool live = (gi != 0.0f) || (nhi != 0.0f);
   const float ngi = -gi;
   const f32x4* src = reinterpret_cast<const f32x4*>(a.logits2 + q * V);
-  uint4* hi = reinterpret_cast<uint4*>(a.dl_hi + (int64_t)lrow * V);
-  uint4* lo = reinterpret_cast<uint4*>(a.dl_lo + (int64_t)lrow * V);
-  const int groups = (int)(V / 8);
-  for (int g = threadIdx.x; g < groups; g += 256) {
-    uint32_t oh[4] = {0, 0, 0, 0}, ol[4] = {0, 0, 0, 0};
-    if (live) {
-      const f32x4 x0 = __builtin_nontemporal_load(src + 2 * g), x1 = __builtin_nontemporal_load(src + 2 * g + 1);
-      const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  uint2* hi = reinterpret_cast<uint2*>(a.dl_hi + (int64_t)lrow * V);
+  uint2* lo = reinterpret_cast<uint2*>(a.dl_lo + (int64_t)lrow * V);
+  const int quads = (int)(V / 4);
+  for (int g0 = threadIdx.x; g0 < quads; g0 += 256 * U) {
+    f32x4 x[U];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d2 = x[e] - l2;  // log2 p
-        const float pr = fast_exp2(d2);
-        float val = ngi * pr;
-        if (nhi != 0.0f) val = __builtin_fmaf(nhi * pr, __builtin_fmaf(d2, kLn2, H), val);
-        if (g * 8 + e == id) val += gi;
-        uint16_t h16, l16;
-        split2(val, h16, l16);
-        oh[e >> 1] |= (uint32_t)h16 << (16 * (e & 1));
-        ol[e >> 1] |= (uint32_t)l16 << (16 * (e & 1));
-      }
+    for (int k = 0; k < U; ++k) {
+      const int g = g0 + k * 256;
+      x[k] = (live && g < quads) ? __builtin_nontemporal_load(src + g) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
-    hi[g] = uint4{oh[0], oh[1], oh[2], oh[3]};
-    lo[g] = uint4{ol[0], ol[1], ol[2], ol[3]};
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int g = g0 + k * 256;
+      if (g >= quads) break;
+      uint32_t oh[2] = {0, 0}, ol[2] = {0, 0};
+      if (live) {
+        const float xe[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d2 = xe[e] - l2;  // log2 p
+          const float pr = fast_exp2(d2);
+          float val = ngi * pr;
+          if (nhi != 0.0f) val = __builtin_fmaf(nhi * pr, __builtin_fmaf(d2, kLn2, H), val);
+          if (g * 4 + e == id) val += gi;
+          uint16_t h16, l16;
+          split2(val, h16, l16);
+          oh[e >> 1] |= (uint32_t)h16 << (16 * (e & 1));
+          ol[e >> 1] |= (uint32_t)l16 << (16 * (e & 1));
+        }
+      }
+      hi[g] = uint2{oh[0], oh[1]};
+      lo[g] = uint2{ol[0], ol[1]};
+    }
   }
 }
 
@@ -2710,7 +2725,7 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
     if (kept_logits2) {
       KeptArgs k{kept_logits2, vocab, r0, cols, (int)m, input_ids, lse2, entropy, grad_new_logprobs, grad_entropy, upstream,
                  1.0f / temperature, dl_hi, dl_lo};
-      hipLaunchKernelGGL(dlogits_from_kept_kernel, dim3((unsigned)m_pad), dim3(256), 0, s, k);
+      hipLaunchKernelGGL(dlogits_from_kept_kernel<8>, dim3((unsigned)m_pad), dim3(256), 0, s, k);
       PRL_LAUNCH_CHECK("dlogits_from_kept_kernel");
     } else {
       DlArgs d;
