@@ -1005,6 +1005,9 @@ __device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], co
 // The phase-shifted step (gemm_mainloop_dual_ps<true>, bit 4) - the forward's best schedule, prefetch two and a half steps deep -
 // is slower still: 21.1 ms against 16.6 and 18.9, bit-identical d W (profiles/r04t_dw_phase_shift_ab.jsonl).  What this kernel
 // rewards is the BURST: the 512-byte row segments of a stage (rows 304 KB apart in the planes) requested together.
+// Three more forms were measured and removed again (profiles/r04v_*, same box each): the hand-placed reads WITH the burst
+// (16.80-16.92 ms against 16.81-16.94: the MFMA / read placement is not what bounds this kernel), every wave issuing its burst
+// right after the barrier (18.7-19.1) and every wave after its MFMAs (17.1-17.2) against the staggered roles (16.8).
 template <int HAND>
 __device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
                                                       const Geom& g, int m0, int n0, char* lds) {
