@@ -1008,6 +1008,9 @@ __device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], co
 // Three more forms were measured and removed again (profiles/r04v_*, same box each): the hand-placed reads WITH the burst
 // (16.80-16.92 ms against 16.81-16.94: the MFMA / read placement is not what bounds this kernel), every wave issuing its burst
 // right after the barrier (18.7-19.1) and every wave after its MFMAs (17.1-17.2) against the staggered roles (16.8).
+// Nor is it DRAM page locality: a timing-only run with the planes ADDRESSED as contiguous [32 tokens x 256 entries] blocks (one
+// 16 KB block per staged tile instead of 32 row segments 304 KB apart) took 16.67-16.74 ms against 16.73-16.90
+// (profiles/r04w_*) - a block-tiled plane layout is not worth building.
 template <int HAND>
 __device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
                                                       const Geom& g, int m0, int n0, char* lds) {
