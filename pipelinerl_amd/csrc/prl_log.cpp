@@ -174,7 +174,10 @@ struct Prefaulter {
       int rc = 0;
       if (e > a) rc = madvise(reinterpret_cast<void*>(a), e - a, MADV_POPULATE_WRITE);
       lk.lock();
-      if (rc != 0 && errno == EINVAL) disabled = true;  // kernel without MADV_POPULATE_WRITE: appends fault their pages themselves
+      const int err = rc != 0 ? errno : 0;
+      // kernel without MADV_POPULATE_WRITE: appends fault their pages themselves.  Only believed while the segment is still the one
+      // the call was aimed at: after a switch the old range may be unmapped or belong to someone else, and its errors mean nothing
+      if (err == EINVAL && g == gen) disabled = true;
       if (g == gen) done = from + n;  // a segment change in between restarts from its own offset
     }
   }
