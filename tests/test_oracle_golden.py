@@ -83,3 +83,24 @@ def test_sentinel_oracle_matches_reference():
     assert_batch_equal(got, {k: z[k] for k in z.files})
     want_ex = json.loads((GOLDEN / "sentinel_example.json").read_text())
     assert opre.sentinel_example(3, 7, 9) == want_ex
+
+
+def test_value_head_closed_form_gradient_is_the_derivative_of_the_oracle_loss():
+    """Second witness for `g_value` (the goldens compare it with the reference's autograd): central differences of the
+    oracle's own fp32 loss along random directions of the value predictions, accumulated in fp64 over the labelled tokens."""
+    case = load_rl_case("c18_ppo_value_head")
+    cur, mx = case["steps"]
+    b, cfg = case["batch"], dict(case["config"], value_loss_coef=0.7)
+    nlp, ent, _, _ = orl.logprob_entropy(case["logits"], b["input_ids"], cfg.get("temperature", 1.0))
+    base = orl.token_loss(b, nlp, ent, cfg, cur, mx, True, value=case["value"])
+    g = base["g_value"].astype(np.float64)
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        d = rng.standard_normal(case["value"].shape)
+        # advantages = rewards - V is DETACHED in the reference (:274): only the value loss moves with V, so evaluate it alone
+        lo, hi = (orl.token_loss(b, nlp, ent, cfg, cur, mx, True, value=(case["value"] + s * 1e-2 * d).astype(np.float32))["stats"]["value_loss"]
+                  for s in (-1.0, 1.0))
+        numeric = cfg["value_loss_coef"] * (hi - lo) / 2e-2
+        analytic = float((g * d).sum())
+        assert abs(numeric - analytic) <= 2e-3 * max(1.0, abs(analytic)), (numeric, analytic)
+    assert np.count_nonzero(g[:, :-1][(b["labels"] == -100)[:, 1:]]) == 0 and np.all(g[:, -1] == 0)
