@@ -916,7 +916,8 @@ def main():
         "grpo_loss_step": tokens_per_rank * 52,                   # 56 B/token minus the unwritten 4 B gradient
         "preprocess_K5_K6": tokens_per_rank * (84 + 8),           # K6 16 B read + 68 B written; K5 scan 8 B read
         "pack_collate_kernel": tokens_per_rank * 84,              # the K6 kernel alone
-        "group_advantages_K5": tokens_per_rank * 8,               # the K5 scan (+ O(S) group arithmetic)
+        "group_advantages_K5": tokens_per_rank * 8,               # the K5 scan (+ O(S) group arithmetic), host planning + upload included
+        "group_advantages_K5_kernels": tokens_per_rank * 8,       # the two K5 launches alone
     }
     for name, k in kernels.items():
         if name in algo:

@@ -633,7 +633,8 @@ def plan_groups(group_index: np.ndarray, step_index: np.ndarray, rollout_index: 
     return key_off, key_members, group_off, group_members, counts.astype(np.int32)
 
 
-def populate_rl_data_ragged(rollouts: RaggedRollouts, eos_token_id: int, config: RLConfig, plan: Sequence[torch.Tensor] | None = None) -> PreparedRollouts:
+def populate_rl_data_ragged(rollouts: RaggedRollouts, eos_token_id: int, config: RLConfig, plan: Sequence[torch.Tensor] | None = None,
+                            timer: Any = None) -> PreparedRollouts:
     """K5 on device: num_labels / overflow per sequence, leave-one-out advantages per
     (group_id, step_index), mean rollout tokens per group (reference rl/__init__.py:453-570).
     `plan`: the five arrays of `plan_groups` already on the device (they rode along with the rollouts' upload,
@@ -652,7 +653,10 @@ def populate_rl_data_ragged(rollouts: RaggedRollouts, eos_token_id: int, config:
     out32 = torch.empty((4, S), dtype=torch.float32, device=dev)
     adv64, gt64 = out64[0], out64[1]
     num_labels, overflow, adv32, gt32 = out32[0], out32[1], out32[2], out32[3]
-    with torch.cuda.device(dev):
+    import contextlib
+
+    # `timer` (bench.py's EventTimer): HIP events around the two launches alone, next to the all-in figure of the caller
+    with torch.cuda.device(dev), (timer.time("group_advantages_K5_kernels") if timer is not None else contextlib.nullcontext()):
         stream = _lib.current_stream_ptr(dev)
         _lib.check(
             lib.prl_seq_scan(

@@ -81,7 +81,7 @@ class HotPathStep:
             # the five CSR tables of K5 in ONE page-locked copy (five pageable `.to(device)` calls blocked the host for
             # ~130 us of this launch's 200; profiles/r03ah_*), the three of K6 in another
             plan = self._stager.upload(plan_groups(rollouts.host_group_index, rollouts.host_step_index, rollouts.host_rollout_index))
-            prep: PreparedRollouts = populate_rl_data_ragged(rollouts, self.eos_token_id, self.config, plan=plan)
+            prep: PreparedRollouts = populate_rl_data_ragged(rollouts, self.eos_token_id, self.config, plan=plan, timer=timer)
         self.batches = pack_prepared(prep, micro_batches, self.eos_token_id, timer=timer, stager=self._stager)
         self.offsets = [int(x) for x in self.batches.token_off]
         total = self.offsets[-1]
