@@ -319,6 +319,8 @@ def collate_packed(
     on the HIP device."""
     if label_pad_value != MASKED_TOKEN_ID:
         raise ValueError("label_pad_value other than -100 is not supported")
+    if not examples:  # the reference's first failure on an empty list is examples[0] (data.py:246): same exception, before any device work
+        raise IndexError("list index out of range")
     total = sum(len(e["input_ids"]) for e in examples)
     pad = (seq_parallel - total % seq_parallel) % seq_parallel if seq_parallel > 0 else 0
     prep, bits = _examples_to_prepared(examples, _device_for_collate())
@@ -339,6 +341,8 @@ def collate(
     data.py:163-212); padding side from `tokenizer.padding_side`."""
     if label_mask_value != MASKED_TOKEN_ID:
         raise ValueError("label_mask_value other than -100 is not supported")
+    if not examples:  # the reference reads examples[0].keys() first (data.py:170)
+        raise IndexError("list index out of range")
     prep, bits = _examples_to_prepared(examples, _device_for_collate())
     return pad_prepared(
         prep, list(range(len(examples))), padding_side=getattr(tokenizer, "padding_side", "right"),

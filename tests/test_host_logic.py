@@ -307,3 +307,14 @@ def test_host_stats_with_and_without_a_value_head():
     dev[STAT_INDEX["loss"]] = float("inf")
     with pytest.raises(AssertionError, match="Non-finite loss"):
         host_stats(torch.tensor(dev + vs, dtype=torch.float64), 7, 0.01, 0.0, coef)
+
+
+def test_empty_example_lists_raise_what_the_reference_raises():
+    """collate([]) / collate_packed([]) index examples[0] in the reference (data.py:170, 246): IndexError, before any device work."""
+    from pipelinerl_amd.finetune.data import collate, collate_packed
+
+    tok = type("Tok", (), {"eos_token_id": 2, "padding_side": "right"})()
+    with pytest.raises(IndexError):
+        collate_packed([], tok, seq_parallel=1)
+    with pytest.raises(IndexError):
+        collate([], tok)
