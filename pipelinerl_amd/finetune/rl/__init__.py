@@ -683,7 +683,8 @@ def populate_rl_data(dataset: list[dict[str, Any]], eos_token_id: int, config: R
     Entries are what `preprocess_fn(..., is_rl=True)` produced (+ group_id, rollout_index,
     step_index).  The numbers come from the device kernels."""
     if not dataset:
-        return dataset
+        # the reference builds a DataFrame and selects its columns (rl/__init__.py:456-459): on an empty list pandas raises this
+        raise KeyError("None of [Index(['group_id', 'rollout_index', 'step_index', 'rewards'], dtype='object')] are in the [columns]")
     entries = []
     for e in dataset:
         if len(e["rewards"]) == 0:

@@ -318,3 +318,7 @@ def test_empty_example_lists_raise_what_the_reference_raises():
         collate_packed([], tok, seq_parallel=1)
     with pytest.raises(IndexError):
         collate([], tok)
+    from pipelinerl_amd.finetune.rl import RLConfig, populate_rl_data
+
+    with pytest.raises(KeyError, match="group_id"):  # pandas' column selection on an empty frame (rl/__init__.py:456-459)
+        populate_rl_data([], 2, RLConfig())
