@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: a full BASELINE-size case checked against the CPU oracle (tens of seconds; still part of -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The >= 2-GPU tests (tests/test_gpu_multi.py) go LAST.  They are skipped on the 1-GPU boxes every round of this build ran
+    on; the first node with several GPUs is the first time RCCL carries these paths between devices, and a run with `-x` should
+    have reported on everything else before it gets there."""
+    multi = [it for it in items if it.fspath.basename == "test_gpu_multi.py"]
+    if multi:
+        rest = [it for it in items if it.fspath.basename != "test_gpu_multi.py"]
+        items[:] = rest + multi
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built_library():
     """A fresh checkout has no libprl.so (it is git-ignored): build it once per session before any
