@@ -404,6 +404,12 @@ def _body_and_head(model: Any):
     return body, lm_head
 
 
+def _lm_of(model: Any) -> Any:
+    """The causal LM inside an actor-critic wrapper (`AutoModelForCausalLMWithValueHead.pretrained_model`, reference
+    finetune/value_model.py:54-116); any other model is its own LM."""
+    return getattr(model, "pretrained_model", model) if getattr(model, "value_head", None) is not None else model
+
+
 def _hidden_states(body: Any, batch: PipelineBatchEncoding) -> torch.Tensor:
     inputs = {"input_ids": batch.input_ids, "attention_mask": batch.attention_mask}
     if batch.is_packed:
@@ -442,7 +448,7 @@ def install_fused_head(model: Any, chunk_rows: int = 8192, hidden_grad_terms: in
     gathers a parameter in its module's pre-forward hook, which a bypassed module never fires - there the call
     has to sit inside `deepspeed.zero.GatheredParameters([model.lm_head.weight])` (a partitioned placeholder is
     refused by shape, not silently used)."""
-    _body_and_head(model)
+    _body_and_head(_lm_of(model))
     if getattr(model, "_prl_fused_head", None) is not None:
         return model
     original = model.forward
@@ -453,13 +459,21 @@ def install_fused_head(model: Any, chunk_rows: int = 8192, hidden_grad_terms: in
             return original(*args, **kwargs)
         if rl_config.policy_loss == "gspo":
             raise NotImplementedError("the fused head covers ppo / reinforce; gspo goes through rl_step")
-        body, lm_head = _body_and_head(model)
+        body, lm_head = _body_and_head(_lm_of(model))
         hidden = _hidden_states(body, rl_batch)
         w = lm_head.weight
         cfg, _, _ = make_loss_config(rl_config, current_step, max_step)
         opts = model._prl_fused_head
-        return _FusedHeadLossFn.apply(hidden, w, _head_for(lm_head, w, opts["chunk_rows"], opts["hidden_grad_terms"], opts["keep_logits"]), rl_batch, cfg,
-                                      rl_config.temperature, opts["chunk_rows"])
+        value_head = getattr(model, "value_head", None)
+        if value_head is not None:  # actor-critic wrapper: advantages := rewards - V, value loss and its five statistics ride along
+            value_loss, value_advantages, vstats_dev = _ValueLossFn.apply(value_head(hidden), rl_batch, cfg)
+            rl_batch = _with_advantages(rl_batch, value_advantages)
+        loss, stats_dev = _FusedHeadLossFn.apply(hidden, w, _head_for(lm_head, w, opts["chunk_rows"], opts["hidden_grad_terms"], opts["keep_logits"]),
+                                                 rl_batch, cfg, rl_config.temperature, opts["chunk_rows"])
+        if value_head is not None:
+            loss = loss + rl_config.value_loss_coef * value_loss
+            stats_dev = torch.cat([stats_dev, vstats_dev])
+        return loss, stats_dev
 
     # `keep_logits`: None = the default (on, unless PRL_LMHEAD_KEEP_LOGITS=0, and only while two copies of the micro-batch's logits
     # fit in free device memory); False = never (no logits anywhere, 2 more plane products in the backward); `chunk_rows`: rows of
@@ -484,10 +498,10 @@ def rl_step_fused_head(model: Any, batch: PipelineBatchEncoding, current_step: i
     if getattr(inner, "_prl_fused_head", None) is not None:
         _, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
         loss, stats_dev = model(rl_batch=batch, rl_config=config, current_step=current_step, max_step=max_step)
-        return loss, _host_stats(stats_dev, batch, kl_coef, ent_coef)
+        return loss, _host_stats(stats_dev, batch, kl_coef, ent_coef, config.value_loss_coef)
     # an actor-critic wrapper (finetune/value_model.py:54-116): the LM is `.pretrained_model`, the critic reads the same hidden states
     value_head = getattr(model, "value_head", None)
-    body, lm_head = _body_and_head(getattr(model, "pretrained_model", model) if value_head is not None else model)
+    body, lm_head = _body_and_head(_lm_of(model))
     hidden = _hidden_states(body, batch)
     values = value_head(hidden) if value_head is not None else None
     w = lm_head.weight

@@ -191,8 +191,23 @@ def test_actor_critic_model_through_rl_step_and_the_fused_head(libprl, cuda_devi
     b["ref_logprobs"] = batch.ref_logprobs.cpu().numpy()
     want = orl.rl_step(out.logits.cpu().numpy(), b, config, 0, 10, True, value=out.value.cpu().numpy())
 
+    from pipelinerl_amd.fused_head import install_fused_head
+
+    class Wrapper(torch.nn.Module):  # what DistributedDataParallel / accelerate present: the model as `.module`, calls forwarded
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+
+        def forward(self, *a, **k):
+            return self.module(*a, **k)
+
+    def installed_step(m, *a, **k):  # the loss produced INSIDE the wrapped model's forward (what DDP / FSDP need)
+        if getattr(m, "_prl_fused_head", None) is None:
+            install_fused_head(m)
+        return rl_step_fused_head(Wrapper(m), *a, **k)
+
     results = []
-    for step in (rl_step, rl_step_fused_head):
+    for step in (rl_step, rl_step_fused_head, installed_step):
         model.zero_grad(set_to_none=True)
         loss, stats = step(model, batch, 0, 10, cfg)
         loss.backward()
@@ -201,11 +216,13 @@ def test_actor_critic_model_through_rl_step_and_the_fused_head(libprl, cuda_devi
         assert abs(loss.item() - float(want["loss"])) <= FP_TOL * max(1.0, abs(float(want["loss"])))
         for k, w in want["stats"].items():
             assert abs(float(stats[k]) - float(w)) <= 2 * FP_TOL * max(1.0, abs(float(w))), (step.__name__, k, stats[k], w)
-    (l0, s0, g0), (l1, s1, g1) = results
-    assert abs(l0 - l1) <= FP_TOL * max(1.0, abs(l0))
+    (l0, s0, g0), (l1, s1, g1), (l2, s2, g2) = results
+    assert abs(l0 - l1) <= FP_TOL * max(1.0, abs(l0)) and l1 == l2 and s1 == s2  # bare and installed: the same launches
     for n in g0:
         scale = g0[n].abs().max().item()
         assert scale > 0 and (g0[n] - g1[n]).abs().max().item() <= 2e-3 * scale, n  # bf16x2 head vs fp32 autograd of a bf16 hidden state
+        assert (g1[n] - g2[n]).abs().max().item() <= 1e-6 * scale, n  # (the embedding's backward accumulates with atomics)
+    assert model(input_ids=batch.input_ids).logits.shape == (1, T, V)  # every other call is still the model's own forward
     # the critic's weight gradient = hidden^T (coef * d value_loss / d V), from the oracle's closed form
     h = model.pretrained_model.model(input_ids=batch.input_ids).last_hidden_state.detach().float()[0].double().cpu().numpy()
     want_gw = want["g_value"][0].astype(np.float64) @ h
