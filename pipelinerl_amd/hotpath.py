@@ -64,7 +64,6 @@ class HotPathStep:
         self.step_batch: PipelineBatchEncoding | None = None
         self.buffers: StepBuffers | None = None
         self.offsets: list[int] = []
-        self._stager: Any = None  # page-locked ring for the planning tables of K5 / K6 (one upload each), made on first use
 
     # -- preprocess ---------------------------------------------------------------------------
     def preprocess(self, rollouts: RaggedRollouts, micro_batches: Sequence[Sequence[int]], timer: Any = None):
@@ -72,17 +71,11 @@ class HotPathStep:
         `timer`: optional event timer (bench.py) for the two device parts alone."""
         import contextlib
 
-        from .finetune.rl import plan_groups
-        from .staging import PinnedStager
-
-        if self._stager is None or self._stager.device != rollouts.device:
-            self._stager = PinnedStager(rollouts.device)
+        # (the planning tables go up as they are: at step scale - five + three small arrays - the page-locked ring of the
+        # preprocessor loop, `staging.PinnedStager`, measured 10-50 us SLOWER than the plain copies; profiles/r04zy vs r04z)
         with (timer.time("group_advantages_K5") if timer is not None else contextlib.nullcontext()):
-            # the five CSR tables of K5 in ONE page-locked copy (five pageable `.to(device)` calls blocked the host for
-            # ~130 us of this launch's 200; profiles/r03ah_*), the three of K6 in another
-            plan = self._stager.upload(plan_groups(rollouts.host_group_index, rollouts.host_step_index, rollouts.host_rollout_index))
-            prep: PreparedRollouts = populate_rl_data_ragged(rollouts, self.eos_token_id, self.config, plan=plan, timer=timer)
-        self.batches = pack_prepared(prep, micro_batches, self.eos_token_id, timer=timer, stager=self._stager)
+            prep: PreparedRollouts = populate_rl_data_ragged(rollouts, self.eos_token_id, self.config, timer=timer)
+        self.batches = pack_prepared(prep, micro_batches, self.eos_token_id, timer=timer)
         self.offsets = [int(x) for x in self.batches.token_off]
         total = self.offsets[-1]
         dev = rollouts.device
