@@ -142,3 +142,50 @@ def test_rollouts_round_trip_through_both_wire_formats(seqs, with_ref, seed):
     same(batch_codec.decode(batch_codec.encode_rollouts(rag)), rag)
     # the JSONL form survives a text round trip as well (fp32 values print exactly as python floats)
     same(RaggedRollouts.from_entries(json.loads(json.dumps(rag.to_entries()))), rag)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.lists(st.tuples(st.integers(1, 4), st.integers(1, 70), st.booleans()), min_size=1, max_size=8), st.sampled_from([256, 4096, 1 << 16]),
+       st.integers(0, 2**31 - 1))
+def test_batches_gathered_into_the_log_come_back_identical(shapes, segment_bytes, seed):
+    """`batch_codec.append_batch` gathers a batch's tensors straight into the shared-memory segment (`prl_log_appendv`, no
+    intermediate record) - for any mix of shapes, segment sizes small enough to force a rollover inside the sequence and records
+    larger than a segment, every batch a reader gets back equals the one written, and equals the one-copy `encode_batch` form."""
+    import time
+
+    from pipelinerl_amd import batch_codec
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.ring import Log
+
+    rng = np.random.default_rng(seed)
+    batches = []
+    for rows, cols, packed in shapes:
+        rows = 1 if packed else rows
+        f = lambda: torch.from_numpy(rng.standard_normal((rows, cols)).astype(np.float32))  # noqa: E731
+        i = lambda hi: torch.from_numpy(rng.integers(-100, hi, size=(rows, cols), dtype=np.int64))  # noqa: E731
+        kw = dict(input_ids=i(1000), attention_mask=torch.ones(rows, cols, dtype=torch.int64), labels=i(1000), rewards=f(), advantages=f(),
+                  ref_logprobs=f(), old_logprobs=f(), group_tokens=f(), num_labels=f(), overflow=f(), model_version=int(rng.integers(0, 99)),
+                  is_packed=packed)
+        if packed:
+            kw.update(position_ids=i(cols), segment_ids=i(4), seq_boundaries=torch.tensor([0, cols], dtype=torch.int32))
+        batches.append(PipelineBatchEncoding(**kw))
+    name = f"prl_prop_{time.time_ns()}"
+    w = Log(name, create=True, segment_bytes=segment_bytes)
+    try:
+        r = Log(name, reader=True)
+        for b in batches:
+            batch_codec.append_batch(w, b)
+        for b in batches:
+            rec = r.read(block=False)
+            assert bytes(rec) == bytes(batch_codec.encode_batch(b))  # the gathered record IS the one-copy record
+            got = PipelineBatchEncoding(**batch_codec.decode(rec))  # a batch record decodes to the constructor's kwargs
+            for k in ("input_ids", "attention_mask", "labels", "position_ids", "segment_ids", "seq_boundaries", "rewards", "advantages",
+                      "ref_logprobs", "old_logprobs", "group_tokens", "num_labels", "overflow"):
+                x, y = getattr(got, k, None), getattr(b, k, None)
+                assert (x is None) == (y is None), k
+                assert x is None or (x.dtype == y.dtype and torch.equal(x, y)), k
+            assert got.model_version == b.model_version and bool(got.is_packed) == bool(b.is_packed)
+        r.close()
+    finally:
+        w.close()
+        Log.unlink_name(name)
