@@ -189,3 +189,35 @@ def test_batches_gathered_into_the_log_come_back_identical(shapes, segment_bytes
     finally:
         w.close()
         Log.unlink_name(name)
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(st.one_of(st.none(), st.tuples(st.sampled_from(["int32", "int64", "float32", "float64", "uint8"]),
+                                               st.lists(st.integers(0, 9), min_size=1, max_size=3))), min_size=1, max_size=12),
+       st.integers(1, 4), st.integers(0, 2**31 - 1))
+def test_stager_round_trips_any_mix_of_arrays(specs, slots, seed):
+    """`PinnedStager.upload` (many host arrays -> one buffer -> views) and `.download`: any mix of dtypes, empty arrays and None
+    entries, ring slots reused - every view has the array's dtype, shape and contents, starts on a 256-byte boundary of the one
+    allocation, and earlier results survive later uploads (CPU device: the same layout code the GPU path runs)."""
+    from pipelinerl_amd.staging import PinnedStager
+
+    rng = np.random.default_rng(seed)
+    st_ = PinnedStager("cpu", slots=slots, min_bytes=64)
+    rounds = []
+    for _ in range(slots + 2):  # more rounds than slots: every slot is reused at least once
+        arrays = [None if sp is None else (rng.integers(0, 200, size=sp[1]).astype(sp[0])) for sp in specs]
+        out = st_.upload(arrays)
+        rounds.append((arrays, out))
+    for arrays, out in rounds:
+        bases = set()
+        for a, t in zip(arrays, out):
+            assert (a is None) == (t is None)
+            if a is None:
+                continue
+            assert tuple(t.shape) == a.shape and np.array_equal(t.numpy(), a) and t.numpy().dtype == a.dtype
+            if a.size:
+                assert t.storage_offset() * t.element_size() % 256 == 0
+                bases.add(t.untyped_storage().data_ptr())
+        assert len(bases) <= 1
+    block = torch.from_numpy(rng.standard_normal(37).astype(np.float32))
+    assert torch.equal(st_.download(block), block) and st_.downloads == 1 and st_.uploads == sum(1 for arrays, _ in rounds if any(a is not None and a.size for a in arrays))
