@@ -211,6 +211,8 @@ RL_CASES = {
     "c19_reinforce_value_head_unpacked": (dict(vocab=64, with_ref=True, unpacked=True, padding_side="left", seed_offset=22, value_head=True), dict(policy_loss="reinforce", epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0, overlong_filtering=True, value_loss_coef=0.5, entropy_bonus=0.01, final_entropy_bonus=0.01, batch_size=16), (2, 10)),
     "c20_ppo_value_head_rewards_sp": (dict(vocab=64, seq_parallel=8, seed_offset=23, value_head=True), dict(policy_loss="ppo", epsilon_low=0.1, epsilon_high=0.1, kl_coef=0.0, final_kl_coef=0.0, use_advantages=False, relu_log_p_weights=True, value_loss_coef=1.0, temperature=0.8, batch_size=8), (0, 10)),
     "c21_gspo_value_head": (dict(vocab=97, with_ref=True, seed_offset=24, value_head=True), dict(policy_loss="gspo", epsilon_low=0.05, epsilon_high=0.05, kl_coef=0.05, final_kl_coef=0.05, value_loss_coef=0.2, batch_size=16), (0, 10)),
+    "c22_ppo_value_head_groupnorm_overlong": (dict(vocab=64, with_ref=True, seed_offset=25, value_head=True), dict(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.02, final_kl_coef=0.0, group_normalization=True, overlong_filtering=True, value_loss_coef=0.3, entropy_bonus=0.01, final_entropy_bonus=0.0, batch_size=16), (5, 10)),
+    "c23_sentinel_value_head": (dict(vocab=64, sentinel=True, value_head=True), dict(policy_loss="ppo", kl_coef=0.0, final_kl_coef=0.0, value_loss_coef=0.5, batch_size=16), (0, 10)),
 }
 
 

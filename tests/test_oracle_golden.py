@@ -17,7 +17,10 @@ def test_rl_step_oracle_matches_reference(name):
     res = orl.rl_step(case["logits"], case["batch"], case["config"], cur, mx, bool(case["batch"]["is_packed"]), value=case.get("value"))
     assert res["finite"]
     if "value" in case:  # value-head branch: d loss / d outputs.value vs the reference's autograd
-        assert len(case["stats"]) == 37 and np.abs(case["grad_value"]).max() > 0
+        if "sentinel" in name:  # every label masked: the one-key dict and no gradient anywhere (rl/__init__.py:388-392)
+            assert list(case["stats"]) == ["input_size"] and np.abs(case["grad_value"]).max() == 0
+        else:
+            assert len(case["stats"]) == 37 and np.abs(case["grad_value"]).max() > 0
         np.testing.assert_allclose(res["g_value"], case["grad_value"], rtol=1e-5, atol=1e-9)
     # fp: loss / stats within 1e-5 relative of the reference's fp32 torch result
     assert abs(float(res["loss"]) - case["loss"]) <= 1e-5 * max(1.0, abs(case["loss"]))
