@@ -30,7 +30,7 @@ def load_rl_case(name: str) -> dict:
         if k in batch:
             batch[k] = batch[k].item()
     stats = dict(zip([str(k) for k in z["stats_keys"]], [float(v) for v in z["stats_values"]]))
-    extra = {k: z[k] for k in ("value", "grad_value") if k in z.files}  # value-head cases (c18-c20)
+    extra = {k: z[k] for k in ("value", "grad_value") if k in z.files}  # value-head cases (c18-c23)
     return {
         **extra,
         "batch": batch,

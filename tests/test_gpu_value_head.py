@@ -1,5 +1,5 @@
 """The value-head (actor-critic) branch of rl_step on the GPU (csrc/prl_value.hip through the C ABI) against the CPU
-oracle (`oracle.rl_loss.token_loss(value=...)`, pinned to the reference's own outputs by the c18-c20 goldens, which
+oracle (`oracle.rl_loss.token_loss(value=...)`, pinned to the reference's own outputs by the c18-c23 goldens, which
 tests/test_gpu_parity.py runs through `rl_step` in all four logits modes).  Reference: rl/__init__.py:162, 265-272,
 367-381, 441-448; finetune/value_model.py."""
 
