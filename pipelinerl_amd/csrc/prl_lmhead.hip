@@ -1011,6 +1011,9 @@ __device__ __forceinline__ void gemm_mainloop_one(f32x16 (&acc)[4][BN_ / 64], co
 // Nor is it DRAM page locality: a timing-only run with the planes ADDRESSED as contiguous [32 tokens x 256 entries] blocks (one
 // 16 KB block per staged tile instead of 32 row segments 304 KB apart) took 16.67-16.74 ms against 16.73-16.90
 // (profiles/r04w_*) - a block-tiled plane layout is not worth building.
+// And it is not the LDS DMA as such: the same stage moved global -> VGPR -> LDS (global_load_dwordx4 at the top of the step into
+// 24 registers, ds_write_b128 into the DMA's slots at its end, published by the next barrier; 204 VGPRs, no scratch) took
+// 18.3-18.5 ms against 16.4-16.6, bit-identical (profiles/r04vs_*); removed again.
 template <int HAND>
 __device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const uint16_t* A1, const uint16_t* A2, const uint16_t* B,
                                                       const Geom& g, int m0, int n0, char* lds) {
