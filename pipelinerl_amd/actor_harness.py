@@ -80,6 +80,7 @@ class ActorHarness:
         self.published_samples = 0
         self.published_groups = 0
         self.retries = 0
+        self.timing: dict[str, float] = {}
 
     # -- plugins ---------------------------------------------------------------------------------
     def load_problems(self, split: str = "train") -> list[dict]:
@@ -173,3 +174,79 @@ class ActorHarness:
 
     def run(self, problems: Sequence[dict] | None = None, n_groups: int | None = None, **kw: Any) -> int:
         return asyncio.run(self.run_async(self.load_problems() if problems is None else problems, n_groups, **kw))
+
+    # -- the training actor loop's pacing (actor.py:510-557) ----------------------------------------
+    @staticmethod
+    def submission_budget(attempts: int, train_batch_size: int, gradient_accumulation_passes: int, weight_update_interval: int,
+                          max_lag: int | None) -> tuple[float, int | None]:
+        """(groups that may be submitted before the first weight update, groups added per weight update) - the arithmetic of
+        actor.py:510-534: with `max_lag` the actor may run `ceil(max_lag / attempts)` groups ahead of what one update consumes
+        (`ceil(ceil(interval / B) * B / attempts)`, B = samples per optimizer step); without it nothing holds it back."""
+        import math
+
+        if max_lag is None:
+            return math.inf, None
+        total_batch_size = train_batch_size * gradient_accumulation_passes
+        total_update_size = math.ceil(weight_update_interval / total_batch_size) * total_batch_size
+        groups_per_update = math.ceil(total_update_size / attempts)
+        return math.ceil(max_lag / attempts) + groups_per_update, groups_per_update
+
+    async def run_paced_async(self, problems: Sequence[dict], samples_target: int, train_batch_size: int, gradient_accumulation_passes: int,
+                              weight_update_interval: int = 1, max_lag: int | None = None, concurrent_groups: int = 4, poll_s: float = 0.002,
+                              max_groups: int | None = None, on_group: Callable | None = None) -> int:
+        """The TRAINING actor loop's rules around the same rollouts (actor.py:536-557): stop once the trainer reports
+        `samples_target` processed samples; never have more than the submission budget of groups submitted (`max_lag`), the
+        budget growing by one update's worth every time a new weight version has PROPAGATED (`trainer_state`); problems are
+        drawn for ever (epoch after epoch - the problem dict carries `epoch`).  Needs a `trainer_state` that is being
+        followed.  Fills `self.timing` (seconds rolling out + publishing, seconds held back by the lag rule)."""
+        import time
+
+        if self.trainer_state is None:
+            raise ValueError("the paced loop follows the trainer: pass trainer_state")
+        if not problems:
+            raise ValueError("no problems to roll out (the dataset loader returned an empty list)")
+        ts = self.trainer_state
+        while ts.propagated_weight_version is None:  # actor.py:497 asserts it; a stage started early simply waits
+            await asyncio.sleep(poll_s)
+        last_version = ts.propagated_weight_version
+        can_submit, per_update = self.submission_budget(self.attempts, train_batch_size, gradient_accumulation_passes, weight_update_interval, max_lag)
+        submitted = 0
+        timing = self.timing = {"busy_s": 0.0, "blocked_by_lag_s": 0.0, "wall_s": 0.0, "groups": 0, "versions_seen": 1}
+        t_start = time.perf_counter()
+        start = self.published_samples
+        with write_to_streams(self.data_stream) as writer:
+            while True:
+                if ts.samples_processed is not None and ts.samples_processed >= samples_target:
+                    logger.info("Trainer signalled completion; stopping actor loop")
+                    break
+                if max_groups is not None and submitted >= max_groups:
+                    break
+                if ts.propagated_weight_version > last_version:
+                    if per_update is not None:
+                        can_submit += per_update
+                    last_version = ts.propagated_weight_version
+                    timing["versions_seen"] += 1
+                room = min(concurrent_groups, can_submit - submitted, (max_groups - submitted) if max_groups is not None else concurrent_groups)
+                if room <= 0:  # blocked_by_lag (actor.py:556)
+                    t0 = time.perf_counter()
+                    await asyncio.sleep(poll_s)
+                    timing["blocked_by_lag_s"] += time.perf_counter() - t0
+                    continue
+                t0 = time.perf_counter()
+                todo = []
+                for k in range(int(room)):
+                    i = submitted + k
+                    todo.append(({**problems[i % len(problems)], "epoch": i // len(problems)}, i))
+                groups = await asyncio.gather(*[self.rollout_group(p, gid) for p, gid in todo])
+                submitted += len(todo)
+                for g in groups:
+                    self.publish(writer, g)
+                    if on_group is not None:
+                        on_group(g)
+                timing["busy_s"] += time.perf_counter() - t0
+                timing["groups"] += len(groups)
+        timing["wall_s"] = time.perf_counter() - t_start
+        return self.published_samples - start
+
+    def run_paced(self, problems: Sequence[dict] | None = None, **kw: Any) -> int:
+        return asyncio.run(self.run_paced_async(self.load_problems() if problems is None else problems, **kw))

@@ -150,17 +150,37 @@ def calculate_train_steps(args: Any, interrupt_train_steps: int) -> int:
 # ---------------------------------------------------------------------------------------------
 
 
-def run_data_loader(data_stream: SingleStreamSpec, batch_queue: Queue, device: Any, stop: threading.Event | None = None) -> None:
+def annotate_host_batch(batch: PipelineBatchEncoding) -> PipelineBatchEncoding:
+    """What the loader thread knows about a batch while it is still on the HOST, stored in `batch.model_extra` so that the
+    training thread never has to ask the device for it: `tokens` (the real-token count, `get_batch_token_count`) and
+    `labelled_rows` (flat indices of the logits rows that predict a labelled token, `fused_head._labelled_rows`)."""
+    if batch.input_ids.is_cuda:
+        return batch
+    batch.model_extra["tokens"] = int(batch.attention_mask.sum())
+    live = torch.zeros_like(batch.labels, dtype=torch.bool)
+    live[:, :-1] = batch.labels[:, 1:] != -100
+    batch.model_extra["labelled_rows"] = live.flatten().nonzero().squeeze(1)
+    return batch
+
+
+def run_data_loader(data_stream: SingleStreamSpec, batch_queue: Queue, device: Any, stop: threading.Event | None = None,
+                    annotate: bool = False) -> None:
     """Read `training_data/<instance>/<rank>` records, rebuild the batch, move it to `device`,
-    hand it to the training thread.  Exceptions travel through the queue like in the reference."""
+    hand it to the training thread.  Exceptions travel through the queue like in the reference.
+    `annotate`: also leave the host-side facts `StreamedLearnerStep` wants in `batch.model_extra` (`annotate_host_batch`)."""
     try:
         with read_stream(data_stream) as reader:
             for record in reader.read():
                 if stop is not None and stop.is_set():
                     return
                 batch = PipelineBatchEncoding(**record)
+                if annotate:
+                    annotate_host_batch(batch)
                 if device is not None:
                     batch = batch.to_device(device)
+                    rows = batch.model_extra.get("labelled_rows")
+                    if rows is not None:
+                        batch.model_extra["labelled_rows"] = rows.to(device, non_blocking=True)
                 batch_queue.put(batch)
     except Exception as e:  # noqa: BLE001 - forwarded to the consumer
         logger.error(f"Error in stream reader: {e}")
@@ -644,6 +664,112 @@ class LearnerStep:
         if self._writer_cm is not None:
             self._writer_cm.__exit__(None, None, None)
             self._writer_cm = self._writer = None
+
+
+class StreamedLearnerStep(LearnerStep):
+    """`LearnerStep` for a model prepared with `fused_head.install_fused_head`, fed from the `training_data` stream, WITHOUT a
+    host synchronisation per micro-batch: the same contract (sample accounting, sentinel rule, `SamplesProcessed`, optimizer
+    step at the accumulation boundary, `maybe_send_weights`), but
+
+      * the loss comes from the model's own forward (`model(rl_batch=...)` -> loss, device statistics): hidden states ->
+        MFMA head -> K2+K3, no `[T, V]` logits;
+      * the statistics of a micro-batch STAY ON THE DEVICE until the accumulation boundary, where all of them come over in
+        one copy and go through the reference's asserts and its per-step aggregation (`check_finite`, `aggregate_rl_stats`);
+        `step()` of a micro-batch inside the step returns `stats = None`.  The reference pays ~31 `.item()` per micro-batch
+        (rl/__init__.py:398-439), `LearnerStep` one copy per micro-batch; with a 0.5B model at 2048 tokens per micro-batch the
+        GPU work of one is short enough that ANY per-micro-batch sync leaves the device idle while the host queues the next;
+      * token counts and the rows that carry a label come from the loader thread, which sees the batch on the HOST before it
+        uploads it (`batch.model_extra["tokens" / "labelled_rows"]`, `run_data_loader(..., annotate=True)`) - the two
+        remaining per-micro-batch syncs of the drop-in path (`attention_mask.sum().item()`, `nonzero()`).
+
+    A non-finite value is therefore reported at the END of the step it occurred in, not at its micro-batch."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        inner = self.model
+        while getattr(inner, "_prl_fused_head", None) is None and hasattr(inner, "module"):
+            inner = inner.module
+        if getattr(inner, "_prl_fused_head", None) is None:
+            raise TypeError("StreamedLearnerStep drives a model prepared with pipelinerl_amd.fused_head.install_fused_head")
+        self._stats_dev: list[torch.Tensor] = []
+        self._input_sizes: list[int] = []
+        self.lag_samples: list[int] = []  # per real micro-batch: samples trained so far - the batch's model version
+
+    def step(self, batch: PipelineBatchEncoding) -> dict[str, Any]:
+        from .finetune.rl import VALUE_STAT_KEYS, check_finite, make_loss_config, stats_to_dict
+        from . import _lib
+
+        m = self.metrics
+        is_sentinel = bool(batch.sentinel)
+        if self.local_samples == self.target_samples_per_lead:
+            assert is_sentinel, "We should get a sentinel batch"
+        if self.max_lag is not None and m.last_broadcasted_version - batch.model_version > self.max_lag:
+            m.samples_too_old_to_train += self.train_batch_size
+        self._lag["min_version"] = min(self._lag.get("min_version", batch.model_version), batch.model_version)
+        self._lag["max_version"] = max(self._lag.get("max_version", batch.model_version), batch.model_version)
+        if not is_sentinel:
+            m.passes += 1
+            n = get_batch_sequence_count(batch)
+            self._micro_batch_sizes.append(n)
+            self.local_samples += n
+            tokens = batch.model_extra.get("tokens") if hasattr(batch, "model_extra") else None
+            self._tokens.append(int(tokens) if tokens is not None else get_batch_token_count(batch))
+            self.lag_samples.append(m.samples - int(batch.model_version))
+        overcounted = self._sum_over_ranks(self.local_samples)
+        assert overcounted % self.seq_parallel == 0
+        self.total_samples = overcounted // self.seq_parallel
+        do_optimizer_step = self.total_samples == self.target_samples
+
+        with self._sync_context(do_optimizer_step):
+            loss, stats_dev = self.model(rl_batch=batch, rl_config=self.rl_config, current_step=m.completed_steps, max_step=self.max_train_steps)
+            if is_sentinel:
+                loss = loss * 0.0
+            else:
+                self._stats_dev.append(stats_dev)
+                self._input_sizes.append(int(batch.input_ids.numel()))
+            loss.backward()
+        self.publish(SamplesProcessed(samples_processed=self.start_samples + self.total_samples))
+        result: dict[str, Any] = {"loss": loss.detach(), "did_optimizer_step": False, "stats": None, "metrics": {}}
+        if not do_optimizer_step:
+            return result
+
+        # ---- accumulation boundary: the step's statistics in ONE copy, then the optimizer step (:810-857)
+        _, kl_coef, ent_coef = make_loss_config(self.rl_config, m.completed_steps, self.max_train_steps)
+        if self._stats_dev:
+            rows = torch.stack(self._stats_dev).cpu().tolist()
+            for row, size in zip(rows, self._input_sizes):
+                vstats = row[_lib.PRL_NUM_STATS:]
+                if vstats:
+                    row[_lib.STAT_INDEX["loss"]] = float(np.float32(row[_lib.STAT_INDEX["loss"]]) + np.float32(
+                        self.rl_config.value_loss_coef * np.float32(vstats[VALUE_STAT_KEYS.index("value_loss")])))
+                check_finite(row)
+                if int(row[_lib.STAT_INDEX["num_output_tokens_sum"]]) == 0:
+                    stats = {"input_size": float(size)}
+                else:
+                    stats = stats_to_dict(row, kl_coef, ent_coef, size)
+                    stats.update({k: float(np.float32(v)) for k, v in zip(VALUE_STAT_KEYS, vstats)})
+                for k, v in stats.items():
+                    self._rl_metrics[k].append(v)
+            result["stats"] = stats
+        self._stats_dev, self._input_sizes = [], []
+        self.target_samples_per_lead += self.samples_per_lead_per_step
+        self.target_samples += self.samples_per_step
+        m.completed_steps += 1
+        m.samples = self.start_samples + self.total_samples
+        m.tokens += sum(self._tokens) * self.world
+        assert sum(self._micro_batch_sizes) == self.samples_per_lead_per_step
+        if self.gradient_clipping_threshold is not None:
+            gn = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.gradient_clipping_threshold)
+            m.grad_norm = float(gn)
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        result["did_optimizer_step"] = True
+        result["metrics"] = self._aggregate_metrics()
+        self._rl_metrics = defaultdict(list)
+        self._micro_batch_sizes, self._tokens, self._lag = [], [], {}
+        return result
 
 
 class NativeLearnerStep:

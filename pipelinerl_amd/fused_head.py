@@ -274,7 +274,10 @@ class _FusedHeadLossFn(torch.autograd.Function):
         rows = None
         if head.skip_unlabelled and not batch.sentinel:
             _lib.require_device(hidden, batch.labels)
-            rows = _labelled_rows(batch.labels)
+            # the loader thread may have found the rows on the host already (finetune_loop.annotate_host_batch): no sync here then
+            rows = getattr(batch, "model_extra", {}).get("labelled_rows")
+            if rows is None or rows.device != hidden.device:
+                rows = _labelled_rows(batch.labels)
         ctx.sentinel = bool(batch.sentinel) or (rows is not None and rows.numel() == 0)
         if ctx.sentinel:
             # a sentinel batch (finetune/utils.py:17-78), or any batch without a labelled token: loss 0, statistics of an

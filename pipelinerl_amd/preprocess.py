@@ -502,6 +502,10 @@ class PreprocessorLoop:
             self.stager = PinnedStager(device, slots=4)
         self.prof: dict[str, float] | None = {} if profile else None
         self._kernel_events: list = []
+        # profiling only: (seconds since run() started, raw chunks waiting, samples in the ring, samples published but not yet trained on)
+        self.gauges: list[tuple[float, int, int, int]] = []
+        self.backpressure_waits = 0
+        self._t_run = self._t_gauge = 0.0
         self.trainer_state = trainer_state
         self.ref_model = ref_model
         self.oov_patcher = oov_patcher
@@ -556,6 +560,16 @@ class PreprocessorLoop:
         for name, a, b in self._kernel_events:
             out[name] = out.get(name, 0.0) + a.elapsed_time(b) * 1e-3
         return out
+
+    def _gauge(self, raw_chunks: int) -> None:
+        """Queue depths of the loop, at most one sample per 20 ms (profiling only)."""
+        now = time.perf_counter()
+        if self.prof is None or now - self._t_gauge < 0.02:
+            return
+        self._t_gauge = now
+        ts = self.trainer_state
+        done = ts.samples_processed if ts is not None and ts.samples_processed is not None else 0
+        self.gauges.append((now - self._t_run, raw_chunks, len(self.ring.entries) + len(self.buffer), self.sched.published_samples - int(done)))
 
     def _tick(self, name: str, t0: float) -> float:
         """Charge the time since `t0` to phase `name` (profiling only); returns now."""
@@ -695,11 +709,13 @@ class PreprocessorLoop:
         start = self.sched.published_samples
         last_data = time.time()
         ts = self.trainer_state
+        self._t_run = time.perf_counter()
         with write_to_streams(self.out_spec) as writer, write_to_streams(self.stats_spec) as stats_writer:
             while max_published_samples is None or self.sched.published_samples - start < max_published_samples:
                 if cfg.samples_target is not None and ts is not None and ts.samples_processed is not None and ts.samples_processed >= cfg.samples_target:
                     logger.info("Trainer signalled completion; stopping preprocessor loop")
                     break
+                self._gauge(raw_q.qsize())
                 t = time.perf_counter()
                 try:
                     chunk = raw_q.get(timeout=0.01)
@@ -720,6 +736,7 @@ class PreprocessorLoop:
                 self._tick("schedule", t)
                 if ts is not None and ts.samples_processed is not None:
                     if self.sched.published_samples - ts.samples_processed > cfg.max_ready_samples_per_lead * cfg.num_trainers:
+                        self.backpressure_waits += 1
                         continue  # wait for the finetune loop to catch up
                 batch_done = False
                 while self.ring.entries and not batch_done:

@@ -1,0 +1,123 @@
+"""The hot path as FOUR PROCESSES on one GPU (pipelinerl_amd/pipeline_run.py: actor harness -> shm streams ->
+PreprocessorLoop -> StreamedLearnerStep with the fused head -> colocated weight hand-off through the engine-side update
+manager), and a WHOLE optimizer step of it against the oracle driven over the same records:
+
+  * the `actor` records the run produced (JSONL mirror, the reference's text record) go through `oracle.preprocess`
+    (preprocess_fn + populate_rl_data, reference rl/__init__.py:453-594) chunk by chunk and through an independent
+    restatement of the packing rule (preprocess.py:610-625); every micro-batch the learner consumed in step 0 must equal the
+    oracle's `collate_packed` of the same samples - integers bit for bit, floats to 1e-6;
+  * the policy is rebuilt from its seed; per micro-batch its fp32 logits (hidden states in bf16 times the fp32 head, the
+    reference's `apply_fp32_lm_head`, checkpoints.py:87-103) go through `oracle.rl_loss_torch.rl_step`; the summed loss, the
+    aggregated statistics (`aggregate_rl_stats`, finetune_loop.py:908-922) and the parameter delta after the SGD step (autograd
+    through the same model, fed the oracle's d loss / d logits) are compared with what the pipelined learner reported and
+    saved: 1e-4 relative for loss and statistics (north_star), 2e-3 of the delta's scale for the parameters."""
+
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _first_fit(lengths, seq_length, quota):
+    """preprocess.py:610-625 for one trainer: pop while the next sample fits, flush on overflow or when the step's quota is full."""
+    out, cur, used, taken = [], [], 0, 0
+    for i, n in enumerate(lengths):
+        if taken == quota:
+            break
+        if cur and used + n > seq_length:
+            out.append(cur)
+            cur, used = [], 0
+        cur.append(i)
+        used += n
+        taken += 1
+        if taken == quota:
+            out.append(cur)
+            cur = []
+    return out
+
+
+@pytest.mark.parametrize("learner", ["streamed", "dropin"])
+def test_four_process_pipeline_and_step0_vs_oracle(libprl, cuda_device, tmp_path, learner):
+    from oracle import preprocess as opre
+    from oracle import rl_loss_torch as orlt
+    from pipelinerl_amd.finetune.rl.utils import aggregate_rl_stats
+    from pipelinerl_amd.pipeline_run import PipelineSpec, build_policy, rl_config_of, run_pipeline
+
+    exp, cap = tmp_path / "exp", tmp_path / "cap"
+    bs, seq, lr = 16, 128, 0.05
+    spec = PipelineSpec(exp_path=str(exp), model="tiny", global_batch=bs, seq_length=seq, attempts=4, steps=3, optimizer="sgd", lr=lr,
+                        param_dtype="fp32", mirror_jsonl=True, capture_step0=str(cap), n_problems=5, concurrent_groups=2,
+                        stage_timeout_s=600.0, learner=learner, engine_load=True)
+    res = run_pipeline(spec)
+    assert "error" not in res, json.dumps(res.get("error"), indent=1)[:4000]
+    s, st = res["summary"], res["stages"]
+    # -- the run as a pipeline -----------------------------------------------------------------------------
+    assert s["optimizer_steps"] == 3 and st["learner"]["samples"] == 3 * bs
+    assert st["engine"]["updates"] == 4 and st["engine"]["last_version"] == 3 * bs, "version 0 + one update per optimizer step"
+    assert s["engine_weights_equal_trainer_at_last_version"] is True
+    assert st["engine"]["generation_quanta"] > 0, "the scripted engine generated between the updates"
+    assert st["actor"]["published_samples"] >= 3 * bs and st["preprocessor"]["published_samples"] >= 3 * bs
+    budget0, per_update = st["actor"]["pacing"]["budget"]
+    assert st["actor"]["published_groups"] <= budget0 + 3 * per_update, "the actor stayed inside its max_lag budget"
+    versions = {int(k): v for k, v in st["actor"]["groups_per_model_version"].items()}
+    assert set(versions) <= {0, bs, 2 * bs, 3 * bs} and versions.get(0, 0) >= budget0 - per_update
+    assert len(st["learner"]["weight_sync"]["under_load_ms"]) == 3 and all(x > 0 for x in st["learner"]["weight_sync"]["under_load_ms"])
+    lag = {int(k): v for k, v in s["lag_optimizer_steps_histogram"].items()}
+    assert sum(lag.values()) == st["learner"]["micro_batches"] and min(lag) >= 0 and max(lag) <= 2
+    assert all(0.0 <= f <= 1.0 for f in s["busy_frac"].values())
+
+    # -- step 0 against the oracle over the same records ---------------------------------------------------
+    groups = [json.loads(line) for line in (exp / "streams" / "actor" / "0" / "0" / "0.jsonl").read_text().splitlines()]
+    samples = []
+    for lo in range(0, len(groups), spec.chunk_n_groups):  # the preprocessor's chunks (preprocess.py:206-210)
+        chunk = [e for g in groups[lo: lo + spec.chunk_n_groups] for e in g]
+        samples += opre.preprocess_chunk(chunk, 2, False)
+    plan = _first_fit([len(e["input_ids"]) for e in samples], seq, bs)
+    captured = torch.load(cap / "step0_batches.pt")
+    assert [len(b["seq_boundaries"]) - 1 for b in captured] == [len(p) for p in plan], "micro-batch composition of step 0"
+    want_batches = [opre.collate_packed([samples[i] for i in p], 2, 1) for p in plan]
+    for got, want in zip(captured, want_batches):
+        for k, w in want.items():
+            if isinstance(w, np.ndarray):
+                g = got[k].numpy()
+                if w.dtype.kind in "iu":
+                    np.testing.assert_array_equal(g, w, err_msg=k)
+                else:
+                    np.testing.assert_allclose(g, w, rtol=1e-6, atol=1e-7, err_msg=k)
+            else:
+                assert got[k] == w, k
+
+    model = build_policy(spec, cuda_device, seed=spec.seed)
+    before = torch.load(cap / "params_before.pt")
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach().cpu(), before[n]), f"the policy is a pure function of its seed: {n}"
+    cfg = rl_config_of(spec)
+    total_loss, stats = 0.0, {}
+    for want in want_batches:
+        ids = torch.from_numpy(want["input_ids"]).to(cuda_device)
+        hidden = model.model(input_ids=ids, attention_mask=torch.ones_like(ids), position_ids=torch.from_numpy(want["position_ids"]).to(cuda_device))[0]
+        # the head reads the hidden states in bf16; the VALUE is rounded, the gradient is not (autograd's own backward of a bf16
+        # cast would round d hidden to bf16 - right for the reference's bf16 models, 2^-9 too coarse for this fp32 check)
+        hq = hidden + (hidden.to(torch.bfloat16).float() - hidden).detach()
+        logits = hq @ model.lm_head.weight.float().t()
+        out = orlt.rl_step(logits.detach().cpu().numpy(), want, cfg, 0, spec.steps, True)
+        total_loss += float(out["loss"])
+        for k, v in out["stats"].items():
+            stats.setdefault(k, []).append(v)
+        logits.backward(out["grad_logits"].to(cuda_device))
+    metrics = json.loads((cap / "step0_metrics.json").read_text())
+    assert metrics["rl/loss"] == pytest.approx(total_loss, rel=1e-4, abs=1e-7)
+    want_metrics = aggregate_rl_stats(stats, bs)
+    for k, w in want_metrics.items():
+        assert metrics[k] == pytest.approx(w, rel=1e-4, abs=1e-6), k
+    after = torch.load(cap / "params_after.pt")
+    for n, p in model.named_parameters():
+        want_delta = (-lr * p.grad).cpu()
+        got_delta = after[n] - before[n]
+        scale = float(want_delta.abs().max())
+        assert scale > 0, f"{n} got no gradient"
+        assert float((got_delta - want_delta).abs().max()) <= 2e-3 * scale, n
