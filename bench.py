@@ -74,6 +74,9 @@ def parse_args():
     p.add_argument("--no-transport", action="store_true", help="skip the host-side transport probe (shm log / files backend round trips)")
     p.add_argument("--no-preprocess-loop", action="store_true", help="skip the actor-record -> published micro-batch measurement (preprocess_loop)")
     p.add_argument("--no-ref-logprob", action="store_true", help="skip the reference-policy head measurement (ref_logprob)")
+    p.add_argument("--no-pipeline", action="store_true",
+                   help="N = 1: skip BASELINE configs[1] run AS a pipeline (actor -> preprocessor -> learner -> engine, four processes on this GPU)")
+    p.add_argument("--pipeline-steps", type=int, default=int(os.environ.get("PRL_BENCH_PIPELINE_STEPS", 4)), help="optimizer steps of the pipeline run (the first is warm-up)")
     p.add_argument("--cpu-baseline-threads", default=None,
                    help="comma-separated thread counts: time ONLY the cpu_baseline loss leg at each count and exit (no GPU work)")
     p.add_argument("--backend", default=os.environ.get("PRL_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
@@ -279,8 +282,11 @@ def cpu_baseline(seq_length: int, vocab: int) -> dict:
         # Lead with the REFERENCE's own functions (kind "reference"): they cannot travel to the GPU box (/root/reference exists in the build
         # container only), so this is a stated constant from that container's cores; the port timed on THIS box follows as the second witness.
         return {
-            "value": ref["samples_per_s_extrapolated"], "unit": "samples/s", "cores": ref.get("threads", 8), "kind": "reference",
-            "measured_in_this_run": False,
+            "value": ref["samples_per_s_extrapolated"], "unit": "samples/s", "kind": "reference",
+            # two hosts, both named: the reference's own functions ran on the build container's cores (a stated constant), the port on THIS box's
+            "cores": {"reference": ref.get("threads", 8), "port": cores},
+            "hosts": {"reference": ref.get("host"), "port": port["host"]},
+            "measured_in_this_run": {"reference": False, "port": True},
             "host": ref.get("host"),
             "sample": f"the reference's own preprocess_fn + populate_rl_data + collate_packed on {ref['workload']['sequences']} x {ref['workload']['seq_length']}-token "
                       f"sequences and rl_step forward + autograd backward on {ref['workload']['loss_tokens']} tokens x V={ref['workload']['vocab']}, "
@@ -740,6 +746,10 @@ def weight_sync_probe(rank: int, world: int, dev: torch.device, out: dict) -> di
         out["full_update_ms"] = 1e3 * t.item()
         out["full_update_tensors"] = len(shapes)
         out["full_update_verified"] = bool(ok.item())
+        # the same keys the 1-GPU (colocated) object carries, so that the two layouts read alike
+        nbytes = sum(int(np.prod(s_)) * 2 for _, s_ in shapes)
+        out.update({"median_ms": out["full_update_ms"], "tensors": len(shapes), "gbytes": round(nbytes / 1e9, 3),
+                    "effective_GBps": round(nbytes / t.item() / 1e9, 1), "layout": f"trainer rank 0 -> {world - 1} receiver GPU(s) over RCCL / xGMI"})
         out["stage"] = "done"
     except Exception as e:  # noqa: BLE001 - keep the wire numbers
         out["full_update_error"] = f"{type(e).__name__}: {e}"
@@ -751,6 +761,75 @@ def weight_sync_probe(rank: int, world: int, dev: torch.device, out: dict) -> di
     return out
 
 
+def self_launch(n: int, share_device: bool) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this same command under torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1) and return their exit code.  Refuses when the node has fewer than N devices, unless the dry-run mode
+    (PRL_BENCH_SHARE_DEVICE=1, gloo) was asked for."""
+    import socket
+    import subprocess
+
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < n and not share_device:
+        print(f"bench.py: --gpus {n} needs {n} HIP devices, {n_dev} visible; not running (a {n}-GPU line measured on fewer devices would be invalid)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+    return subprocess.call(cmd, env=env)
+
+
+def pipeline_probe(steps: int, tiny: bool = False) -> dict:
+    """BASELINE `configs[1]` (Qwen2.5-0.5B GRPO, one MI355X, actor + learner colocated, synthetic rollouts bs = 512 seq = 2048) run AS the
+    pipeline it is (pipelinerl_amd/pipeline_run.py): four OS processes on this GPU - actor harness over the rollout plugin surface, paced by
+    max_lag against the propagated weight version; PreprocessorLoop over shm streams; a random-init policy of the 0.5B shape with the fused
+    head, AdamW and `StreamedLearnerStep`; the engine-side update manager receiving every optimizer step's weights over HIP IPC.  Reports
+    steady-state samples/s (first step excluded), per-stage busy fraction, queue depths, weight-sync request -> ack under load, the lag
+    histogram, and the stages' busy seconds per step added up next to the pipelined step time.  Extra object, never `value`."""
+    import tempfile
+
+    from pipelinerl_amd.pipeline_run import PipelineSpec, run_pipeline
+
+    out: dict = {"what": "BASELINE configs[1] as four concurrent processes on ONE GPU: actor (plugin surface, PRLROL01 records, max_lag pacing) -> PreprocessorLoop "
+                         "(shm, chunk_n_groups 2) -> StreamedLearnerStep (Qwen2.5-0.5B shape, random init, bf16, tied fused head, AdamW, activations kept) -> "
+                         "weight hand-off to the engine-side update manager over HIP IPC after EVERY optimizer step"}
+    cases = [("bs512_seq2048", {}, steps), ("bs512_seq2048_pack_budget_8192", {"pack_budget": 8192}, max(2, steps - 1))]
+    if tiny:  # the contract test's workload: the same four processes around a two-layer model
+        cases = [("bs512_seq2048", {"model": "tiny", "global_batch": 32, "seq_length": 128, "n_problems": 8}, max(2, min(steps, 3)))]
+    for name, kw, n_steps in cases:
+        if name != "bs512_seq2048" and os.environ.get("PRL_BENCH_PIPELINE_VARIANTS", "1") == "0":
+            continue
+        exp = tempfile.mkdtemp(prefix="prl_bench_pipeline_")
+        try:
+            res = run_pipeline(PipelineSpec(exp_path=exp, steps=n_steps, stage_timeout_s=float(os.environ.get("PRL_BENCH_PIPELINE_TIMEOUT", 600)), **kw))
+        except Exception as e:  # noqa: BLE001
+            res = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            import shutil
+
+            shutil.rmtree(exp, ignore_errors=True)
+        if "summary" in res:
+            entry = dict(res["summary"])
+            entry["wall_s_incl_start_up"] = res["wall_s_incl_start_up"]
+            entry["stages"] = {k: {kk: v.get(kk) for kk in ("wall_s", "busy_s", "busy_frac", "published_samples", "updates", "micro_batches", "tokens", "init_s")
+                                   if kk in v} for k, v in res["stages"].items()}
+            entry["per_step"] = res["stages"]["learner"]["per_step"]
+        else:
+            entry = {"error": res.get("error")}
+        if name == "bs512_seq2048":
+            out.update(entry)
+            out["config"] = ({"model": "Qwen2.5-0.5B shape (494 M parameters, tied head), random init, bf16", "global_batch": 512, "seq_len": 2048, "attempts": 8,
+                              "rollouts": "ragged (P ~ U{64..512}, C ~ U{512..2048-P}), SURVEY §8(d)", "pack_budget_tokens": 2048, "max_lag_samples": 512,
+                              "weight_update_interval": 1, "optimizer_steps": n_steps} if not tiny else {**kw, "optimizer_steps": n_steps})
+        else:
+            entry["what"] = ("the same pipeline with `finetune.seq_length` (the packing budget of a micro-batch) at 8192 tokens instead of the longest rollout: "
+                             "the 0.5B body is launch-bound at ~1400 tokens per micro-batch (scripts/learner_microbatch_profile.py)")
+            out["pack_budget_8192"] = entry
+    return out
+
+
 def main():
     args = parse_args()
     if args.cpu_baseline_threads:
@@ -759,14 +838,23 @@ def main():
         return
     import torch.distributed as dist
 
+    share_device = os.environ.get("PRL_BENCH_SHARE_DEVICE") == "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and relays their exit code.  A run that
+        # asks for N GPUs NEVER continues as one rank: the line would read "n_gpus": 1 with all of the batch on GPU 0.
+        sys.exit(self_launch(args.gpus, share_device))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a line for a job that is not the one asked for")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if torch.cuda.device_count() < world and not share_device:
+        sys.exit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s) visible (PRL_BENCH_SHARE_DEVICE=1 + --backend gloo is the dry-run mode)")
     # host-side torch ops (stream decode, codec, the CPU baseline) use the cores this process was GRANTED: the GPU boxes show 256
     # CPUs behind a 16-core quota, and an intra-op pool sized for 256 spends the quota on its own wake-ups
     torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_host_cores())))
-    if os.environ.get("PRL_BENCH_SHARE_DEVICE") == "1":
+    if share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -776,7 +864,16 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # what the process group itself says (never argv): ranks, and how many DISTINCT devices they sit on
+    n_ranks, distinct_devices = 1, 1
+    if world > 1:
+        n_ranks = dist.get_world_size()
+        props = torch.cuda.get_device_properties(dev)
+        ident = f"{getattr(props, 'uuid', '')}|{getattr(props, 'pci_bus_id', '')}|{getattr(props, 'pci_device_id', '')}|{local_rank if not share_device else 0}"
+        idents: list = [None] * n_ranks
+        dist.all_gather_object(idents, ident)
+        distinct_devices = len(set(idents))
+        assert n_ranks == world, f"the process group has {n_ranks} ranks, the launcher announced {world}"
 
     from pipelinerl_amd import _lib
     from pipelinerl_amd.finetune.rl import RLConfig
@@ -1042,6 +1139,14 @@ def main():
             preprocess_loop = preprocess_loop_probe(dev, seq_length, vocab, attempts)
         except Exception as e:  # noqa: BLE001
             preprocess_loop = {"error": f"{type(e).__name__}: {e}"}
+    pipeline = None
+    if world == 1 and not args.no_pipeline and os.environ.get("PRL_BENCH_PIPELINE", "1") != "0":
+        try:
+            logits = grad_logits = None
+            torch.cuda.empty_cache()
+            pipeline = pipeline_probe(args.pipeline_steps, tiny=args.workload == "tiny")
+        except Exception as e:  # noqa: BLE001 - must never take the benchmark line down
+            pipeline = {"error": f"{type(e).__name__}: {e}"}
     transport = None
     if rank == 0 and not args.no_transport:
         try:
@@ -1056,10 +1161,13 @@ def main():
         if rank != 0:
             return
         line = {
-            "metric": f"learner samples/sec, {label} (post-model hot path: K5+K6 preprocess, fused logits->GRPO loss->dlogits, step stats; trainer->actor weight-sync ms in weight_sync)",
+            "metric": f"learner samples/sec, {label} (POST-MODEL hot path on resident fp32 logits: K5+K6 preprocess, fused logits->GRPO loss->dlogits, step stats; "
+                      "`value` EXCLUDES the transformer forward/backward - the model-in-the-loop rate is `value_e2e`, the pipelined configs[1] rate is "
+                      "`pipeline.samples_per_s`; trainer->actor weight-sync ms in weight_sync)",
             "value": bs / (elapsed / args.steps),
+            "value_e2e": (e2e or {}).get("samples_per_s"),
             "unit": "samples/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -1073,14 +1181,16 @@ def main():
                        "policy_loss": "ppo", "kl_coef": kl_coef, "ref_logprobs": ("old + N(0, 0.05)" if kl_coef > 0 else "== old (KL off)"),
                        "param_set": param_set, "head_hidden": hidden, "old_logprob_sigma": sigma, "labelled_token_fraction": live_frac,
                        "grad_allreduce_bytes_per_step": sum(b.numel() * 2 for b in grad_buckets) if grad_buckets else 0,
-                       "torch_distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices_visible": torch.cuda.device_count()}
-                                             if world > 1 else None),
+                       "torch_distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
+                                              "distinct_devices": distinct_devices, "rccl_comm_size": (wsync or {}).get("rccl_comm_size"),
+                                              "share_device_dry_run": share_device} if world > 1 else None),
                        "h2d_ragged_input": {"bytes": h2d_bytes, "ms": 1e3 * t_h2d, "ms_pinned": 1e3 * t_h2d_pinned,
                                             "note": "one step's ragged rollouts, pageable vs page-locked host memory; not part of value"}},
             "roofline": roofline,
             "roofline_mfma": roofline_mfma,
             "ref_logprob": ref_logprob,
             "preprocess_loop": preprocess_loop,
+            "pipeline": pipeline,
             "e2e": e2e,
             "transport": transport,
             "kernels": kernels,
@@ -1102,6 +1212,9 @@ def main():
             from pipelinerl_amd.weight_sync_probe import colocated_probe
 
             wsync = colocated_probe(param_set, iters=5, rehome=True, ready_timeout=240.0 if param_set != "32b" else 600.0)
+            wsync = {"transport": "hip_ipc_colocated", **wsync,
+                     "transport_note": "ONE GPU: trainer and inference worker share it, the bytes never touch a link - this figure says nothing about xGMI; the RCCL "
+                                       "broadcast BASELINE's metric names needs >= 2 GPUs (`bench.py --gpus N` reports it under the same keys, transport rccl_xgmi)"}
         except Exception as e:  # noqa: BLE001 - the probe must never take the benchmark line down
             wsync = {"error": f"{type(e).__name__}: {e}"}
     force = os.environ.get("PRL_BENCH_FORCE_WSYNC") == "1"  # dry runs: exercise the probe's error handling under gloo
@@ -1109,7 +1222,7 @@ def main():
         import threading
 
         done = threading.Event()
-        wsync = {"params": param_set, "param_bytes": grad_bytes_default}
+        wsync = {"params": param_set, "param_bytes": grad_bytes_default, "transport": "rccl_xgmi", "metric": "trainer_to_actor_weight_sync_ms"}
 
         def watchdog():
             if not done.wait(float(os.environ.get("PRL_BENCH_WSYNC_TIMEOUT", 90 if param_set != "32b" else 300))):

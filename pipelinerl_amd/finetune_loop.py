@@ -802,7 +802,7 @@ class NativeLearnerStep:
                  ref_model: torch.nn.Module | None = None, training_metrics: TrainingMetrics | None = None,
                  weight_update_manager: WeightUpdateManager | None = None, weight_update_interval: int = 1,
                  send_weight_updates: bool = True, trainer_stream: SingleStreamSpec | None = None,
-                 equalize_micro_batches: bool = True, fused_ref_head: bool = True):
+                 equalize_micro_batches: bool = True, fused_ref_head: bool = True, skip_unlabelled: bool = True):
         """`ref_model`: a frozen reference policy on this GPU.  When given, the KL-to-reference term
         uses ITS log-probabilities, computed per micro-batch right before the policy forward (SURVEY
         §8f-3: replaces the HTTP round trip to a second inference server for KL-enabled configs).
@@ -811,8 +811,17 @@ class NativeLearnerStep:
         `fused_ref_head=False`, go through their logits and K1.
         `samples_per_step`: the GLOBAL number of samples per optimizer step (the loss normaliser).
         `equalize_micro_batches`: pad with sentinel micro-batches up to the largest count over the ranks
-        (needed by ZeRO / FSDP; plain DDP only needs every rank to run at least one)."""
+        (needed by ZeRO / FSDP; plain DDP only needs every rank to run at least one).
+        `skip_unlabelled`: see `HotPathStep` - False keeps the reference's finiteness assert over every logits row (rl/__init__.py:213).
+        An actor-critic model (`.value_head`, finetune/value_model.py) is refused: this step reads `.logits` only - the value
+        branch of `rl_step` (rl/__init__.py:162, 265-272, 367-381) lives in `rl_step` / `rl_step_fused_head` / `StreamedLearnerStep`;
+        training such a model here would silently drop the value loss and use the stored advantages."""
         import torch.distributed as dist
+
+        if getattr(getattr(model, "module", model), "value_head", None) is not None:
+            raise NotImplementedError("NativeLearnerStep has no value-head branch (rewards - V advantages, value loss, value_* statistics): drive an "
+                                      "actor-critic model through LearnerStep with rl_step / rl_step_fused_head, or StreamedLearnerStep")
+        self.skip_unlabelled = bool(skip_unlabelled)
 
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
         self.ref_model = ref_model
@@ -867,7 +876,8 @@ class NativeLearnerStep:
         """`rollouts`: THIS rank's share of the step (ragged, on the device); `micro_batches`: its packing plan."""
         from .hotpath import HotPathStep
 
-        hp = HotPathStep(self.rl_config, self.eos_token_id, self.metrics.completed_steps, self.max_train_steps, group=self.group)
+        hp = HotPathStep(self.rl_config, self.eos_token_id, self.metrics.completed_steps, self.max_train_steps, group=self.group,
+                         skip_unlabelled=self.skip_unlabelled)
         batches = hp.preprocess(rollouts, micro_batches)
         n = len(batches)
         n_max, n_samples = self._share_counts(n, rollouts.n_seqs, rollouts.device)

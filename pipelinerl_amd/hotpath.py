@@ -54,11 +54,16 @@ class HotPathStep:
     """Drives K5 -> K6 -> (per micro-batch logits kernel) -> one K2+K3 for a step's rollouts."""
 
     def __init__(self, config: RLConfig, eos_token_id: int, current_step: int = 0, max_step: int = 1,
-                 group: Any = None):
+                 group: Any = None, skip_unlabelled: bool = True):
+        """`skip_unlabelled` (default): the logits kernel does not READ rows whose next token carries no label (prompt and
+        observation tokens, sequence starts, padding) - they reach neither the loss nor a statistic (rl/__init__.py:238-250),
+        so nothing changes numerically and ~3-30 % of the logits traffic goes away; the price is that a non-finite logit in
+        such a row passes unnoticed, where the reference asserts `isfinite(new_logprobs)` over EVERY position
+        (rl/__init__.py:213).  `False` keeps that assert: every row is read, `stats_dict()` raises for a NaN / inf anywhere."""
         self.config = config
         self.eos_token_id = eos_token_id
         self.cfg, self.kl_coef, self.ent_coef = make_loss_config(config, current_step, max_step)
-        self.cfg.skip_unlabelled = 1  # the logits kernel does not read rows whose next token is unlabelled (prl.h)
+        self.cfg.skip_unlabelled = 1 if skip_unlabelled else 0
         self.group = group
         self.batches: Any = []
         self.step_batch: PipelineBatchEncoding | None = None

@@ -47,7 +47,8 @@ class PipelineSpec:
     exp_path: str
     model: str = "0p5b"
     global_batch: int = 512            # samples per optimizer step (train_batch_size 1 x gradient_accumulation_passes, App. E)
-    seq_length: int = 2048             # packing budget of a micro-batch = longest rollout
+    seq_length: int = 2048             # longest rollout (prompt + completion)
+    pack_budget: int | None = None     # tokens per packed micro-batch (`finetune.seq_length`); default: seq_length, the reference's coupling
     attempts: int = 8
     steps: int = 5
     vocab: int | None = None           # default: the model's
@@ -78,6 +79,10 @@ class PipelineSpec:
         if self.vocab:
             s["vocab"] = int(self.vocab)
         return s
+
+    @property
+    def budget(self) -> int:
+        return int(self.pack_budget or self.seq_length)
 
     @property
     def lag(self) -> int:
@@ -138,7 +143,7 @@ def build_policy(spec: PipelineSpec, device, seed: int):
 
     s = spec.shape
     cfg = transformers.Qwen2Config(vocab_size=s["vocab"], hidden_size=s["hidden"], intermediate_size=s["inter"], num_hidden_layers=s["layers"],
-                                   num_attention_heads=s["heads"], num_key_value_heads=s["kv"], max_position_embeddings=max(32768, spec.seq_length),
+                                   num_attention_heads=s["heads"], num_key_value_heads=s["kv"], max_position_embeddings=max(32768, spec.budget),
                                    tie_word_embeddings=s["tied"], attn_implementation="sdpa")
     torch.manual_seed(seed)
     with torch.device(device):
@@ -218,7 +223,7 @@ def preprocessor_stage(spec: PipelineSpec) -> None:
     state.start_listening()
     state.wait_for_processed_samples()  # the trainer's first message (finetune_loop.py:462-465)
     cfg = PreprocessorConfig(exp_path=Path(spec.exp_path), num_trainers=1, train_batch_size=1, gradient_accumulation_passes=spec.global_batch,
-                             seq_length=spec.seq_length, attempts=spec.attempts, rl=rl_config_of(spec), eos_token_id=2, chunk_n_groups=spec.chunk_n_groups,
+                             seq_length=spec.budget, attempts=spec.attempts, rl=rl_config_of(spec), eos_token_id=2, chunk_n_groups=spec.chunk_n_groups,
                              max_lag=spec.lag, samples_target=spec.steps * spec.global_batch,
                              ring_buffer_size=max(128, 2 * spec.global_batch), max_ready_samples_per_lead=max(64, spec.global_batch))
     loop = PreprocessorLoop(cfg, dev, trainer_state=state, profile=True)
@@ -345,6 +350,14 @@ def learner_stage(spec: PipelineSpec) -> None:
     if capture is not None:
         capture.mkdir(parents=True, exist_ok=True)
         torch.save({n: p.detach().cpu().clone() for n, p in model.named_parameters()}, capture / "params_before.pt")
+        first_step = opt.step
+
+        def step_and_keep_gradients(*a_, **k_):  # step 0's accumulated gradients, as the optimizer sees them
+            torch.save({n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}, capture / "grads_step0.pt")
+            opt.step = first_step
+            return first_step(*a_, **k_)
+
+        opt.step = step_and_keep_gradients
     captured: list = []
 
     # the trainer's first two messages (finetune_loop.py:462-485): where it stands, and the first weight version
@@ -362,6 +375,7 @@ def learner_stage(spec: PipelineSpec) -> None:
                      name="learner-loader", daemon=True).start()
 
     wait_s = 0.0
+    lags: list[int] = []
     depth: list[int] = []
     step_marks: list[dict] = []
     micro_batches = tokens = 0
@@ -387,6 +401,8 @@ def learner_stage(spec: PipelineSpec) -> None:
         if capture is not None and step.metrics.completed_steps == 0:
             captured.append({k: v.detach().cpu().clone() for k, v in batch.tensors()} | {"model_version": batch.model_version, "sentinel": batch.sentinel,
                                                                                             "padding": batch.padding, "is_packed": batch.is_packed})
+        if not batch.sentinel:
+            lags.append(step.metrics.samples - int(batch.model_version))
         res = step.step(batch)
         micro_batches += 1
         tokens += int(batch.input_ids.numel())
@@ -413,7 +429,6 @@ def learner_stage(spec: PipelineSpec) -> None:
     stop.set()
     step.finish()
     mgr.shutdown()
-    lags = getattr(step, "lag_samples", [])
     hist: dict[int, int] = {}
     for x in lags:
         k = int(x) // spec.global_batch  # in optimizer steps

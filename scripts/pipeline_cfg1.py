@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--model", default="0p5b", choices=["0p5b", "7b", "tiny"])
     ap.add_argument("--global-batch", type=int, default=512)
     ap.add_argument("--seq-length", type=int, default=2048)
+    ap.add_argument("--pack-budget", type=int, default=None, help="tokens per packed micro-batch (default: --seq-length)")
     ap.add_argument("--attempts", type=int, default=8)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--max-lag", type=int, default=None, help="samples (default: one optimizer step)")
@@ -34,7 +35,7 @@ def main():
     from pipelinerl_amd.pipeline_run import PipelineSpec, run_pipeline
 
     exp = a.exp_path or tempfile.mkdtemp(prefix="prl_pipeline_")
-    spec = PipelineSpec(exp_path=exp, model=a.model, global_batch=a.global_batch, seq_length=a.seq_length, attempts=a.attempts, steps=a.steps,
+    spec = PipelineSpec(exp_path=exp, model=a.model, global_batch=a.global_batch, seq_length=a.seq_length, pack_budget=a.pack_budget, attempts=a.attempts, steps=a.steps,
                         max_lag=a.max_lag, weight_update_interval=a.weight_update_interval, dense=a.dense, engine_load=a.engine_load,
                         gradient_checkpointing=a.gradient_checkpointing, learner=a.learner, stage_timeout_s=a.timeout)
     res = run_pipeline(spec)

@@ -33,7 +33,8 @@ def test_bench_json_contract(libprl, cuda_device):
     assert r["launches"] == d["steps"] * d["config"]["global_batch"] and r["avg_us"] >= r["min_us"] > 0
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9) <= 1e-9 * r["achieved"]
     c = d["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    cores = c["cores"] if isinstance(c["cores"], int) else min(c["cores"].values())  # kind "reference": {"reference": n, "port": m}, both hosts named
+    assert c["kind"] in ("port", "reference") and cores >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert "traffic_source" in r  # the counter traffic is a committed figure, labelled as such
     assert {"fused_logits_loss", "grpo_loss_step", "preprocess_K5_K6", "pack_collate_kernel", "group_advantages_K5"} <= set(d["kernels"])
     k = d["kernels"]
@@ -65,4 +66,28 @@ def test_bench_json_contract(libprl, cuda_device):
         assert h["fused_ms"] > 0 and h["old_ms"] > 0 and h["max_abs_difference"] < (1e-3 if name == "fp32_head" else 0.1) and h["hbm_bytes_saved"] > 0
     w = d["weight_sync"]  # N = 1: colocated hand-off over HIP IPC
     assert "error" not in w, w
-    assert w["metric"] == "trainer_to_actor_weight_sync_ms" and w["median_ms"] > 0 and w["gbytes"] > 0.9
+    assert w["metric"] == "trainer_to_actor_weight_sync_ms" and w["median_ms"] > 0 and w["gbytes"] > 0.9 and w["transport"] == "hip_ipc_colocated"
+    assert "EXCLUDES the transformer" in d["metric"] and "value_e2e" in d
+    pl = d["pipeline"]  # the four stages as processes (here around the two-layer model)
+    assert "error" not in pl, pl
+    assert pl["samples_per_s"] > 0 and pl["optimizer_steps"] >= 2 and pl["engine_weights_equal_trainer_at_last_version"] is True
+    assert set(pl["busy_frac"]) == {"actor", "preprocessor", "learner", "engine"} and pl["weight_sync_under_load_ms"]["updates"] == pl["optimizer_steps"]
+    assert pl["overlap"]["pipelined_s_per_step"] > 0 and sum(pl["lag_optimizer_steps_histogram"].values()) > 0
+
+
+def test_bare_multi_gpu_invocation_becomes_n_ranks(libprl, cuda_device):
+    """`python bench.py --gpus 2` with no launcher re-executes itself as 2 ranks (here both on this GPU over gloo, the dry-run mode)
+    and the line's `n_gpus` comes from the process group, not from argv."""
+    import os
+
+    env = {**os.environ, "PRL_BENCH_SHARE_DEVICE": "1"}
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "tiny", "--steps", "1", "--warmup", "0",
+                          "--no-fused-head", "--no-transport", "--no-weight-sync"], capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    td = d["config"]["torch_distributed"]
+    assert d["n_gpus"] == 2 and td["world_size"] == 2 and td["backend"] == "gloo" and td["share_device_dry_run"] is True and td["distinct_devices"] == 1
+    assert d["config"]["parallelism"] == "dp2" and d.get("pipeline") is None

@@ -509,3 +509,42 @@ def test_oov_patch_kernel_matches_the_reference(libprl, cuda_device):
     assert [labs[off[i]:off[i + 1]] for i in range(len(entries))] == g["labels_after"]
     n_bad = sum(a != b for e, p in zip(g["data"], g["patched_input_ids"]) for a, b in zip(e["input_ids"], p))
     assert int(patcher.count.item()) == n_bad
+
+
+def test_native_step_finiteness_assert_over_every_row_is_a_switch(libprl, cuda_device):
+    """The reference asserts `isfinite(new_logprobs)` over EVERY position (rl/__init__.py:213).  The native step skips the logits
+    rows that predict an unlabelled token by default (they reach neither the loss nor a statistic), so a NaN there passes;
+    `skip_unlabelled=False` reads every row and the step's statistics raise the reference's assert."""
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.finetune_loop import NativeLearnerStep
+    from pipelinerl_amd.hotpath import dense_micro_batches
+    from pipelinerl_amd.synthetic import make_ragged
+
+    V = 64
+    rag_h, _ = make_ragged(2, attempts=4, seq_length=40, vocab=V, seed=9, prompt_min=4, prompt_max=8)
+    rag = rag_h.to(cuda_device)
+    mbs = dense_micro_batches(rag_h, 100)
+    rl = RLConfig(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.0, final_kl_coef=0.0, divide_advantage_by_std=False,
+                  clamp_log_ratio_ref_new_value=5)
+
+    class PoisonedLM(TinyLM):
+        """NaN logits in row 1 of every micro-batch: it predicts token 2, a PROMPT token (prompts are >= 4 tokens) - unlabelled."""
+
+        def forward(self, input_ids=None, **kw):
+            logits = self.head(self.emb(input_ids)).float()
+            mask = torch.zeros_like(logits)
+            mask[:, 1] = float("nan")
+            return types.SimpleNamespace(logits=logits + mask)
+
+    for skip, raises in ((True, False), (False, True)):
+        torch.manual_seed(0)
+        model = PoisonedLM(V).to(cuda_device)
+        native = NativeLearnerStep(model, torch.optim.SGD(model.parameters(), lr=0.0), rl, eos_token_id=2, samples_per_step=8, max_train_steps=10,
+                                   skip_unlabelled=skip)
+        res = native.step(rag, mbs)
+        if raises:
+            with pytest.raises(AssertionError, match="new_logprobs is not finite"):
+                native.stats_dict(res["stats"])
+        else:
+            stats = native.stats_dict(res["stats"])
+            assert stats["num_output_tokens_sum"] > 0 and torch.isfinite(res["loss"]).item()

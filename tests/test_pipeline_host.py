@@ -319,3 +319,43 @@ def test_pipeline_spec_defaults_are_baseline_config_1():
         shapes = dict(qwen25_shapes(name))
         assert shapes["model.embed_tokens.weight"] == (s["vocab"], s["hidden"]) and ("lm_head.weight" in shapes) == (not s["tied"])
         assert shapes["model.layers.0.mlp.gate_proj.weight"] == (s["inter"], s["hidden"])
+
+
+def test_bench_refuses_to_run_n_gpus_as_one_rank():
+    """`python bench.py --gpus N` on a node with fewer devices exits non-zero and prints no line (it used to continue as ONE rank and
+    report n_gpus 1 with the whole batch on GPU 0); a launcher that started a different number of ranks is refused too."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    n = (torch.cuda.device_count() if torch.cuda.is_available() else 0) + 7
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PRL_BENCH_SHARE_DEVICE")}
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(n), "--workload", "tiny"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 2 and "HIP devices" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4", "--workload", "tiny"], capture_output=True, text=True, timeout=300,
+                         env={**env, "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_native_learner_step_refuses_an_actor_critic_model():
+    """rl_step's value-head branch (rl/__init__.py:162, 265-272, 367-381) is not part of NativeLearnerStep, which reads `.logits` only:
+    a model with a `value_head` must not train silently as plain GRPO."""
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.finetune_loop import NativeLearnerStep
+
+    class ActorCritic(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.pretrained_model = torch.nn.Linear(2, 2)
+            self.value_head = torch.nn.Linear(2, 1)
+
+    m = ActorCritic()
+    with pytest.raises(NotImplementedError, match="value-head"):
+        NativeLearnerStep(m, torch.optim.SGD(m.parameters(), lr=0.1), RLConfig(), eos_token_id=2, samples_per_step=8, max_train_steps=2)
+    wrapped = types.SimpleNamespace(module=m, parameters=m.parameters)
+    with pytest.raises(NotImplementedError):
+        NativeLearnerStep(wrapped, torch.optim.SGD(m.parameters(), lr=0.1), RLConfig(), eos_token_id=2, samples_per_step=8, max_train_steps=2)
+    plain = torch.nn.Linear(2, 2)
+    NativeLearnerStep(plain, torch.optim.SGD(plain.parameters(), lr=0.1), RLConfig(), eos_token_id=2, samples_per_step=8, max_train_steps=2)
