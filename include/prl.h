@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 9
+#define PRL_ABI_VERSION 10
 
 #define PRL_OK 0
 #define PRL_EINVAL (-22)   /* bad argument                                  */
@@ -69,26 +69,18 @@ typedef void* prl_stream_t; /* hipStream_t */
 
 int prl_abi_version(void);
 
-/* Diagnostic launch overrides (A/B measurements, tests that force a fallback shape).  A process-wide table of integers
- * read by the launch code - there is NO getenv() on any launch path; the Python host maps its PRL_* environment
- * variables onto this call.  `value` PRL_TUNE_UNSET restores the built-in choice.  No reference counterpart. */
+/* Launch overrides a caller may need (a shape the default choice handles badly, a split count pinned for bit-reproducibility
+ * across GPUs with a different CU count, a test that forces a fallback shape).  A process-wide table of integers read by the
+ * launch code - there is NO getenv() on any launch path; the Python host maps its PRL_* environment variables onto this call.
+ * `value` PRL_TUNE_UNSET restores the built-in choice.  No reference counterpart.  (The measurement-only keys of earlier ABI
+ * versions - schedule A/B bits, raster groups, tokens per lane - are gone with the variants they selected.) */
 enum prl_tune_key {
-  PRL_TUNE_FUSED_VARIANT = 0,       /* prl_fused_logits_loss: 0 two-sweep 256 threads | 4 two-sweep 2 x 512 (bf16 default) |
-                                       6 two-sweep 1024 (fallback of short / unaligned rows) | 21 row-resident (fp32 default) */
-  PRL_TUNE_LMHEAD_TILE = 1,         /* fused head: 128 | 256 (256 x 128, ring of 3) | 512 (256 x 256) */
-  PRL_TUNE_LMHEAD_DUAL = 2,         /* 0: generic core where the dual-plane core would be taken */
-  PRL_TUNE_LMHEAD_NSPLIT = 3,       /* vocabulary splits of the forward */
-  PRL_TUNE_LMHEAD_KSPLIT = 4,       /* split-K factor of the d hidden product */
-  PRL_TUNE_LMHEAD_EXP = 5,          /* 256: the dual-plane forward with its DMA pieces interleaved with the MFMA groups (A/B reference) */
-  PRL_TUNE_LOSS_FAST_STATS = 6,     /* 0: always-nan_to_num statistics path */
-  PRL_TUNE_LOSS_TPL = 7,            /* tokens per lane of the loss kernel: 2 | 4 */
-  PRL_TUNE_LOSS_BLOCKS_PER_CU = 8,
-  PRL_TUNE_PACK_NT = 9,             /* 0: plain stores in the pack kernel */
-  PRL_TUNE_PACK_TPL = 10,           /* tokens per lane of the pack kernel: 2 | 4 */
-  PRL_TUNE_LMHEAD_BWD = 11,         /* backward structure of the fused head, see prl_lmhead.hip */
-  PRL_TUNE_LMHEAD_DW_GROUP = 12,    /* vocabulary tiles per raster group of the d W product */
-  PRL_TUNE_LMHEAD_SEG = 13,         /* 32-deep stages per contraction segment of the d hidden product */
-  PRL_TUNE_COUNT = 14
+  PRL_TUNE_FUSED_VARIANT = 0,  /* prl_fused_logits_loss: 0 two-sweep 256 threads | 4 two-sweep 2 x 512 (bf16 default) |
+                                  6 two-sweep 1024 (fallback of short / unaligned rows) | 21 row-resident (fp32 default) */
+  PRL_TUNE_LMHEAD_TILE = 1,    /* fused head workgroup tile: 128 (128 x 128) | 256 (256 x 128, ring of 3) | 512 (256 x 256) */
+  PRL_TUNE_LMHEAD_NSPLIT = 2,  /* vocabulary splits of the fused head's forward (summation order of the soft-max partials) */
+  PRL_TUNE_LMHEAD_KSPLIT = 3,  /* split-K factor of the d hidden product (summation order of its partial sums) */
+  PRL_TUNE_COUNT = 4
 };
 #define PRL_TUNE_UNSET INT64_MIN
 int prl_set_tuning(int32_t key, int64_t value);
@@ -547,31 +539,6 @@ struct prl_segment {
 int prl_bucket_gather(void* bucket, int64_t bucket_bytes, const struct prl_segment* segments, int64_t n_segments, void* stream);
 int prl_bucket_scatter(const void* bucket, int64_t bucket_bytes, const struct prl_segment* segments, int64_t n_segments, void* stream);
 
-/* ---- fp32 -> two bf16 planes ------------------------------------------------------------
- * hi[i] = bf16(src[i]), lo[i] = bf16(src[i] - float(hi[i])) (round to nearest even), one pass.
- * Operand preparation for evaluating the reference's fp32 output head (checkpoints.py:87-103) as
- * bf16 MFMA GEMMs with fp32 accumulation (pipelinerl_amd/lm_head.py).  Device pointers. */
-int prl_split_bf16(int64_t n, const float* src, uint16_t* hi, uint16_t* lo, void* stream);
-
-/*
- * prl_fused_logits_loss (reference: rl_step's K1 + the autograd backward of rl/__init__.py:207-233
- * into the logits of an fp32 lm_head, finetune/checkpoints.py:87-103) with the gradient delivered as
- * those two planes: grad_hi / grad_lo
- * [rows*cols, plane_row_stride] bf16, hi + lo = d loss / d logits to ~2^-17 relative, bit for bit
- * what prl_split_bf16 makes of prl_fused_logits_loss's fp32 gradient - without the fp32 gradient
- * and without the extra pass over it.  fp32 logits only; the planes must not alias the logits
- * (a row's planes are written while later rows are still being read).
- */
-int prl_fused_logits_loss_planes(const prl_loss_config* cfg, int64_t rows, int64_t cols,
-                                 int64_t vocab, const float* logits, int64_t logits_row_stride,
-                                 float temperature, const int64_t* input_ids,
-                                 const int64_t* labels, const float* old_logprobs,
-                                 const float* ref_logprobs, const float* advantages,
-                                 const float* rewards, const float* group_tokens,
-                                 const float* overflow, float* new_logprobs, float* entropy,
-                                 float* lse2, uint16_t* grad_hi, uint16_t* grad_lo,
-                                 int64_t plane_row_stride, prl_stream_t stream);
-
 /* ------------------------------------------------------------------------- */
 /* Fused output head: hidden states -> new_logprobs / entropy, logits never   */
 /* written (reference rl/__init__.py:204-233 after the model's */
@@ -642,56 +609,20 @@ int prl_lm_head_logprob_bwd(int64_t rows, int64_t cols, int64_t hidden, int64_t 
                             size_t workspace_bytes, prl_stream_t stream);
 
 /*
- * Mixed-precision form of the same head (reference lines as above: rl/__init__.py:204-233 on top of the fp32 lm_head of
- * checkpoints.py:87-103): the fp32 weight is held as  W S_w = w16 + w8lo 2^-4  with w16 = f16(W S_w) and w8lo the
- * fp8 (e4m3) rounding residual in the slot order of the MX instruction; the bf16 hidden states become f16 (exact) and an fp8
- * copy.  logits S_w S_h = w16 h16^T (f16 MFMA) + 2^3 w8lo h8^T (MX-scaled fp8 MFMA at twice the f16 rate): 3/4 of the
- * matrix-pipe time of the two-bf16-plane form at ~1e-5 instead of ~4e-6 relative error (fp32: 1e-7).
- * `scales`: 4 device floats owned by the caller; prepare writes S_w to [0], every forward S_h to [1] ([2], [3]: scratch).
- * A bf16 weight is f16-exact after scaling: pass w8lo = NULL.
- */
-int prl_lm_head_prepare_mx(int64_t vocab, int64_t hidden, const void* weight, int32_t weight_dtype,
-                           uint16_t* w16, uint8_t* w8lo, float* scales, prl_stream_t stream);
-int prl_lm_head_mx_workspace_bytes(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab, size_t* fwd_bytes);
-int prl_lm_head_logprob_fwd_mx(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
-                               const uint16_t* hidden_bf16, const uint16_t* w16, const uint8_t* w8lo,
-                               float* scales, const int64_t* input_ids, float temperature,
-                               float* new_logprobs, float* entropy, float* lse2, void* workspace,
-                               size_t workspace_bytes, prl_stream_t stream);
-/* Backward of the mixed-precision forward: the logits are RECOMPUTED on the same core (so the probabilities are those
- * the saved lse2 / entropy belong to); d hidden and d W run on the bf16 planes exactly as in prl_lm_head_logprob_bwd
- * (wt_hi / wt_lo from prl_lm_head_prepare, workspace of prl_lm_head_workspace_bytes). */
-int prl_lm_head_logprob_bwd_mx(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
-                               const uint16_t* hidden_bf16, const uint16_t* w16, const uint8_t* w8lo,
-                               float* scales, const uint16_t* wt_hi, const uint16_t* wt_lo,
-                               const int64_t* input_ids, float temperature, const float* lse2,
-                               const float* entropy, const float* grad_new_logprobs,
-                               const float* grad_entropy, const float* upstream, void* grad_hidden,
-                               int32_t grad_hidden_dtype, float* grad_weight, int64_t chunk_rows,
-                               int32_t flags, void* workspace, size_t workspace_bytes,
-                               prl_stream_t stream);
-
-/*
  * The same head with the logits KEPT between forward and backward (reference lines as above: rl/__init__.py:204-233 reads the
  * [T, V] fp32 logits of checkpoints.py:87-103's lm_head, autograd keeps them for the backward).  The *_keep forwards compute
- * exactly what prl_lm_head_logprob_fwd / _fwd_mx compute and also write `logits2` [rows * cols, vocab] fp32 = the logits in
+ * exactly what prl_lm_head_logprob_fwd computes and also write `logits2` [rows * cols, vocab] fp32 = the logits in
  * base-2 units (logit * log2(e) / temperature) straight from the accumulators (vocab must be a multiple of 8).
  * prl_lm_head_logprob_bwd_kept then forms the d-logits planes in one pass over them instead of recomputing the two plane
  * products: 5 products instead of 7 per micro-batch at the price of rows * cols * vocab * 4 bytes that live from the head's
- * forward to its backward (4.98 GB for 8192 x 152 064).  Workspaces: prl_lm_head_workspace_bytes /
- * prl_lm_head_mx_workspace_bytes as for the recomputing forms.  Neither the weight planes nor the mixed-precision operands are
- * read by the backward (d hidden runs on wt_hi / wt_lo, d W on the hidden states).
+ * forward to its backward (4.98 GB for 8192 x 152 064).  Workspace: prl_lm_head_workspace_bytes as for the recomputing form.
+ * The row-major weight planes are not read by the backward (d hidden runs on wt_hi / wt_lo, d W on the hidden states).
  */
 int prl_lm_head_logprob_fwd_keep(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
                                  const uint16_t* hidden_bf16, const uint16_t* w_hi, const uint16_t* w_lo,
                                  const int64_t* input_ids, float temperature, float* new_logprobs,
                                  float* entropy, float* lse2, float* logits2, void* workspace,
                                  size_t workspace_bytes, prl_stream_t stream);
-int prl_lm_head_logprob_fwd_mx_keep(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
-                                    const uint16_t* hidden_bf16, const uint16_t* w16, const uint8_t* w8lo,
-                                    float* scales, const int64_t* input_ids, float temperature,
-                                    float* new_logprobs, float* entropy, float* lse2, float* logits2,
-                                    void* workspace, size_t workspace_bytes, prl_stream_t stream);
 int prl_lm_head_logprob_bwd_kept(int64_t rows, int64_t cols, int64_t hidden, int64_t vocab,
                                  const uint16_t* hidden_bf16, const float* logits2, const uint16_t* wt_hi,
                                  const uint16_t* wt_lo, const int64_t* input_ids, float temperature,

@@ -13,7 +13,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl.so"
 
-PRL_ABI_VERSION = 9
+PRL_ABI_VERSION = 10
 PRL_OK = 0
 PRL_EINVAL = -22
 PRL_ENOMEM = -12
@@ -131,7 +131,6 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_grpo_loss_workspace_bytes": (c_int32, [c_int64, c_int64, POINTER(c_size_t)]),
     "prl_grpo_loss_fwd_bwd": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64] + [_P] * 13 + [_P, _P, _P, _P, _P, c_size_t, _P]),
     "prl_fused_logits_loss": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64, c_int64, _P, c_int32, c_int64, c_float] + [_P] * 8 + [_P, _P, _P, _P, _P]),
-    "prl_fused_logits_loss_planes": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64, c_int64, _P, c_int64, c_float] + [_P] * 8 + [_P, _P, _P, _P, _P, c_int64, _P]),
     "prl_last_fused_kernel": (c_char_p, []),
     "prl_scale_unless": (c_int32, [_P, c_int64, c_int32, _P, c_float, _P]),
     "prl_segment_sums": (c_int32, [c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -176,19 +175,12 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_ipc_close": (c_int32, [c_void_p]),
     "prl_bucket_gather": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "prl_bucket_scatter": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
-    "prl_split_bf16": (c_int32, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "prl_lm_head_prepare": (c_int32, [c_int64, c_int64, _P, c_int32, _P, _P, _P, _P, _P]),
     "prl_lm_head_workspace_bytes": (c_int32, [c_int64, c_int64, c_int64, c_int64, c_int64, POINTER(c_size_t), POINTER(c_size_t)]),
     "prl_lm_head_logprob_fwd": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
-    "prl_lm_head_prepare_mx": (c_int32, [c_int64, c_int64, _P, c_int32, _P, _P, _P, _P]),
-    "prl_lm_head_mx_workspace_bytes": (c_int32, [c_int64, c_int64, c_int64, c_int64, POINTER(c_size_t)]),
-    "prl_lm_head_logprob_fwd_mx": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
-    "prl_lm_head_logprob_bwd_mx": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P,
-                                             c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
     "prl_lm_head_logprob_bwd": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P,
                                           c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
     "prl_lm_head_logprob_fwd_keep": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
-    "prl_lm_head_logprob_fwd_mx_keep": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "prl_lm_head_logprob_bwd_kept": (c_int32, [c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P,
                                                c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
 }
@@ -228,17 +220,12 @@ def load() -> ctypes.CDLL:
 # The C library reads an integer table (prl_set_tuning), never the environment.  The PRL_* variables the
 # measurement scripts and tests use are mapped onto it HERE, on the Python side of the entry points they
 # influence: a dictionary lookup per call in the host language, nothing on the C launch path.
-TUNE_KEYS = {"fused_variant": 0, "lmhead_tile": 1, "lmhead_dual": 2, "lmhead_nsplit": 3, "lmhead_ksplit": 4, "lmhead_exp": 5,
-             "loss_fast_stats": 6, "loss_tpl": 7, "loss_blocks_per_cu": 8, "pack_nt": 9, "pack_tpl": 10, "lmhead_bwd": 11, "lmhead_dw_group": 12, "lmhead_seg": 13}
+TUNE_KEYS = {"fused_variant": 0, "lmhead_tile": 1, "lmhead_nsplit": 2, "lmhead_ksplit": 3}
 PRL_TUNE_UNSET = -(1 << 63)
-_ENV_OF_KEY = {"fused_variant": "PRL_FUSED_VARIANT", "lmhead_tile": "PRL_LMHEAD_TILE", "lmhead_dual": "PRL_LMHEAD_DUAL",
-               "lmhead_nsplit": "PRL_LMHEAD_NSPLIT", "lmhead_ksplit": "PRL_LMHEAD_KSPLIT", "lmhead_exp": "PRL_LMHEAD_EXP",
-               "loss_fast_stats": "PRL_LOSS_FAST_STATS", "loss_tpl": "PRL_LOSS_TPL", "loss_blocks_per_cu": "PRL_LOSS_BLOCKS_PER_CU",
-               "pack_nt": "PRL_PACK_NT", "pack_tpl": "PRL_PACK_TPL", "lmhead_bwd": "PRL_LMHEAD_BWD", "lmhead_dw_group": "PRL_LMHEAD_DW_GROUP", "lmhead_seg": "PRL_LMHEAD_SEG"}
+_ENV_OF_KEY = {"fused_variant": "PRL_FUSED_VARIANT", "lmhead_tile": "PRL_LMHEAD_TILE", "lmhead_nsplit": "PRL_LMHEAD_NSPLIT",
+               "lmhead_ksplit": "PRL_LMHEAD_KSPLIT"}
 _ENV_TUNED_ENTRY_POINTS = ("prl_fused_logits_loss", "prl_lm_head_logprob_fwd", "prl_lm_head_logprob_bwd", "prl_lm_head_workspace_bytes",
-                           "prl_lm_head_logprob_fwd_mx", "prl_lm_head_mx_workspace_bytes", "prl_lm_head_logprob_bwd_mx",
-                           "prl_lm_head_logprob_fwd_keep", "prl_lm_head_logprob_fwd_mx_keep", "prl_lm_head_logprob_bwd_kept",
-                           "prl_grpo_loss_fwd_bwd", "prl_pack_collate")
+                           "prl_lm_head_logprob_fwd_keep", "prl_lm_head_logprob_bwd_kept")
 _env_seen: tuple | None = None
 
 
@@ -249,7 +236,7 @@ def set_tuning(key: str, value: int | None) -> None:
 
 def _parse_tuning(key: str, text: str) -> int:
     if key == "lmhead_tile":  # "128" | "256" | "256x256"
-        return {"128": 128, "256": 256, "256x256": 512, "256x384": 384, "256x320": 320}.get(text.strip(), 0)
+        return {"128": 128, "256": 256, "256x256": 512}.get(text.strip(), 0)
     return int(text)
 
 

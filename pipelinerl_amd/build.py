@@ -40,7 +40,9 @@ SOURCES = [
     "prl_logprob.hip",
     "prl_pack.hip",
     "prl_copy.hip",
-    "prl_lmhead.hip",
+    "prl_lmhead_prepare.hip",
+    "prl_lmhead_fwd.hip",
+    "prl_lmhead_bwd.hip",
 ]
 
 

@@ -100,63 +100,7 @@ static int segment_copy(void* bucket, int64_t bucket_bytes, const prl_segment* s
   return PRL_OK;
 }
 
-// ---------------------------------------------------------------------------------------
-// fp32 -> (hi, lo) bf16 planes:  hi = bf16(x),  lo = bf16(x - float(hi))   (round to nearest even)
-// One pass (4 B read + 4 B written per element) instead of the three elementwise passes a tensor
-// library needs; feeds the bf16 MFMA GEMMs of the split fp32 lm_head (pipelinerl_amd/lm_head.py).
-// ---------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-  const f32x2 p = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(p, bf16x2));  // v_cvt_pk_bf16_f32
-}
-__device__ __forceinline__ float bf16_lo_to_f32(uint32_t packed) { return __uint_as_float(packed << 16); }
-__device__ __forceinline__ float bf16_hi_to_f32(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
-
-__global__ __launch_bounds__(kCopyBlock) void split_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ hi,
-                                                                 uint16_t* __restrict__ lo, int64_t n) {
-  const int64_t nvec = n >> 2;
-  const int64_t stride = (int64_t)gridDim.x * kCopyBlock;
-  const f32x4* sv = reinterpret_cast<const f32x4*>(src);
-  u32x2* hv = reinterpret_cast<u32x2*>(hi);
-  u32x2* lv = reinterpret_cast<u32x2*>(lo);
-  for (int64_t i = (int64_t)blockIdx.x * kCopyBlock + threadIdx.x; i < nvec; i += stride) {
-    const f32x4 x = __builtin_nontemporal_load(sv + i);
-    const uint32_t h01 = pack_bf16(x[0], x[1]), h23 = pack_bf16(x[2], x[3]);
-    const uint32_t l01 = pack_bf16(x[0] - bf16_lo_to_f32(h01), x[1] - bf16_hi_to_f32(h01));
-    const uint32_t l23 = pack_bf16(x[2] - bf16_lo_to_f32(h23), x[3] - bf16_hi_to_f32(h23));
-    __builtin_nontemporal_store(u32x2{h01, h23}, hv + i);
-    __builtin_nontemporal_store(u32x2{l01, l23}, lv + i);
-  }
-  if (blockIdx.x == 0) {  // n % 4 tail
-    for (int64_t j = (nvec << 2) + threadIdx.x; j < n; j += kCopyBlock) {
-      const float x = src[j];
-      const uint32_t h = pack_bf16(x, 0.0f);
-      hi[j] = (uint16_t)(h & 0xffffu);
-      lo[j] = (uint16_t)(pack_bf16(x - bf16_lo_to_f32(h), 0.0f) & 0xffffu);
-    }
-  }
-}
-
 }  // namespace prl
-
-extern "C" int prl_split_bf16(int64_t n, const float* src, uint16_t* hi, uint16_t* lo, void* stream) {
-  PRL_CHECK_ARG(n >= 0, "negative element count");
-  if (n == 0) return PRL_OK;
-  PRL_CHECK_ARG(src && hi && lo, "null pointer");
-  PRL_CHECK_ARG(prl::aligned16(src) && ((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 7u) == 0,
-                "src must be 16-byte aligned, hi / lo 8-byte aligned");
-  int64_t blocks = ((n >> 2) + prl::kCopyBlock - 1) / prl::kCopyBlock;
-  if (blocks < 1) blocks = 1;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(prl::split_bf16_kernel, dim3((unsigned)blocks), dim3(prl::kCopyBlock), 0, static_cast<hipStream_t>(stream), src, hi, lo, n);
-  PRL_LAUNCH_CHECK("split_bf16_kernel");
-  return PRL_OK;
-}
 
 extern "C" int prl_bucket_gather(void* bucket, int64_t bucket_bytes, const prl_segment* segments, int64_t n_segments, void* stream) {
   return prl::segment_copy(bucket, bucket_bytes, segments, n_segments, true, static_cast<hipStream_t>(stream));

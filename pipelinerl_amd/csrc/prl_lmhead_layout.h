@@ -1,4 +1,4 @@
-// Index arithmetic of the MFMA GEMM core in prl_lmhead.hip, kept in one header so that the device
+// Index arithmetic of the MFMA GEMM cores in prl_lmhead_core.h, kept in one header so that the device
 // kernels and the host-compiled unit-test harness (tests/harness/lmhead_layout_host.cpp) use the SAME
 // functions: tile raster, LDS image of a staged operand tile, fragment reads, accumulator layout.
 //
@@ -92,26 +92,6 @@ PRL_LHD int tr_frag_lds_byte(int lane, int wave_row0, int i, int ks, int r) {
 // which (token, entry) the lane's four results are: entry = wave_row0 + 32 i + (lane & 31), tokens 16 ks + 8 (lane >> 5) + 4 r + 0..3
 PRL_LHD int tr_frag_entry(int lane, int wave_row0, int i) { return wave_row0 + 32 * i + (lane & 31); }
 PRL_LHD int tr_frag_token0(int lane, int ks, int r) { return 16 * ks + 8 * (lane >> 5) + 4 * r; }
-
-// ---- the mixed-precision (f16 + MX fp8) core.  The 16-bit planes use the 32-deep layout above.  An fp8 "lo" plane
-// accompanies them: one byte per element, consumed by v_mfma_scale_f32_32x32x64_f8f6f4, whose lane (row, half) supplies
-// 32 K-SLOTS of a 64-deep contraction.  Which contraction index sits in which slot is free as long as both operands
-// agree, so the slots follow the f16 fragments the OTHER operand is converted from in registers: of a 64-deep pair of
-// stages (two 32-deep stages p = 0, 1, two 16-deep sub-steps ks = 0, 1 each) lane-half h holds, in this order,
-//     slot 16 p + 8 ks + e   <->   k = 32 p + 16 ks + 8 h + e        (e = 0..7)
-// The staged fp8 plane is stored in memory already in slot order: per row and 32-deep block 32 bytes,
-// [half 0: 16 slots][half 1: 16 slots], i.e. element k of the block at byte 16 ((k >> 3) & 1) + (k & 7) + 8 (k >> 4).
-PRL_LHD int mx_byte_in_block(int k) { return 16 * ((k >> 3) & 1) + (k & 7) + 8 * (k >> 4); }   // k = 0..31
-PRL_LHD int mx_slot_k(int half, int slot) { return 32 * (slot >> 4) + 16 * ((slot >> 3) & 1) + 8 * half + (slot & 7); }  // slot = 0..31 -> k = 0..63
-// An fp8 tile of a 32-deep stage is R rows x 32 bytes = 2 R chunks of 16; thread `tid` of a 512-thread workgroup moves chunk
-// tid (256 rows): row tid >> 1, LDS slot tid & 1 holding the logical half  slot ^ ((row >> 3) & 1)  (swizzle on the source).
-PRL_LHD int mx8_stage_row(int tid) { return tid >> 1; }
-PRL_LHD int mx8_stage_half(int tid) { return (tid & 1) ^ ((tid >> 4) & 1); }
-// fragment read: lane l supplies row (l & 31), half (l >> 5): 16 bytes
-PRL_LHD int mx8_frag_lds_byte(int lane, int wave_row0, int i) {
-  const int r = frag_row(lane, wave_row0, i);
-  return r * 32 + (((lane >> 5) ^ ((r >> 3) & 1)) << 4);
-}
 
 // ---- accumulators: element `reg` (0..15) of the 32 x 32 tile (i, j) of the wave whose sub-tile starts
 // at (wave_row0, wave_col0) = (64 * (wave >> 1), (BN / 2) * (wave & 1))

@@ -157,9 +157,7 @@ __device__ __forceinline__ void store_vec(V* p, const V& v) {
   }
 }
 
-// ---- where a row of d logits goes.  DenseOut: the logits' own dtype and layout (may alias the logits).
-// PlanesOut: two bf16 planes hi + lo = the fp32 value to ~2^-17 relative - the operand format of the split-bf16
-// head GEMMs (lm_head.py), so the gradient never exists in fp32 and needs no separate split pass.
+// ---- where a row of d logits goes: the logits' own dtype and layout (may alias the logits)
 template <class T>
 struct DenseOut {
   typename T::scalar* p;
@@ -169,35 +167,6 @@ struct DenseOut {
     store_vec<NT>(&reinterpret_cast<typename T::vec*>(p)[j], T::pack(o));
   }
   __device__ __forceinline__ void put1(int j, float x) const { p[j] = T::from_float(x); }
-};
-
-__device__ __forceinline__ void split_hi_lo(float x, uint16_t& hi, uint16_t& lo) {
-  hi = BF16::from_float(x);
-  lo = BF16::from_float(x - BF16::to_float(hi));
-}
-
-struct PlanesOut {  // fp32 logits only: groups of 4 values -> 8 bytes per plane
-  uint16_t* hi;
-  uint16_t* lo;
-  int64_t stride;  // row stride of the planes, elements
-  __device__ __forceinline__ PlanesOut row(int64_t q, int64_t) const { return PlanesOut{hi + q * stride, lo + q * stride, stride}; }
-  template <bool NT>
-  __device__ __forceinline__ void put(int j, const float (&o)[4]) const {
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 h, l;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const f32x2 x = {o[2 * i], o[2 * i + 1]};
-      h[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));  // v_cvt_pk_bf16_f32, RNE
-      const f32x2 r = {x[0] - __uint_as_float(h[i] << 16), x[1] - __uint_as_float(h[i] & 0xffff0000u)};
-      l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
-    }
-    store_vec<NT>(&reinterpret_cast<u32x2*>(hi)[j], h);
-    store_vec<NT>(&reinterpret_cast<u32x2*>(lo)[j], l);
-  }
-  __device__ __forceinline__ void put1(int j, float x) const { split_hi_lo(x, hi[j], lo[j]); }
 };
 
 // REVERSE walks the row back to front: in the fused kernel the tail of the row is what pass 1
@@ -827,72 +796,5 @@ extern "C" int prl_fused_logits_loss(const prl_loss_config* cfg, int64_t rows, i
 #undef PRL_KEEP_LAUNCH2
 #undef PRL_FUSED_LAUNCH
   PRL_LAUNCH_CHECK("fused_logits_loss_kernel");
-  return PRL_OK;
-}
-
-// d logits as two bf16 planes (hi + lo), straight from the fused pass: fp32 logits in, never an fp32 gradient.
-extern "C" int prl_fused_logits_loss_planes(const prl_loss_config* cfg, int64_t rows, int64_t cols,
-                                            int64_t vocab, const float* logits, int64_t logits_row_stride,
-                                            float temperature, const int64_t* input_ids, const int64_t* labels,
-                                            const float* old_logprobs, const float* ref_logprobs,
-                                            const float* advantages, const float* rewards,
-                                            const float* group_tokens, const float* overflow,
-                                            float* new_logprobs, float* entropy, float* lse2,
-                                            uint16_t* grad_hi, uint16_t* grad_lo, int64_t plane_row_stride,
-                                            prl_stream_t stream) {
-  RowGeom geo;
-  if (int rc = check_geom(rows, cols, vocab, logits, PRL_DTYPE_F32, logits_row_stride, &geo)) return rc;
-  PRL_CHECK_ARG(cfg != nullptr, "cfg is null");
-  PRL_CHECK_ARG(cfg->policy_loss == PRL_POLICY_PPO || cfg->policy_loss == PRL_POLICY_REINFORCE,
-                "unknown policy_loss %d", cfg->policy_loss);
-  PRL_CHECK_ARG(input_ids && labels && old_logprobs && ref_logprobs && advantages && rewards &&
-                    group_tokens && overflow && new_logprobs && entropy && lse2 && grad_hi && grad_lo,
-                "null pointer");
-  PRL_CHECK_ARG(temperature > 0.0f, "temperature must be > 0");
-  PRL_CHECK_ARG(plane_row_stride >= vocab, "plane_row_stride %lld < vocab %lld", (long long)plane_row_stride, (long long)vocab);
-  {  // the planes are written while other rows' logits are still being read: they must not overlap them
-    const char* l0 = reinterpret_cast<const char*>(logits);
-    const char* l1 = l0 + (size_t)geo.n * logits_row_stride * 4;
-    const size_t pb = (size_t)geo.n * plane_row_stride * 2;
-    auto overlaps = [&](const uint16_t* q) {
-      const char* a0 = reinterpret_cast<const char*>(q);
-      return a0 < l1 && a0 + pb > l0;
-    };
-    PRL_CHECK_ARG(!overlaps(grad_hi) && !overlaps(grad_lo), "the gradient planes must not alias the logits");
-  }
-  // groups of four values are stored as 8 bytes per plane
-  geo.vec_ok = geo.vec_ok && (reinterpret_cast<uintptr_t>(grad_hi) & 7u) == 0 && (reinterpret_cast<uintptr_t>(grad_lo) & 7u) == 0 &&
-               (plane_row_stride * 2) % 8 == 0;
-  FusedArgs a{*cfg,      input_ids, labels,       old_logprobs, ref_logprobs, advantages,
-              rewards,   group_tokens, overflow,  new_logprobs, entropy,      lse2,
-              cfg->upstream_scale == 0.0f ? 1.0f : cfg->upstream_scale};
-  const float k2 = kLog2e / temperature;
-  const float inv_temp = 1.0f / temperature;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)geo.n);
-  const PlanesOut out{grad_hi, grad_lo, plane_row_stride};
-  constexpr int BLK = 1024, KR = 16, KL = 9;
-  if (geo.vec_ok && geo.vocab / F32::NV >= (KR + KL) * BLK) {  // the row-resident shape of prl_fused_logits_loss (variant 21)
-    auto kfn = fused_logits_loss_keep_kernel<F32, BLK, 2, KR, KL, true, PlanesOut>;
-    g_last_fused = "fused_logits_loss_keep_kernel<F32,1024,2,16,9,true,planes>";
-    const size_t lds_bytes = 256 + (size_t)KL * BLK * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-      PRL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kfn, grid, dim3(BLK), lds_bytes, s, geo, a, logits, k2, inv_temp, out);
-  } else {
-    auto kfn = fused_logits_loss_kernel<F32, BLK, 4, true, true, PlanesOut>;
-    g_last_fused = "fused_logits_loss_kernel<F32,1024,4,true,true,planes>";
-    const size_t lds_bytes = 96 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-      PRL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kfn, grid, dim3(BLK), lds_bytes, s, geo, a, logits, k2, inv_temp, out);
-  }
-  PRL_LAUNCH_CHECK("fused_logits_loss_kernel(planes)");
   return PRL_OK;
 }

@@ -463,19 +463,11 @@ __global__ __launch_bounds__(kFinalBlock) void grpo_loss_finalize_kernel(const d
   }
 }
 
-// PRL_TUNE_LOSS_FAST_STATS = 0 selects the always-nan_to_num statistics path (A/B measurements only).
-bool fast_stats() { return prl::tuning(PRL_TUNE_LOSS_FAST_STATS, 1) != 0; }
-
 // Tokens per lane and iteration.  Two make every load wave-contiguous (the int64 columns are 16
 // bytes per lane at a 16-byte stride instead of two loads at a 32-byte stride) and fit 3 waves per
 // SIMD: 7 % faster for the statistics-only launch of a whole step (347 vs 375 us); with the
 // gradient written as well four tokens per lane (16-byte stores) stay ahead (390 vs 399 us).
-// PRL_TUNE_LOSS_TPL = 2 | 4 overrides (A/B measurements).
-int tokens_per_lane(bool writes_gradient) {
-  const int forced = (int)prl::tuning(PRL_TUNE_LOSS_TPL, 0);
-  if (forced == 2 || forced == 4) return forced;
-  return writes_gradient ? 4 : 2;
-}
+int tokens_per_lane(bool writes_gradient) { return writes_gradient ? 4 : 2; }
 
 int grid_for(int64_t n, int vec) {
   const int64_t items = (n + vec - 1) / vec;
@@ -500,8 +492,7 @@ int resident_grid(int wanted) {
     return p;
   }();
   if (probe.cus <= 0) return wanted < kMaxBlocks ? wanted : kMaxBlocks;
-  const int64_t forced = prl::tuning(PRL_TUNE_LOSS_BLOCKS_PER_CU, 0);  // measurement override
-  const int64_t c = (int64_t)probe.cus * (forced > 0 ? forced : probe.per_cu);
+  const int64_t c = (int64_t)probe.cus * probe.per_cu;
   const int cap = (int)(c < kMaxBlocks ? c : kMaxBlocks);
   return wanted < cap ? wanted : cap;
 }
@@ -588,15 +579,12 @@ extern "C" int prl_grpo_loss_fwd_bwd(const prl_loss_config* cfg, int64_t rows, i
     if (is_gspo) {
       nblocks = resident_grid<grpo_loss_partial_kernel<4, true, true>>(grid_for(a.n, 4));
       hipLaunchKernelGGL((grpo_loss_partial_kernel<4, true, true>), dim3(nblocks), dim3(kBlock), 0, s, a);
-    } else if (fast_stats() && tokens_per_lane(a.g_nlp != nullptr || a.g_ent != nullptr) == 2) {
+    } else if (tokens_per_lane(a.g_nlp != nullptr || a.g_ent != nullptr) == 2) {
       nblocks = resident_grid<grpo_loss_partial_kernel<2, true, false>>(grid_for(a.n, 2));
       hipLaunchKernelGGL((grpo_loss_partial_kernel<2, true, false>), dim3(nblocks), dim3(kBlock), 0, s, a);
-    } else if (fast_stats()) {
+    } else {
       nblocks = resident_grid<grpo_loss_partial_kernel<4, true, false>>(grid_for(a.n, 4));
       hipLaunchKernelGGL((grpo_loss_partial_kernel<4, true, false>), dim3(nblocks), dim3(kBlock), 0, s, a);
-    } else {
-      nblocks = resident_grid<grpo_loss_partial_kernel<4, false, false>>(grid_for(a.n, 4));
-      hipLaunchKernelGGL((grpo_loss_partial_kernel<4, false, false>), dim3(nblocks), dim3(kBlock), 0, s, a);
     }
   } else {
     nblocks = grid_for(a.n, 1);

@@ -610,17 +610,12 @@ extern "C" int prl_pack_collate(int32_t m, int64_t total_tokens, const int32_t* 
                    prl::aligned16(out_old_logprobs) && prl::aligned16(out_group_tokens) &&
                    prl::aligned16(out_num_labels) && prl::aligned16(out_overflow);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool nt = prl::tuning(PRL_TUNE_PACK_NT, kPackNtDefault ? 1 : 0) != 0;
-  const int tpl = prl::tuning(PRL_TUNE_PACK_TPL, 2) == 4 ? 4 : 2;  // measurement override: 4 = four tokens per lane
+  // two tokens per lane + non-temporal stores (every store wave-contiguous; profiles/r01u_pack_variants.txt: the four-tokens-per-lane
+  // and plain-store forms measured slower and are no longer built); unaligned outputs take the scalar-store form
+  const int tpl = vec ? 2 : 4;
   const int nb = blocks_for((total_tokens + tpl - 1) / tpl);
-  if (vec && nt && tpl == 2) {
-    hipLaunchKernelGGL((pack_collate_kernel<true, true, 2>), dim3(nb), dim3(kBlock), 0, s, a);
-  } else if (vec && tpl == 2) {
-    hipLaunchKernelGGL((pack_collate_kernel<true, false, 2>), dim3(nb), dim3(kBlock), 0, s, a);
-  } else if (vec && nt) {
-    hipLaunchKernelGGL((pack_collate_kernel<true, true, 4>), dim3(nb), dim3(kBlock), 0, s, a);
-  } else if (vec) {
-    hipLaunchKernelGGL((pack_collate_kernel<true, false, 4>), dim3(nb), dim3(kBlock), 0, s, a);
+  if (vec) {
+    hipLaunchKernelGGL((pack_collate_kernel<true, kPackNtDefault, 2>), dim3(nb), dim3(kBlock), 0, s, a);
   } else {
     hipLaunchKernelGGL((pack_collate_kernel<false, false, 4>), dim3(nb), dim3(kBlock), 0, s, a);
   }

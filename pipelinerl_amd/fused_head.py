@@ -43,7 +43,7 @@ class FusedLmHead:
     `.data.copy_()` must call `invalidate()` - same contract as lm_head.SplitBf16LmHead."""
 
     def __init__(self, weight: torch.Tensor, backward: bool = True, chunk_rows: int = 8192, hidden_grad_terms: int = 3,
-                 skip_unlabelled: bool = True, precision: str | None = None, keep_logits: bool | None = None):
+                 skip_unlabelled: bool = True, keep_logits: bool | None = None):
         """`chunk_rows`: logits rows whose d logits planes live in the workspace at a time (2 x chunk x V x 2 bytes: 5 GB for
         8192 rows of a 152 064-entry vocabulary; one chunk per 8192-token micro-batch halves the d W epilogues).
         `hidden_grad_terms`: 3 = d hidden from every bf16 product (fp32-GEMM accuracy before the final rounding),
@@ -69,13 +69,7 @@ class FusedLmHead:
         if self.hidden_grad_terms not in (1, 2, 3):
             raise ValueError("hidden_grad_terms must be 1, 2 or 3")
         self.skip_unlabelled = bool(skip_unlabelled)
-        # "bf16x2": the fp32 weight as two bf16 planes (~4e-6 relative); "f16_fp8": an f16 plane + an fp8 residual plane on the
-        # MX instruction (~1e-5 relative, 3/4 of the matrix-pipe time) - forward only so far, the backward keeps the bf16 planes
-        self.precision = precision or os.environ.get("PRL_LMHEAD_PRECISION", "bf16x2")
-        if self.precision not in ("bf16x2", "f16_fp8"):
-            raise ValueError(f"unknown precision {self.precision!r}")
         self.keep_logits = bool(int(os.environ.get("PRL_LMHEAD_KEEP_LOGITS", "1"))) if keep_logits is None else bool(keep_logits)
-        self.w16 = self.w8lo = self.mx_scales = None
         self._key = None
         self.w_hi = self.w_lo = self.wt_hi = self.wt_lo = None
         self._ws: dict[Any, torch.Tensor] = {}
@@ -112,21 +106,13 @@ class FusedLmHead:
             self.wt_hi, self.wt_lo = (plane(H, V) if self.backward else None), None
             outs = (None, None, self.wt_hi, None)
         else:
-            # the row-major bf16 planes feed the forward / recompute of the bf16x2 form only
-            self.w_hi, self.w_lo = (plane(V, H), plane(V, H)) if self.precision == "bf16x2" else (None, None)
+            self.w_hi, self.w_lo = plane(V, H), plane(V, H)
             self.wt_hi, self.wt_lo = (plane(H, V), plane(H, V)) if self.backward else (None, None)
             outs = (self.w_hi, self.w_lo, self.wt_hi, self.wt_lo)
         if any(o is not None for o in outs):
             with torch.cuda.device(dev):
                 _lib.check(lib.prl_lm_head_prepare(V, H, src.data_ptr(), 0 if w.dtype == torch.float32 else 1,
                                                    *[_lib.ptr(o) for o in outs], _lib.current_stream_ptr(dev)))
-        if self.precision == "f16_fp8":
-            self.w16 = torch.empty((V, H), dtype=torch.float16, device=dev)
-            self.w8lo = torch.empty((V, H), dtype=torch.uint8, device=dev) if w.dtype == torch.float32 else None
-            self.mx_scales = torch.zeros(4, dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                _lib.check(lib.prl_lm_head_prepare_mx(V, H, src.data_ptr(), 0 if w.dtype == torch.float32 else 1, self.w16.data_ptr(),
-                                                      _lib.ptr(self.w8lo), self.mx_scales.data_ptr(), _lib.current_stream_ptr(dev)))
         self._key = key
 
     def _workspace(self, kind: str, rows: int, cols: int, dev: torch.device, chunk_rows: int) -> torch.Tensor:
@@ -179,22 +165,6 @@ class FusedLmHead:
         if keep and self.vocab % 8:
             raise ValueError("kept logits need a vocabulary that is a multiple of 8")
         kept = torch.empty((B * L, self.vocab), dtype=torch.float32, device=dev) if keep else None
-        if self.precision == "f16_fp8":
-            need = ctypes.c_size_t(0)
-            _lib.check(lib.prl_lm_head_mx_workspace_bytes(B, L, H, self.vocab, ctypes.byref(need)))
-            key = ("fwd_mx", dev, _lib.current_stream_ptr(dev))
-            ws = self._ws.get(key)
-            if ws is None or ws.numel() < need.value:
-                ws = self._ws[key] = torch.empty(need.value, dtype=torch.uint8, device=dev)
-            head = (B, L, H, self.vocab, h.data_ptr(), self.w16.data_ptr(), _lib.ptr(self.w8lo), self.mx_scales.data_ptr(), ids.data_ptr(),
-                    float(temperature), nlp.data_ptr(), ent.data_ptr(), lse2.data_ptr())
-            tail = (ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev))
-            with torch.cuda.device(dev):
-                if keep:
-                    _lib.check(lib.prl_lm_head_logprob_fwd_mx_keep(*head, kept.data_ptr(), *tail))
-                else:
-                    _lib.check(lib.prl_lm_head_logprob_fwd_mx(*head, *tail))
-            return (nlp, ent, lse2, h, kept) if keep else (nlp, ent, lse2, h)
         ws = self._workspace("fwd", B, L, dev, self.chunk_rows)
         head = (B, L, H, self.vocab, h.data_ptr(), self.w_hi.data_ptr(), _lib.ptr(self.w_lo), ids.data_ptr(), float(temperature),
                 nlp.data_ptr(), ent.data_ptr(), lse2.data_ptr())
@@ -238,9 +208,6 @@ class FusedLmHead:
                     raise ValueError("kept_logits must be the contiguous float32 [rows, vocab] tensor of the forward")
                 _lib.check(lib.prl_lm_head_logprob_bwd_kept(B, L, H, self.vocab, h.data_ptr(), kept_logits.data_ptr(), self.wt_hi.data_ptr(),
                                                             _lib.ptr(self.wt_lo), *tail))
-            elif self.precision == "f16_fp8":  # the recompute runs on the core the forward ran on
-                _lib.check(lib.prl_lm_head_logprob_bwd_mx(B, L, H, self.vocab, h.data_ptr(), self.w16.data_ptr(), _lib.ptr(self.w8lo),
-                                                          self.mx_scales.data_ptr(), self.wt_hi.data_ptr(), _lib.ptr(self.wt_lo), *tail))
             else:
                 _lib.check(lib.prl_lm_head_logprob_bwd(B, L, H, self.vocab, h.data_ptr(), self.w_hi.data_ptr(), _lib.ptr(self.w_lo),
                                                        self.wt_hi.data_ptr(), _lib.ptr(self.wt_lo), *tail))

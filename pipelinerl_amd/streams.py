@@ -23,9 +23,10 @@ Backends
          like a file.  Non-batch records (trainer messages, stats dicts) travel as JSON bytes.  With
          `mirror_jsonl=True` (or a list of topics) every record is also appended to the files-backend
          location, so the run can be replayed with `backend: files` (`debug.streams_from`).
-  redis  the reference's wire format (XADD {index, data = pickle}, XREAD from id 0, streams.py:120-192),
-         implemented against the `redis` client package.  This image ships neither that package nor a
-         server: selecting it without them raises ImportError - it is never silently replaced.
+  redis  NOT provided: the reference's Redis backend (streams.py:106-232) is a network service outside the hot path, and
+         this image ships neither the client package nor a server, so a restatement of it could not even be tested.
+         `backend: redis` raises with a pointer to `shm` (same log semantics - every reader from record 0, fan-out,
+         reopened writers - in shared memory, one node) and `files`.
 """
 
 from __future__ import annotations
@@ -56,19 +57,16 @@ _backend: str | None = None
 _backend_options: dict[str, Any] = {}
 
 
-def set_streams_backend(backend: Literal["files", "shm", "redis"], **kwargs: Any) -> None:
+def set_streams_backend(backend: Literal["files", "shm"], **kwargs: Any) -> None:
     """Select the transport once per process (reference :33-43)."""
     global _backend, _backend_options
     if _backend is not None:
         raise ValueError("Backend already set. Cannot change it.")
     if backend == "redis":
-        try:
-            import redis  # noqa: F401
-        except ImportError as e:
-            raise ImportError("streams backend 'redis' needs the `redis` client package (and a server); it is not installed here. "
-                              "Use backend 'shm' (same log semantics in shared memory, one node) or 'files'.") from e
-    if backend not in ("files", "shm", "redis"):
-        raise ValueError(f"Invalid backend: {backend}. Only 'redis', 'files' and 'shm' are supported.")
+        raise NotImplementedError("streams backend 'redis' is not part of pipelinerl_amd (the reference's Redis transport is a network service "
+                                  "outside the hot path). Use backend 'shm' (the same log semantics in shared memory, one node) or 'files'.")
+    if backend not in ("files", "shm"):
+        raise ValueError(f"Invalid backend: {backend}. Only 'files' and 'shm' are supported.")
     _backend, _backend_options = backend, dict(kwargs)
 
 
@@ -440,92 +438,7 @@ class ShmStreamReader(StreamReader):
 
 
 # ---------------------------------------------------------------------------------------------
-# redis backend (reference streams.py:106-232; needs the `redis` package + a server)
-# ---------------------------------------------------------------------------------------------
-
-
-def _connect_to_redis():
-    import redis
-
-    host, port = _backend_options.get("host", "localhost"), int(_backend_options.get("port", 6379))
-    while True:
-        try:
-            client = redis.Redis(host=host, port=port)
-            client.ping()
-            return client
-        except (redis.exceptions.TimeoutError, redis.ConnectionError) as e:
-            logger.warning(f"Waiting for Redis server ({type(e)}). Retrying in 5 seconds.")
-            time.sleep(5)
-
-
-class RedisStreamWriter(StreamWriter):
-    """XADD {index, data = pickle(record)} with the running index the reference keeps (:121-160)."""
-
-    def __init__(self, stream: SingleStreamSpec, mode: Literal["w", "a"] = "a"):
-        self.stream = stream
-        self._stream_name = str(stream)
-        self._redis = _connect_to_redis()
-        last = self._redis.xrevrange(self._stream_name, count=1)
-        if mode == "a":
-            self._index = int(last[0][1][b"index"].decode()) + 1 if last else 0
-        elif mode == "w":
-            if last:
-                raise ValueError(f"Stream {self.stream} already exists. Cannot overwrite it.")
-            self._index = 0
-        else:
-            raise ValueError(f"Invalid mode: {mode}. Only 'w' and 'a' are supported.")
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, exc_type, exc_value, traceback):
-        self._redis.close()
-
-    def write(self, data, partition: int | None = None):
-        import pickle
-
-        if partition is not None:
-            raise ValueError()
-        if isinstance(data, BaseModel):
-            data = data.model_dump()
-        self._redis.xadd(self._stream_name, {"index": self._index, "data": pickle.dumps(data)}, maxlen=1000000, approximate=True)
-        self._index += 1
-
-
-class RedisStreamReader(StreamReader):
-    """XREAD from id 0, one entry at a time, checking the writer's running index (:163-192)."""
-
-    def __init__(self, stream: SingleStreamSpec):
-        self.stream = stream
-        self._stream_name = str(stream)
-        self._redis = _connect_to_redis()
-        self._last_id: Any = 0
-        self._index = 0
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, exc_type, exc_value, traceback):
-        self._redis.close()
-
-    def read(self):
-        import pickle
-
-        block = int(_REREAD_DELAY * 1000)
-        while True:
-            response = self._redis.xread({self._stream_name: self._last_id}, count=1, block=block)
-            if response:
-                _, result = response[0]
-                entry_id, entry = result[0]
-                if int(entry[b"index"].decode("utf-8")) != self._index:
-                    raise ValueError(f"Index mismatch: expected {self._index}, got {entry[b'index']}")
-                self._last_id = entry_id
-                self._index += 1
-                yield pickle.loads(entry[b"data"])
-
-
-# ---------------------------------------------------------------------------------------------
-# partitioned writers + public entry points
+# partitioned writer (reference :349-384)
 # ---------------------------------------------------------------------------------------------
 
 
@@ -564,7 +477,7 @@ def read_stream(stream: SingleStreamSpec) -> StreamReader:
     raise_if_backend_not_set()
     if not isinstance(stream, SingleStreamSpec):
         raise ValueError(f"Invalid stream spec: {stream}")
-    return {"files": FileStreamReader, "shm": ShmStreamReader, "redis": RedisStreamReader}[_backend](stream)
+    return {"files": FileStreamReader, "shm": ShmStreamReader}[_backend](stream)
 
 
 def write_to_streams(streams: StreamSpec, mode: Literal["w", "a"] = "a") -> StreamWriter:
@@ -572,7 +485,7 @@ def write_to_streams(streams: StreamSpec, mode: Literal["w", "a"] = "a") -> Stre
     raise_if_backend_not_set()
     if not isinstance(streams, (SingleStreamSpec, StreamRangeSpec)):
         raise ValueError(f"Invalid stream spec: {streams}")
-    writer_cls = {"files": FileStreamWriter, "shm": ShmStreamWriter, "redis": RedisStreamWriter}[_backend]
+    writer_cls = {"files": FileStreamWriter, "shm": ShmStreamWriter}[_backend]
     if isinstance(streams, SingleStreamSpec):
         return writer_cls(streams, mode)
     return PartitionedStreamWriter(streams, mode, writer_cls)

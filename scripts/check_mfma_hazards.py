@@ -1,4 +1,4 @@
-"""Static check of the hand-placed (asm) MFMA streams in csrc/prl_lmhead.hip.
+"""Static check of the hand-placed (asm) MFMA streams in csrc/prl_lmhead_core.h (instantiated by prl_lmhead_fwd.hip / prl_lmhead_bwd.hip).
 
 MFMAs written as `asm volatile` are invisible to hipcc's hazard recogniser, so two software-managed hazards of gfx950 have to be
 kept out of the instruction stream by construction (csrc: `mfma_pin_acc`, `mfma_settle`) - and this script verifies the generated
@@ -26,12 +26,19 @@ ROOT = Path(__file__).resolve().parent.parent
 MIN_GAP = 4  # instructions (each >= 1 wait state; an intervening MFMA counts as 4)
 
 
+SOURCES = ("prl_lmhead_fwd.hip", "prl_lmhead_bwd.hip")  # the translation units that instantiate the hand-placed streams of prl_lmhead_core.h
+
+
 def compile_to_asm() -> str:
-    out = Path(tempfile.mkdtemp()) / "prl_lmhead.s"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}",
-                           f"-I{ROOT / 'pipelinerl_amd' / 'csrc'}", "-S", "--cuda-device-only", str(ROOT / "pipelinerl_amd" / "csrc" / "prl_lmhead.hip"),
-                           "-o", str(out)], stderr=subprocess.DEVNULL)
-    return out.read_text()
+    tmp = Path(tempfile.mkdtemp())
+    text = []
+    for name in SOURCES:
+        out = tmp / (name + ".s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}",
+                               f"-I{ROOT / 'pipelinerl_amd' / 'csrc'}", "-S", "--cuda-device-only", str(ROOT / "pipelinerl_amd" / "csrc" / name),
+                               "-o", str(out)], stderr=subprocess.DEVNULL)
+        text.append(out.read_text())
+    return "\n".join(text)
 
 
 def regs(tok: str) -> set[str]:

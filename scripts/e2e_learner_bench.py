@@ -29,7 +29,6 @@ def main():
     ap.add_argument("--fused", action="store_true")
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--model", default="0p5b", choices=["0p5b", "7b"], help="Qwen2.5 shape (random init)")
-    ap.add_argument("--split-head", action="store_true", help="fp32 lm_head evaluated as bf16 MFMA GEMMs (pipelinerl_amd.lm_head)")
     ap.add_argument("--fused-head", action="store_true", help="fused head: hidden states -> loss without materialising the logits (pipelinerl_amd.fused_head)")
     ap.add_argument("--no-checkpointing", action="store_true",
                     help="keep every layer's activations instead of recomputing them in the backward (fits the 288 GB of one MI355X for 7B x 8192 tokens)")
@@ -60,10 +59,6 @@ def main():
     model.lm_head = model.lm_head.float()  # fp32 lm_head (reference checkpoints.py:87-103)
     if args.fused_head:
         pass  # the fp32 nn.Linear stays as the parameter holder; its forward is never called
-    elif args.split_head:
-        from pipelinerl_amd.lm_head import SplitBf16LmHead
-
-        model.lm_head = SplitBf16LmHead.from_linear(model.lm_head)  # same fp32 parameter, bf16 MFMA GEMMs
     else:
         model.lm_head.register_forward_pre_hook(lambda m, a: (a[0].float(),))
     if not args.no_checkpointing:
@@ -131,10 +126,10 @@ def main():
     loss_fwd_ms = sum(a.elapsed_time(b) for a, b in timers["pairs"]) / args.steps
     line = json.dumps({
         "what": "end-to-end learner step incl. model fwd/bwd + AdamW (stock PyTorch-ROCm) + HIP loss path",
-        "head": "fused (log-prob / entropy in the GEMM epilogue, hand-written backward; the training forward keeps its fp32 logits for that backward)" if args.fused_head else ("split-bf16 GEMMs" if args.split_head else "fp32 nn.Linear"),
+        "head": "fused (log-prob / entropy in the GEMM epilogue, hand-written backward; the training forward keeps its fp32 logits for that backward)" if args.fused_head else "fp32 nn.Linear",
         "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9,
         "model": f"Qwen2.5-{args.model} shape, random init, {n_params / 1e6:.0f}M params, {args.layers} layers, bf16 + fp32 lm_head"
-                 f"{' on bf16 matrix cores (2-term split)' if args.split_head else ''}, {'activations kept' if args.no_checkpointing else 'grad checkpointing'}, sdpa",
+                 f", {'activations kept' if args.no_checkpointing else 'grad checkpointing'}, sdpa",
         "activation_recompute": not args.no_checkpointing,
         "global_batch": bs, "seq_len": L, "micro_batch": mb, "logits_mode": "fused" if args.fused else "two_pass",
         "samples_per_s": bs / dt, "s_per_step": dt, "tokens_per_s": bs * L / dt,

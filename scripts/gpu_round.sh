@@ -22,7 +22,7 @@ d = json.loads([l for l in open(out + "/bench_full.log") if l.startswith("{")][0
 print({k: d[k] for k in ("value", "ms_per_step")}, "roofline", round(d["roofline"]["frac"], 4))
 m = d["roofline_mfma"]
 print("head fwd ms", round(m["ms_per_launch"], 2), "keeping fwd ms", m.get("forward_keeping_logits", {}).get("ms"), "bwd ms", round(m["backward"]["ms"], 2),
-      "recomputing bwd ms", m.get("backward_recompute", {}).get("ms"), "mixed fwd", m.get("forward_mixed_precision", {}).get("ms"))
+      "recomputing bwd ms", m.get("backward_recompute", {}).get("ms"))
 e = d["e2e"]
 print({k: e.get(k) for k in ("s_per_step", "samples_per_s", "peak_memory_GB", "source", "error")})
 print({k: round(v["avg_us"], 1) for k, v in d["kernels"].items()})
@@ -36,13 +36,11 @@ cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d 
 # the summary for profiles/: names shortened, ALL numeric columns kept (a width cut lost the dominant kernel's numbers in round 3)
 cd $GRAFT_REPO_ROOT; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do python scripts/kernel_stats_summary.py $f $OUT/bench_kernel_stats.csv; head -8 $OUT/bench_kernel_stats.csv; done
 find $OUT/prof -name "*kernel_trace.csv" -delete
-# the other two BASELINE workloads (configs[4]: 32B, KL on; configs[1]: 0.5B) and the head-tile A/B
+# the other two BASELINE workloads (configs[4]: 32B, KL on; configs[1]: 0.5B)
 ( time timeout 600 python bench.py --workload 32b_grpo_kl_bs4096_seq8192 --steps 2 --warmup 1 --no-preprocess-loop --no-transport ) > $OUT/bench_32b.log 2> $OUT/bench_32b.err
 echo "bench 32b exit $?"
 ( time timeout 300 python bench.py --workload 0p5b_grpo_bs512_seq2048 --steps 5 --warmup 2 --no-preprocess-loop --no-transport ) > $OUT/bench_0p5b.log 2> $OUT/bench_0p5b.err
 echo "bench 0p5b exit $?"
-timeout 600 python scripts/lmhead_fwd_tile_ab.py --rounds 3 --iters 4 --tiles default,256x384,256x384:256,256x320 > $OUT/fwd_tile_ab.jsonl 2> $OUT/fwd_tile_ab.err
-timeout 300 python scripts/lmhead_fwd_tile_ab.py --rounds 3 --iters 4 --shapes 7b --keep --tiles default,256x384 >> $OUT/fwd_tile_ab.jsonl 2>> $OUT/fwd_tile_ab.err
 python - "$OUT" <<'PY'
 import json, sys
 out = sys.argv[1]
@@ -55,6 +53,4 @@ for name in ("bench_32b", "bench_0p5b"):
     print(name, round(d["value"], 1), "samples/s roofline", round(d["roofline"]["frac"], 4), "head fwd", m.get("ms_per_launch"), "bwd", (m.get("backward") or {}).get("ms"),
           "ref_logprob", {k: (round(v["old_ms"], 2), round(v["fused_ms"], 2)) for k, v in ((d.get("ref_logprob") or {}).get("heads") or {}).items()},
           "wsync", (d.get("weight_sync") or {}).get("median_ms"), "cpu", (d.get("cpu_baseline") or {}).get("kind"))
-for l in open(f"{out}/fwd_tile_ab.jsonl"):
-    d = json.loads(l); print(d["shape"], d["weight"], "keep" if d["keep_logits"] else "", d["ms"])
 PY

@@ -104,12 +104,4 @@ void lmh_tr_read(const uint8_t* lds, const int* addr, uint16_t* out /* [64][4] *
 int lmh_tr_frag_byte(int lane, int w, int i, int ks, int r) { return tr_frag_lds_byte(lane, w, i, ks, r); }
 int lmh_tr_frag_entry(int lane, int w, int i) { return tr_frag_entry(lane, w, i); }
 int lmh_tr_frag_token0(int lane, int ks, int r) { return tr_frag_token0(lane, ks, r); }
-
-// ---- mixed-precision core: slot order of the fp8 plane and its staged image
-int lmh_mx_byte_in_block(int k) { return mx_byte_in_block(k); }
-int lmh_mx_slot_k(int half, int slot) { return mx_slot_k(half, slot); }
-void lmh_stage_mx8(const uint8_t* src /* [256 rows][32 bytes] */, uint8_t* lds_out) {
-  for (int tid = 0; tid < 512; ++tid) memcpy(lds_out + tid * 16, src + mx8_stage_row(tid) * 32 + 16 * mx8_stage_half(tid), 16);
-}
-int lmh_mx8_frag_byte(int lane, int w, int i) { return mx8_frag_lds_byte(lane, w, i); }
 }

@@ -1,4 +1,4 @@
-"""Fused output head (csrc/prl_lmhead.hip, pipelinerl_amd/fused_head.py): the logits are never
+"""Fused output head (csrc/prl_lmhead_{core.h,fwd.hip,bwd.hip,prepare.hip}, pipelinerl_amd/fused_head.py): the logits are never
 written, so parity is established against the oracle FED WITH the fp64 product hidden @ W^T:
 
     logits64 = hidden.double() @ W.double().T   (torch, on the GPU, fp64)
@@ -89,8 +89,7 @@ def _compare(loss, stats, gh, gw, want, scale=1.0):
 
 
 @pytest.mark.parametrize("keep", [True, False], ids=["kept_logits", "recompute"])
-@pytest.mark.parametrize("tile", ["256x256", "256", "128", "256x384", "256x320"],
-                         ids=["tile256x256", "tile256x128_ring3", "tile128x128", "one_wave_per_simd_256x384", "one_wave_per_simd_256x320"])
+@pytest.mark.parametrize("tile", ["256x256", "256", "128"], ids=["tile256x256", "tile256x128_ring3", "tile128x128"])
 @pytest.mark.parametrize("T,H,V", [(130, 64, 192), (257, 128, 320), (64, 192, 4160), (300, 64, 1088), (900, 128, 1088)])
 def test_small_ragged_shapes(libprl, cuda_device, monkeypatch, tile, T, H, V, keep):
     """Tile edges everywhere: rows not a multiple of 128, a partly masked last vocabulary tile, one K step
@@ -122,8 +121,7 @@ def test_forward_values_and_split_count_independence(libprl, cuda_device, monkey
     w_nlp = lp[torch.arange(T - 1), ids[0, 1:]]
     w_ent = -(lp.exp() * lp).sum(-1)
     head = FusedLmHead(W, backward=False)
-    for tile, ns in (("256x256", "1"), ("256x256", "3"), ("256x256", "64"), ("256", "1"), ("256", "2"), ("256", "7"), ("256", "64"), ("128", "1"), ("128", "5"), ("128", "64"),
-                     ("256x384", "1"), ("256x384", "3"), ("256x384", "64"), ("256x320", "1"), ("256x320", "5")):
+    for tile, ns in (("256x256", "1"), ("256x256", "3"), ("256x256", "64"), ("256", "1"), ("256", "2"), ("256", "7"), ("256", "64"), ("128", "1"), ("128", "5"), ("128", "64")):
         monkeypatch.setenv("PRL_LMHEAD_NSPLIT", ns)
         monkeypatch.setenv("PRL_LMHEAD_TILE", tile)
         nlp, ent, lse2, _ = head.logprob_entropy(hidden, ids, 0.9)
@@ -132,37 +130,32 @@ def test_forward_values_and_split_count_independence(libprl, cuda_device, monkey
         assert torch.allclose(ent[0, 1:].double(), w_ent[:-1], rtol=FP_TOL, atol=2e-5), ns
 
 
-@pytest.mark.parametrize("T,H,V", [(700, 256, 1088), (520, 3584, 2048)])
-def test_schedules_of_the_dual_plane_core_agree_bit_for_bit(libprl, cuda_device, monkeypatch, T, H, V):
-    """The dual-plane forward exists as four instruction streams over the same arithmetic - the default phase-shifted
-    hand-placed stream (barrier in the middle of the step, `gemm_mainloop_dual_ps`), the hand-placed stream with the barrier at
-    the step start (PRL_LMHEAD_EXP=1024), the round-3 schedule with staggered wave roles (512) and the round-2 one (256) -
-    and every MFMA accumulates the same products in the same order: outputs are identical to the bit, kept logits included.
-    (A race or a missed hazard in one of the hand-placed streams shows up here as a difference.)"""
+@pytest.mark.parametrize("T,H,V,wdt", [(700, 256, 1088, torch.float32), (520, 3584, 2048, torch.float32), (520, 896, 2048, torch.bfloat16)])
+def test_hand_placed_streams_are_stable_run_to_run(libprl, cuda_device, monkeypatch, T, H, V, wdt):
+    """The 256 x 256 forwards are hand-placed instruction streams (asm MFMAs the compiler's hazard recogniser does not see, LDS-DMA
+    pieces and fragment reads pinned between them): the dual-plane phase-shifted stream for an fp32 weight, the generic 64-deep
+    stream for a bf16 weight.  A race or a missed hazard in one of them shows up as a run-to-run difference or as a difference to
+    the compiler-scheduled 256 x 128 shape beyond the summation order: outputs are identical to the bit run to run, kept logits
+    included, and agree with the other shape to fp32 rounding."""
     from pipelinerl_amd.fused_head import FusedLmHead
 
-    monkeypatch.setenv("PRL_LMHEAD_TILE", "256x256")
-    hidden, W, batch, _ = _problem(T, H, V, cuda_device, seed=T + H)
+    hidden, W, batch, _ = _problem(T, H, V, cuda_device, weight_dtype=wdt, seed=T + H)
     ids = torch.from_numpy(batch["input_ids"]).to(cuda_device)
     head = FusedLmHead(W, backward=False)
-    monkeypatch.delenv("PRL_LMHEAD_EXP", raising=False)
+    monkeypatch.setenv("PRL_LMHEAD_TILE", "256x256")
     want = [t.clone() for t in head.logprob_entropy(hidden, ids, 0.9, keep=True)]
-    for exp in ("1024", "512", "256"):
-        monkeypatch.setenv("PRL_LMHEAD_EXP", exp)
-        for _ in range(2):
-            got = head.logprob_entropy(hidden, ids, 0.9, keep=True)
-            torch.cuda.synchronize()
-            for a, b in zip(got[:3] + got[4:], want[:3] + want[4:]):
-                assert torch.equal(a, b), exp
-    monkeypatch.delenv("PRL_LMHEAD_EXP", raising=False)
-    for _ in range(3):  # and the default is stable run to run
+    for _ in range(4):
         got = head.logprob_entropy(hidden, ids, 0.9, keep=True)
+        torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(got[:3] + got[4:], want[:3] + want[4:]))
+    monkeypatch.setenv("PRL_LMHEAD_TILE", "256")
+    other = head.logprob_entropy(hidden, ids, 0.9, keep=True)
+    assert torch.allclose(other[4], want[4], rtol=0, atol=1e-4 * float(want[4].abs().max()))
+    assert torch.allclose(other[0], want[0], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("tile", ["256x256", "256", "128", None, "recompute", "256x384", "256x320"],
-                         ids=["tile256x256", "tile256x128_ring3", "tile128x128", "default_dispatch", "default_dispatch_recompute",
-                              "one_wave_per_simd_256x384", "one_wave_per_simd_256x320"])
+@pytest.mark.parametrize("tile", ["256x256", "256", "128", None, "recompute"],
+                         ids=["tile256x256", "tile256x128_ring3", "tile128x128", "default_dispatch", "default_dispatch_recompute"])
 def test_qwen7b_head_shape_vs_oracle(libprl, cuda_device, monkeypatch, tile):
     """H = 3584, V = 152 064, fp32 weight (two bf16 planes): loss, statistics, d hidden, d W."""
     keep = tile != "recompute"  # the default keeps the logits for the backward; "recompute": no logits anywhere
@@ -244,9 +237,8 @@ def test_split_k_hidden_gradient(libprl, cuda_device, monkeypatch, tile, ksplit)
     assert np.array_equal(gh[0].cpu().numpy(), out[ksplit, torch.float32])
 
 
-@pytest.mark.parametrize("T,H,V,wdt,prec", [(300, 128, 4160, torch.float32, "bf16x2"), (257, 64, 1088, torch.bfloat16, "bf16x2"),
-                                             (300, 128, 1088, torch.float32, "f16_fp8")])
-def test_kept_logits_are_the_logits_and_give_the_recomputed_gradients(libprl, cuda_device, T, H, V, wdt, prec):
+@pytest.mark.parametrize("T,H,V,wdt", [(300, 128, 4160, torch.float32), (257, 64, 1088, torch.bfloat16)])
+def test_kept_logits_are_the_logits_and_give_the_recomputed_gradients(libprl, cuda_device, T, H, V, wdt):
     """`logprob_entropy(keep=True)` leaves [T, V] fp32 logits in base-2 units (logit * log2(e) / temperature) next to the same
     three outputs; the backward from them equals the recomputing backward up to one fp32 rounding of the logit (the recompute
     fuses the scale into a multiply-add) - including vocabularies whose last tile is partial and rows without a gradient."""
@@ -258,14 +250,14 @@ def test_kept_logits_are_the_logits_and_give_the_recomputed_gradients(libprl, cu
 
     hidden, W, batch, logits64 = _problem(T, H, V, cuda_device, weight_dtype=wdt, seed=V)
     pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(cuda_device)
-    head = FusedLmHead(W, chunk_rows=128, precision=prec)
+    head = FusedLmHead(W, chunk_rows=128)
     plain = head.logprob_entropy(hidden, pb.input_ids, CFG["temperature"])
     nlp, ent, lse2, h, kept = head.logprob_entropy(hidden, pb.input_ids, CFG["temperature"], keep=True)
     for a, b in zip(plain[:3], (nlp, ent, lse2)):
         assert torch.equal(a, b)
     assert kept.shape == (T, V) and kept.dtype == torch.float32
     want2 = logits64 * (math.log2(math.e) / CFG["temperature"])
-    tol = 2e-5 if prec == "bf16x2" else 2e-4  # of the largest logit: the plane split / the mixed-precision core
+    tol = 2e-5  # of the largest logit: the plane split
     assert float((kept.double() - want2).abs().max()) <= tol * float(want2.abs().max())
     c_cfg, _, _ = make_loss_config(RLConfig(**CFG), 2, 10)
     _, _, g_nlp, g_ent = grpo_loss_from_logprobs(c_cfg, pb, nlp, ent)
@@ -449,138 +441,3 @@ def test_unlabelled_rows_are_skipped_without_changing_the_result(libprl, cuda_de
     assert rel_err(a[3], (dl.t() @ hidden.reshape(-1, H).double()).cpu().numpy()) <= FP_TOL
 
 
-@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16], ids=["fp32_weight_opt_in", "bf16_weight_exact"])
-def test_two_product_hidden_gradient_on_the_dual_plane_core(libprl, cuda_device, wdt):
-    """hidden_grad_terms = 2: (d logits_hi + d logits_lo) x W_hi.  For a bf16 weight that IS d hidden (the default path of a tied
-    head: 1e-4 of the fp64 product, split-K slices of uneven length included); for an fp32 weight it drops the weight's low plane
-    only - a bf16 rounding of each weight, between the full and the leading-term form."""
-    from pipelinerl_amd.finetune.rl import RLConfig, grpo_loss_from_logprobs, make_loss_config
-    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
-    from pipelinerl_amd.fused_head import FusedLmHead
-
-    hidden, W, batch, logits64 = _problem(300, 256, 4160, cuda_device, weight_dtype=wdt, seed=17)
-    want = _oracle(hidden, W, batch, logits64)
-    pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(cuda_device)
-    c_cfg, _, _ = make_loss_config(RLConfig(**CFG), 2, 10)
-    err = {}
-    for terms in (3, 2, 1):
-        head = FusedLmHead(W, hidden_grad_terms=terms)
-        nlp, ent, lse2, h = head.logprob_entropy(hidden, pb.input_ids, CFG["temperature"])
-        _, _, g_nlp, g_ent = grpo_loss_from_logprobs(c_cfg, pb, nlp, ent)
-        gh = head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, grad_hidden_dtype=torch.float32)
-        torch.cuda.synchronize()
-        err[terms] = rel_err(gh[0].cpu().numpy(), want["d_hidden"])
-    assert err[3] <= FP_TOL
-    if wdt == torch.bfloat16:
-        assert err[2] <= FP_TOL  # nothing was dropped: the weight has no low plane
-    else:
-        assert err[3] < err[2] <= 4e-3 and err[2] < err[1], err  # measured 1.4e-5 / 2.1e-3 / 2.8e-3: the weight's low plane is most of it
-    with pytest.raises(ValueError):
-        FusedLmHead(W, hidden_grad_terms=4)
-
-
-def test_weight_gradient_accumulates_or_overwrites(libprl, cuda_device):
-    """`grad_weight` is `+=` by contract (gradient accumulation over micro-batches); PRL_LM_HEAD_DW_OVERWRITE stores
-    instead, into memory that may hold anything - with several row chunks (the later chunks still add)."""
-    from pipelinerl_amd.finetune.rl import RLConfig, grpo_loss_from_logprobs, make_loss_config
-    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
-    from pipelinerl_amd.fused_head import FusedLmHead
-
-    hidden, W, batch, logits64 = _problem(300, 128, 1024, cuda_device, seed=41)
-    want = _oracle(hidden, W, batch, logits64)
-    pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(cuda_device)
-    head = FusedLmHead(W, chunk_rows=128)
-    nlp, ent, lse2, h = head.logprob_entropy(hidden, pb.input_ids, CFG["temperature"])
-    c_cfg, _, _ = make_loss_config(RLConfig(**CFG), 2, 10)
-    _, _, g_nlp, g_ent = grpo_loss_from_logprobs(c_cfg, pb, nlp, ent)
-    gw = torch.full((1024, 128), float("nan"), device=cuda_device)
-    head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, want_hidden=False, grad_weight=gw, overwrite_weight_grad=True)
-    once = gw.clone()
-    assert rel_err(once.cpu().numpy(), want["d_weight"]) <= FP_TOL
-    head.backward_from_token_grads(h, pb.input_ids, CFG["temperature"], lse2, ent, g_nlp, g_ent, None, want_hidden=False, grad_weight=gw)
-    assert rel_err(gw.cpu().numpy(), 2 * want["d_weight"]) <= FP_TOL
-    assert torch.allclose(gw, 2 * once, rtol=1e-5, atol=1e-6 * once.abs().max().item())  # only the fp32 order of the additions differs
-
-
-def test_sentinel_batch_skips_the_head(libprl, cuda_device):
-    """A sentinel batch (every label masked, reference finetune/utils.py:17-78) gives loss 0, the empty-batch
-    statistics and zero gradients for hidden states and weight without running a GEMM - same as `rl_step`."""
-    from pipelinerl_amd import _lib
-    from pipelinerl_amd.finetune.rl import RLConfig, rl_step
-    from pipelinerl_amd.finetune.utils import create_sentinel_batch
-    from pipelinerl_amd.fused_head import FusedLmHead, fused_head_loss
-
-    V, H = 1024, 128
-    torch.manual_seed(1)
-    sb = create_sentinel_batch(cuda_device)
-    T = sb.input_ids.shape[1]
-    hidden = torch.randn(1, T, H, device=cuda_device).to(torch.bfloat16).requires_grad_(True)
-    w = (torch.randn(V, H, device=cuda_device) * 0.1).requires_grad_(True)
-    head = FusedLmHead(w)
-    loss, stats = fused_head_loss(hidden, w, head, sb, RLConfig(**CFG), 2, 10)
-    assert head.w_hi is None  # nothing was prepared, no kernel of the head ran
-    loss.backward()
-    assert loss.item() == 0.0 and stats == {"input_size": float(T)}
-    assert torch.count_nonzero(hidden.grad) == 0 and torch.count_nonzero(w.grad) == 0
-    assert hidden.grad.dtype == torch.bfloat16 and w.grad.shape == w.shape
-
-    class LM(torch.nn.Module):
-        def forward(self, input_ids=None, **kw):
-            import types
-
-            return types.SimpleNamespace(logits=(hidden.float() @ w.t()))
-
-    l2, s2 = rl_step(LM(), sb, 2, 10, RLConfig(**CFG))
-    assert l2.item() == 0.0 and s2 == stats
-
-
-def test_workspace_too_small_and_bad_shapes_are_refused(libprl, cuda_device):
-    from pipelinerl_amd import _lib
-
-    t = torch.zeros(1 << 20, dtype=torch.uint8, device=cuda_device)
-    P = t.data_ptr()
-    s = _lib.current_stream_ptr(cuda_device)
-    assert libprl.prl_lm_head_logprob_fwd(1, 128, 100, 1024, P, P, None, P, 1.0, P, P, P, P, 1 << 20, s) == _lib.PRL_EINVAL  # hidden % 64
-    assert libprl.prl_lm_head_logprob_fwd(1, 4096, 64, 1024, P, P, None, P, 1.0, P, P, P, P, 1024, s) == _lib.PRL_ENOMEM
-    assert libprl.prl_lm_head_logprob_bwd(1, 128, 64, 1000, P, P, None, P, None, P, 1.0, P, P, P, None, None, P, 1, None, 128, 0, P, 1 << 20, s) == _lib.PRL_EINVAL  # vocab % 64
-    fwd, bwd = ctypes.c_size_t(), ctypes.c_size_t()
-    _lib.check(libprl.prl_lm_head_workspace_bytes(1, 8192, 3584, 152064, 2048, ctypes.byref(fwd), ctypes.byref(bwd)))
-    # 2 bf16 planes of 2048 x 152064 (row-major only: d W gathers its fragments with transposing LDS reads; round 2 wrote
-    # four) + the transposed hidden chunk + 8 fp32 split-K slices of the d hidden chunk + the f16 / fp8 copies of the chunk's
-    # hidden states for the mixed-precision recompute
-    # forward: per-split partial softmax states, sized for whichever tile a launch may pick - the one-wave-per-SIMD tiles
-    # (256 x 320: 26 token tiles x 39 vocabulary splits) need the most, 5.3 MB
-    assert fwd.value < 8 << 20 and 1.45e9 < bwd.value < 1.6e9
-
-
-@pytest.mark.parametrize("T,H,V,wdt", [(300, 64, 1088, torch.float32), (257, 128, 320, torch.float32), (300, 128, 1088, torch.bfloat16),
-                                       (1024, 896, 8192, torch.float32)])
-def test_mixed_precision_head_opt_in(libprl, cuda_device, T, H, V, wdt):
-    """`FusedLmHead(precision="f16_fp8")` (opt-in): the weight as an f16 plane + an fp8 residual plane, the 2^-11 cross term
-    on the MX-scaled fp8 MFMA.  Stated accuracy ~1e-5 of the logits' scale - log-probs within 3e-4 absolute of the fp64
-    reference here (the default two-bf16-plane form: 3e-5), loss / d hidden / d W within 3e-4 relative - NOT the 1e-4 bar
-    of the default, which is why it is not the default.  An f16-exact (bf16) weight has no residual plane and is as exact
-    as the default.  The recompute of the backward runs on the same core, so the probabilities are consistent with the
-    saved statistics."""
-    from pipelinerl_amd.finetune.rl import RLConfig
-    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
-    from pipelinerl_amd.fused_head import FusedLmHead, fused_head_loss
-
-    hidden, W, batch, logits64 = _problem(T, H, V, cuda_device, weight_dtype=wdt, seed=T + 1)
-    want = _oracle(hidden, W, batch, logits64)
-    lp = torch.log_softmax(logits64 / CFG["temperature"], -1)
-    ids = torch.from_numpy(batch["input_ids"]).to(cuda_device)
-    want_nlp = lp[torch.arange(T - 1), ids[0, 1:]]
-    head = FusedLmHead(W, precision="f16_fp8")
-    nlp, ent, _, _ = head.logprob_entropy(hidden, ids, CFG["temperature"])
-    tol = 3e-4 if wdt == torch.float32 else 3e-5
-    assert float((nlp[0, 1:].double() - want_nlp).abs().max()) <= tol
-    pb = PipelineBatchEncoding(**{k: torch.from_numpy(v) for k, v in batch.items()}, model_version=0, is_packed=True).to_device(cuda_device)
-    h = hidden.clone().requires_grad_(True)
-    w = W.clone().requires_grad_(True)
-    loss, stats = fused_head_loss(h, w, FusedLmHead(w, precision="f16_fp8"), pb, RLConfig(**CFG), 2, 10)
-    loss.backward()
-    rel = 3e-4 if wdt == torch.float32 else FP_TOL
-    assert abs(loss.item() - float(want["loss"])) <= rel * abs(float(want["loss"]))
-    assert rel_err(w.grad.float().cpu().numpy(), want["d_weight"]) <= (rel if wdt == torch.float32 else 4e-3)
-    assert rel_err(h.grad[0].float().cpu().numpy(), want["d_hidden"]) <= 4e-3  # delivered in bf16

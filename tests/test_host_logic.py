@@ -262,22 +262,6 @@ def test_rlconfig_accepts_the_reference_keys_with_the_reference_defaults():
                                     "fused_head_keep_logits", "fused_head_chunk_rows"}  # MI355X extensions
 
 
-def test_split_bf16_host_formulation():
-    """lm_head.split_bf16 on host tensors (the torch formulation the HIP kernel is checked against):
-    each extra bf16 term removes 8 more bits of the residual."""
-    import torch
-
-    from pipelinerl_amd.lm_head import split_bf16
-
-    torch.manual_seed(0)
-    w = torch.randn(64, 33) * torch.logspace(-2, 2, 33)
-    for terms, bits in ((1, 8), (2, 16), (3, 24)):
-        parts = split_bf16(w, terms)
-        assert len(parts) == terms and all(p.dtype == torch.bfloat16 for p in parts)
-        rebuilt = sum(p.double() for p in parts)
-        assert ((rebuilt - w.double()).abs() <= 2.0 ** -(bits - 1) * w.double().abs() + 1e-30).all()
-
-
 def test_host_stats_with_and_without_a_value_head():
     """`host_stats`: the step's statistics vector -> the reference's dict.  With the value head's five entries appended
     the reported (and asserted) loss is policy + value_loss_coef * value_loss and the five keys close the dict, in the

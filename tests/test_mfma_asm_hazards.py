@@ -1,5 +1,5 @@
-"""The hand-placed MFMA streams of csrc/prl_lmhead.hip are `asm volatile` statements, invisible to hipcc's hazard recogniser.
-`scripts/check_mfma_hazards.py` compiles the file to gfx950 assembly and verifies that no VALU write of an MFMA operand sits
+"""The hand-placed MFMA streams of csrc/prl_lmhead_core.h are `asm volatile` statements, invisible to hipcc's hazard recogniser.
+`scripts/check_mfma_hazards.py` compiles the two translation units that instantiate them to gfx950 assembly and verifies that no VALU write of an MFMA operand sits
 directly in front of an asm MFMA and that nothing touches an asm MFMA's result directly behind it - the two hazards
 `mfma_pin_acc` / `mfma_settle` exist for.  (Found on hardware in round 4: hipcc had sunk the zero fill of one accumulator tile
 right in front of the first MFMA into it; one register of the tile kept its stale contents.)"""
@@ -20,7 +20,7 @@ def _checker():
 def test_no_valu_write_in_front_of_and_no_use_behind_an_asm_mfma():
     chk = _checker()
     text = chk.compile_to_asm()
-    assert text.count(";;#ASMSTART") > 1000  # the streams are there (6 cores x 32-96 MFMAs x their instantiations)
+    assert text.count(";;#ASMSTART") > 300  # the streams are there (4 hand-placed cores x 32-48 MFMAs x their instantiations)
     problems = chk.scan(text)
     assert not problems, "\n".join(problems[:10])
 
