@@ -523,7 +523,7 @@ def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attemp
     out: dict = {"what": f"actor stream -> PreprocessorLoop (chunk_n_groups = 2, packed, seq_length {seq_length}) -> training_data; groups of "
                          f"{attempts} x {seq_length}-token rollouts; wall clock of run() incl. stream read + decode (loader thread)", "cases": {}}
 
-    def one_case(backend: str, binary: bool, trainers: int, n_groups: int, batched: bool):
+    def one_case(backend: str, binary: bool, trainers: int, n_groups: int, batched: bool, overlap: bool = True):
         tmp = tempfile.mkdtemp(prefix="prl_bench_pre_")
         try:
             streams.reset_streams_backend()
@@ -535,7 +535,7 @@ def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attemp
             cfg = PreprocessorConfig(exp_path=Path(tmp), num_trainers=trainers, train_batch_size=1, gradient_accumulation_passes=4096,
                                      seq_length=seq_length, attempts=attempts, rl=rl, eos_token_id=2, chunk_n_groups=2,
                                      pop_old_data=False)  # lossless: with the default the loader DROPS old chunks when the loop is the slower side
-            loop = PreprocessorLoop(cfg, dev, batched_transfers=batched, profile=True)
+            loop = PreprocessorLoop(cfg, dev, batched_transfers=batched, profile=True, overlap_publish=overlap)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             # the packer flushes a micro-batch when the NEXT sample no longer fits (preprocess.py:610-625): the very last
@@ -555,8 +555,10 @@ def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attemp
                    "host_planning_frac": planning / dt,
                    "host_planning_is": "ingest_flatten + k5_plan + k5_launch + schedule + k6_plan_launch (plan AND launch calls; transfers, codec, publish, waiting for input excluded)"}
             if loop.stager is not None:
-                res["transfers_per_chunk"] = {"h2d": loop.stager.uploads / chunks, "d2h": loop.stager.downloads / chunks,
-                                              "h2d_bytes": loop.stager.bytes_up / chunks, "d2h_bytes": loop.stager.bytes_down / chunks}
+                res["transfers_per_chunk"] = {"h2d": loop.stager.uploads / chunks, "d2h": loop.down_stager.downloads / chunks,
+                                              "h2d_bytes": loop.stager.bytes_up / chunks, "d2h_bytes": loop.down_stager.bytes_down / chunks}
+            res["publish"] = ("publisher thread: device -> host copy + framing + append of drain k overlap ingest / K5 / K6 of drain k + 1 "
+                              "(d2h and encode_publish are that thread's time, off the loop's critical path)") if loop.overlap_publish else "inline"
             assert n == target, f"published {n} of {target} samples"
             return res
         finally:
@@ -568,6 +570,7 @@ def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attemp
         one_case("shm", True, 1, min(8, n_fast), True)  # warm-up: library, page-locked ring, the allocator's block cache (several chunks are alive at once)
         out["cases"]["PRLROL01_to_shm_1_trainer"] = one_case("shm", True, 1, n_fast, True)
         out["cases"]["PRLROL01_to_shm_4_trainers"] = one_case("shm", True, 4, n_fast, True)
+        out["cases"]["PRLROL01_to_shm_1_trainer_inline_publish"] = one_case("shm", True, 1, n_fast, True, overlap=False)  # the round-4 loop
         out["cases"]["PRLROL01_to_shm_1_trainer_one_copy_per_array"] = one_case("shm", True, 1, n_fast, False)
         out["cases"]["JSONL_to_files_1_trainer"] = one_case("files", False, 1, n_text, True)
     finally:

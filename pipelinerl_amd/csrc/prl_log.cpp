@@ -157,6 +157,8 @@ struct Prefaulter {
   std::thread* th = nullptr;  // on the heap: a forked child abandons it (the thread does not exist there) instead of destroying it
   pid_t owner = 0;
   bool stop = false, disabled = false;
+  bool busy = false;        // a madvise slice is in flight (the mutex is NOT held during the call)
+  std::condition_variable idle;
   uint8_t* base = nullptr;  // payload start of the segment being written
   uint64_t capacity = 0, want = 0, done = 0, gen = 0;
 
@@ -167,19 +169,34 @@ struct Prefaulter {
       if (stop) return;
       const uint64_t g = gen, from = done, n = (want - done < kSlice) ? want - done : kSlice;
       uint8_t* p = base + from;
+      busy = true;
       lk.unlock();
       // page-align inwards: the first partial page was touched by the header / previous record already
       const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
       const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + n) & ~uintptr_t(4095);
       int rc = 0;
       if (e > a) rc = madvise(reinterpret_cast<void*>(a), e - a, MADV_POPULATE_WRITE);
-      lk.lock();
       const int err = rc != 0 ? errno : 0;
+      lk.lock();
+      busy = false;
+      idle.notify_all();
       // kernel without MADV_POPULATE_WRITE: appends fault their pages themselves.  Only believed while the segment is still the one
       // the call was aimed at: after a switch the old range may be unmapped or belong to someone else, and its errors mean nothing
       if (err == EINVAL && g == gen) disabled = true;
       if (g == gen) done = from + n;  // a segment change in between restarts from its own offset
     }
+  }
+  // called by the appending thread BEFORE it unmaps (or replaces) the segment the helper may be populating: forget the range and
+  // wait for a slice in flight to return.  Without it the madvise of a stale range could land on whatever is mapped at that
+  // address next - another log's tmpfs segment, a fresh anonymous arena - and allocate up to 2 MiB of pages there per slice: no
+  // data is touched, but shm / RSS grow silently (round-4 advisor finding).
+  void quiesce() {
+    if (getpid() != owner) return;
+    std::unique_lock<std::mutex> lk(m);
+    base = nullptr;
+    want = done = 0;
+    ++gen;
+    idle.wait(lk, [&] { return !busy; });
   }
   // called by the appending thread (under the log's writer lock): the segment now being written and how far it is filled
   void target(uint8_t* payload, uint64_t cap, uint64_t committed, bool new_segment) {
@@ -399,6 +416,7 @@ int reserve_record(prl_log* l, uint64_t nbytes, uint8_t** dst, SegHeader** hdr, 
   for (;;) {  // find (or open) the segment this record goes to
     const uint64_t last = c->n_segments.load(std::memory_order_acquire) - 1;
     if (l->wseg_index != last) {
+      if (l->prefault) l->prefault->quiesce();
       rc = open_segment(l->name, last, &l->wseg);
       if (rc != PRL_OK) break;
       l->wseg_index = last;
@@ -412,6 +430,7 @@ int reserve_record(prl_log* l, uint64_t nbytes, uint8_t** dst, SegHeader** hdr, 
       rc = open_segment(l->name, last + 1, &next);
       if (rc != PRL_OK) break;
       c->n_segments.store(last + 2, std::memory_order_release);
+      if (l->prefault) l->prefault->quiesce();
       l->wseg.reset();
       l->wseg = next;
       l->wseg_index = last + 1;
@@ -429,6 +448,7 @@ int reserve_record(prl_log* l, uint64_t nbytes, uint8_t** dst, SegHeader** hdr, 
     if (rc != PRL_OK) break;
     h->sealed.store(1, std::memory_order_release);
     c->n_segments.store(last + 2, std::memory_order_release);
+    if (l->prefault) l->prefault->quiesce();
     l->wseg.reset();
     l->wseg = next;
     l->wseg_index = last + 1;

@@ -366,11 +366,37 @@ def fused_head_loss(hidden: torch.Tensor, weight: torch.Tensor, head: FusedLmHea
 
 
 
+def _logits_postprocessing(model: Any) -> str | None:
+    """Why `model(...).logits` is NOT simply `lm_head(body(...))` for this model, or None when it is.  The fused head computes
+    hidden @ W^T and nothing else: an architecture that post-processes its logits (Gemma-2's `final_logit_softcapping`, Cohere's
+    `logit_scale`, Granite's `logits_scaling`), or whose head is wider than the vocabulary it samples from (a padded head whose
+    extra columns the model's own forward cuts off), would get different log-probabilities - a wrong KL term - without a
+    warning.  Judged from the model's `config`; a model without one is taken at its word."""
+    cfg = getattr(model, "config", None)
+    if cfg is None:
+        return None
+    if getattr(cfg, "final_logit_softcapping", None):
+        return f"config.final_logit_softcapping = {cfg.final_logit_softcapping}"
+    for key in ("logit_scale", "logits_scaling"):
+        v = getattr(cfg, key, None)
+        if v is not None and float(v) != 1.0:
+            return f"config.{key} = {v}"
+    head = getattr(model, "lm_head", None)
+    rows = getattr(head, "out_features", None)
+    vocab = getattr(cfg, "vocab_size", None)
+    if rows is not None and vocab is not None and int(rows) != int(vocab):
+        return f"lm_head has {rows} rows, config.vocab_size is {vocab}"
+    return None
+
+
 def _body_and_head(model: Any):
     body = getattr(model, "model", None)
     lm_head = getattr(model, "lm_head", None)
     if body is None or lm_head is None or getattr(lm_head, "bias", None) is not None:
         raise TypeError("the fused head needs model.model (body) and a bias-free model.lm_head")
+    why = _logits_postprocessing(model)
+    if why is not None:
+        raise TypeError(f"the fused head computes hidden @ W^T only, but this model post-processes its logits ({why}); use rl_step on its .logits")
     return body, lm_head
 
 
@@ -520,11 +546,17 @@ def ref_head_for(ref_model: Any) -> tuple[Any, FusedLmHead] | None:
     """(body, no-grad FusedLmHead) of a frozen causal LM in the Hugging Face layout (`.model` + bias-free `.lm_head`),
     None for anything else (a bare callable that only returns logits).  The head lives on the lm_head module and
     follows its weight like the training head does (`_head_for`); it holds the row-major planes only (`backward=False`:
-    no transposed copies, half the memory of a training head)."""
+    no transposed copies, half the memory of a training head).
+    None as well - i.e. the caller goes through the model's own `.logits` and K1 - for an architecture that post-processes its
+    logits or pads its head (`_logits_postprocessing`).  The hidden states enter the product in bf16 (the head's operand type):
+    exact for a bf16 reference policy, a 2^-9 rounding of each hidden value for an fp32 one, whose old path was an fp32
+    `F.linear`; pass `fused_head=False` to `annotate_ref_logprobs` to keep that."""
     body = getattr(ref_model, "model", None)
     lm_head = getattr(ref_model, "lm_head", None)
     w = getattr(lm_head, "weight", None)
     if body is None or w is None or getattr(lm_head, "bias", None) is not None or not callable(body):
+        return None
+    if _logits_postprocessing(ref_model) is not None:
         return None
     if w.dim() != 2 or w.dtype not in (torch.float32, torch.bfloat16) or not w.is_cuda:
         return None

@@ -480,7 +480,7 @@ class PreprocessorLoop:
     published - trainer_state.samples_processed exceeds max_ready_samples_per_lead * num_trainers."""
 
     def __init__(self, cfg: PreprocessorConfig, device, trainer_state=None, ref_model=None, oov_patcher: OovPatcher | None = None,
-                 batched_transfers: bool = True, profile: bool = False):
+                 batched_transfers: bool = True, profile: bool = False, overlap_publish: bool = True):
         """`ref_model`: a frozen reference policy on the preprocessor's GPU.  When given, every real
         micro-batch gets its `ref_logprobs` from a no-grad forward of that model (hidden states -> MFMA head for a
         model in the Hugging Face layout, K1 on its logits otherwise)
@@ -490,18 +490,31 @@ class PreprocessorLoop:
         through a page-locked ring, `staging.PinnedStager`), the K6 plan in one more, and a drain's packed micro-batches
         come back in ONE device -> host copy before they are encoded into stream records; off = one copy per array
         (the round-3 form, kept for A/B).
+        `overlap_publish` (default, with `batched_transfers` on a GPU): the device -> host copy of a drain's packed block and the
+        framing + append of its records run on a PUBLISHER thread (its own copy stream and its own page-locked ring), in drain
+        order, at most two drains deep - chunk k leaves the device and enters the log while chunk k + 1 is ingested, scanned (K5)
+        and packed (K6).  The reference publishes inline (preprocess.py:356-367, 629-648); what a reader of `training_data` sees
+        is the same record sequence.  Off: publish inline (the round-4 form, kept for A/B).
         `profile`: accumulate host wall time per phase in `self.prof` (seconds; `perf_counter` pairs, no device sync)."""
         from .streams import SingleStreamSpec, StreamRangeSpec
 
         self.cfg = cfg
         self.device = device
-        self.stager = None
+        self.stager = self.down_stager = None
         if batched_transfers and torch.device(device).type == "cuda":
             from .staging import PinnedStager
 
             self.stager = PinnedStager(device, slots=4)
+            # downloads (packed blocks on their way to the log) never share a slot with uploads: a host view of a published
+            # drain stays valid however many chunks are ingested meanwhile
+            self.down_stager = PinnedStager(device, slots=2)
         self.prof: dict[str, float] | None = {} if profile else None
         self._kernel_events: list = []
+        self.overlap_publish = bool(overlap_publish) and self.stager is not None
+        self._pub_queue = None
+        self._pub_thread = None
+        self._pub_error: list = []
+        self._pub_stager = None
         # profiling only: (seconds since run() started, raw chunks waiting, samples in the ring, samples published but not yet trained on)
         self.gauges: list[tuple[float, int, int, int]] = []
         self.backpressure_waits = 0
@@ -651,13 +664,45 @@ class PreprocessorLoop:
                         t0_, t1_ = int(packed.token_off[k]), int(packed.token_off[k + 1])
                         packed.flat["ref_logprobs"][t0_:t1_].copy_(b.ref_logprobs.reshape(-1))
                     t = self._tick("ref_logprobs", t)
-                if self.stager is not None and packed.block is not None:
-                    packed = packed.to_host(self.stager)  # ONE device -> host copy for every micro-batch of this drain
-                    t = self._tick("d2h", t)
+        job = {"mbs": mbs, "packed": packed, "merged": merged, "base": base, "max_model_version": self.max_model_version, "ready": None}
+        if self.overlap_publish and self._pub_queue is not None and self.cfg.seq_packing:
+            if packed is not None and packed.block is not None:
+                ev = torch.cuda.Event()
+                ev.record()  # K6 (and the reference-policy annotation) of this drain are complete once this event has fired
+                job["ready"] = ev
+            t0 = time.perf_counter()
+            self._pub_queue.put(job)  # blocks while two drains are already waiting: the publisher is the slower side then
+            t = self._tick("publish_queue_wait", t0)
+        else:
+            self._write_out(writer, job, self.down_stager)
+            t = time.perf_counter()
+        self._prune_chunks()
+        self._tick("schedule", t)
+        return done
+
+    def _write_out(self, writer, job: dict, stager, stream=None) -> None:
+        """Second half of a drain: the packed block leaves the device in ONE copy, every micro-batch (and sentinel) is framed
+        and appended to its trainer's partition, in the scheduler's order.  Runs inline or on the publisher thread."""
+        from .finetune.data import pad_prepared
+        from .finetune.utils import create_sentinel_batch
+
+        sp = self.cfg.seq_parallel
+        packed, merged, base = job["packed"], job["merged"], job["base"]
+        t = time.perf_counter()
+        if packed is not None and stager is not None and packed.block is not None:
+            if stream is not None:  # publisher thread: its own copy stream, ordered behind the drain's kernels
+                with torch.cuda.stream(stream):
+                    if job["ready"] is not None:
+                        stream.wait_event(job["ready"])
+                    packed.block.record_stream(stream)
+                    packed = packed.to_host(stager)
+            else:
+                packed = packed.to_host(stager)  # ONE device -> host copy for every micro-batch of this drain
+            t = self._tick("d2h", t)
         k = 0
-        for mb in mbs:
+        for mb in job["mbs"]:
             if mb.sentinel:
-                batch = create_sentinel_batch(None, tokenizer=type("T", (), {"eos_token_id": self.cfg.eos_token_id})(), model_version=self.max_model_version)
+                batch = create_sentinel_batch(None, tokenizer=type("T", (), {"eos_token_id": self.cfg.eos_token_id})(), model_version=job["max_model_version"])
             elif self.cfg.seq_packing:
                 batch = packed[k]
                 k += 1
@@ -670,10 +715,44 @@ class PreprocessorLoop:
             slices = batch.make_slices(sp) if sp > 1 else [batch]
             for off, piece in enumerate(slices):
                 writer.write(piece, partition=mb.trainer_id + off)
-        t = self._tick("encode_publish", t)
-        self._prune_chunks()
-        self._tick("schedule", t)
-        return done
+        self._tick("encode_publish", t)
+
+    def _publisher(self, writer) -> None:
+        """Publisher thread: drains leave the device and enter the log in the order the scheduler emitted them."""
+        try:
+            dev = torch.device(self.device)
+            torch.cuda.set_device(dev)
+            self._pub_stager = self.down_stager
+            stream = torch.cuda.Stream(dev)
+            while True:
+                job = self._pub_queue.get()
+                if job is None:
+                    return
+                self._write_out(writer, job, self._pub_stager, stream)
+                self._pub_queue.task_done()
+        except BaseException as e:  # noqa: BLE001 - surfaced by the main loop
+            self._pub_error.append(e)
+            while True:  # keep the main loop from blocking on a full queue
+                if self._pub_queue.get() is None:
+                    return
+                self._pub_queue.task_done()
+
+    def _start_publisher(self, writer) -> None:
+        import queue
+        import threading
+
+        self._pub_queue = queue.Queue(maxsize=2)
+        self._pub_thread = threading.Thread(target=self._publisher, args=(writer,), name="preprocessor-publisher", daemon=True)
+        self._pub_thread.start()
+
+    def _stop_publisher(self) -> None:
+        """Everything handed to the publisher is in the log when this returns; its error, if any, is raised here."""
+        if self._pub_thread is not None:
+            self._pub_queue.put(None)
+            self._pub_thread.join()
+            self._pub_thread = self._pub_queue = None
+        if self._pub_error:
+            raise self._pub_error.pop(0)
 
     def _prune_chunks(self) -> None:
         """Release the device-resident chunks whose samples have all been scheduled or dropped.  Called after every
@@ -707,44 +786,56 @@ class PreprocessorLoop:
         self.loader = ChunkLoader(raw_q, self.in_spec, cfg.attempts, cfg.chunk_n_groups, cfg.drops_old_data)
         threading.Thread(target=self.loader.run, name="preprocessor-loader", daemon=True).start()
         start = self.sched.published_samples
-        last_data = time.time()
-        ts = self.trainer_state
         self._t_run = time.perf_counter()
         with write_to_streams(self.out_spec) as writer, write_to_streams(self.stats_spec) as stats_writer:
-            while max_published_samples is None or self.sched.published_samples - start < max_published_samples:
-                if cfg.samples_target is not None and ts is not None and ts.samples_processed is not None and ts.samples_processed >= cfg.samples_target:
-                    logger.info("Trainer signalled completion; stopping preprocessor loop")
-                    break
-                self._gauge(raw_q.qsize())
-                t = time.perf_counter()
-                try:
-                    chunk = raw_q.get(timeout=0.01)
-                    t = self._tick("input_wait", t)
-                    if isinstance(chunk, Exception):
-                        raise chunk
-                    self._ingest(chunk)
-                    last_data = time.time()
-                except queue.Empty:
-                    self._tick("input_wait", t)
-                    if time.time() - last_data > idle_timeout and not self.ring.entries and not self.buffer:
-                        break
-                if len(self.buffer) < cfg.dataset_buffer_size:
-                    continue
-                t = time.perf_counter()
-                self.ring.admit(self.buffer)
-                self._prune_chunks()
-                self._tick("schedule", t)
-                if ts is not None and ts.samples_processed is not None:
-                    if self.sched.published_samples - ts.samples_processed > cfg.max_ready_samples_per_lead * cfg.num_trainers:
-                        self.backpressure_waits += 1
-                        continue  # wait for the finetune loop to catch up
-                batch_done = False
-                while self.ring.entries and not batch_done:
-                    before = self.sched.published_samples
-                    batch_done = self._publish(writer)
-                    if self.sched.published_samples == before and not batch_done:
-                        break
-                    if max_published_samples is not None and self.sched.published_samples - start >= max_published_samples:
-                        break
-                self._maybe_write_stats(stats_writer, batch_done, raw_q.qsize())
+            if self.overlap_publish and cfg.seq_packing:
+                self._start_publisher(writer)
+            try:
+                self._run_loop(raw_q, writer, stats_writer, start, max_published_samples, idle_timeout)
+            finally:
+                self._stop_publisher()  # every drain handed over is in the log before the writers close
         return self.sched.published_samples - start
+
+    def _run_loop(self, raw_q, writer, stats_writer, start: int, max_published_samples: int | None, idle_timeout: float) -> None:
+        import queue
+
+        cfg, ts = self.cfg, self.trainer_state
+        last_data = time.time()
+        while max_published_samples is None or self.sched.published_samples - start < max_published_samples:
+            if self._pub_error:
+                break
+            if cfg.samples_target is not None and ts is not None and ts.samples_processed is not None and ts.samples_processed >= cfg.samples_target:
+                logger.info("Trainer signalled completion; stopping preprocessor loop")
+                break
+            self._gauge(raw_q.qsize())
+            t = time.perf_counter()
+            try:
+                chunk = raw_q.get(timeout=0.01)
+                t = self._tick("input_wait", t)
+                if isinstance(chunk, Exception):
+                    raise chunk
+                self._ingest(chunk)
+                last_data = time.time()
+            except queue.Empty:
+                self._tick("input_wait", t)
+                if time.time() - last_data > idle_timeout and not self.ring.entries and not self.buffer:
+                    break
+            if len(self.buffer) < cfg.dataset_buffer_size:
+                continue
+            t = time.perf_counter()
+            self.ring.admit(self.buffer)
+            self._prune_chunks()
+            self._tick("schedule", t)
+            if ts is not None and ts.samples_processed is not None:
+                if self.sched.published_samples - ts.samples_processed > cfg.max_ready_samples_per_lead * cfg.num_trainers:
+                    self.backpressure_waits += 1
+                    continue  # wait for the finetune loop to catch up
+            batch_done = False
+            while self.ring.entries and not batch_done:
+                before = self.sched.published_samples
+                batch_done = self._publish(writer)
+                if self.sched.published_samples == before and not batch_done:
+                    break
+                if max_published_samples is not None and self.sched.published_samples - start >= max_published_samples:
+                    break
+            self._maybe_write_stats(stats_writer, batch_done, raw_q.qsize())

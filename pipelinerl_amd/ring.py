@@ -166,7 +166,10 @@ class Log:
         sidecar, and only if, under that lock, the object is STILL the one this waiter timed (same inode) and STILL answers
         "being created".  Without the re-check a waiter whose timer expires a moment after another one already replaced
         the object would unlink the live replacement (round-3 advisor finding), and its creator would write into an
-        orphan.  Returns True when this call removed it."""
+        orphan.  The sidecar is NEVER unlinked here: a waiter blocked in flock holds the old inode, a newcomer after an unlink
+        would lock a fresh file, and the two would be in the critical section together (round-4 advisor finding) - it is a
+        zero-byte file that `streams.clean_shm_streams` / `begin_run` remove with the experiment's other shm objects (same
+        name prefix).  Returns True when this call removed the control block."""
         import fcntl
 
         lock_path = "/dev/shm/" + name.lstrip("/") + ".takeover"
@@ -188,11 +191,7 @@ class Log:
             lib.prl_log_unlink(name.encode())
             return True
         finally:
-            try:
-                os.unlink(lock_path)
-            except OSError:
-                pass
-            os.close(fd)
+            os.close(fd)  # releases the flock; the sidecar stays (see above)
 
     def append(self, data: bytes | bytearray | memoryview) -> None:
         if isinstance(data, bytes):

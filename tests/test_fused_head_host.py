@@ -77,3 +77,22 @@ def test_no_cpu_fallback():
         FusedLmHead(torch.zeros(4))
     with pytest.raises(TypeError):
         FusedLmHead(torch.zeros(4, 4, dtype=torch.float16))
+
+
+@pytest.mark.parametrize("config,reason", [({"final_logit_softcapping": 30.0}, "softcapping"), ({"logit_scale": 0.0625}, "logit_scale"),
+                                           ({"logits_scaling": 8.0}, "logits_scaling"), ({"vocab_size": V - 8}, "rows")])
+def test_models_that_postprocess_their_logits_are_not_given_the_fused_head(config, reason):
+    """hidden @ W^T is not the model's `.logits` for an architecture with soft-capping, a logit scale or a padded head: the training
+    path refuses (TypeError naming the attribute), the reference-policy path quietly keeps using the model's own logits."""
+    from pipelinerl_amd.fused_head import _logits_postprocessing, ref_head_for
+
+    lm = _LM()
+    lm.config = types.SimpleNamespace(vocab_size=V, **config) if "vocab_size" not in config else types.SimpleNamespace(**config)
+    assert reason in _logits_postprocessing(lm)
+    with pytest.raises(TypeError, match="post-processes its logits"):
+        install_fused_head(lm)
+    assert ref_head_for(lm) is None
+    # the neutral values of the same attributes are fine
+    ok = _LM()
+    ok.config = types.SimpleNamespace(vocab_size=V, final_logit_softcapping=None, logit_scale=1.0)
+    assert _logits_postprocessing(ok) is None and install_fused_head(ok) is ok
