@@ -557,8 +557,12 @@ def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attemp
             if loop.stager is not None:
                 res["transfers_per_chunk"] = {"h2d": loop.stager.uploads / chunks, "d2h": loop.down_stager.downloads / chunks,
                                               "h2d_bytes": loop.stager.bytes_up / chunks, "d2h_bytes": loop.down_stager.bytes_down / chunks}
-            res["publish"] = ("publisher thread: device -> host copy + framing + append of drain k overlap ingest / K5 / K6 of drain k + 1 "
-                              "(d2h and encode_publish are that thread's time, off the loop's critical path)") if loop.overlap_publish else "inline"
+            if loop.publisher_ns[0]:
+                res["publish"] = ("native publisher thread (csrc/prl_publish.cpp): device -> host copy + gathering of drain k's records into the logs overlap ingest / "
+                                  "K5 / K6 of drain k + 1; the loop itself only builds headers and a piece table (publish_submit)")
+                res["publisher_us_per_chunk"] = {"busy": 1e-3 * loop.publisher_ns[0] / chunks, "d2h": 1e-3 * loop.publisher_ns[1] / chunks}
+            else:
+                res["publish"] = "inline (device -> host copy, framing and append inside the loop: d2h + encode_publish)"
             assert n == target, f"published {n} of {target} samples"
             return res
         finally:

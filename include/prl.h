@@ -39,6 +39,7 @@
  *                                 pipelinerl/finetune/checkpoints.py:87-103 (fp32 head)
  *   prl_ring_*                    pipelinerl/shared_memory_array.py:9-196
  *   prl_log_*                     pipelinerl/streams.py:120-192, 249-346
+ *   prl_publisher_*               pipelinerl/preprocess.py:356-367, 629-648
  *   prl_wsync_* / prl_ipc_* /
  *   prl_bucket_*                  pipelinerl/finetune_loop.py:205-292,
  *                                 pipelinerl/vllm1.py:62-134,
@@ -486,6 +487,43 @@ int prl_log_stats(prl_log* l, uint64_t* n_records, uint64_t* n_bytes,
                   uint64_t* first_segment, uint64_t* n_segments);
 int prl_log_close(prl_log* l);
 int prl_log_unlink(const char* name); /* remove the control block and every segment */
+
+/*
+ * Publisher: the last leg of the preprocessing loop - `write_micro_batch_slices` at pipelinerl/preprocess.py:356-367, called
+ * inline from the loop at :629-648 - on a native worker thread.  A JOB is one drain of the scheduler: the packed block the
+ * pack kernel wrote (device memory, nullable), the event that certifies it (hipEvent_t, nullable), and the records to append,
+ * in order, each to the log of its trainer partition.  A record is gathered from PIECES: ranges of the block once it has been
+ * copied to page-locked host memory (PRL_PUB_FROM_BLOCK, `src` = byte offset into the block) and ranges of the job's inline
+ * bytes (PRL_PUB_INLINE: record headers, sentinel batches; copied at submit, the caller may free them at once).  submit
+ * returns a ticket and blocks only while two jobs are pending; the caller must keep `dev_block` and `ready_event` alive until
+ * prl_publisher_completed reports the ticket.  Records reach the logs in submit order.  An error of the worker (HIP, a log
+ * append) is sticky: every later call returns it.
+ */
+typedef struct prl_publisher prl_publisher;
+#define PRL_PUB_FROM_BLOCK 0
+#define PRL_PUB_INLINE 1
+typedef struct prl_pub_piece {
+  uint64_t src;    /* byte offset into the staged block / the inline bytes */
+  uint64_t offset; /* byte offset inside the record (ascending, non-overlapping, as for prl_log_appendv) */
+  uint64_t nbytes;
+  uint32_t kind;   /* PRL_PUB_FROM_BLOCK | PRL_PUB_INLINE */
+  uint32_t _pad;
+} prl_pub_piece;
+typedef struct prl_pub_record {
+  void* log;            /* prl_log* of the partition (a writer handle no other thread appends to meanwhile) */
+  uint64_t nbytes;      /* record size */
+  uint32_t first_piece; /* index into the job's piece table */
+  uint32_t n_pieces;
+} prl_pub_record;
+int prl_publisher_create(int32_t device, prl_publisher** out);
+int prl_publisher_submit(prl_publisher* p, const void* dev_block, uint64_t block_bytes, void* ready_event,
+                         const prl_pub_record* recs, int32_t n_recs, const prl_pub_piece* pieces,
+                         int32_t n_pieces, const void* inline_bytes, uint64_t inline_nbytes,
+                         uint64_t* ticket);
+int prl_publisher_completed(prl_publisher* p, uint64_t* ticket); /* highest ticket whose records are in the logs */
+int prl_publisher_wait(prl_publisher* p, uint64_t ticket, int64_t timeout_ms); /* < 0: block; PRL_ETIMEDOUT */
+int prl_publisher_stats(prl_publisher* p, uint64_t* busy_ns, uint64_t* copy_ns); /* worker time: whole jobs / their device -> host copies */
+int prl_publisher_destroy(prl_publisher* p); /* finishes what was submitted, then joins the worker */
 
 /* ------------------------------------------------------------------------- */
 /* Weight sync: trainer -> inference workers over RCCL / xGMI                */

@@ -83,6 +83,18 @@ class PrlLogIov(ctypes.Structure):
     _fields_ = [("ptr", ctypes.c_void_p), ("offset", ctypes.c_uint64), ("nbytes", ctypes.c_uint64)]
 
 
+class PrlPubPiece(ctypes.Structure):
+    """`prl_pub_piece` of include/prl.h."""
+
+    _fields_ = [("src", ctypes.c_uint64), ("offset", ctypes.c_uint64), ("nbytes", ctypes.c_uint64), ("kind", ctypes.c_uint32), ("_pad", ctypes.c_uint32)]
+
+
+class PrlPubRecord(ctypes.Structure):
+    """`prl_pub_record` of include/prl.h."""
+
+    _fields_ = [("log", ctypes.c_void_p), ("nbytes", ctypes.c_uint64), ("first_piece", ctypes.c_uint32), ("n_pieces", ctypes.c_uint32)]
+
+
 class PrlLossConfig(ctypes.Structure):
     """Mirror of `struct prl_loss_config` (include/prl.h)."""
 
@@ -157,6 +169,12 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_ring_unlink": (c_int32, [c_char_p]),
     "prl_log_open": (c_int32, [c_char_p, c_uint64, c_int32, POINTER(c_void_p)]),
     "prl_log_append": (c_int32, [c_void_p, c_void_p, c_uint64]),
+    "prl_publisher_create": (c_int32, [c_int32, POINTER(c_void_p)]),
+    "prl_publisher_submit": (c_int32, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_uint64, POINTER(c_uint64)]),
+    "prl_publisher_completed": (c_int32, [c_void_p, POINTER(c_uint64)]),
+    "prl_publisher_wait": (c_int32, [c_void_p, c_uint64, c_int64]),
+    "prl_publisher_stats": (c_int32, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
+    "prl_publisher_destroy": (c_int32, [c_void_p]),
     "prl_log_appendv": (c_int32, [c_void_p, c_void_p, c_int32, c_uint64]),
     "prl_log_read": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_uint64), c_int64]),
     "prl_log_stats": (c_int32, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),

@@ -105,6 +105,47 @@ def append_framed(log, magic: bytes, scalars: dict, named_tensors) -> int:
     return base + offset
 
 
+def describe_batch(batch: PipelineBatchEncoding, block_ptr: int, block_nbytes: int, inline: bytearray):
+    """The record `append_batch` would write, as a recipe for the native publisher (csrc/prl_publish.cpp): returns
+    (record size, [(kind, src, offset in the record, nbytes)]) with kind 0 = a range of the packed block at `block_ptr` (device
+    memory now, page-locked host memory by the time the publisher gathers the record), kind 1 = a range of `inline`, to which
+    the record's header and its host-resident tensors (seq_boundaries, a sentinel batch) are appended here.  Same framing and
+    byte layout as `_frame` / `append_framed`: a reader cannot tell which path wrote a record."""
+    scalars = {"model_version": batch.model_version, "sentinel": batch.sentinel, "padding": batch.padding, "is_packed": batch.is_packed}
+    layout, offset = [], 0
+    for name, t in batch.tensors():
+        t = t.detach()
+        dt = str(t.dtype).replace("torch.", "")
+        if dt not in _TORCH:
+            raise TypeError(f"stream record field {name!r} has dtype {t.dtype}; the binary record carries {sorted(_TORCH)}")
+        if not t.is_contiguous():
+            raise ValueError(f"stream record field {name!r} is not contiguous")
+        offset += (-offset) % _ALIGN
+        nbytes = t.numel() * t.element_size()
+        layout.append((name, dt, t, offset, nbytes))
+        offset += nbytes
+    header = json.dumps({"scalars": scalars, "tensors": [[name, dt, list(t.shape), off, nb] for name, dt, t, off, nb in layout]}).encode("utf-8")
+    pieces = []
+    at = len(inline)
+    inline += MAGIC_BATCH + struct.pack("<I", len(header)) + header
+    head_len = 12 + len(header)
+    pieces.append((1, at, 0, head_len))
+    base = head_len + (-head_len) % _ALIGN
+    for name, _, t, off, nb in layout:
+        if not nb:
+            continue
+        if t.device.type == "cpu":
+            at = len(inline)
+            inline += t.reshape(-1).view(torch.uint8).numpy().tobytes()
+            pieces.append((1, at, base + off, nb))
+        else:
+            src = t.data_ptr() - block_ptr
+            if src < 0 or src + nb > block_nbytes:
+                raise ValueError(f"stream record field {name!r} does not live in the packed block")
+            pieces.append((0, src, base + off, nb))
+    return base + offset, pieces
+
+
 def append_batch(log, batch: PipelineBatchEncoding) -> int:
     scalars = {"model_version": batch.model_version, "sentinel": batch.sentinel, "padding": batch.padding, "is_packed": batch.is_packed}
     return append_framed(log, MAGIC_BATCH, scalars, list(batch.tensors()))

@@ -33,6 +33,7 @@ SOURCES = [
     "prl_api.cpp",
     "prl_ring.cpp",
     "prl_log.cpp",
+    "prl_publish.cpp",
     "prl_wsync.cpp",
     "prl_ipc.cpp",
     "prl_loss.hip",

@@ -490,11 +490,12 @@ class PreprocessorLoop:
         through a page-locked ring, `staging.PinnedStager`), the K6 plan in one more, and a drain's packed micro-batches
         come back in ONE device -> host copy before they are encoded into stream records; off = one copy per array
         (the round-3 form, kept for A/B).
-        `overlap_publish` (default, with `batched_transfers` on a GPU): the device -> host copy of a drain's packed block and the
-        framing + append of its records run on a PUBLISHER thread (its own copy stream and its own page-locked ring), in drain
-        order, at most two drains deep - chunk k leaves the device and enters the log while chunk k + 1 is ingested, scanned (K5)
-        and packed (K6).  The reference publishes inline (preprocess.py:356-367, 629-648); what a reader of `training_data` sees
-        is the same record sequence.  Off: publish inline (the round-4 form, kept for A/B).
+        `overlap_publish` (default; shm backend, packed mode, on a GPU): the device -> host copy of a drain's packed block and the
+        gathering of its records into the trainers' logs run on the NATIVE publisher thread of libprl (csrc/prl_publish.cpp: its
+        own copy stream and page-locked double buffer), in drain order, at most two drains deep - chunk k leaves the device and
+        enters the log while chunk k + 1 is ingested, scanned (K5) and packed (K6).  The reference publishes inline
+        (preprocess.py:356-367, 629-648); what a reader of `training_data` sees is the same record sequence, byte for byte.
+        Off, another backend, a JSONL mirror, unpacked mode: publish inline.
         `profile`: accumulate host wall time per phase in `self.prof` (seconds; `perf_counter` pairs, no device sync)."""
         from .streams import SingleStreamSpec, StreamRangeSpec
 
@@ -511,10 +512,10 @@ class PreprocessorLoop:
         self.prof: dict[str, float] | None = {} if profile else None
         self._kernel_events: list = []
         self.overlap_publish = bool(overlap_publish) and self.stager is not None
-        self._pub_queue = None
-        self._pub_thread = None
-        self._pub_error: list = []
-        self._pub_stager = None
+        self._pub = None                      # prl_publisher handle while run() is active and the writer allows it
+        self._pub_logs: list = []             # per partition: the prl_log handle the publisher appends to
+        self._pub_inflight: deque = deque()   # (ticket, what must stay alive until that job is in the logs)
+        self.publisher_ns = (0, 0)            # worker time of the last run: (whole jobs, their device -> host copies)
         # profiling only: (seconds since run() started, raw chunks waiting, samples in the ring, samples published but not yet trained on)
         self.gauges: list[tuple[float, int, int, int]] = []
         self.backpressure_waits = 0
@@ -664,15 +665,10 @@ class PreprocessorLoop:
                         t0_, t1_ = int(packed.token_off[k]), int(packed.token_off[k + 1])
                         packed.flat["ref_logprobs"][t0_:t1_].copy_(b.ref_logprobs.reshape(-1))
                     t = self._tick("ref_logprobs", t)
-        job = {"mbs": mbs, "packed": packed, "merged": merged, "base": base, "max_model_version": self.max_model_version, "ready": None}
-        if self.overlap_publish and self._pub_queue is not None and self.cfg.seq_packing:
-            if packed is not None and packed.block is not None:
-                ev = torch.cuda.Event()
-                ev.record()  # K6 (and the reference-policy annotation) of this drain are complete once this event has fired
-                job["ready"] = ev
-            t0 = time.perf_counter()
-            self._pub_queue.put(job)  # blocks while two drains are already waiting: the publisher is the slower side then
-            t = self._tick("publish_queue_wait", t0)
+        job = {"mbs": mbs, "packed": packed, "merged": merged, "base": base, "max_model_version": self.max_model_version}
+        if self._pub is not None:
+            self._submit(job)
+            t = self._tick("publish_submit", t)
         else:
             self._write_out(writer, job, self.down_stager)
             t = time.perf_counter()
@@ -680,25 +676,13 @@ class PreprocessorLoop:
         self._tick("schedule", t)
         return done
 
-    def _write_out(self, writer, job: dict, stager, stream=None) -> None:
-        """Second half of a drain: the packed block leaves the device in ONE copy, every micro-batch (and sentinel) is framed
-        and appended to its trainer's partition, in the scheduler's order.  Runs inline or on the publisher thread."""
+    def _batches_of(self, job: dict, packed):
+        """(trainer partition, batch) of a drain in the scheduler's order, sequence-parallel slices side by side."""
         from .finetune.data import pad_prepared
         from .finetune.utils import create_sentinel_batch
 
         sp = self.cfg.seq_parallel
-        packed, merged, base = job["packed"], job["merged"], job["base"]
-        t = time.perf_counter()
-        if packed is not None and stager is not None and packed.block is not None:
-            if stream is not None:  # publisher thread: its own copy stream, ordered behind the drain's kernels
-                with torch.cuda.stream(stream):
-                    if job["ready"] is not None:
-                        stream.wait_event(job["ready"])
-                    packed.block.record_stream(stream)
-                    packed = packed.to_host(stager)
-            else:
-                packed = packed.to_host(stager)  # ONE device -> host copy for every micro-batch of this drain
-            t = self._tick("d2h", t)
+        merged, base = job["merged"], job["base"]
         k = 0
         for mb in job["mbs"]:
             if mb.sentinel:
@@ -714,45 +698,88 @@ class PreprocessorLoop:
                     annotate_ref_logprobs(self.ref_model, batch, self.cfg.rl.temperature)
             slices = batch.make_slices(sp) if sp > 1 else [batch]
             for off, piece in enumerate(slices):
-                writer.write(piece, partition=mb.trainer_id + off)
+                yield mb.trainer_id + off, piece
+
+    def _write_out(self, writer, job: dict, stager) -> None:
+        """Inline second half of a drain: the packed block leaves the device in ONE copy, every micro-batch (and sentinel) is
+        framed and appended to its trainer's partition, in the scheduler's order."""
+        packed = job["packed"]
+        t = time.perf_counter()
+        if packed is not None and stager is not None and packed.block is not None:
+            packed = packed.to_host(stager)  # ONE device -> host copy for every micro-batch of this drain
+            t = self._tick("d2h", t)
+        for partition, piece in self._batches_of(job, packed):
+            writer.write(piece, partition=partition)
         self._tick("encode_publish", t)
 
-    def _publisher(self, writer) -> None:
-        """Publisher thread: drains leave the device and enter the log in the order the scheduler emitted them."""
-        try:
-            dev = torch.device(self.device)
-            torch.cuda.set_device(dev)
-            self._pub_stager = self.down_stager
-            stream = torch.cuda.Stream(dev)
-            while True:
-                job = self._pub_queue.get()
-                if job is None:
-                    return
-                self._write_out(writer, job, self._pub_stager, stream)
-                self._pub_queue.task_done()
-        except BaseException as e:  # noqa: BLE001 - surfaced by the main loop
-            self._pub_error.append(e)
-            while True:  # keep the main loop from blocking on a full queue
-                if self._pub_queue.get() is None:
-                    return
-                self._pub_queue.task_done()
+    def _submit(self, job: dict) -> None:
+        """Hand a drain to the native publisher: record headers and the piece table are built here (host arithmetic only), the
+        device -> host copy and the gathering into the logs happen on its thread."""
+        import ctypes
+
+        from . import _lib, batch_codec
+
+        lib = _lib.load()
+        packed = job["packed"]
+        block = packed.block if packed is not None else None
+        block_ptr, block_nbytes = (block.data_ptr(), block.numel()) if block is not None else (0, 0)
+        inline = bytearray()
+        recs, pieces = [], []
+        for partition, piece in self._batches_of(job, packed):
+            nbytes, ps = batch_codec.describe_batch(piece, block_ptr, block_nbytes, inline)
+            recs.append((self._pub_logs[partition], nbytes, len(pieces), len(ps)))
+            pieces += ps
+        rec_arr = (_lib.PrlPubRecord * len(recs))(*recs)
+        piece_arr = (_lib.PrlPubPiece * len(pieces))(*[(src, off, nb, kind, 0) for kind, src, off, nb in pieces])
+        ready = None
+        if block is not None:
+            ready = torch.cuda.Event()
+            ready.record()  # K6 (and the reference-policy annotation) of this drain are complete once this event has fired
+        inline_c = (ctypes.c_char * len(inline)).from_buffer(inline) if inline else None
+        ticket = ctypes.c_uint64()
+        _lib.check(lib.prl_publisher_submit(self._pub, block_ptr or None, block_nbytes, ready.cuda_event if ready is not None else None, rec_arr, len(recs),
+                                            piece_arr, len(pieces), inline_c, len(inline), ctypes.byref(ticket)))
+        self._pub_inflight.append((ticket.value, block, ready))
+        done = ctypes.c_uint64()
+        _lib.check(lib.prl_publisher_completed(self._pub, ctypes.byref(done)))
+        while self._pub_inflight and self._pub_inflight[0][0] <= done.value:
+            self._pub_inflight.popleft()  # its block goes back to the allocator
 
     def _start_publisher(self, writer) -> None:
-        import queue
-        import threading
+        """The native publisher appends through the partition writers' own log handles; anything it cannot serve - another
+        backend, a JSONL mirror that wants every record as text too - keeps the inline path."""
+        import ctypes
 
-        self._pub_queue = queue.Queue(maxsize=2)
-        self._pub_thread = threading.Thread(target=self._publisher, args=(writer,), name="preprocessor-publisher", daemon=True)
-        self._pub_thread.start()
+        from . import _lib
+
+        parts = getattr(writer, "_writers", None)
+        if not parts or any(getattr(w, "_mirror", None) is not None or getattr(w, "_log", None) is None for w in parts):
+            return
+        h = ctypes.c_void_p()
+        dev = torch.device(self.device)
+        _lib.check(_lib.load().prl_publisher_create(dev.index or 0, ctypes.byref(h)))
+        self._pub, self._pub_logs = h, [getattr(w._log._h, "value", w._log._h) for w in parts]
 
     def _stop_publisher(self) -> None:
-        """Everything handed to the publisher is in the log when this returns; its error, if any, is raised here."""
-        if self._pub_thread is not None:
-            self._pub_queue.put(None)
-            self._pub_thread.join()
-            self._pub_thread = self._pub_queue = None
-        if self._pub_error:
-            raise self._pub_error.pop(0)
+        """Everything handed to the publisher is in the logs when this returns; its error, if any, is raised here."""
+        import ctypes
+
+        from . import _lib
+
+        if self._pub is None:
+            return
+        lib, pub = _lib.load(), self._pub
+        self._pub = None
+        try:
+            if self._pub_inflight:
+                _lib.check(lib.prl_publisher_wait(pub, self._pub_inflight[-1][0], -1))
+        finally:
+            busy, copy = ctypes.c_uint64(), ctypes.c_uint64()
+            lib.prl_publisher_stats(pub, ctypes.byref(busy), ctypes.byref(copy))
+            self.publisher_ns = (busy.value, copy.value)
+            lib.prl_publisher_destroy(pub)
+            self._pub_inflight.clear()
+            self._pub_logs = []
 
     def _prune_chunks(self) -> None:
         """Release the device-resident chunks whose samples have all been scheduled or dropped.  Called after every
@@ -802,8 +829,6 @@ class PreprocessorLoop:
         cfg, ts = self.cfg, self.trainer_state
         last_data = time.time()
         while max_published_samples is None or self.sched.published_samples - start < max_published_samples:
-            if self._pub_error:
-                break
             if cfg.samples_target is not None and ts is not None and ts.samples_processed is not None and ts.samples_processed >= cfg.samples_target:
                 logger.info("Trainer signalled completion; stopping preprocessor loop")
                 break

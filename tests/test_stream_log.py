@@ -536,3 +536,77 @@ def test_bulk_writer_prefaults_ahead_across_segment_rollovers_and_survives_fork(
     finally:
         w.close()
         Log.unlink_name(name)
+
+
+def test_native_publisher_gathers_records_in_order_and_reports_errors(tmp_path):
+    """csrc/prl_publish.cpp without a device: jobs whose records are made of inline pieces only (what a drain of sentinel batches
+    is) reach two logs in submit order, byte for byte what `append_batch` writes; tickets complete in order; a piece that reads
+    outside its source is refused at submit; a failing append is sticky."""
+    import ctypes
+    import os
+
+    from pipelinerl_amd import _lib, batch_codec
+    from pipelinerl_amd.finetune.types import PipelineBatchEncoding
+    from pipelinerl_amd.finetune.utils import create_sentinel_batch
+    from pipelinerl_amd.ring import Log
+
+    lib = _lib.load()
+    names = [f"prl_test_pub_{os.getpid()}_{k}" for k in range(2)]
+    logs = [Log(n, create=True, segment_bytes=1 << 20) for n in names]
+    want = [Log(n + "_want", create=True, segment_bytes=1 << 20) for n in names]
+    pub = ctypes.c_void_p()
+    _lib.check(lib.prl_publisher_create(0, ctypes.byref(pub)))
+    try:
+        tok = type("T", (), {"eos_token_id": 2})()
+        tickets = []
+        for job in range(5):
+            inline = bytearray()
+            recs, pieces = [], []
+            for r in range(3):
+                part = (job + r) % 2
+                b = create_sentinel_batch(None, tokenizer=tok, model_version=10 * job + r)
+                nbytes, ps = batch_codec.describe_batch(b, 0, 0, inline)
+                recs.append((logs[part]._h.value, nbytes, len(pieces), len(ps)))
+                pieces += ps
+                batch_codec.append_batch(want[part], b)
+            rec_arr = (_lib.PrlPubRecord * len(recs))(*recs)
+            piece_arr = (_lib.PrlPubPiece * len(pieces))(*[(src, off, nb, kind, 0) for kind, src, off, nb in pieces])
+            t = ctypes.c_uint64()
+            _lib.check(lib.prl_publisher_submit(pub, None, 0, None, rec_arr, len(recs), piece_arr, len(pieces),
+                                                (ctypes.c_char * len(inline)).from_buffer(inline), len(inline), ctypes.byref(t)))
+            tickets.append(t.value)
+            del inline  # the job owns a copy
+        assert tickets == [1, 2, 3, 4, 5]
+        _lib.check(lib.prl_publisher_wait(pub, 5, 5000))
+        done = ctypes.c_uint64()
+        _lib.check(lib.prl_publisher_completed(pub, ctypes.byref(done)))
+        assert done.value == 5
+        for got_log, want_log, name in zip(logs, want, names):
+            r1, r2 = Log(name, reader=True), Log(name + "_want", reader=True)
+            n = want_log.stats()["records"]
+            assert got_log.stats()["records"] == n and n in (7, 8)
+            for _ in range(n):
+                a, b = r1.read(timeout=1), r2.read(timeout=1)
+                assert bytes(a) == bytes(b)
+                assert PipelineBatchEncoding(**batch_codec.decode(a)).sentinel
+            r1.close(), r2.close()
+        # a piece outside its source is refused before anything is queued
+        bad = (_lib.PrlPubPiece * 1)((0, 0, 64, 1, 0))
+        rec = (_lib.PrlPubRecord * 1)((logs[0]._h.value, 64, 0, 1))
+        t = ctypes.c_uint64()
+        assert lib.prl_publisher_submit(pub, None, 0, None, rec, 1, bad, 1, None, 0, ctypes.byref(t)) == _lib.PRL_EINVAL
+        # a record whose pieces overlap fails in the worker's append: the error is sticky and names the cause
+        data = bytearray(b"x" * 64)
+        two = (_lib.PrlPubPiece * 2)((0, 0, 32, 1, 0), (0, 16, 32, 1, 0))
+        rec = (_lib.PrlPubRecord * 1)((logs[0]._h.value, 64, 0, 2))
+        _lib.check(lib.prl_publisher_submit(pub, None, 0, None, rec, 1, two, 2, (ctypes.c_char * 64).from_buffer(data), 64, ctypes.byref(t)))
+        assert lib.prl_publisher_wait(pub, t.value, 5000) == _lib.PRL_EFAULT
+        assert b"does not fit" in lib.prl_last_error()
+        assert lib.prl_publisher_submit(pub, None, 0, None, rec, 1, two, 2, (ctypes.c_char * 64).from_buffer(data), 64, ctypes.byref(t)) == _lib.PRL_EFAULT
+    finally:
+        lib.prl_publisher_destroy(pub)
+        for log in logs + want:
+            log.close()
+        for n in names:
+            Log.unlink_name(n)
+            Log.unlink_name(n + "_want")
