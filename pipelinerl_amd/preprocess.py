@@ -459,6 +459,10 @@ class PreprocessorConfig:
         return self.max_lag is None and self.pop_old_data and not self.debug_mode
 
 
+_PUB_RECORD_DT = np.dtype([("log", "<u8"), ("nbytes", "<u8"), ("first_piece", "<u4"), ("n_pieces", "<u4")])  # prl_pub_record
+_PUB_PIECE_DT = np.dtype([("src", "<u8"), ("offset", "<u8"), ("nbytes", "<u8"), ("kind", "<u4"), ("_pad", "<u4")])  # prl_pub_piece
+
+
 @dataclass
 class _Sample:
     chunk: int
@@ -725,20 +729,36 @@ class PreprocessorLoop:
         block_ptr, block_nbytes = (block.data_ptr(), block.numel()) if block is not None else (0, 0)
         inline = bytearray()
         recs, pieces = [], []
-        for partition, piece in self._batches_of(job, packed):
-            nbytes, ps = batch_codec.describe_batch(piece, block_ptr, block_nbytes, inline)
-            recs.append((self._pub_logs[partition], nbytes, len(pieces), len(ps)))
-            pieces += ps
-        rec_arr = (_lib.PrlPubRecord * len(recs))(*recs)
-        piece_arr = (_lib.PrlPubPiece * len(pieces))(*[(src, off, nb, kind, 0) for kind, src, off, nb in pieces])
+        if self.cfg.seq_parallel == 1 and block is not None:
+            # the common case by arithmetic on the block's geometry: no per-micro-batch tensor views
+            from .finetune.utils import create_sentinel_batch
+
+            k = 0
+            for mb in job["mbs"]:
+                if mb.sentinel:
+                    s_batch = create_sentinel_batch(None, tokenizer=type("T", (), {"eos_token_id": self.cfg.eos_token_id})(), model_version=job["max_model_version"])
+                    nbytes, ps = batch_codec.describe_batch(s_batch, 0, 0, inline)
+                else:
+                    nbytes, ps = packed.describe_record(k, inline)
+                    k += 1
+                recs.append((self._pub_logs[mb.trainer_id], nbytes, len(pieces), len(ps)))
+                pieces += ps
+        else:
+            for partition, piece in self._batches_of(job, packed):
+                nbytes, ps = batch_codec.describe_batch(piece, block_ptr, block_nbytes, inline)
+                recs.append((self._pub_logs[partition], nbytes, len(pieces), len(ps)))
+                pieces += ps
+        # the two tables as numpy records laid out like `prl_pub_record` / `prl_pub_piece` (building ~230 ctypes structs costs 3 x as much)
+        rec_arr = np.array(recs, dtype=_PUB_RECORD_DT)
+        piece_arr = np.array([(src, off, nb, kind, 0) for kind, src, off, nb in pieces], dtype=_PUB_PIECE_DT)
         ready = None
         if block is not None:
             ready = torch.cuda.Event()
             ready.record()  # K6 (and the reference-policy annotation) of this drain are complete once this event has fired
         inline_c = (ctypes.c_char * len(inline)).from_buffer(inline) if inline else None
         ticket = ctypes.c_uint64()
-        _lib.check(lib.prl_publisher_submit(self._pub, block_ptr or None, block_nbytes, ready.cuda_event if ready is not None else None, rec_arr, len(recs),
-                                            piece_arr, len(pieces), inline_c, len(inline), ctypes.byref(ticket)))
+        _lib.check(lib.prl_publisher_submit(self._pub, block_ptr or None, block_nbytes, ready.cuda_event if ready is not None else None,
+                                            rec_arr.ctypes.data, len(recs), piece_arr.ctypes.data, len(pieces), inline_c, len(inline), ctypes.byref(ticket)))
         self._pub_inflight.append((ticket.value, block, ready))
         done = ctypes.c_uint64()
         _lib.check(lib.prl_publisher_completed(self._pub, ctypes.byref(done)))

@@ -311,3 +311,39 @@ def test_shm_backend_jsonl_mirror_allows_replay(streams, tmp_path):
     assert [back.group_ids[i] for i in back.host_group_index] == [rag.group_ids[i] for i in rag.host_group_index]
     with streams.read_stream(t) as r:
         _same(next(iter(r.read())), want_batch)
+
+
+def test_packed_step_record_recipe_equals_the_generic_encoding():
+    """`PackedStep.describe_record(j)` (arithmetic on the block's geometry, what the native publisher is handed) gathers to exactly
+    the bytes `batch_codec.encode_batch(packed[j])` produces - header, alignment gaps, every column, seq_boundaries."""
+    import numpy as np
+    import torch
+
+    from pipelinerl_amd import batch_codec
+    from pipelinerl_amd.finetune.data import PackedStep, _alloc_outputs
+
+    rng = np.random.default_rng(3)
+    lens = [5, 9, 3, 12, 7, 1, 4]
+    pk_dst = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    mb_off = np.array([0, 2, 3, 7], dtype=np.int64)  # three micro-batches: 2, 1 and 4 sequences
+    total = int(pk_dst[-1])
+    out = _alloc_outputs(total, torch.device("cpu"), packed=True)
+    out["__block__"].copy_(torch.from_numpy(rng.integers(0, 255, out["__block__"].numel(), dtype=np.uint8)))
+    packed = PackedStep(out, pk_dst, mb_off, np.array([3, 7, 7], dtype=np.int64), np.array([0, 1, 0], dtype=np.int64))
+    block = packed.block.numpy().tobytes()
+    for j in range(3):
+        inline = bytearray(b"junk")  # recipes append to what is there already
+        nbytes, pieces = packed.describe_record(j, inline)
+        rec = bytearray(nbytes)
+        for kind, src, off, nb in pieces:
+            rec[off:off + nb] = (block if kind == 0 else bytes(inline))[src:src + nb]
+        want = batch_codec.encode_batch(packed[j])
+        assert bytes(rec) == bytes(want), j
+        d = batch_codec.decode(rec)
+        assert d["model_version"] == [3, 7, 7][j] and d["padding"] == [0, 1, 0][j] and d["seq_boundaries"].tolist()[-1] == d["input_ids"].shape[1]
+    # the generic recipe (tensor views: sequence-parallel slices, sentinels) agrees with it where both apply
+    inline_a, inline_b = bytearray(), bytearray()
+    na, pa = packed.describe_record(1, inline_a)
+    dev_like = packed[1]
+    nb_, pb = batch_codec.describe_batch(dev_like, packed.block.data_ptr(), packed.block.numel(), inline_b)
+    assert na == nb_
