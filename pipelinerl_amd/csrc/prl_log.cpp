@@ -152,20 +152,15 @@ int map_object(const std::string& name, size_t create_bytes, bool may_create, Ma
 struct Prefaulter {
   static constexpr uint64_t kWindow = 32ull << 20;  // stay this far ahead of `committed`
   static constexpr uint64_t kSlice = 2ull << 20;    // one madvise call
-  // Two helpers: populating fresh tmpfs pages (allocate + zero + insert into the page cache) runs at ~3 GB/s per thread, a
-  // preprocessor publishing flat out appends 4-5 GB/s into one trainer's log - with one helper the appending thread ended up
-  // faulting its own pages (memcpy into the segment at 5.5 GB/s against 13.7 GB/s when four logs, i.e. four helpers, shared
-  // the same stream of records; profiles/r05g_*).  Slices are CLAIMED under the mutex, so the helpers never populate the same range.
-  static constexpr int kThreads = 2;
   std::mutex m;
   std::condition_variable cv;
-  std::thread* th[kThreads] = {nullptr, nullptr};  // on the heap: a forked child abandons them (the threads do not exist there) instead of destroying them
+  std::thread* th = nullptr;  // on the heap: a forked child abandons it (the thread does not exist there) instead of destroying it
   pid_t owner = 0;
   bool stop = false, disabled = false;
-  int busy = 0;             // madvise slices in flight (the mutex is NOT held during the call)
+  bool busy = false;        // a madvise slice is in flight (the mutex is NOT held during the call)
   std::condition_variable idle;
   uint8_t* base = nullptr;  // payload start of the segment being written
-  uint64_t capacity = 0, want = 0, done = 0, gen = 0;  // done: claimed up to here
+  uint64_t capacity = 0, want = 0, done = 0, gen = 0;
 
   void run() {
     std::unique_lock<std::mutex> lk(m);
@@ -174,8 +169,7 @@ struct Prefaulter {
       if (stop) return;
       const uint64_t g = gen, from = done, n = (want - done < kSlice) ? want - done : kSlice;
       uint8_t* p = base + from;
-      done = from + n;  // claimed: the other helper takes the next slice
-      ++busy;
+      busy = true;
       lk.unlock();
       // page-align inwards: the first partial page was touched by the header / previous record already
       const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
@@ -184,11 +178,12 @@ struct Prefaulter {
       if (e > a) rc = madvise(reinterpret_cast<void*>(a), e - a, MADV_POPULATE_WRITE);
       const int err = rc != 0 ? errno : 0;
       lk.lock();
-      --busy;
+      busy = false;
       idle.notify_all();
       // kernel without MADV_POPULATE_WRITE: appends fault their pages themselves.  Only believed while the segment is still the one
       // the call was aimed at: after a switch the old range may be unmapped or belong to someone else, and its errors mean nothing
       if (err == EINVAL && g == gen) disabled = true;
+      if (g == gen) done = from + n;  // a segment change in between restarts from its own offset
     }
   }
   // called by the appending thread BEFORE it unmaps (or replaces) the segment the helper may be populating: forget the range and
@@ -201,7 +196,7 @@ struct Prefaulter {
     base = nullptr;
     want = done = 0;
     ++gen;
-    idle.wait(lk, [&] { return busy == 0; });
+    idle.wait(lk, [&] { return !busy; });
   }
   // called by the appending thread (under the log's writer lock): the segment now being written and how far it is filled
   void target(uint8_t* payload, uint64_t cap, uint64_t committed, bool new_segment) {
@@ -217,26 +212,25 @@ struct Prefaulter {
     const uint64_t w = committed + kWindow < cap ? committed + kWindow : cap;
     if (w > want || new_segment) want = w;
     if (want > cap) want = cap;
-    if (done < want) cv.notify_all();
+    if (done < want) cv.notify_one();
   }
   void start() {
     owner = getpid();
-    for (auto& t : th) t = new (std::nothrow) std::thread([this] { run(); });
+    th = new (std::nothrow) std::thread([this] { run(); });
   }
   // true: the helper is gone and the object may be deleted; false (a forked child): leave everything alone
   bool shutdown() {
     if (getpid() != owner) return false;
-    {
-      std::lock_guard<std::mutex> lk(m);
-      stop = true;
-    }
-    cv.notify_all();
-    for (auto& t : th)
-      if (t) {
-        t->join();
-        delete t;
-        t = nullptr;
+    if (th) {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        stop = true;
       }
+      cv.notify_all();
+      th->join();
+      delete th;
+      th = nullptr;
+    }
     return true;
   }
 };
