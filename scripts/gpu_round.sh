@@ -30,16 +30,22 @@ p = d.get("preprocess_loop") or {}
 for k, c in (p.get("cases") or {}).items():
     print(" pre", k, round(c["us_per_token"], 4), "us/tok planning", round(c["host_planning_frac"], 3))
 print(" pre speedup", p.get("speedup_vs_reference_preprocess_plus_collate"), "ref_logprob", {k: (round(v["old_ms"], 2), round(v["fused_ms"], 2)) for k, v in ((d.get("ref_logprob") or {}).get("heads") or {}).items()})
-print(" cpu_baseline", d["cpu_baseline"]["kind"], d["cpu_baseline"]["value"], "port", (d["cpu_baseline"].get("port") or {}).get("value"))
+print(" cpu_baseline", d["cpu_baseline"]["kind"], d["cpu_baseline"]["value"], "port", (d["cpu_baseline"].get("port") or {}).get("value"), "cores", d["cpu_baseline"]["cores"])
+pl = d.get("pipeline") or {}
+print(" pipeline", {k: pl.get(k) for k in ("samples_per_s", "s_per_step", "busy_frac", "error")}, "budget8192", (pl.get("pack_budget_8192") or {}).get("samples_per_s"),
+      "wsync under load", (pl.get("weight_sync_under_load_ms") or {}).get("median"))
+for k, h in ((d.get("ref_logprob") or {}).get("heads") or {}).items():
+    print(" ref head", k, "err vs fp64", h.get("max_abs_error_vs_fp64"), "equal-accuracy library", (h.get("old_equal_accuracy") or {}))
+print(" value_e2e", d.get("value_e2e"), "wsync transport", (d.get("weight_sync") or {}).get("transport"))
 PY
-cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-weight-sync --no-e2e --no-transport --no-live-pmc > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
+cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-weight-sync --no-e2e --no-transport --no-live-pmc --no-pipeline > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
 # the summary for profiles/: names shortened, ALL numeric columns kept (a width cut lost the dominant kernel's numbers in round 3)
 cd $GRAFT_REPO_ROOT; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do python scripts/kernel_stats_summary.py $f $OUT/bench_kernel_stats.csv; head -8 $OUT/bench_kernel_stats.csv; done
 find $OUT/prof -name "*kernel_trace.csv" -delete
 # the other two BASELINE workloads (configs[4]: 32B, KL on; configs[1]: 0.5B)
-( time timeout 600 python bench.py --workload 32b_grpo_kl_bs4096_seq8192 --steps 2 --warmup 1 --no-preprocess-loop --no-transport ) > $OUT/bench_32b.log 2> $OUT/bench_32b.err
+( time timeout 600 python bench.py --workload 32b_grpo_kl_bs4096_seq8192 --steps 2 --warmup 1 --no-preprocess-loop --no-transport --no-pipeline ) > $OUT/bench_32b.log 2> $OUT/bench_32b.err
 echo "bench 32b exit $?"
-( time timeout 300 python bench.py --workload 0p5b_grpo_bs512_seq2048 --steps 5 --warmup 2 --no-preprocess-loop --no-transport ) > $OUT/bench_0p5b.log 2> $OUT/bench_0p5b.err
+( time timeout 300 python bench.py --workload 0p5b_grpo_bs512_seq2048 --steps 5 --warmup 2 --no-preprocess-loop --no-transport --no-pipeline ) > $OUT/bench_0p5b.log 2> $OUT/bench_0p5b.err
 echo "bench 0p5b exit $?"
 python - "$OUT" <<'PY'
 import json, sys
