@@ -514,7 +514,9 @@ def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attemp
     shm_free = shutil.disk_usage("/dev/shm").free if Path("/dev/shm").exists() else 0
     tok_per_group = attempts * seq_length
     # shm: the actor records (12 B/token) and the published batches (68 B/token) of one case live in /dev/shm together
-    n_fast = int(max(4, min(int(os.environ.get("PRL_BENCH_PREPROCESS_GROUPS", 32)), shm_free // 4 // (tok_per_group * 80)))) // 2 * 2
+    # 128 groups = 64 chunks per case: the loop's fill and drain (first chunk's latency, the last drain's publish) are ~ one chunk
+    # each, which was ~10 % of the 16-chunk runs of rounds 4 and 5 (r05j and before) and is 2-3 % here
+    n_fast = int(max(4, min(int(os.environ.get("PRL_BENCH_PREPROCESS_GROUPS", 128)), shm_free // 4 // (tok_per_group * 80)))) // 2 * 2
     n_text = 4
     rl = RLConfig(policy_loss="ppo", epsilon_low=0.02, epsilon_high=0.02, kl_coef=0.0, final_kl_coef=0.0, clamp_log_ratio_ref_new_value=5,
                   temperature=1.0, divide_advantage_by_std=False, group_normalization=False, batch_size=4096)
@@ -523,7 +525,7 @@ def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attemp
     out: dict = {"what": f"actor stream -> PreprocessorLoop (chunk_n_groups = 2, packed, seq_length {seq_length}) -> training_data; groups of "
                          f"{attempts} x {seq_length}-token rollouts; wall clock of run() incl. stream read + decode (loader thread)", "cases": {}}
 
-    def one_case(backend: str, binary: bool, trainers: int, n_groups: int, batched: bool, overlap: bool = True):
+    def one_case(backend: str, binary: bool, trainers: int, n_groups: int, batched: bool, overlap: bool = True, wire: str = "full", consumer: bool = False):
         tmp = tempfile.mkdtemp(prefix="prl_bench_pre_")
         try:
             streams.reset_streams_backend()
@@ -535,7 +537,7 @@ def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attemp
             cfg = PreprocessorConfig(exp_path=Path(tmp), num_trainers=trainers, train_batch_size=1, gradient_accumulation_passes=4096,
                                      seq_length=seq_length, attempts=attempts, rl=rl, eos_token_id=2, chunk_n_groups=2,
                                      pop_old_data=False)  # lossless: with the default the loader DROPS old chunks when the loop is the slower side
-            loop = PreprocessorLoop(cfg, dev, batched_transfers=batched, profile=True, overlap_publish=overlap)
+            loop = PreprocessorLoop(cfg, dev, batched_transfers=batched, profile=True, overlap_publish=overlap, wire=wire)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             # the packer flushes a micro-batch when the NEXT sample no longer fits (preprocess.py:610-625): the very last
@@ -563,7 +565,31 @@ def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attemp
                 res["publisher_us_per_chunk"] = {"busy": 1e-3 * loop.publisher_ns[0] / chunks, "d2h": 1e-3 * loop.publisher_ns[1] / chunks}
             else:
                 res["publish"] = "inline (device -> host copy, framing and append inside the loop: d2h + encode_publish)"
+            if wire == "compact":
+                res["publish"] = ("compact wire: no K6 and no per-token device -> host traffic here; the native publisher gathers every micro-batch's ragged "
+                                  "columns from the decoded actor records on the host (PRLCMP01, 12-16 B/token); K6 runs in the learner's loader")
             assert n == target, f"published {n} of {target} samples"
+            if consumer:  # the other end of the wire: what the learner's loader thread does per record (finetune_loop.RecordToBatch)
+                from pipelinerl_amd.finetune_loop import RecordToBatch
+                from pipelinerl_amd.ring import Log
+
+                to_batch = RecordToBatch(dev, annotate=True)
+                part = streams.SingleStreamSpec(exp_path=Path(tmp), topic="training_data", partition=0)
+                want = Log(streams.ring_name(part), reader=True).stats()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                got = toks = 0
+                with streams.read_stream(part) as r:
+                    for rec in r.read():
+                        b = to_batch(rec)
+                        toks += int(b.input_ids.shape[1]) if not b.sentinel else 0
+                        got += 1
+                        if got == want["records"]:
+                            break
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t1
+                res["consumer"] = {"what": "learner's loader over partition 0: log read + decode + host facts + upload" + (" + K6 on the learner's GPU" if wire == "compact" else " (12 columns)"),
+                                   "records": got, "tokens": toks, "log_bytes_per_token": want["bytes"] / max(toks, 1), "us_per_token": 1e6 * dt1 / max(toks, 1)}
             return res
         finally:
             if backend == "shm":
@@ -572,8 +598,11 @@ def preprocess_loop_probe(dev: torch.device, seq_length: int, vocab: int, attemp
 
     try:
         one_case("shm", True, 1, min(8, n_fast), True)  # warm-up: library, page-locked ring, the allocator's block cache (several chunks are alive at once)
-        out["cases"]["PRLROL01_to_shm_1_trainer"] = one_case("shm", True, 1, n_fast, True)
+        out["cases"]["PRLROL01_to_shm_1_trainer"] = one_case("shm", True, 1, n_fast, True, consumer=True)
         out["cases"]["PRLROL01_to_shm_4_trainers"] = one_case("shm", True, 4, n_fast, True)
+        one_case("shm", True, 1, min(8, n_fast), True, wire="compact", consumer=True)  # warm-up of the compact path (publisher without a block, the loader's ring)
+        out["cases"]["PRLROL01_to_shm_1_trainer_compact_wire"] = one_case("shm", True, 1, n_fast, True, wire="compact", consumer=True)
+        out["cases"]["PRLROL01_to_shm_4_trainers_compact_wire"] = one_case("shm", True, 4, n_fast, True, wire="compact")
         out["cases"]["PRLROL01_to_shm_1_trainer_inline_publish"] = one_case("shm", True, 1, n_fast, True, overlap=False)  # the round-4 loop
         out["cases"]["PRLROL01_to_shm_1_trainer_one_copy_per_array"] = one_case("shm", True, 1, n_fast, False)
         out["cases"]["JSONL_to_files_1_trainer"] = one_case("files", False, 1, n_text, True)

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 10
+#define PRL_ABI_VERSION 11
 
 #define PRL_OK 0
 #define PRL_EINVAL (-22)   /* bad argument                                  */
@@ -493,20 +493,23 @@ int prl_log_unlink(const char* name); /* remove the control block and every segm
  * inline from the loop at :629-648 - on a native worker thread.  A JOB is one drain of the scheduler: the packed block the
  * pack kernel wrote (device memory, nullable), the event that certifies it (hipEvent_t, nullable), and the records to append,
  * in order, each to the log of its trainer partition.  A record is gathered from PIECES: ranges of the block once it has been
- * copied to page-locked host memory (PRL_PUB_FROM_BLOCK, `src` = byte offset into the block) and ranges of the job's inline
- * bytes (PRL_PUB_INLINE: record headers, sentinel batches; copied at submit, the caller may free them at once).  submit
- * returns a ticket and blocks only while two jobs are pending; the caller must keep `dev_block` and `ready_event` alive until
- * prl_publisher_completed reports the ticket.  Records reach the logs in submit order.  An error of the worker (HIP, a log
+ * copied to page-locked host memory (PRL_PUB_FROM_BLOCK, `src` = byte offset into the block), ranges of the job's inline
+ * bytes (PRL_PUB_INLINE: record headers, sentinel batches; copied at submit, the caller may free them at once) and ranges of
+ * host memory the caller owns (PRL_PUB_FROM_HOST, `src` = the address: the compact `training_data` wire gathers a micro-batch's
+ * ragged columns straight from the decoded `actor` records - nothing per token ever goes through the device).  submit
+ * returns a ticket and blocks only while two jobs are pending; the caller must keep `dev_block`, `ready_event` and every
+ * PRL_PUB_FROM_HOST range alive until prl_publisher_completed reports the ticket.  Records reach the logs in submit order.  An error of the worker (HIP, a log
  * append) is sticky: every later call returns it.
  */
 typedef struct prl_publisher prl_publisher;
 #define PRL_PUB_FROM_BLOCK 0
 #define PRL_PUB_INLINE 1
+#define PRL_PUB_FROM_HOST 2
 typedef struct prl_pub_piece {
-  uint64_t src;    /* byte offset into the staged block / the inline bytes */
+  uint64_t src;    /* byte offset into the staged block / the inline bytes; PRL_PUB_FROM_HOST: a host address */
   uint64_t offset; /* byte offset inside the record (ascending, non-overlapping, as for prl_log_appendv) */
   uint64_t nbytes;
-  uint32_t kind;   /* PRL_PUB_FROM_BLOCK | PRL_PUB_INLINE */
+  uint32_t kind;   /* PRL_PUB_FROM_BLOCK | PRL_PUB_INLINE | PRL_PUB_FROM_HOST */
   uint32_t _pad;
 } prl_pub_piece;
 typedef struct prl_pub_record {

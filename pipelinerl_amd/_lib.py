@@ -13,7 +13,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl.so"
 
-PRL_ABI_VERSION = 10
+PRL_ABI_VERSION = 11
 PRL_OK = 0
 PRL_EINVAL = -22
 PRL_ENOMEM = -12
@@ -81,6 +81,9 @@ class PrlLogIov(ctypes.Structure):
     """`prl_log_iov` of include/prl.h: one source range of a gathered record."""
 
     _fields_ = [("ptr", ctypes.c_void_p), ("offset", ctypes.c_uint64), ("nbytes", ctypes.c_uint64)]
+
+
+PRL_PUB_FROM_BLOCK, PRL_PUB_INLINE, PRL_PUB_FROM_HOST = 0, 1, 2  # prl_pub_piece.kind
 
 
 class PrlPubPiece(ctypes.Structure):

@@ -5,6 +5,10 @@ Record = 8-byte magic/kind + payload.
   kind "PRLROL01": a chunk of rollouts as ragged SoA (`RaggedRollouts`: int32 tokens/labels, fp32
         completion logprobs, offsets, per-sequence scalars) - the binary form of the `actor` stream
         record, 8-16 bytes per token instead of a JSON list per field; same framing as PRLBAT01.
+  kind "PRLCMP01": a packed micro-batch BEFORE expansion - the ragged columns of its sequences in packing order (int32 ids / labels,
+        fp32 completion log-probs, offsets, five per-sequence scalars): 12-16 bytes per token instead of 68; the learner's
+        loader runs the pack kernel on ITS device (`finetune.data.CompactBatch.to_batch`) and gets the identical batch.
+        Same framing as PRLBAT01.
   kind "PRLBAT01": a PipelineBatchEncoding as SoA:
         u32 header_len | header JSON | raw buffers, each 16-byte aligned
      header = {"scalars": {model_version, sentinel, padding, is_packed},
@@ -30,6 +34,7 @@ from .finetune.types import PipelineBatchEncoding
 MAGIC_JSON = b"PRLJSON1"
 MAGIC_BATCH = b"PRLBAT01"
 MAGIC_ROLLOUTS = b"PRLROL01"
+MAGIC_COMPACT = b"PRLCMP01"
 _ALIGN = 16
 _TORCH = {"int64": torch.int64, "float32": torch.float32, "int32": torch.int32, "float64": torch.float64, "uint8": torch.uint8,
           "bool": torch.bool, "bfloat16": torch.bfloat16, "float16": torch.float16}
@@ -166,6 +171,38 @@ def encode_rollouts(rollouts) -> bytearray:
     return _frame(MAGIC_ROLLOUTS, {"group_ids": list(rollouts.group_ids)}, tensors)
 
 
+_COMPACT_FIELDS = ("tokens", "labels", "logprobs", "ref_logprobs", "seq_off", "lp_off", "seq_scalars")
+
+
+def compact_layout(n: int, nc: int, m: int, has_ref: bool, model_version: int, padding: int, eos_token_id: int):
+    """(header bytes incl. magic and length, offset of the first tensor, {name: (offset from there, nbytes)}, record size) of the
+    compact record of a micro-batch of `n` tokens / `nc` completion tokens / `m` sequences.  One definition for the generic
+    encoder (`encode_compact`) and for the preprocessor's gather recipe (the native publisher copies every column's per-sequence
+    slices straight from the decoded `actor` records)."""
+    shapes = [("tokens", "int32", [n], 4 * n), ("labels", "int32", [n], 4 * n), ("logprobs", "float32", [nc], 4 * nc)]
+    if has_ref:
+        shapes.append(("ref_logprobs", "float32", [nc], 4 * nc))
+    shapes += [("seq_off", "int64", [m + 1], 8 * (m + 1)), ("lp_off", "int64", [m + 1], 8 * (m + 1)), ("seq_scalars", "float32", [5, m], 20 * m)]
+    offset, tensors, where = 0, [], {}
+    for name, dt, shape, nb in shapes:
+        offset += (-offset) % _ALIGN
+        tensors.append([name, dt, shape, offset, nb])
+        where[name] = (offset, nb)
+        offset += nb
+    scalars = {"model_version": int(model_version), "padding": int(padding), "eos_token_id": int(eos_token_id)}
+    header = json.dumps({"scalars": scalars, "tensors": tensors}).encode("utf-8")
+    head = MAGIC_COMPACT + struct.pack("<I", len(header)) + header
+    base = len(head) + (-len(head)) % _ALIGN
+    return head, base, where, base + offset
+
+
+def encode_compact(cb) -> bytearray:
+    """`finetune.data.CompactBatch` -> one record (the generic path: every column copied once into a record buffer)."""
+    t = torch.from_numpy
+    tensors = [(k, t(np.ascontiguousarray(getattr(cb, k)))) for k in _COMPACT_FIELDS if getattr(cb, k) is not None]
+    return _frame(MAGIC_COMPACT, {"model_version": int(cb.model_version), "padding": int(cb.padding), "eos_token_id": int(cb.eos_token_id)}, tensors)
+
+
 def encode_batch(batch: PipelineBatchEncoding) -> bytearray:
     scalars = {"model_version": batch.model_version, "sentinel": batch.sentinel, "padding": batch.padding, "is_packed": batch.is_packed}
     return _frame(MAGIC_BATCH, scalars, list(batch.tensors()))
@@ -182,7 +219,7 @@ def decode(record: "bytes | bytearray") -> Any:
     magic = bytes(record[:8])
     if magic == MAGIC_JSON:
         return json.loads(bytes(record[8:]).decode("utf-8"))
-    if magic not in (MAGIC_BATCH, MAGIC_ROLLOUTS):
+    if magic not in (MAGIC_BATCH, MAGIC_ROLLOUTS, MAGIC_COMPACT):
         raise ValueError(f"unknown record kind {magic!r}")
     if not isinstance(record, bytearray):
         record = bytearray(record)
@@ -197,6 +234,11 @@ def decode(record: "bytes | bytearray") -> Any:
             continue
         dt = _TORCH[dtype]
         out[name] = torch.frombuffer(record, dtype=dt, count=nbytes // dt.itemsize, offset=base + off).view(shape)
+    if magic == MAGIC_COMPACT:
+        from .finetune.data import CompactBatch
+
+        return CompactBatch(**{k: (out[k].numpy() if k in out else None) for k in _COMPACT_FIELDS},
+                            model_version=out["model_version"], padding=out["padding"], eos_token_id=out["eos_token_id"])
     if magic == MAGIC_ROLLOUTS:
         from .ragged import RaggedRollouts
 

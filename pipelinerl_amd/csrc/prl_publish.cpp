@@ -108,7 +108,9 @@ struct prl_publisher {
       iov.clear();
       for (uint32_t p = r.first_piece; p < r.first_piece + r.n_pieces; ++p) {
         const prl_pub_piece& pc = j.pieces[p];
-        const uint8_t* src = pc.kind == PRL_PUB_FROM_BLOCK ? host + pc.src : j.inline_bytes.data() + pc.src;
+        const uint8_t* src = pc.kind == PRL_PUB_FROM_BLOCK ? host + pc.src
+                             : pc.kind == PRL_PUB_INLINE   ? j.inline_bytes.data() + pc.src
+                                                           : reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(pc.src));
         iov.push_back(prl_log_iov{src, pc.offset, pc.nbytes});
       }
       const int rc = prl_log_appendv(static_cast<prl_log*>(r.log), iov.data(), (int32_t)iov.size(), r.nbytes);
@@ -228,7 +230,11 @@ extern "C" int prl_publisher_submit(prl_publisher* p, const void* dev_block, uin
     PRL_CHECK_ARG(recs[r].log != nullptr && (uint64_t)recs[r].first_piece + recs[r].n_pieces <= (uint64_t)n_pieces, "record %d: bad piece range", r);
     for (uint32_t q = recs[r].first_piece; q < recs[r].first_piece + recs[r].n_pieces; ++q) {
       const prl_pub_piece& pc = pieces[q];
-      PRL_CHECK_ARG(pc.kind == PRL_PUB_FROM_BLOCK || pc.kind == PRL_PUB_INLINE, "piece %u: unknown kind %u", q, pc.kind);
+      PRL_CHECK_ARG(pc.kind == PRL_PUB_FROM_BLOCK || pc.kind == PRL_PUB_INLINE || pc.kind == PRL_PUB_FROM_HOST, "piece %u: unknown kind %u", q, pc.kind);
+      if (pc.kind == PRL_PUB_FROM_HOST) {
+        PRL_CHECK_ARG(pc.src != 0 || pc.nbytes == 0, "piece %u: null host address", q);
+        continue;
+      }
       const uint64_t limit = pc.kind == PRL_PUB_FROM_BLOCK ? block_bytes : inline_nbytes;
       PRL_CHECK_ARG(pc.src <= limit && pc.nbytes <= limit - pc.src, "piece %u reads outside its source (%llu + %llu > %llu)", q,
                     (unsigned long long)pc.src, (unsigned long long)pc.nbytes, (unsigned long long)limit);

@@ -16,6 +16,7 @@ from __future__ import annotations
 import contextlib
 
 import logging
+from dataclasses import dataclass
 from typing import Any, Iterable, Sequence
 
 import numpy as np
@@ -294,6 +295,98 @@ def pack_prepared(
         versions = np.zeros(0, dtype=np.int64)
     pads = None if sentinel_pad is None else np.asarray(sentinel_pad, dtype=np.int64)
     return PackedStep(out, pk_dst, mb_off, versions, pads)
+
+
+@dataclass
+class CompactBatch:
+    """One packed micro-batch BEFORE expansion: the ragged columns of its sequences in packing order, on the host - the payload
+    of the compact `training_data` wire (`batch_codec` kind PRLCMP01, 12-16 bytes per token instead of the 68 of a
+    `PipelineBatchEncoding`).  The reference ships the expanded batch (preprocess.py:356-367 writes what `collate_packed`
+    returned); here the pack kernel (K6, data.py:215-283) can run where the batch is consumed: `to_batch(device)` uploads the
+    columns in one copy and launches it on the learner's GPU - the same kernel on the same inputs the preprocessor would have
+    given it, so the batch is identical to the last bit (tests/test_gpu_compact_wire.py)."""
+
+    tokens: np.ndarray               # int32 [n]
+    labels: np.ndarray               # int32 [n]
+    logprobs: np.ndarray             # fp32 [nc]  completion tokens only, right-aligned inside a sequence
+    ref_logprobs: np.ndarray | None  # fp32 [nc]  (None: the KL term is off, `ref_logprobs` := `old_logprobs`)
+    seq_off: np.ndarray              # int64 [m + 1]
+    lp_off: np.ndarray               # int64 [m + 1]
+    seq_scalars: np.ndarray          # fp32 [5, m]: rewards, advantages, group_tokens, num_labels, overflow per sequence
+    model_version: int = 0
+    padding: int = 0                 # sequence-parallel filler tokens appended by the pack kernel (0 on this wire today)
+    eos_token_id: int = 0
+
+    @property
+    def n_tokens(self) -> int:
+        return int(self.tokens.shape[0])
+
+    @property
+    def n_seqs(self) -> int:
+        return int(self.seq_off.shape[0]) - 1
+
+    def host_facts(self) -> dict[str, Any]:
+        """What `finetune_loop.annotate_host_batch` derives from an expanded batch on the host, from the ragged columns: the
+        real-token count and the flat indices of the logits rows that predict a labelled token (the first token of every
+        sequence but the first carries no label in the packed batch, data.py:264-265)."""
+        lab = self.labels.copy()
+        first = self.seq_off[1:-1]
+        lab[first[first < len(lab)]] = MASKED_TOKEN_ID
+        live = np.flatnonzero(lab[1:] != MASKED_TOKEN_ID)
+        return {"tokens": self.n_tokens + int(self.padding), "labelled_rows": torch.from_numpy(live.astype(np.int64))}
+
+    def to_batch(self, device: torch.device | str, stager: Any = None) -> PipelineBatchEncoding:
+        """Upload (ONE copy through `stager`, a `staging.PinnedStager`, when given) + one K6 launch on `device`'s current
+        stream -> the packed `PipelineBatchEncoding` on that device."""
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("a compact micro-batch is expanded by the pack kernel: it needs a HIP device; there is no CPU fallback")
+        m = self.n_seqs
+        cols = [self.tokens, self.labels, self.logprobs, self.ref_logprobs, self.seq_off, self.lp_off, self.seq_scalars]
+        if stager is not None:
+            up = stager.upload(cols)
+        else:
+            up = [None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True) for a in cols]
+        tokens, labels, lp, ref, seq_off, lp_off, sc = up
+        none = torch.empty(0, device=dev)
+        rag = RaggedRollouts(
+            tokens=tokens, labels=labels, logprobs=lp, ref_logprobs=ref, seq_off=seq_off, lp_off=lp_off, reward=none, group_index=none,
+            step_index=none, rollout_index=none, model_version=none, finished=none, finish_code=none,
+            host_seq_off=np.asarray(self.seq_off, dtype=np.int64), host_lp_off=np.asarray(self.lp_off, dtype=np.int64),
+            host_model_version=np.full(m, int(self.model_version), dtype=np.int64),
+        )
+        prep = PreparedRollouts(rollouts=rag, reward32=sc[0], advantage=sc[1], group_tokens=sc[2], num_labels=sc[3], overflow=sc[4],
+                                advantage64=none, group_tokens64=none)
+        return pack_prepared(prep, [range(m)], self.eos_token_id, sentinel_pad=[int(self.padding)] if self.padding else None, stager=stager)[0]
+
+
+def compact_micro_batch(host_chunks: Sequence[RaggedRollouts], seq_scalars: Sequence[np.ndarray], members: Sequence[tuple[int, int]],
+                        eos_token_id: int, padding: int = 0) -> CompactBatch:
+    """The compact form of the micro-batch whose sequences are `members` = (chunk, index into that chunk) in packing order:
+    `host_chunks[c]` the chunk's rollouts on the host, `seq_scalars[c]` its fp32 [5, S_c] per-sequence columns (rewards + the
+    four K5 outputs).  The plain-numpy statement of what the preprocessor's publisher gathers piece by piece."""
+    toks, labs, lps, refs, lens, lp_lens, scal, versions = [], [], [], [], [], [], [], []
+    any_ref = any(host_chunks[c].ref_logprobs is not None for c, _ in members)
+    for c, i in members:
+        r = host_chunks[c]
+        a, b = int(r.host_seq_off[i]), int(r.host_seq_off[i + 1])
+        la, lb = int(r.host_lp_off[i]), int(r.host_lp_off[i + 1])
+        toks.append(r.tokens.numpy()[a:b])
+        labs.append(r.labels.numpy()[a:b])
+        lps.append(r.logprobs.numpy()[la:lb])
+        if any_ref:  # a chunk without reference log-probs contributes its rollout log-probs, like the pack kernel does
+            refs.append((r.ref_logprobs if r.ref_logprobs is not None else r.logprobs).numpy()[la:lb])
+        lens.append(b - a)
+        lp_lens.append(lb - la)
+        scal.append(seq_scalars[c][:, i])
+        versions.append(int(r.host_model_version[i]))
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt, copy=False) if xs else np.zeros(0, dtype=dt)  # noqa: E731
+    off = lambda ls: np.concatenate([[0], np.cumsum(ls)]).astype(np.int64)  # noqa: E731
+    return CompactBatch(
+        tokens=cat(toks, np.int32), labels=cat(labs, np.int32), logprobs=cat(lps, np.float32), ref_logprobs=cat(refs, np.float32) if any_ref else None,
+        seq_off=off(lens), lp_off=off(lp_lens), seq_scalars=np.ascontiguousarray(np.stack(scal, axis=1), dtype=np.float32) if scal else np.zeros((5, 0), np.float32),
+        model_version=min(versions) if versions else 0, padding=padding, eos_token_id=eos_token_id,
+    )
 
 
 def pad_prepared(

@@ -605,6 +605,7 @@ class PreparedRollouts:
     overflow: torch.Tensor       # fp32 [S]
     advantage64: torch.Tensor    # fp64 [S]   (what the reference's python lists hold)
     group_tokens64: torch.Tensor  # fp64 [S]
+    k5_out32: torch.Tensor | None = None  # fp32 [4, S]: the allocation behind num_labels / overflow / advantage / group_tokens (one copy takes all four to the host)
 
 
 def _csr(keys: np.ndarray) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
@@ -673,7 +674,7 @@ def populate_rl_data_ragged(rollouts: RaggedRollouts, eos_token_id: int, config:
         )
     return PreparedRollouts(
         rollouts=r, reward32=r.reward.to(torch.float32), advantage=adv32, group_tokens=gt32,
-        num_labels=num_labels, overflow=overflow, advantage64=adv64, group_tokens64=gt64,
+        num_labels=num_labels, overflow=overflow, advantage64=adv64, group_tokens64=gt64, k5_out32=out32,
     )
 
 

@@ -163,25 +163,58 @@ def annotate_host_batch(batch: PipelineBatchEncoding) -> PipelineBatchEncoding:
     return batch
 
 
+class RecordToBatch:
+    """One `training_data` record -> the batch on `device`, as the loader thread does it: a full-wire record (the kwargs of a
+    `PipelineBatchEncoding`) is rebuilt and its columns copied over; a compact-wire record (`finetune.data.CompactBatch`: the
+    micro-batch before expansion, `PreprocessorLoop(wire="compact")`) is EXPANDED here - one upload through a page-locked ring
+    + one pack-kernel launch on `device`.  `annotate`: leave the host-side facts `StreamedLearnerStep` wants in
+    `batch.model_extra` (`annotate_host_batch`)."""
+
+    def __init__(self, device: Any, annotate: bool = False):
+        self.device, self.annotate = device, annotate
+        self._stager = None
+
+    def __call__(self, record: Any) -> PipelineBatchEncoding:
+        from .finetune.data import CompactBatch
+
+        device = self.device
+        if isinstance(record, CompactBatch):
+            if device is None or torch.device(device).type != "cuda":
+                raise RuntimeError("a compact training_data record is expanded by the pack kernel: the loader needs the learner's HIP device")
+            if self._stager is None:
+                from .staging import PinnedStager
+
+                self._stager = PinnedStager(device, slots=4)
+            with torch.cuda.device(device):
+                batch = record.to_batch(device, self._stager)
+            if self.annotate:
+                facts = record.host_facts()
+                batch.model_extra["tokens"] = facts["tokens"]
+                batch.model_extra["labelled_rows"] = facts["labelled_rows"].to(device, non_blocking=True)
+            return batch
+        batch = PipelineBatchEncoding(**record)
+        if self.annotate:
+            annotate_host_batch(batch)
+        if device is not None:
+            batch = batch.to_device(device)
+            rows = batch.model_extra.get("labelled_rows")
+            if rows is not None:
+                batch.model_extra["labelled_rows"] = rows.to(device, non_blocking=True)
+        return batch
+
+
 def run_data_loader(data_stream: SingleStreamSpec, batch_queue: Queue, device: Any, stop: threading.Event | None = None,
                     annotate: bool = False) -> None:
     """Read `training_data/<instance>/<rank>` records, rebuild the batch, move it to `device`,
     hand it to the training thread.  Exceptions travel through the queue like in the reference.
-    `annotate`: also leave the host-side facts `StreamedLearnerStep` wants in `batch.model_extra` (`annotate_host_batch`)."""
+    Both wires are understood (`RecordToBatch`)."""
     try:
+        to_batch = RecordToBatch(device, annotate)
         with read_stream(data_stream) as reader:
             for record in reader.read():
                 if stop is not None and stop.is_set():
                     return
-                batch = PipelineBatchEncoding(**record)
-                if annotate:
-                    annotate_host_batch(batch)
-                if device is not None:
-                    batch = batch.to_device(device)
-                    rows = batch.model_extra.get("labelled_rows")
-                    if rows is not None:
-                        batch.model_extra["labelled_rows"] = rows.to(device, non_blocking=True)
-                batch_queue.put(batch)
+                batch_queue.put(to_batch(record))
     except Exception as e:  # noqa: BLE001 - forwarded to the consumer
         logger.error(f"Error in stream reader: {e}")
         batch_queue.put(e)

@@ -65,7 +65,8 @@ class PipelineSpec:
     learner: str = "streamed"          # "streamed" (StreamedLearnerStep) or "dropin" (LearnerStep + rl_step_fused_head)
     optimizer: str = "adamw"           # "adamw" | "sgd" (parity tests)
     param_dtype: str = "bf16"          # "bf16" (the reference's training dtype) | "fp32" (parity tests: tight parameter deltas)
-    mirror_jsonl: bool = False         # JSONL mirrors of `actor` and `training_data` (replay / parity tests)
+    wire: str = "full"                 # `training_data` records: "full" (the reference's expanded batch) | "compact" (ragged columns; K6 on the learner's GPU)
+    mirror_jsonl: bool = False         # JSONL mirrors of `actor` and `training_data` (replay / parity tests; compact wire: `actor` only)
     retain_streams: bool = False       # keep consumed segments of the bulk topics (isolated-stage reruns read them again)
     capture_step0: str | None = None   # directory: the learner saves step 0's micro-batches and the parameters around it
     segment_mb: int = 64
@@ -97,7 +98,7 @@ def _set_backend(spec: PipelineSpec, owner: bool = False) -> None:
     if spec.retain_streams:
         opts["trim_topics"] = ()
     if spec.mirror_jsonl:
-        opts["mirror_jsonl"] = ["actor", "training_data"]
+        opts["mirror_jsonl"] = ["actor"] if spec.wire == "compact" else ["actor", "training_data"]
     streams.set_streams_backend("shm", **opts)
 
 
@@ -226,7 +227,7 @@ def preprocessor_stage(spec: PipelineSpec) -> None:
                              seq_length=spec.budget, attempts=spec.attempts, rl=rl_config_of(spec), eos_token_id=2, chunk_n_groups=spec.chunk_n_groups,
                              max_lag=spec.lag, samples_target=spec.steps * spec.global_batch,
                              ring_buffer_size=max(128, 2 * spec.global_batch), max_ready_samples_per_lead=max(64, spec.global_batch))
-    loop = PreprocessorLoop(cfg, dev, trainer_state=state, profile=True)
+    loop = PreprocessorLoop(cfg, dev, trainer_state=state, profile=True, wire=spec.wire)
     t0 = time.perf_counter()
     n = loop.run(idle_timeout=spec.stage_timeout_s)
     wall = time.perf_counter() - t0

@@ -463,6 +463,58 @@ _PUB_RECORD_DT = np.dtype([("log", "<u8"), ("nbytes", "<u8"), ("first_piece", "<
 _PUB_PIECE_DT = np.dtype([("src", "<u8"), ("offset", "<u8"), ("nbytes", "<u8"), ("kind", "<u4"), ("_pad", "<u4")])  # prl_pub_piece
 
 
+def compact_sources(rollouts: RaggedRollouts, k5_out32: np.ndarray) -> dict:
+    """Where the compact wire gathers a chunk's columns from: base addresses of the HOST arrays of its decoded `actor` records,
+    its offsets, and the fp32 [5, S] per-sequence scalars in the order of `CompactBatch.seq_scalars` - rewards from the host record
+    (the same fp64 -> fp32 rounding the device applies) + K5's outputs (`k5_out32` rows: num_labels, overflow, advantage, group_tokens)."""
+    r = rollouts
+    scal = np.empty((5, r.n_seqs), dtype=np.float32)
+    scal[0] = r.reward.numpy().astype(np.float32)
+    scal[1], scal[2], scal[3], scal[4] = k5_out32[2], k5_out32[3], k5_out32[0], k5_out32[1]
+    ref = r.ref_logprobs if r.ref_logprobs is not None else r.logprobs  # like the pack kernel: no reference log-probs = the rollout's own
+    return dict(rollouts=r, scalars=scal, tok=r.tokens.data_ptr(), lab=r.labels.data_ptr(), lp=r.logprobs.data_ptr(), ref=ref.data_ptr(),
+                has_ref=r.ref_logprobs is not None, seq_off=r.host_seq_off, lp_off=r.host_lp_off)
+
+
+def describe_compact(members: Sequence[tuple[dict, int]], model_version: int, eos_token_id: int, inline: bytearray, pieces: list) -> int:
+    """The PRLCMP01 record of the micro-batch whose sequences are `members` = (chunk sources, index in that chunk) in packing
+    order, as a recipe for the native publisher: appends `prl_pub_piece` rows (src, offset in the record, nbytes, kind, 0) to
+    `pieces` - one PRL_PUB_FROM_HOST piece per sequence and per-token column, header and per-sequence arrays PRL_PUB_INLINE in
+    `inline` - and returns the record size.  Byte for byte `batch_codec.encode_compact(finetune.data.compact_micro_batch(...))`."""
+    from . import _lib, batch_codec
+
+    FROM_HOST, INLINE = _lib.PRL_PUB_FROM_HOST, _lib.PRL_PUB_INLINE
+    spans = [(int(hc["seq_off"][i]), int(hc["seq_off"][i + 1]), int(hc["lp_off"][i]), int(hc["lp_off"][i + 1])) for hc, i in members]
+    lens = [b - a for a, b, _, _ in spans]
+    lp_lens = [lb - la for _, _, la, lb in spans]
+    m = len(members)
+    has_ref = any(hc["has_ref"] for hc, _ in members)
+    head, base, where, total = batch_codec.compact_layout(sum(lens), sum(lp_lens), m, has_ref, model_version, 0, eos_token_id)
+    at = len(inline)
+    inline += head
+    pieces.append((at, 0, len(head), INLINE, 0))
+    for col, key, width in (("tokens", "tok", 0), ("labels", "lab", 0), ("logprobs", "lp", 2), ("ref_logprobs", "ref", 2)):
+        if col == "ref_logprobs" and not has_ref:
+            continue
+        off = base + where[col][0]
+        for (hc, _), span in zip(members, spans):
+            a, b = span[width], span[width + 1]
+            if b > a:
+                pieces.append((hc[key] + 4 * a, off, 4 * (b - a), FROM_HOST, 0))
+                off += 4 * (b - a)
+    seq_off = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(lens, out=seq_off[1:])
+    lp_off = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(lp_lens, out=lp_off[1:])
+    scal = np.ascontiguousarray(np.stack([hc["scalars"][:, i] for hc, i in members], axis=1), dtype=np.float32) if m else np.zeros((5, 0), np.float32)
+    for col, arr in (("seq_off", seq_off), ("lp_off", lp_off), ("seq_scalars", scal)):
+        if arr.nbytes:
+            at = len(inline)
+            inline += arr.tobytes()
+            pieces.append((at, base + where[col][0], arr.nbytes, INLINE, 0))
+    return total
+
+
 @dataclass
 class _Sample:
     chunk: int
@@ -484,7 +536,7 @@ class PreprocessorLoop:
     published - trainer_state.samples_processed exceeds max_ready_samples_per_lead * num_trainers."""
 
     def __init__(self, cfg: PreprocessorConfig, device, trainer_state=None, ref_model=None, oov_patcher: OovPatcher | None = None,
-                 batched_transfers: bool = True, profile: bool = False, overlap_publish: bool = True):
+                 batched_transfers: bool = True, profile: bool = False, overlap_publish: bool = True, wire: str = "full"):
         """`ref_model`: a frozen reference policy on the preprocessor's GPU.  When given, every real
         micro-batch gets its `ref_logprobs` from a no-grad forward of that model (hidden states -> MFMA head for a
         model in the Hugging Face layout, K1 on its logits otherwise)
@@ -500,8 +552,28 @@ class PreprocessorLoop:
         enters the log while chunk k + 1 is ingested, scanned (K5) and packed (K6).  The reference publishes inline
         (preprocess.py:356-367, 629-648); what a reader of `training_data` sees is the same record sequence, byte for byte.
         Off, another backend, a JSONL mirror, unpacked mode: publish inline.
+        `wire`: what a `training_data` record holds.  "full" (default) = the reference's record, the expanded
+        `PipelineBatchEncoding` (68 bytes per token: K6 runs here, the packed block comes back over the bus and into the log).
+        "compact" = the micro-batch BEFORE expansion (`batch_codec` kind PRLCMP01, 12-16 bytes per token): the ragged columns of
+        its sequences, gathered by the publisher straight from the decoded `actor` records on the host, + the five per-sequence
+        scalars (K5's outputs: 16 bytes per SEQUENCE come back from the device); K6 then runs on the learner's GPU
+        (`finetune.data.CompactBatch.to_batch`, called by `finetune_loop.run_data_loader`) and produces the identical batch.
+        Needs the shm backend, packing, seq_parallel = 1, and no stage that rewrites per-token data on this GPU (`ref_model`,
+        `oov_patcher`).
         `profile`: accumulate host wall time per phase in `self.prof` (seconds; `perf_counter` pairs, no device sync)."""
         from .streams import SingleStreamSpec, StreamRangeSpec
+
+        if wire not in ("full", "compact"):
+            raise ValueError(f"wire must be 'full' or 'compact', not {wire!r}")
+        if wire == "compact":
+            if not cfg.seq_packing or cfg.seq_parallel != 1:
+                raise ValueError("the compact wire carries packed micro-batches of one sequence-parallel rank (seq_packing=True, seq_parallel=1)")
+            if ref_model is not None or oov_patcher is not None:
+                raise ValueError("the compact wire gathers per-token data from the host records: ref_model / oov_patcher rewrite it on the device - use wire='full'")
+            if torch.device(device).type != "cuda":
+                raise RuntimeError("the preprocessor's kernels need a HIP device; there is no CPU fallback")
+        self.wire = wire
+        self.host_chunks: dict[int, dict] = {}  # compact wire: per chunk, the host arrays its records are gathered from
 
         self.cfg = cfg
         self.device = device
@@ -513,6 +585,10 @@ class PreprocessorLoop:
             # downloads (packed blocks on their way to the log) never share a slot with uploads: a host view of a published
             # drain stays valid however many chunks are ingested meanwhile
             self.down_stager = PinnedStager(device, slots=2)
+        if self.wire == "compact" and self.down_stager is None:
+            from .staging import PinnedStager
+
+            self.down_stager = PinnedStager(device, slots=2)  # K5's per-sequence outputs come back through it
         self.prof: dict[str, float] | None = {} if profile else None
         self._kernel_events: list = []
         self.overlap_publish = bool(overlap_publish) and self.stager is not None
@@ -629,6 +705,10 @@ class PreprocessorLoop:
         cid = self._next_chunk
         self._next_chunk += 1
         self.chunks[cid] = prep
+        if self.wire == "compact":
+            if host.tokens.is_cuda:
+                raise RuntimeError("compact wire: the chunk's rollouts must arrive as host records")
+            self.host_chunks[cid] = {"rollouts": host, "scalars": None}
         lens = prep.rollouts.seq_lengths()
         versions = prep.rollouts.host_model_version
         self.buffer.extend(_Sample(cid, i, int(lens[i]), int(versions[i])) for i in range(len(lens)) if keep[i])
@@ -646,6 +726,12 @@ class PreprocessorLoop:
         t = self._tick("schedule", t)
         packed: Any = None
         merged = base = None
+        if self.wire == "compact":
+            self._submit_compact(mbs)
+            t = self._tick("publish_submit", t)
+            self._prune_chunks()
+            self._tick("schedule", t)
+            return done
         if real:
             used = sorted({s.chunk for mb in real for s in mb.samples})
             merged = concat_prepared([self.chunks[c] for c in used])
@@ -765,6 +851,51 @@ class PreprocessorLoop:
         while self._pub_inflight and self._pub_inflight[0][0] <= done.value:
             self._pub_inflight.popleft()  # its block goes back to the allocator
 
+    def _chunk_sources(self, cid: int) -> dict:
+        """Compact wire: a chunk's gather sources, built the first time a micro-batch needs the chunk - K5's four outputs come back
+        in ONE small device -> host copy (16 bytes per sequence)."""
+        hc = self.host_chunks[cid]
+        if hc["scalars"] is None:
+            k5 = self.down_stager.download(self.chunks[cid].k5_out32).numpy()  # rows: num_labels, overflow, advantage, group_tokens
+            hc.update(compact_sources(hc["rollouts"], k5))
+        return hc
+
+    def _submit_compact(self, mbs: list) -> None:
+        """One drain on the compact wire: per micro-batch a PRLCMP01 record whose per-token columns the publisher copies from
+        the chunks' host arrays (PRL_PUB_FROM_HOST pieces, one per sequence and column), header and per-sequence arrays inline."""
+        import ctypes
+
+        from . import _lib, batch_codec
+        from .finetune.utils import create_sentinel_batch
+
+        if not mbs:
+            return
+        lib = _lib.load()
+        inline = bytearray()
+        recs, pieces, keep = [], [], []
+        for mb in mbs:
+            first = len(pieces)
+            if mb.sentinel:
+                s_batch = create_sentinel_batch(None, tokenizer=type("T", (), {"eos_token_id": self.cfg.eos_token_id})(), model_version=self.max_model_version)
+                nbytes, ps = batch_codec.describe_batch(s_batch, 0, 0, inline)
+                pieces += [(src, off, nb, kind, 0) for kind, src, off, nb in ps]
+            else:
+                members = [(self._chunk_sources(s.chunk), s.index) for s in mb.samples]
+                nbytes = describe_compact(members, min(s.model_version for s in mb.samples), self.cfg.eos_token_id, inline, pieces)
+                keep += [hc["rollouts"] for hc, _ in members]
+            recs.append((self._pub_logs[mb.trainer_id], nbytes, first, len(pieces) - first))
+        rec_arr = np.array(recs, dtype=_PUB_RECORD_DT)
+        piece_arr = np.array(pieces, dtype=_PUB_PIECE_DT)
+        inline_c = (ctypes.c_char * len(inline)).from_buffer(inline) if inline else None
+        ticket = ctypes.c_uint64()
+        _lib.check(lib.prl_publisher_submit(self._pub, None, 0, None, rec_arr.ctypes.data, len(recs), piece_arr.ctypes.data, len(pieces),
+                                            inline_c, len(inline), ctypes.byref(ticket)))
+        self._pub_inflight.append((ticket.value, keep, None))  # the host arrays stay alive until the publisher has copied them
+        done = ctypes.c_uint64()
+        _lib.check(lib.prl_publisher_completed(self._pub, ctypes.byref(done)))
+        while self._pub_inflight and self._pub_inflight[0][0] <= done.value:
+            self._pub_inflight.popleft()
+
     def _start_publisher(self, writer) -> None:
         """The native publisher appends through the partition writers' own log handles; anything it cannot serve - another
         backend, a JSONL mirror that wants every record as text too - keeps the inline path."""
@@ -808,6 +939,7 @@ class PreprocessorLoop:
         alive = {s.chunk for s in self.ring.entries} | {s.chunk for s in self.sched._current} | {s.chunk for s in self.buffer}
         for c in [c for c in self.chunks if c not in alive]:
             del self.chunks[c]
+            self.host_chunks.pop(c, None)
 
     def _maybe_write_stats(self, stats_writer, batch_done: bool, raw_queue_chunks: int) -> None:
         pub = self.sched.published_samples
@@ -835,8 +967,10 @@ class PreprocessorLoop:
         start = self.sched.published_samples
         self._t_run = time.perf_counter()
         with write_to_streams(self.out_spec) as writer, write_to_streams(self.stats_spec) as stats_writer:
-            if self.overlap_publish and cfg.seq_packing:
+            if (self.overlap_publish and cfg.seq_packing) or self.wire == "compact":
                 self._start_publisher(writer)
+                if self.wire == "compact" and self._pub is None:
+                    raise ValueError("the compact wire is written by the native publisher: it needs `backend: shm` partitions without a JSONL mirror")
             try:
                 self._run_loop(raw_q, writer, stats_writer, start, max_published_samples, idle_timeout)
             finally:

@@ -28,7 +28,7 @@ print({k: e.get(k) for k in ("s_per_step", "samples_per_s", "peak_memory_GB", "s
 print({k: round(v["avg_us"], 1) for k, v in d["kernels"].items()})
 p = d.get("preprocess_loop") or {}
 for k, c in (p.get("cases") or {}).items():
-    print(" pre", k, round(c["us_per_token"], 4), "us/tok planning", round(c["host_planning_frac"], 3))
+    print(" pre", k, round(c["us_per_token"], 4), "us/tok planning", round(c["host_planning_frac"], 3), "consumer", {a: round(b, 4) for a, b in (c.get("consumer") or {}).items() if isinstance(b, float)})
 print(" pre speedup", p.get("speedup_vs_reference_preprocess_plus_collate"), "ref_logprob", {k: (round(v["old_ms"], 2), round(v["fused_ms"], 2)) for k, v in ((d.get("ref_logprob") or {}).get("heads") or {}).items()})
 print(" cpu_baseline", d["cpu_baseline"]["kind"], d["cpu_baseline"]["value"], "port", (d["cpu_baseline"].get("port") or {}).get("value"), "cores", d["cpu_baseline"]["cores"])
 pl = d.get("pipeline") or {}

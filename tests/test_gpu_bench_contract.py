@@ -59,6 +59,10 @@ def test_bench_json_contract(libprl, cuda_device):
     assert fast["tokens_per_s"] > text["tokens_per_s"] > 0 and fast["published_samples"] == slow["published_samples"]
     assert fast["transfers_per_chunk"]["h2d"] <= 2.5 and fast["transfers_per_chunk"]["d2h"] <= 1.5  # one upload per chunk + one K6 plan, one download
     assert {"K5", "K6"} <= set(fast["kernel_us_per_chunk"]) and 0 < fast["host_planning_frac"] < 1
+    cmp = p["cases"]["PRLROL01_to_shm_1_trainer_compact_wire"]  # the micro-batch before expansion on the wire; K6 in the learner's loader
+    assert cmp["published_samples"] == fast["published_samples"] and "K6" not in cmp["kernel_us_per_chunk"]
+    assert cmp["consumer"]["tokens"] == fast["consumer"]["tokens"] > 0
+    assert cmp["consumer"]["log_bytes_per_token"] < 20 < 60 < fast["consumer"]["log_bytes_per_token"] < 80
     q = d["ref_logprob"]  # reference-policy head: stock GEMM + [T, V] logits + K1 vs the MFMA head
     assert "error" not in q, q
     for name, h in q["heads"].items():

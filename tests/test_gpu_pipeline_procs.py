@@ -40,8 +40,10 @@ def _first_fit(lengths, seq_length, quota):
     return out
 
 
-@pytest.mark.parametrize("learner", ["streamed", "dropin"])
+@pytest.mark.parametrize("learner", ["streamed", "dropin", "streamed+compact_wire"])
 def test_four_process_pipeline_and_step0_vs_oracle(libprl, cuda_device, tmp_path, learner):
+    learner, _, wire = learner.partition("+")
+    wire = "compact" if wire else "full"  # compact: the pack kernel runs in the LEARNER's loader; step 0 must still be the oracle's
     from oracle import preprocess as opre
     from oracle import rl_loss_torch as orlt
     from pipelinerl_amd.finetune.rl.utils import aggregate_rl_stats
@@ -51,7 +53,7 @@ def test_four_process_pipeline_and_step0_vs_oracle(libprl, cuda_device, tmp_path
     bs, seq, lr = 16, 128, 0.05
     spec = PipelineSpec(exp_path=str(exp), model="tiny", global_batch=bs, seq_length=seq, attempts=4, steps=3, optimizer="sgd", lr=lr,
                         param_dtype="fp32", mirror_jsonl=True, capture_step0=str(cap), n_problems=5, concurrent_groups=2,
-                        stage_timeout_s=600.0, learner=learner, engine_load=True)
+                        stage_timeout_s=600.0, learner=learner, engine_load=True, wire=wire)
     res = run_pipeline(spec)
     assert "error" not in res, json.dumps(res.get("error"), indent=1)[:4000]
     s, st = res["summary"], res["stages"]
