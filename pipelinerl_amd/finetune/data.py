@@ -341,23 +341,39 @@ class CompactBatch:
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("a compact micro-batch is expanded by the pack kernel: it needs a HIP device; there is no CPU fallback")
-        m = self.n_seqs
-        cols = [self.tokens, self.labels, self.logprobs, self.ref_logprobs, self.seq_off, self.lp_off, self.seq_scalars]
+        m, n = self.n_seqs, self.n_tokens
+        seq_off = np.ascontiguousarray(self.seq_off, dtype=np.int64)
+        # the launch plan of ONE micro-batch whose sequences already lie in packing order: source = segment = 0 .. m - 1, destination
+        # offsets = the sequence offsets themselves - it rides along with the columns (one copy), nothing is planned
+        order = np.arange(m, dtype=np.int32)
+        cols = [self.tokens, self.labels, self.logprobs, self.ref_logprobs, seq_off, self.lp_off, self.seq_scalars, order]
         if stager is not None:
             up = stager.upload(cols)
         else:
             up = [None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True) for a in cols]
-        tokens, labels, lp, ref, seq_off, lp_off, sc = up
-        none = torch.empty(0, device=dev)
-        rag = RaggedRollouts(
-            tokens=tokens, labels=labels, logprobs=lp, ref_logprobs=ref, seq_off=seq_off, lp_off=lp_off, reward=none, group_index=none,
-            step_index=none, rollout_index=none, model_version=none, finished=none, finish_code=none,
-            host_seq_off=np.asarray(self.seq_off, dtype=np.int64), host_lp_off=np.asarray(self.lp_off, dtype=np.int64),
-            host_model_version=np.full(m, int(self.model_version), dtype=np.int64),
-        )
-        prep = PreparedRollouts(rollouts=rag, reward32=sc[0], advantage=sc[1], group_tokens=sc[2], num_labels=sc[3], overflow=sc[4],
-                                advantage64=none, group_tokens64=none)
-        return pack_prepared(prep, [range(m)], self.eos_token_id, sentinel_pad=[int(self.padding)] if self.padding else None, stager=stager)[0]
+        tokens, labels, lp, ref, d_off, lp_off, sc, d_order = up
+        if self.padding:  # sequence-parallel filler: the general planner knows how to append it
+            none = torch.empty(0, device=dev)
+            rag = RaggedRollouts(
+                tokens=tokens, labels=labels, logprobs=lp, ref_logprobs=ref, seq_off=d_off, lp_off=lp_off, reward=none, group_index=none,
+                step_index=none, rollout_index=none, model_version=none, finished=none, finish_code=none,
+                host_seq_off=seq_off, host_lp_off=np.asarray(self.lp_off, dtype=np.int64), host_model_version=np.full(m, int(self.model_version), dtype=np.int64),
+            )
+            prep = PreparedRollouts(rollouts=rag, reward32=sc[0], advantage=sc[1], group_tokens=sc[2], num_labels=sc[3], overflow=sc[4],
+                                    advantage64=none, group_tokens64=none)
+            return pack_prepared(prep, [range(m)], self.eos_token_id, sentinel_pad=[int(self.padding)], stager=stager)[0]
+        out = _alloc_outputs(n, dev, packed=True)
+        out.pop("__block__")
+        if m and n:
+            p = _lib.ptr
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().prl_pack_collate(
+                    m, n, p(d_order), p(d_off), p(d_order), p(tokens), p(labels), p(lp), p(ref), p(d_off), p(lp_off), p(sc[0]), p(sc[1]), p(sc[2]),
+                    p(sc[3]), p(sc[4]), 0, int(self.eos_token_id), p(out["input_ids"]), p(out["labels"]), p(out["attention_mask"]), p(out["position_ids"]),
+                    p(out["segment_ids"]), p(out["rewards"]), p(out["advantages"]), p(out["ref_logprobs"]), p(out["old_logprobs"]), p(out["group_tokens"]),
+                    p(out["num_labels"]), p(out["overflow"]), _lib.current_stream_ptr(dev)))
+        return PipelineBatchEncoding(**{k: v.unsqueeze(0) for k, v in out.items()}, model_version=int(self.model_version), is_packed=True,
+                                     seq_boundaries=torch.from_numpy(seq_off.astype(np.int32)), padding=0)
 
 
 def compact_micro_batch(host_chunks: Sequence[RaggedRollouts], seq_scalars: Sequence[np.ndarray], members: Sequence[tuple[int, int]],
