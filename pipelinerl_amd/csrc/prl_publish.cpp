@@ -211,7 +211,11 @@ extern "C" int prl_publisher_create(int32_t device, prl_publisher** out) {
   prl_publisher* p = new (std::nothrow) prl_publisher();
   if (!p) return prl::set_error(PRL_ENOMEM, "out of memory");
   p->device = device;
-  p->th = new (std::nothrow) std::thread([p] { p->run(); });
+  try {  // std::thread reports a failed start by throwing: nothing may unwind through the C boundary
+    p->th = new std::thread([p] { p->run(); });
+  } catch (...) {
+    p->th = nullptr;
+  }
   if (!p->th) {
     delete p;
     return prl::set_error(PRL_ENOMEM, "cannot start the publisher thread");
