@@ -100,14 +100,21 @@ class FusedLmHead:
         src = w.detach()
         if not src.is_contiguous():
             src = src.contiguous()
-        plane = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dev)  # noqa: E731
+
+        def plane(old, *shape):
+            """A plane buffer is REUSED across refreshes (same address: launches captured in a HIP graph keep reading the right
+            memory after an optimizer step, and a step does not re-allocate 2-4 planes of V x H)."""
+            if old is not None and tuple(old.shape) == shape and old.device == dev and old.dtype == torch.bfloat16 and old.data_ptr() != src.data_ptr():
+                return old
+            return torch.empty(shape, dtype=torch.bfloat16, device=dev)
+
         if w.dtype == torch.bfloat16:  # a bf16 weight (tied embedding) is its own exact plane
             self.w_hi, self.w_lo = src, None
-            self.wt_hi, self.wt_lo = (plane(H, V) if self.backward else None), None
+            self.wt_hi, self.wt_lo = (plane(self.wt_hi, H, V) if self.backward else None), None
             outs = (None, None, self.wt_hi, None)
         else:
-            self.w_hi, self.w_lo = plane(V, H), plane(V, H)
-            self.wt_hi, self.wt_lo = (plane(H, V), plane(H, V)) if self.backward else (None, None)
+            self.w_hi, self.w_lo = plane(self.w_hi, V, H), plane(self.w_lo, V, H)
+            self.wt_hi, self.wt_lo = (plane(self.wt_hi, H, V), plane(self.wt_lo, H, V)) if self.backward else (None, None)
             outs = (self.w_hi, self.w_lo, self.wt_hi, self.wt_lo)
         if any(o is not None for o in outs):
             with torch.cuda.device(dev):
