@@ -407,7 +407,7 @@ class WeightUpdateManager:
     def send_weight_update(self, version: int) -> None:
         """Blocking; every trainer rank calls it (gathering sharded parameters is a collective among
         them), rank 0 sends."""
-        from .weight_sync import BucketedSender, ParamSpec, bucket_nbytes, plan_buckets
+        from .weight_sync import BucketedSender, ParamSpec, plan_buckets
 
         src = self.source
         if isinstance(src, FsdpParameters):

@@ -71,6 +71,7 @@ class PipelineSpec:
     capture_step0: str | None = None   # directory: the learner saves step 0's micro-batches and the parameters around it
     segment_mb: int = 64
     stage_timeout_s: float = 900.0
+    stacks_after_s: float = 0.0        # diagnosis: every stage still alive after this many seconds dumps its threads' Python stacks
     device: int = 0
     extra: dict = field(default_factory=dict)
 
@@ -102,6 +103,15 @@ def _set_backend(spec: PipelineSpec, owner: bool = False) -> None:
     streams.set_streams_backend("shm", **opts)
 
 
+def _trace(spec: PipelineSpec, stage: str, what: str) -> None:
+    """Start-up milestones of a stage, appended to `<exp>/reports/<stage>.trace` (a run that times out before any stage has
+    reported says where each stage was)."""
+    d = Path(spec.exp_path) / "reports"
+    d.mkdir(parents=True, exist_ok=True)
+    with open(d / f"{stage}.trace", "a") as f:
+        f.write(f"{time.time():.3f} {what}\n")
+
+
 def _report(spec: PipelineSpec, stage: str, data: dict) -> None:
     d = Path(spec.exp_path) / "reports"
     d.mkdir(parents=True, exist_ok=True)
@@ -116,6 +126,13 @@ def _stage(fn):
     def main(spec_dict: dict) -> None:
         spec = PipelineSpec(**spec_dict)
         logging.basicConfig(level=os.environ.get("PRL_PIPELINE_LOG", "WARNING"), format=f"%(asctime)s {fn.__name__} %(levelname)s %(message)s")
+        name = fn.__name__.replace("_stage", "")
+        if spec.stacks_after_s:  # a stage that is still running then leaves the Python stacks of all its threads behind
+            import faulthandler
+
+            d = Path(spec.exp_path) / "reports"
+            d.mkdir(parents=True, exist_ok=True)
+            faulthandler.dump_traceback_later(spec.stacks_after_s, repeat=False, file=open(d / f"{name}.stacks", "w"), exit=False)
         try:
             fn(spec)
         except BaseException:  # noqa: BLE001 - the orchestrator reads it
@@ -251,7 +268,6 @@ def preprocessor_stage(spec: PipelineSpec) -> None:
 
 @_stage
 def engine_stage(spec: PipelineSpec) -> None:
-    import asyncio  # noqa: F401 - the manager's loop lives in UpdateServer
     import torch
 
     from .engine_update import InflightUpdateManager, ScriptedEngine, UpdateServer
@@ -261,7 +277,9 @@ def engine_stage(spec: PipelineSpec) -> None:
     _set_backend(spec)
     dev = torch.device("cuda", spec.device)
     torch.cuda.set_device(dev)
+    _trace(spec, "engine", "building the policy")
     model = build_policy(spec, dev, seed=spec.seed + 999)  # different values than the trainer's: an update must really land
+    _trace(spec, "engine", "policy built")
     model.eval()
     for p in model.parameters():
         p.requires_grad_(False)
@@ -279,6 +297,7 @@ def engine_stage(spec: PipelineSpec) -> None:
     server = UpdateServer(manager)
     (Path(spec.exp_path) / "reports").mkdir(parents=True, exist_ok=True)
     (Path(spec.exp_path) / "reports" / "engine_url.txt").write_text(server.url)
+    _trace(spec, "engine", "serving " + server.url)
     state = TrainerState(Path(spec.exp_path))
     state.start_listening()
     t0 = time.perf_counter()
@@ -315,7 +334,9 @@ def learner_stage(spec: PipelineSpec) -> None:
     dev = torch.device("cuda", spec.device)
     torch.cuda.set_device(dev)
     t_init = time.perf_counter()
+    _trace(spec, "learner", "building the policy")
     model = build_policy(spec, dev, seed=spec.seed)
+    _trace(spec, "learner", "policy built")
     install_fused_head(model)
     if spec.gradient_checkpointing:
         model.gradient_checkpointing_enable()
@@ -330,10 +351,12 @@ def learner_stage(spec: PipelineSpec) -> None:
             raise TimeoutError("the engine never announced its url")
         time.sleep(0.05)
     url = url_file.read_text().strip()
+    _trace(spec, "learner", "engine found at " + url)
     topic = streams.SingleStreamSpec(exp_path=Path(spec.exp_path), topic=TRAINER_TOPIC)
     mgr = WeightUpdateManager(llm_urls=[url], accelerated_model=model, update_stream=topic, actor_update_group=None, transport="ipc")
     mgr._sender = ColocatedSender(dev, mgr.bucket_bytes)
     mgr._sender.rehome(model.named_parameters())  # the parameters LIVE in the exported buckets: publishing an update copies nothing
+    _trace(spec, "learner", "parameters rehomed into the exported buckets")
     if spec.optimizer == "sgd":
         opt = torch.optim.SGD(model.parameters(), lr=spec.lr)
     else:
@@ -365,8 +388,10 @@ def learner_stage(spec: PipelineSpec) -> None:
     step.publish(SamplesProcessed(samples_processed=step.metrics.samples))
     sync_ms: list[float] = []
     t0 = time.perf_counter()
+    _trace(spec, "learner", "sending weight version 0")
     mgr.send_weight_update(step.metrics.samples)
     first_sync_ms = 1e3 * (time.perf_counter() - t0)
+    _trace(spec, "learner", f"weight version 0 acknowledged after {first_sync_ms:.0f} ms")
     probes = {str(step.metrics.samples): _param_probe(model.named_parameters())}
 
     q: queue.Queue = queue.Queue(maxsize=8)
@@ -515,7 +540,17 @@ def run_pipeline(spec: PipelineSpec, timeout_s: float | None = None) -> dict:
     errors = {n: r["error"] for n, r in reports.items() if "error" in r}
     out: dict[str, Any] = {"spec": {k: v for k, v in asdict(spec).items() if k not in ("extra",)}, "wall_s_incl_start_up": wall, "stages": reports}
     if failed or timed_out or errors:
-        out["error"] = {"failed_stage": failed, "timed_out": timed_out, "stage_errors": {n: e[-1500:] for n, e in errors.items()}}
+        traces = {}
+        for name in STAGES:
+            f = exp / "reports" / f"{name}.trace"
+            if f.exists():
+                lines = f.read_text().splitlines()
+                t0 = float(lines[0].split()[0]) if lines else 0.0
+                traces[name] = [f"+{float(x.split()[0]) - t0:.1f}s {' '.join(x.split()[1:])}" for x in lines]
+        stacks = {n: (exp / "reports" / f"{n}.stacks").read_text()[-6000:] for n in STAGES if (exp / "reports" / f"{n}.stacks").exists()
+                  and (exp / "reports" / f"{n}.stacks").stat().st_size}
+        out["error"] = {"failed_stage": failed, "timed_out": timed_out, "stage_errors": {n: e[-1500:] for n, e in errors.items()}, "start_up_traces": traces,
+                        "stacks": stacks}
         return out
     out["summary"] = summarize(spec, reports)
     return out

@@ -716,8 +716,7 @@ class PreprocessorLoop:
 
     def _publish(self, writer) -> bool:
         """Drain the scheduler once and write what it emitted.  Returns batch_done."""
-        from .finetune.data import pack_prepared, pad_prepared
-        from .finetune.utils import create_sentinel_batch
+        from .finetune.data import pack_prepared
 
         t = time.perf_counter()
         sp = self.cfg.seq_parallel

@@ -72,6 +72,43 @@ def bucket_nbytes(bucket: Sequence[tuple[ParamSpec, int]]) -> int:
     return off + _align(sp.nbytes)
 
 
+# `hipIpcOpenMemHandle` never returns for an allocation of 2 GiB or more on this stack (ROCm 7.0 / dmabuf IPC; measured with
+# scripts/exp/ipc_large_allocation_probe.py: 1.9 GiB opens in 0.2 ms, 2.0 GiB and above not within 40 s - the 7B-shaped
+# pipeline, whose fp32 output head is ONE 2.18 GB tensor, stalled there).  No exported bucket may reach it.
+IPC_MAX_ALLOCATION = (1 << 31) - (1 << 20)
+_ROWS = "#rows"
+
+
+def split_for_ipc(specs: Sequence[ParamSpec], piece_bytes: int = DEFAULT_BUCKET_BYTES, max_allocation: int = IPC_MAX_ALLOCATION) -> list[ParamSpec]:
+    """The parameter list of the HIP-IPC transport: a tensor too large for ONE exportable allocation becomes consecutive row
+    ranges, pseudo-parameters named `<name>#rows<a>:<b>` of at most `piece_bytes` each (every other tensor is itself).  Sender
+    and receiver derive the same list from `parameters_info`, so nothing about it travels."""
+    out: list[ParamSpec] = []
+    for sp in specs:
+        if _align(sp.nbytes) < max_allocation:
+            out.append(sp)
+            continue
+        rows = sp.shape[0] if sp.shape else 0
+        row_bytes = sp.nbytes // rows if rows else 0
+        if rows < 2 or _align(row_bytes) >= max_allocation:
+            raise ValueError(f"{sp.name}: {sp.nbytes} bytes cannot be exported over HIP IPC (allocations stay below {max_allocation} bytes) "
+                             "and has no leading dimension to cut")
+        per = max(1, min(piece_bytes, max_allocation - 256) // row_bytes)
+        for a in range(0, rows, per):
+            b = min(rows, a + per)
+            out.append(ParamSpec(f"{sp.name}{_ROWS}{a}:{b}", (b - a,) + tuple(sp.shape[1:]), sp.dtype))
+    return out
+
+
+def rows_piece(name: str) -> tuple[str, int, int] | None:
+    """`<name>#rows<a>:<b>` -> (name, a, b); any other name -> None."""
+    base, sep, rng = name.rpartition(_ROWS)
+    if not sep or ":" not in rng:
+        return None
+    a, _, b = rng.partition(":")
+    return (base, int(a), int(b)) if a.isdigit() and b.isdigit() else None
+
+
 def plan_shard_buckets(specs: Sequence[ParamSpec], shards: dict, tp_rank: int, tp_size: int,
                        bucket_bytes: int = DEFAULT_BUCKET_BYTES):
     """Bucket plan of the TP-aware update, derived identically by the trainer (for every TP rank) and by each worker
@@ -547,15 +584,32 @@ class ColocatedSender:
     """Trainer side when the inference worker lives on the same GPU: flatten the parameters into
     IPC-exportable device buckets and describe them; nothing travels over any link."""
 
-    def __init__(self, device: torch.device, bucket_bytes: int = DEFAULT_BUCKET_BYTES):
+    def __init__(self, device: torch.device, bucket_bytes: int = DEFAULT_BUCKET_BYTES, max_allocation: int = IPC_MAX_ALLOCATION):
         self.device = device
         self.bucket_bytes = bucket_bytes
+        self.max_allocation = int(max_allocation)
         self._buckets: list[DeviceBucket] = []
+
+    def _pieces(self, params: list[tuple[str, torch.Tensor]]) -> list[tuple[str, torch.Tensor]]:
+        """`params` with every tensor too large for one exportable allocation replaced by views of its row ranges (`split_for_ipc`)."""
+        tensors = dict(params)
+        out = []
+        for sp in split_for_ipc([ParamSpec(n, tuple(p.shape), p.dtype) for n, p in params], self.bucket_bytes, self.max_allocation):
+            piece = rows_piece(sp.name)
+            if piece is not None and sp.name not in tensors:
+                base, a, b = piece
+                t = tensors[base]
+                out.append((sp.name, (t if t.is_contiguous() else t.contiguous())[a:b]))
+            else:
+                out.append((sp.name, tensors[sp.name]))
+        return out
 
     def _ensure_buckets(self, params: list[tuple[str, torch.Tensor]]):
         specs = [ParamSpec(n, tuple(p.shape), p.dtype) for n, p in params]
         plan = plan_buckets(specs, self.bucket_bytes)
         sizes = [bucket_nbytes(b) for b in plan]
+        if any(n >= self.max_allocation for n in sizes):
+            raise ValueError(f"an IPC bucket of {max(sizes)} bytes: allocations of {self.max_allocation} bytes or more cannot be opened by the peer")
         if [b.nbytes for b in self._buckets] != sizes:
             for b in self._buckets:
                 b.free()
@@ -567,11 +621,13 @@ class ColocatedSender:
         every later `publish` is zero-copy: the optimizer updates the shared memory in place.
         Call once after the model is built (before optimizer state captures `p.data` pointers)."""
         params = list(named_parameters)
-        plan, _ = self._ensure_buckets([(n, p.data) for n, p in params])
+        plan, _ = self._ensure_buckets(self._pieces([(n, p.data) for n, p in params]))
         by_name = dict(params)
         for bucket, dev_bucket in zip(plan, self._buckets):
             buf = dev_bucket.tensor()
             for sp, off in bucket:
+                if sp.name not in by_name:
+                    continue  # a row range of a tensor too large for one allocation: it stays where it is and is copied per update
                 view = buf[off : off + sp.nbytes].view(sp.dtype).view(sp.shape)
                 view.copy_(by_name[sp.name].data)
                 by_name[sp.name].data = view
@@ -581,7 +637,7 @@ class ColocatedSender:
         """Returns {"ipc_handles": [hex...], "ipc_nbytes": [...]} for the update request; the buckets
         are complete (device-synchronised) when this returns.  Parameters that already live in their
         bucket slot (`rehome`) are not copied."""
-        params = [(n, p.detach()) for n, p in named_parameters]
+        params = self._pieces([(n, p.detach()) for n, p in named_parameters])
         plan, sizes = self._ensure_buckets(params)
         tensors = dict(params)
         for bucket, dev_bucket in zip(plan, self._buckets):
@@ -603,9 +659,10 @@ class ColocatedReceiver:
     """Worker side: map the trainer's buckets (once per handle) and hand (name, view) pairs to
     `load_weights`, which copies them into the engine's own weights device-to-device."""
 
-    def __init__(self, device: torch.device, bucket_bytes: int = DEFAULT_BUCKET_BYTES):
+    def __init__(self, device: torch.device, bucket_bytes: int = DEFAULT_BUCKET_BYTES, max_allocation: int = IPC_MAX_ALLOCATION):
         self.device = device
         self.bucket_bytes = bucket_bytes
+        self.max_allocation = int(max_allocation)
         self._mapped: dict[str, MappedBucket] = {}
 
     def receive(self, parameters_info: Sequence[dict | ParamSpec], ipc_handles: Sequence[str], ipc_nbytes: Sequence[int],
@@ -615,17 +672,46 @@ class ColocatedReceiver:
             p if isinstance(p, ParamSpec) else ParamSpec(p["name"], tuple(p["shape"]), string_to_dtype(p["dtype"]))
             for p in parameters_info
         ]
+        full = {sp.name: sp for sp in specs}
+        specs = split_for_ipc(specs, self.bucket_bytes, self.max_allocation)
         plan = plan_buckets(specs, self.bucket_bytes)
         if len(plan) != len(ipc_handles):
             raise ValueError(f"{len(ipc_handles)} IPC buckets announced, the parameter list implies {len(plan)}")
+        # row ranges of a tensor that travelled in pieces: straight into the rows of its destination when one is registered,
+        # otherwise collected and handed to `load_weights` as ONE tensor once every piece is there
+        pieces = {sp.name: rows_piece(sp.name) for sp in specs if sp.name not in full}
+        dest = dict(destinations or {})
+        for name, (base, a, b) in pieces.items():
+            d = (destinations or {}).get(base)
+            if d is not None and d.dtype == full[base].dtype and tuple(d.shape) == tuple(full[base].shape) and d.is_contiguous():
+                dest[name] = d[a:b]
+        parts: dict[str, list] = {}
+
+        def deliver_views(views):
+            whole = []
+            for name, v in views:
+                if name in pieces:
+                    base, a, _ = pieces[name]
+                    parts.setdefault(base, []).append((a, v))
+                else:
+                    whole.append((name, v))
+            if whole:
+                if load_weights is None:
+                    raise ValueError(f"no destination registered for {[n for n, _ in whole][:4]}... and no load_weights callback")
+                load_weights(whole)
+
         n = 0
         for bucket, hx, nb in zip(plan, ipc_handles, ipc_nbytes):
             mapped = self._mapped.get(hx)
             if mapped is None:
                 mapped = self._mapped[hx] = MappedBucket(bytes.fromhex(hx), nb, self.device)
-            n += _deliver(mapped.tensor(), bucket, load_weights, destinations)
+            n += _deliver(mapped.tensor(), bucket, deliver_views, dest)
+        for base, got in parts.items():
+            if load_weights is None:
+                raise ValueError(f"no destination registered for {base} and no load_weights callback")
+            load_weights([(base, torch.cat([v for _, v in sorted(got, key=lambda x: x[0])]))])
         torch.cuda.synchronize(self.device)  # the trainer may overwrite the buckets after the ack
-        return n
+        return n - len(pieces) + len({p[0] for p in pieces.values()})
 
     def close(self) -> None:
         for m in self._mapped.values():

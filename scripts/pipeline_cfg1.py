@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--gradient-checkpointing", action="store_true")
     ap.add_argument("--learner", default="streamed", choices=["streamed", "dropin"])
     ap.add_argument("--wire", default="full", choices=["full", "compact"], help="training_data records: the expanded batch, or the ragged columns (K6 on the learner's GPU)")
+    ap.add_argument("--stacks-after", type=float, default=0.0, help="diagnosis: stages still alive after this many seconds dump their Python stacks")
     ap.add_argument("--timeout", type=float, default=900.0)
     ap.add_argument("--exp-path", default=None)
     ap.add_argument("--out", default=None)
@@ -38,7 +39,7 @@ def main():
     exp = a.exp_path or tempfile.mkdtemp(prefix="prl_pipeline_")
     spec = PipelineSpec(exp_path=exp, model=a.model, global_batch=a.global_batch, seq_length=a.seq_length, pack_budget=a.pack_budget, attempts=a.attempts, steps=a.steps,
                         max_lag=a.max_lag, weight_update_interval=a.weight_update_interval, dense=a.dense, engine_load=a.engine_load,
-                        gradient_checkpointing=a.gradient_checkpointing, learner=a.learner, wire=a.wire, stage_timeout_s=a.timeout)
+                        gradient_checkpointing=a.gradient_checkpointing, learner=a.learner, wire=a.wire, stage_timeout_s=a.timeout, stacks_after_s=a.stacks_after)
     res = run_pipeline(spec)
     line = json.dumps(res)
     print(line)

@@ -78,3 +78,65 @@ def test_colocated_ipc_weight_update(cuda_device):
         proc.join(timeout=60)
         if proc.is_alive():
             proc.kill()
+
+
+def _cut_worker(req_q, ack_q, bucket_bytes, max_allocation):
+    import torch
+
+    from pipelinerl_amd.weight_sync import ColocatedReceiver, ParamSpec
+
+    device = torch.device("cuda:0")
+    torch.cuda.set_device(device)
+    rx = ColocatedReceiver(device, bucket_bytes, max_allocation)
+    ack_q.put("ready")
+    while True:
+        msg = req_q.get()
+        if msg is None:
+            break
+        info = [ParamSpec(n, tuple(s), getattr(torch, dt)) for n, s, dt in msg["info"]]
+        # `big.direct` has a registered destination (its row ranges are scattered straight into it), `big.loaded` comes back whole
+        dest = {n: torch.zeros(tuple(s), dtype=getattr(torch, dt), device=device) for n, s, dt in msg["info"] if n in ("big.direct", "small")}
+        loaded = {}
+        n = rx.receive(info, msg["handles"], msg["nbytes"], lambda views: loaded.update({k: v.clone() for k, v in views}), dest)
+        out = {k: v.double().sum().item() for k, v in {**dest, **loaded}.items()}
+        ack_q.put((n, out, sorted(loaded)))
+    rx.close()
+
+
+def test_ipc_hand_off_of_tensors_cut_into_row_ranges(cuda_device):
+    """Tensors too large for one exportable allocation (`weight_sync.IPC_MAX_ALLOCATION`; small limits here) cross in row ranges:
+    the sender keeps such a tensor where it is and copies its ranges per update, every other parameter is rehomed; the receiver
+    scatters ranges into a registered destination or reassembles the tensor for `load_weights`."""
+    from pipelinerl_amd.weight_sync import ColocatedSender
+
+    bucket_bytes, max_allocation = 4096, 8192
+    g = torch.Generator(device="cpu").manual_seed(3)
+    params = [(n, torch.nn.Parameter(torch.randn(s, generator=g).to(dt).to(cuda_device), requires_grad=False)) for n, s, dt in
+              (("small", (7, 9), torch.float32), ("big.direct", (300, 16), torch.float32), ("mid", (40, 8), torch.bfloat16), ("big.loaded", (257, 24), torch.bfloat16))]
+    ctx = mp.get_context("spawn")
+    req_q, ack_q = ctx.Queue(), ctx.Queue()
+    proc = ctx.Process(target=_cut_worker, args=(req_q, ack_q, bucket_bytes, max_allocation), daemon=True)
+    proc.start()
+    tx = ColocatedSender(cuda_device, bucket_bytes, max_allocation)
+    try:
+        assert ack_q.get(timeout=300) == "ready"
+        before = {n: p.data_ptr() for n, p in params}
+        tx.rehome(params)
+        moved = {n for n, p in params if p.data_ptr() != before[n]}
+        assert moved == {"small", "mid"}, "the two tensors that fit were rehomed, the cut ones stay where they are"
+        for version in range(2):
+            if version:
+                for _, p in params:
+                    p.data.mul_(0.5).add_(1.0)
+            pub = tx.publish([(n, p.data) for n, p in params])
+            assert max(pub["ipc_nbytes"]) < max_allocation and len(pub["ipc_handles"]) > 4
+            req_q.put({"info": [(n, list(p.shape), str(p.dtype).replace("torch.", "")) for n, p in params], "handles": pub["ipc_handles"], "nbytes": pub["ipc_nbytes"]})
+            n, sums, loaded = ack_q.get(timeout=120)
+            assert n == 4 and loaded == ["big.loaded", "mid"]
+            assert sums == pytest.approx({k: p.data.double().sum().item() for k, p in params}, rel=0, abs=0)
+    finally:
+        req_q.put(None)
+        proc.join(timeout=60)
+        if proc.is_alive():
+            proc.kill()
+        tx.close()

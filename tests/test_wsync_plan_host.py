@@ -56,3 +56,48 @@ def test_small_buckets_leave_trailing_slices_empty(plan):
     assert plan.prl_wsync_plan_check(8, 300, 1) == 0
     assert plan.prl_wsync_plan_check(1, 123, 1) == 0  # a group of one: nothing to do
     assert plan.prl_wsync_plan_check(4, 0, 1) == 0
+
+
+def test_ipc_transport_cuts_tensors_too_large_for_one_exportable_allocation(monkeypatch):
+    """`hipIpcOpenMemHandle` does not return for allocations of 2 GiB and more on this stack (scripts/exp/ipc_large_allocation_probe.py):
+    the IPC transport turns such a tensor into row ranges on both sides (same arithmetic from `parameters_info`), no bucket reaches the
+    limit, and a receiver without a registered destination gets the tensor back in one piece."""
+    import torch
+
+    from pipelinerl_amd.weight_sync import (IPC_MAX_ALLOCATION, ColocatedReceiver, ParamSpec, bucket_nbytes, plan_buckets, rows_piece, split_for_ipc)
+
+    # the real case: a 7B fp32 output head
+    specs = [ParamSpec("model.norm.weight", (3584,), torch.bfloat16), ParamSpec("lm_head.weight", (152064, 3584), torch.float32)]
+    cut = split_for_ipc(specs)
+    assert cut[0] == specs[0] and [rows_piece(s.name) for s in cut[1:]] == [("lm_head.weight", 0, 74898), ("lm_head.weight", 74898, 149796), ("lm_head.weight", 149796, 152064)]
+    assert sum(s.shape[0] for s in cut[1:]) == 152064 and all(s.shape[1:] == (3584,) and s.dtype == torch.float32 for s in cut[1:])
+    assert all(bucket_nbytes(b) < IPC_MAX_ALLOCATION for b in plan_buckets(cut))
+    assert split_for_ipc(specs[:1]) == specs[:1] and rows_piece("a#rowsx:3") is None and rows_piece("plain.name") is None
+    assert len(split_for_ipc([ParamSpec("flat", (1 << 30,), torch.float32)])) == 4  # a 4 GiB vector: element ranges of 1 GiB
+    with pytest.raises(ValueError, match="no leading dimension"):
+        split_for_ipc([ParamSpec("one_row", (1, 1 << 30), torch.float32)])
+
+    # small limits: the receiver's side of the arithmetic with hand-filled buckets (no device needed on the load_weights path)
+    torch.manual_seed(0)
+    tensors = {"a": torch.randn(5, 8), "big": torch.randn(100, 16), "z": torch.randn(3)}
+    info = [ParamSpec(n, tuple(t.shape), t.dtype) for n, t in tensors.items()]
+    limit, piece = 2048, 1024
+    cut = split_for_ipc(info, piece, limit)
+    assert [s.name for s in cut][:3] == ["a", "big#rows0:16", "big#rows16:32"] and len(cut) == 2 + 7
+    plan = plan_buckets(cut, piece)
+    bufs = []
+    for bucket in plan:
+        buf = torch.zeros(bucket_nbytes(bucket), dtype=torch.uint8)
+        for sp, off in bucket:
+            p = rows_piece(sp.name)
+            src = tensors[p[0]][p[1]:p[2]] if p else tensors[sp.name]
+            buf[off:off + sp.nbytes] = src.contiguous().view(torch.uint8).reshape(-1)
+        bufs.append(buf)
+    rx = ColocatedReceiver(torch.device("cpu"), piece, limit)
+    rx._mapped = {f"{k:02x}": type("M", (), {"tensor": (lambda self, b=b: b), "close": lambda self: None})() for k, b in enumerate(bufs)}
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)  # the CPU "device" has nothing to wait for
+    got = {}
+    n = rx.receive(info, [f"{k:02x}" for k in range(len(bufs))], [b.numel() for b in bufs], lambda views: got.update({k: v.clone() for k, v in views}))
+    assert n == 3 and set(got) == set(tensors) and all(torch.equal(got[k], tensors[k]) for k in tensors)
+    with pytest.raises(ValueError, match="IPC buckets announced"):
+        rx.receive(info, ["00"], [1], lambda v: None)
