@@ -469,15 +469,22 @@ __device__ __forceinline__ void gemm_mainloop_dual_ps(f32x16 (&acc)[2][4], const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int kcol = stage_kcol32(tid);
-  int64_t offA[C::Q], offB[C::Q];
+  // DMA sources as (wave-uniform tile base in SGPRs) + (32-bit per-lane byte offset inside the tile's rows): the loads take the
+  // `saddr + voffset` form, a stream costs ONE register instead of a 64-bit pair that has to be advanced per stage - with 64-bit
+  // per-lane addresses the kernel sat at the 256-register limit and reloaded 16 spilled address pairs from scratch, three of
+  // them inside the contraction loop, where a scratch load also counts against the hand-counted vmcnt waits of the DMA pipeline
+  const char* baseA1 = reinterpret_cast<const char*>(A1 + (int64_t)m0 * g.lda);
+  const char* baseA2 = reinterpret_cast<const char*>(A2 + (int64_t)m0 * g.lda);
+  const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * g.ldb);
+  uint32_t offA[C::Q], offB[C::Q];
 #pragma unroll
   for (int q = 0; q < C::Q; ++q) {
     int ra = m0 + stage_row32(tid, q, C::NT);
     ra = ra < g.M ? ra : g.M - 1;
-    offA[q] = (int64_t)ra * g.lda + kcol;
+    offA[q] = (uint32_t)(((int64_t)(ra - m0) * g.lda + kcol) * 2);
     int rb = n0 + stage_row32(tid, q, C::NT);
     rb = rb < g.N ? rb : g.N - 1;
-    offB[q] = (int64_t)rb * g.ldb + kcol;
+    offB[q] = (uint32_t)(((int64_t)(rb - n0) * g.ldb + kcol) * 2);
   }
   int rdA[2], rdB[2];
 #pragma unroll
@@ -489,7 +496,9 @@ __device__ __forceinline__ void gemm_mainloop_dual_ps(f32x16 (&acc)[2][4], const
   auto stage_piece = [&](int buf, int stage_k, int idx) {
     const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
     const int tile = idx / C::Q, q = idx % C::Q;
-    const uint16_t* src = tile == 0 ? A1 + offA[q] + stage_k : tile == 1 ? A2 + offA[q] + stage_k : B + offB[q] + stage_k;
+    const char* ub = (tile == 0 ? baseA1 : tile == 1 ? baseA2 : baseB) + (int64_t)stage_k * 2;  // uniform
+    asm volatile("" : "+s"(ub));  // keeps the base in SGPRs and the sum below out of the optimiser's hands: `saddr + voffset` is chosen at instruction selection
+    const char* src = ub + (size_t)(tile == 2 ? offB[q] : offA[q]);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lds + dst + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
   };

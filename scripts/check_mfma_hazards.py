@@ -29,16 +29,35 @@ MIN_GAP = 4  # instructions (each >= 1 wait state; an intervening MFMA counts as
 SOURCES = ("prl_lmhead_fwd.hip", "prl_lmhead_bwd.hip")  # the translation units that instantiate the hand-placed streams of prl_lmhead_core.h
 
 
-def compile_to_asm() -> str:
+def compile_to_asm(sources=SOURCES) -> str:
     tmp = Path(tempfile.mkdtemp())
     text = []
-    for name in SOURCES:
+    for name in sources:
         out = tmp / (name + ".s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}",
                                f"-I{ROOT / 'pipelinerl_amd' / 'csrc'}", "-S", "--cuda-device-only", str(ROOT / "pipelinerl_amd" / "csrc" / name),
                                "-o", str(out)], stderr=subprocess.DEVNULL)
         text.append(out.read_text())
     return "\n".join(text)
+
+
+def kernel_resources(text: str) -> dict[str, dict[str, int]]:
+    """Per kernel of an assembly listing: scratch bytes per lane (spills / arrays the compiler could not keep in registers), VGPRs,
+    AGPRs and LDS bytes, from its `.amdhsa_kernel` block."""
+    import re
+
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+        body = m.group(2)
+
+        def field(key, default=0):
+            f = re.search(rf"\.amdhsa_{key} (\d+)", body)
+            return int(f.group(1)) if f else default
+
+        vgpr, accum = field("next_free_vgpr"), field("accum_offset")
+        out[m.group(1)] = {"scratch": field("private_segment_fixed_size"), "vgpr": vgpr, "agpr": max(0, vgpr - accum) if accum else 0,
+                           "lds": field("group_segment_fixed_size")}
+    return out
 
 
 def regs(tok: str) -> set[str]:
