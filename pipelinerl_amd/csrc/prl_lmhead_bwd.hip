@@ -475,6 +475,7 @@ static int lm_head_bwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
   PRL_CHECK_ARG(vocab >= BK && vocab % BK == 0 && vocab < ((int64_t)1 << 31) - 256,
                 "the fused backward contracts over the vocabulary: vocab %lld must be a multiple of %d", (long long)vocab, BK);
   PRL_CHECK_ARG(rows * cols < ((int64_t)1 << 31) - 256, "too many rows");
+  PRL_CHECK_ARG(vocab <= ((int64_t)1 << 23) && hidden <= ((int64_t)1 << 23), "vocab / hidden beyond 2^23: a tile's rows would not fit a 32-bit byte offset");
   PRL_CHECK_ARG(hidden_bf16 && (w_hi || kept_logits2) && wt_hi && input_ids && lse2 && entropy && grad_new_logprobs && workspace, "null pointer");
   PRL_CHECK_ARG(kept_logits2 || (w_lo == nullptr) == (wt_lo == nullptr), "w_lo and wt_lo go together");
   PRL_CHECK_ARG(grad_hidden || grad_weight, "nothing to compute");

@@ -139,6 +139,16 @@ __device__ __forceinline__ void mfma_pin_acc(f32x16 (&acc)[NI][NJ]) {
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 }
 
+// Source address of one LDS-DMA piece: `base` is wave-uniform (a tile's first row at the current contraction offset), `lane_bytes` the
+// lane's 32-bit byte offset inside the tile's rows.  The empty asm pins the base in SGPRs and keeps the optimiser from folding the sum
+// back into a per-lane 64-bit address (which costs a register pair per stream and a 64-bit VALU add per piece - with those the
+// dual-plane kernels spilled): instruction selection then picks `global_load_lds ... v_off, s[base]`.
+__device__ __forceinline__ const char* dma_src(const uint16_t* base, uint32_t lane_bytes) {
+  const char* ub = reinterpret_cast<const char*>(base);
+  asm volatile("" : "+s"(ub));
+  return ub + (size_t)lane_bytes;
+}
+
 // -----------------------------------------------------------------------------------------------
 // main loop: acc[i][j] (32 x 32 tiles of this wave's 64 x 64) += sum over terms and K
 // -----------------------------------------------------------------------------------------------
@@ -162,18 +172,20 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
   // ---- staging (layout: prl_lmhead_layout.h): this thread fetches chunks q * NT + tid of each tile,
   // i.e. rows stage_row(tid, q), all from source column stage_kcol(tid)
   const int kcol = stage_kcol(tid);
-  int64_t offA[C::QA], offB[C::QB];
+  // DMA sources = wave-uniform tile base (SGPRs) + a 32-bit byte offset per lane and stream (`dma_src`): the `saddr + voffset` form
+  const int64_t tileA = (int64_t)m0 * g.lda, tileB = (int64_t)n0 * g.ldb;
+  uint32_t offA[C::QA], offB[C::QB];
 #pragma unroll
   for (int q = 0; q < C::QA; ++q) {
     int ra = m0 + stage_row(tid, q, C::NT);
     ra = ra < g.M ? ra : g.M - 1;  // rows past the edge re-read the last row; their results are discarded
-    offA[q] = (int64_t)ra * g.lda + kcol;
+    offA[q] = (uint32_t)(((int64_t)(ra - m0) * g.lda + kcol) * 2);
   }
 #pragma unroll
   for (int q = 0; q < C::QB; ++q) {
     int rb = n0 + stage_row(tid, q, C::NT);
     rb = rb < g.N ? rb : g.N - 1;
-    offB[q] = (int64_t)rb * g.ldb + kcol;
+    offB[q] = (uint32_t)(((int64_t)(rb - n0) * g.ldb + kcol) * 2);
   }
   // ---- fragment reads: byte offsets of MFMA tile i = 0 for the four 16-deep sub-steps; tile i = 1 adds
   // 32 rows * 128 bytes (the swizzle term depends on (row >> 1) & 7 only, unchanged by + 32)
@@ -204,11 +216,11 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][C::NJ], const Ter
   auto stage_piece = [&](int buf, int idx) {
     const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
     if (idx < C::QA) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sA + offA[idx] + st_k),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)dma_src(sA + tileA + st_k, offA[idx]),
                                        (__attribute__((address_space(3))) void*)(lds + dst + idx * C::NT * 16), 16, 0, 0);
     } else {
       const int q = idx - C::QA;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sB + offB[q] + st_k),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)dma_src(sB + tileB + st_k, offB[q]),
                                        (__attribute__((address_space(3))) void*)(lds + dst + C::A_BYTES + q * C::NT * 16), 16, 0, 0);
     }
   };
@@ -332,15 +344,16 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int kcol = stage_kcol32(tid);
-  int64_t offA[C::Q], offB[C::Q];
+  const int64_t tileA = (int64_t)m0 * g.lda, tileB = (int64_t)n0 * g.ldb;
+  uint32_t offA[C::Q], offB[C::Q];
 #pragma unroll
   for (int q = 0; q < C::Q; ++q) {
     int ra = m0 + stage_row32(tid, q, C::NT);
     ra = ra < g.M ? ra : g.M - 1;
     int rb = n0 + stage_row32(tid, q, C::NT);
     rb = rb < g.N ? rb : g.N - 1;
-    offA[q] = (int64_t)ra * g.lda + kcol;
-    offB[q] = (int64_t)rb * g.ldb + kcol;
+    offA[q] = (uint32_t)(((int64_t)(ra - m0) * g.lda + kcol) * 2);
+    offB[q] = (uint32_t)(((int64_t)(rb - n0) * g.ldb + kcol) * 2);
   }
   int rdA[2], rdB[2];
 #pragma unroll
@@ -353,8 +366,8 @@ __device__ __forceinline__ void gemm_mainloop_dual(f32x16 (&acc)[2][4], const ui
   auto stage_piece = [&](int buf, int idx) {  // idx 0..5: A1 q0 q1, A2 q0 q1, B q0 q1
     const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
     const int tile = idx / C::Q, q = idx % C::Q;
-    const uint16_t* src = tile == 0 ? A1 + offA[q] : tile == 1 ? A2 + offA[q] : B + offB[q];
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + st_k),
+    const char* src = tile == 0 ? dma_src(A1 + tileA + st_k, offA[q]) : tile == 1 ? dma_src(A2 + tileA + st_k, offA[q]) : dma_src(B + tileB + st_k, offB[q]);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lds + dst + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
   };
   // NEXT (a type tag): whether a stage is issued during this step
@@ -496,9 +509,7 @@ __device__ __forceinline__ void gemm_mainloop_dual_ps(f32x16 (&acc)[2][4], const
   auto stage_piece = [&](int buf, int stage_k, int idx) {
     const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
     const int tile = idx / C::Q, q = idx % C::Q;
-    const char* ub = (tile == 0 ? baseA1 : tile == 1 ? baseA2 : baseB) + (int64_t)stage_k * 2;  // uniform
-    asm volatile("" : "+s"(ub));  // keeps the base in SGPRs and the sum below out of the optimiser's hands: `saddr + voffset` is chosen at instruction selection
-    const char* src = ub + (size_t)(tile == 2 ? offB[q] : offA[q]);
+    const char* src = dma_src(reinterpret_cast<const uint16_t*>(tile == 0 ? baseA1 : tile == 1 ? baseA2 : baseB) + stage_k, tile == 2 ? offB[q] : offA[q]);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lds + dst + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
   };
@@ -625,15 +636,16 @@ __device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int kcol = stage_kcol32(tid);
-  int64_t offA[C::Q], offB[C::Q];
+  const int64_t tileB = (int64_t)n0 * g.ldb;
+  uint32_t offA[C::Q], offB[C::Q];  // lane offsets in bytes from the tile's uniform base (`dma_src`)
 #pragma unroll
   for (int q = 0; q < C::Q; ++q) {
     int v = m0 + 8 * tr_stage_chunk(tid, q, C::NT);
     v = v + 8 <= g.M ? v : g.M - 8;  // entries past the edge re-read the last eight; their results are discarded (M % 8 == 0)
-    offA[q] = (int64_t)tr_stage_row(tid, q, C::NT) * g.lda + v;
+    offA[q] = (uint32_t)(((int64_t)tr_stage_row(tid, q, C::NT) * g.lda + (v - m0)) * 2);
     int rb = n0 + stage_row32(tid, q, C::NT);
     rb = rb < g.N ? rb : g.N - 1;
-    offB[q] = (int64_t)rb * g.ldb + kcol;
+    offB[q] = (uint32_t)(((int64_t)(rb - n0) * g.ldb + kcol) * 2);
   }
   // tile i = 1 is 4 chunks further: bit 2 of the chunk index, which the swizzle may flip - an XOR with 64 bytes, not an add
   int rdA[2], rdB[2];
@@ -646,7 +658,8 @@ __device__ __forceinline__ void gemm_mainloop_dual_tr(f32x16 (&acc)[2][4], const
   auto stage_piece = [&](int buf, int idx) {  // idx 0..5: A1 q0 q1, A2 q0 q1, B q0 q1
     const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
     const int tile = idx / C::Q, q = idx % C::Q;
-    const uint16_t* src = tile == 0 ? A1 + offA[q] + (int64_t)st_k * g.lda : tile == 1 ? A2 + offA[q] + (int64_t)st_k * g.lda : B + offB[q] + st_k;
+    const int64_t rowA = (int64_t)st_k * g.lda + m0;
+    const char* src = tile == 0 ? dma_src(A1 + rowA, offA[q]) : tile == 1 ? dma_src(A2 + rowA, offA[q]) : dma_src(B + tileB + st_k, offB[q]);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lds + dst + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
   };
@@ -746,15 +759,16 @@ __device__ __forceinline__ void gemm_mainloop_triple(f32x16 (&acc)[2][4], const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int kcol = stage_kcol32(tid);
-  int64_t offA[C::Q], offB[C::Q];
+  const int64_t tileA = (int64_t)m0 * g.lda, tileB = (int64_t)n0 * g.ldb;
+  uint32_t offA[C::Q], offB[C::Q];  // lane offsets in bytes from the tile's uniform base (`dma_src`)
 #pragma unroll
   for (int q = 0; q < C::Q; ++q) {
     int ra = m0 + stage_row32(tid, q, C::NT);
     ra = ra < g.M ? ra : g.M - 1;
     int rb = n0 + stage_row32(tid, q, C::NT);
     rb = rb < g.N ? rb : g.N - 1;
-    offA[q] = (int64_t)ra * g.lda + kcol;
-    offB[q] = (int64_t)rb * g.ldb + kcol;
+    offA[q] = (uint32_t)(((int64_t)(ra - m0) * g.lda + kcol) * 2);
+    offB[q] = (uint32_t)(((int64_t)(rb - n0) * g.ldb + kcol) * 2);
   }
   int rdA[2], rdB[2];
 #pragma unroll
@@ -767,8 +781,9 @@ __device__ __forceinline__ void gemm_mainloop_triple(f32x16 (&acc)[2][4], const 
   auto stage_piece = [&](int buf, int idx) {  // idx 0..7: A1 q0 q1, A2 q0 q1, B1 q0 q1, B2 q0 q1
     const unsigned dst = buf * C::STAGE_BYTES + stage_lds_byte(wave * 64, 0, C::NT);  // + lane * 16 by the hardware
     const int tile = idx / C::Q, q = idx % C::Q;
-    const uint16_t* src = tile == 0 ? A1 + offA[q] : tile == 1 ? A2 + offA[q] : tile == 2 ? B1 + offB[q] : B2 + offB[q];
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + st_k),
+    const char* src = tile == 0 ? dma_src(A1 + tileA + st_k, offA[q]) : tile == 1 ? dma_src(A2 + tileA + st_k, offA[q])
+                      : tile == 2 ? dma_src(B1 + tileB + st_k, offB[q]) : dma_src(B2 + tileB + st_k, offB[q]);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lds + dst + tile * C::TILE_BYTES + q * C::NT * 16), 16, 0, 0);
   };
   auto compute = [&](int buf, int sbuf) {

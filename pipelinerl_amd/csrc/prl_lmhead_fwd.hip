@@ -205,6 +205,8 @@ static int lm_head_fwd_impl(int64_t rows, int64_t cols, int64_t hidden, int64_t 
   PRL_CHECK_ARG(hidden >= BK && hidden % BK == 0, "hidden size %lld must be a multiple of %d", (long long)hidden, BK);
   PRL_CHECK_ARG(vocab >= 1 && vocab < ((int64_t)1 << 31) - 256, "vocab out of range");
   PRL_CHECK_ARG(rows * cols < ((int64_t)1 << 31) - 256, "too many rows");
+  // the DMA sources are a tile base + a 32-bit byte offset per lane (prl_lmhead_core.h `dma_src`): 255 rows x leading dimension x 2 bytes
+  PRL_CHECK_ARG(vocab <= ((int64_t)1 << 23) && hidden <= ((int64_t)1 << 23), "vocab / hidden beyond 2^23: a tile's rows would not fit a 32-bit byte offset");
   PRL_CHECK_ARG(hidden_bf16 && w_hi && input_ids && new_logprobs && entropy && lse2 && workspace, "null pointer");
   PRL_CHECK_ARG(prl::aligned16(hidden_bf16) && prl::aligned16(w_hi) && (!w_lo || prl::aligned16(w_lo)), "operands must be 16-byte aligned");
   PRL_CHECK_ARG(temperature > 0.0f, "temperature must be > 0");

@@ -51,3 +51,17 @@ def test_register_budgets_of_the_launch_geometries(resources):
     loss = one("grpo_loss_partial_kernelILi4ELb1ELb1E")
     assert loss["vgpr"] <= 256
     assert one("segment_copy_kernel")["vgpr"] <= 64
+
+
+def test_the_fused_head_kernels_do_not_spill_either():
+    """Every kernel of the fused head (the two translation units with the hand-placed MFMA streams): zero scratch, and the cores that
+    run two waves per SIMD stay inside their 256 registers.  Before the DMA sources became `SGPR base + 32-bit lane offset`
+    (prl_lmhead_core.h `dma_src`) the dual-plane forward and d-logits kernels kept 16 address pairs in scratch and reloaded three of
+    them inside the contraction loop (forward 13.14 -> 12.75 ms once they were gone, profiles/r05t_*)."""
+    chk = _checker()
+    res = chk.kernel_resources(chk.compile_to_asm())
+    assert len(res) >= 15, sorted(res)
+    assert not {k: v for k, v in res.items() if v["scratch"]}, {k: v for k, v in res.items() if v["scratch"]}
+    assert all(v["vgpr"] <= 256 for v in res.values())
+    dual = [v for k, v in res.items() if "CfgDual" in k]
+    assert len(dual) == 2 and all(v["vgpr"] <= 248 for v in dual), dual  # a few registers of slack: the next fragment set must not tip them over
