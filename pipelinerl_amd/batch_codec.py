@@ -178,19 +178,20 @@ def compact_layout(n: int, nc: int, m: int, has_ref: bool, model_version: int, p
     """(header bytes incl. magic and length, offset of the first tensor, {name: (offset from there, nbytes)}, record size) of the
     compact record of a micro-batch of `n` tokens / `nc` completion tokens / `m` sequences.  One definition for the generic
     encoder (`encode_compact`) and for the preprocessor's gather recipe (the native publisher copies every column's per-sequence
-    slices straight from the decoded `actor` records)."""
-    shapes = [("tokens", "int32", [n], 4 * n), ("labels", "int32", [n], 4 * n), ("logprobs", "float32", [nc], 4 * nc)]
+    slices straight from the decoded `actor` records).  The header text is formatted by hand - the preprocessor builds one per
+    micro-batch - and is the text `json.dumps` produces for the same structure (tests/test_compact_wire_host.py)."""
+    shapes = [("tokens", "int32", f"[{n}]", 4 * n), ("labels", "int32", f"[{n}]", 4 * n), ("logprobs", "float32", f"[{nc}]", 4 * nc)]
     if has_ref:
-        shapes.append(("ref_logprobs", "float32", [nc], 4 * nc))
-    shapes += [("seq_off", "int64", [m + 1], 8 * (m + 1)), ("lp_off", "int64", [m + 1], 8 * (m + 1)), ("seq_scalars", "float32", [5, m], 20 * m)]
+        shapes.append(("ref_logprobs", "float32", f"[{nc}]", 4 * nc))
+    shapes += [("seq_off", "int64", f"[{m + 1}]", 8 * (m + 1)), ("lp_off", "int64", f"[{m + 1}]", 8 * (m + 1)), ("seq_scalars", "float32", f"[5, {m}]", 20 * m)]
     offset, tensors, where = 0, [], {}
     for name, dt, shape, nb in shapes:
         offset += (-offset) % _ALIGN
-        tensors.append([name, dt, shape, offset, nb])
+        tensors.append(f'["{name}", "{dt}", {shape}, {offset}, {nb}]')
         where[name] = (offset, nb)
         offset += nb
-    scalars = {"model_version": int(model_version), "padding": int(padding), "eos_token_id": int(eos_token_id)}
-    header = json.dumps({"scalars": scalars, "tensors": tensors}).encode("utf-8")
+    header = ('{"scalars": {"model_version": %d, "padding": %d, "eos_token_id": %d}, "tensors": [%s]}'
+              % (int(model_version), int(padding), int(eos_token_id), ", ".join(tensors))).encode("utf-8")
     head = MAGIC_COMPACT + struct.pack("<I", len(header)) + header
     base = len(head) + (-len(head)) % _ALIGN
     return head, base, where, base + offset

@@ -502,16 +502,20 @@ def describe_compact(members: Sequence[tuple[dict, int]], model_version: int, eo
             if b > a:
                 pieces.append((hc[key] + 4 * a, off, 4 * (b - a), FROM_HOST, 0))
                 off += 4 * (b - a)
-    seq_off = np.zeros(m + 1, dtype=np.int64)
-    np.cumsum(lens, out=seq_off[1:])
-    lp_off = np.zeros(m + 1, dtype=np.int64)
-    np.cumsum(lp_lens, out=lp_off[1:])
-    scal = np.ascontiguousarray(np.stack([hc["scalars"][:, i] for hc, i in members], axis=1), dtype=np.float32) if m else np.zeros((5, 0), np.float32)
-    for col, arr in (("seq_off", seq_off), ("lp_off", lp_off), ("seq_scalars", scal)):
-        if arr.nbytes:
+    from itertools import accumulate
+
+    seq_off = np.array([0, *accumulate(lens)], dtype=np.int64).tobytes()
+    lp_off = np.array([0, *accumulate(lp_lens)], dtype=np.int64).tobytes()
+    if m == 1:
+        hc, i = members[0]
+        scal = hc["scalars"][:, i].tobytes()  # [5, 1] row-major = the column itself
+    else:
+        scal = np.ascontiguousarray(np.stack([hc["scalars"][:, i] for hc, i in members], axis=1), dtype=np.float32).tobytes() if m else b""
+    for col, raw in (("seq_off", seq_off), ("lp_off", lp_off), ("seq_scalars", scal)):
+        if raw:
             at = len(inline)
-            inline += arr.tobytes()
-            pieces.append((at, base + where[col][0], arr.nbytes, INLINE, 0))
+            inline += raw
+            pieces.append((at, base + where[col][0], len(raw), INLINE, 0))
     return total
 
 
