@@ -7,6 +7,7 @@ import math
 import threading
 import time
 import types
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -359,3 +360,23 @@ def test_native_learner_step_refuses_an_actor_critic_model():
         NativeLearnerStep(wrapped, torch.optim.SGD(m.parameters(), lr=0.1), RLConfig(), eos_token_id=2, samples_per_step=8, max_train_steps=2)
     plain = torch.nn.Linear(2, 2)
     NativeLearnerStep(plain, torch.optim.SGD(plain.parameters(), lr=0.1), RLConfig(), eos_token_id=2, samples_per_step=8, max_train_steps=2)
+
+
+def test_summary_of_a_recorded_pipeline_run_recomputes():
+    """`pipeline_run.summarize` over the stage reports of a run recorded on an MI355X (profiles/r05s_*: the 7B-shaped pipeline) gives the
+    summary that run printed, and the summary is consistent with itself: throughput = batch / step time, the busy fractions are
+    fractions, every micro-batch has a lag, the sum of the stages' busy seconds is what `overlap` quotes."""
+    import json
+
+    from pipelinerl_amd.pipeline_run import PipelineSpec, summarize
+
+    rec = json.loads((Path(__file__).resolve().parent.parent / "profiles" / "r05s_pipeline_7b_shape_bs16_seq8192.json").read_text())
+    spec = PipelineSpec(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in rec["spec"].items() if k in PipelineSpec.__dataclass_fields__})
+    assert spec.model == "7b" and spec.global_batch == 16 and spec.lag == 16 and spec.budget == 8192
+    s = summarize(spec, rec["stages"])
+    assert json.loads(json.dumps(s)) == rec["summary"]
+    assert s["samples_per_s"] == pytest.approx(spec.global_batch / s["s_per_step"], rel=1e-9)
+    assert all(0.0 <= f <= 1.0 for f in s["busy_frac"].values()) and s["busy_frac"]["learner"] > 0.9
+    assert sum(s["lag_optimizer_steps_histogram"].values()) == rec["stages"]["learner"]["micro_batches"]
+    assert s["overlap"]["stages_back_to_back_s_per_step"] == pytest.approx(sum(s["stage_busy_s_per_step"].values()))
+    assert s["weight_sync_under_load_ms"]["updates"] == s["optimizer_steps"] == 3 and s["engine_weights_equal_trainer_at_last_version"] is True
