@@ -61,3 +61,31 @@ def test_condenser_keeps_the_numbers_of_a_400_character_signature(tmp_path):
     assert rows[0]["Name"] == "fused_logits_loss_keep_kernel<F32, 1024, 2, 16, 9, true, DenseOut<F32> >"  # sorted by total time
     assert (int(rows[0]["Calls"]), float(rows[0]["AverageNs"]), int(rows[0]["MaxNs"])) == (28672, 1796881.802211, 2657158)
     assert rows[1]["Name"] == "small_kernel"
+
+
+def test_the_final_bench_line_recomputes_from_its_own_fields():
+    """The committed bench line of the round's final validation (profiles/r05z_bench_default.json) is consistent with itself and with the
+    rocprofv3 summary of the same command next to it: value = samples / step time, roofline = algorithmic bytes / event average / peak,
+    the tracer's average for the dominant kernel within a few per cent of the HIP-event one, traffic above the algorithmic bytes."""
+    import json
+
+    d = json.loads((ROOT / "profiles" / "r05z_bench_default.json").read_text())
+    assert d["metric"].startswith("samples_per_s") or "samples" in d["metric"]
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["dtype"] == "f32" and d["data"].startswith("synthetic")
+    assert d["value"] == pytest.approx(4096 / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9, rel=1e-6)
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9) and 0.6 < r["frac"] < 0.8
+    assert 1.0 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.25  # what the kernel moves beyond the unavoidable bytes: the re-read tail
+    assert r["launches"] == 4096 * d["steps"]
+    rows = [l for l in (ROOT / "profiles" / "r05z_bench_kernel_stats.csv").read_text().splitlines() if l.startswith('"fused_logits_loss_keep_kernel')]
+    assert len(rows) == 1
+    avg_ns = float(rows[0].split('",')[1].split(",")[2])
+    assert abs(avg_ns * 1e-3 - r["avg_us"]) / r["avg_us"] < 0.06  # the tracer spaces the dispatches (DESIGN §3): a few per cent faster
+    c = d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] == {"reference": 8, "port": 16} and c["value"] > 0
+    p = d["pipeline"]
+    assert p["samples_per_s"] == pytest.approx(512 / p["s_per_step"], rel=1e-6) and p["engine_weights_equal_trainer_at_last_version"] is True
+    m = d["roofline_mfma"]
+    assert m["bound"] == "mfma" and m["peak"] == 2500.0 and m["frac"] == pytest.approx(m["achieved"] / m["peak"], rel=1e-9)
