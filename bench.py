@@ -36,6 +36,8 @@ import torch
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+T_START = time.perf_counter()
+LINE_LIMIT_BYTES = 4096  # the driver keeps the tail of stdout: a line that does not fit in it is an unparsed (= unmeasured) round
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, same guide (AMD's 5 PF figure includes 2:1 sparsity)
 
@@ -62,20 +64,28 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--workload", default=os.environ.get("PRL_BENCH_WORKLOAD", "7b_grpo_bs4096_seq8192"), choices=list(WORKLOADS))
     p.add_argument("--logits-mode", default=os.environ.get("PRL_BENCH_LOGITS_MODE", "fused"), choices=["fused", "two_pass"])
+    p.add_argument("--detail", action="store_true",
+                   help="also run the side measurements (MFMA head roofline, model-in-the-loop step, reference-policy head, preprocessor loop, "
+                        "configs[1] pipeline, transport) - they go to the detail file, never into the printed line")
+    p.add_argument("--detail-out", default=os.environ.get("PRL_BENCH_DETAIL_OUT", "gpurun_out/bench_detail.json"),
+                   help="where rank 0 writes everything that is not on the printed line (relative to the repo root)")
+    p.add_argument("--budget-s", type=float, default=float(os.environ.get("PRL_BENCH_BUDGET_S", 250)),
+                   help="wall-clock budget of a default run: an optional leg (weight-sync hand-off, live PMC passes) is skipped, and says so, when it would not fit")
+    p.add_argument("--skip-unlabelled-steps", type=int, default=int(os.environ.get("PRL_BENCH_OPTOUT_STEPS", 2)),
+                   help="steps timed AFTER the timed region with HotPathStep(skip_unlabelled=True) for `value_skip_unlabelled` (0 = leave it out)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-weight-sync", action="store_true")
-    p.add_argument("--no-fused-head", action="store_true", help="skip the MFMA fused-head measurement (roofline_mfma)")
+    p.add_argument("--no-fused-head", action="store_true", help="--detail: skip the MFMA fused-head measurement (roofline_mfma)")
     p.add_argument("--no-grad-allreduce", action="store_true", help="N > 1: leave the gradient-sized all-reduce out of the step")
     p.add_argument("--grad-bytes", type=int, default=int(os.environ.get("PRL_BENCH_GRAD_BYTES", 0)),
                    help="N > 1: bytes of data-parallel gradients all-reduced per step (default: the workload's model in bf16)")
-    p.add_argument("--e2e", action="store_true", help="(default at N = 1 on the 7B workload) run scripts/e2e_learner_bench.py live")
-    p.add_argument("--no-e2e", action="store_true", help="N = 1: quote the committed model-in-the-loop step from profiles/ instead of running it (source: committed)")
+    p.add_argument("--no-e2e", action="store_true", help="--detail: quote the committed model-in-the-loop step from profiles/ instead of running it (source: committed)")
     p.add_argument("--no-live-pmc", action="store_true", help="quote the committed PMC traffic figure instead of measuring it with two rocprofv3 --pmc sub-runs")
-    p.add_argument("--no-transport", action="store_true", help="skip the host-side transport probe (shm log / files backend round trips)")
-    p.add_argument("--no-preprocess-loop", action="store_true", help="skip the actor-record -> published micro-batch measurement (preprocess_loop)")
-    p.add_argument("--no-ref-logprob", action="store_true", help="skip the reference-policy head measurement (ref_logprob)")
+    p.add_argument("--no-transport", action="store_true", help="--detail: skip the host-side transport probe (shm log / files backend round trips)")
+    p.add_argument("--no-preprocess-loop", action="store_true", help="--detail: skip the actor-record -> published micro-batch measurement (preprocess_loop)")
+    p.add_argument("--no-ref-logprob", action="store_true", help="--detail: skip the reference-policy head measurement (ref_logprob)")
     p.add_argument("--no-pipeline", action="store_true",
-                   help="N = 1: skip BASELINE configs[1] run AS a pipeline (actor -> preprocessor -> learner -> engine, four processes on this GPU)")
+                   help="--detail: skip BASELINE configs[1] run AS a pipeline (actor -> preprocessor -> learner -> engine, four processes on this GPU)")
     p.add_argument("--pipeline-steps", type=int, default=int(os.environ.get("PRL_BENCH_PIPELINE_STEPS", 4)), help="optimizer steps of the pipeline run (the first is warm-up)")
     p.add_argument("--cpu-baseline-threads", default=None,
                    help="comma-separated thread counts: time ONLY the cpu_baseline loss leg at each count and exit (no GPU work)")
@@ -278,24 +288,6 @@ def cpu_baseline(seq_length: int, vocab: int) -> dict:
                         "sample": f"same path, single-thread numpy on {t_np} tokens ({t_np_tok * 1e6:.0f} us/token)"},
         "host": {"nproc": os.cpu_count(), "cgroup_cpu_quota": cores},
     }
-    if ref and ref.get("samples_per_s_extrapolated") and (seq_length, vocab) == (ref.get("workload", {}).get("seq_length"), ref.get("workload", {}).get("vocab")):
-        # Lead with the REFERENCE's own functions (kind "reference"): they cannot travel to the GPU box (/root/reference exists in the build
-        # container only), so this is a stated constant from that container's cores; the port timed on THIS box follows as the second witness.
-        return {
-            "value": ref["samples_per_s_extrapolated"], "unit": "samples/s", "kind": "reference",
-            # two hosts, both named: the reference's own functions ran on the build container's cores (a stated constant), the port on THIS box's
-            "cores": {"reference": ref.get("threads", 8), "port": cores},
-            "hosts": {"reference": ref.get("host"), "port": port["host"]},
-            "measured_in_this_run": {"reference": False, "port": True},
-            "host": ref.get("host"),
-            "sample": f"the reference's own preprocess_fn + populate_rl_data + collate_packed on {ref['workload']['sequences']} x {ref['workload']['seq_length']}-token "
-                      f"sequences and rl_step forward + autograd backward on {ref['workload']['loss_tokens']} tokens x V={ref['workload']['vocab']}, "
-                      f"{ref.get('threads', 8)} threads of the build container ({(ref.get('host') or {}).get('model', '?')}), extrapolated to {seq_length}-token samples; "
-                      "committed constant (profiles/r03_reference_cpu_legs.json, scripts/reference_cpu_legs.py), NOT re-measured on this box",
-            "legs": ref.get("legs"),
-            "port": port,
-            "reference": ref,
-        }
     port["reference"] = ref
     return port
 
@@ -882,6 +874,98 @@ def pipeline_probe(steps: int, tiny: bool = False) -> dict:
     return out
 
 
+def e2e_probe(live: bool) -> dict | None:
+    """--detail: a MODEL-IN-THE-LOOP step (random-init Qwen2.5-7B shape, stock PyTorch-ROCm forward/backward + AdamW on ONE MI355X, bs 16 x 8192,
+    scripts/e2e_learner_bench.py) in a fresh process - or, with --no-e2e, the committed figure labelled as such."""
+    import subprocess
+
+    committed = _committed_json("profiles/r02_e2e_learner_7b_fused_head.json",
+                                note="measured separately with scripts/e2e_learner_bench.py and committed; `value` is the post-model hot path on resident "
+                                     "logits, NOT learner throughput")
+    if not live:
+        if committed is not None:
+            committed["source"] = "committed (profiles/r02_e2e_learner_7b_fused_head.json), NOT measured in this run"
+        return committed
+    torch.cuda.empty_cache()
+    out = ROOT / "gpurun_out" / "bench_e2e_7b.json"
+    out.parent.mkdir(exist_ok=True)
+    base = [sys.executable, str(ROOT / "scripts" / "e2e_learner_bench.py"), "--model", "7b", "--batch-size", "16", "--seq-len", "8192",
+            "--micro-batch", "1", "--fused", "--fused-head", "--steps", "1", "--warmup", "1", "--out", str(out)]
+
+    def run(extra):
+        if out.exists():
+            out.unlink()
+        try:
+            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=float(os.environ.get("PRL_BENCH_E2E_TIMEOUT", 900)))
+            return json.loads(out.read_text().splitlines()[0]) if r.returncode == 0 and out.exists() else {"error": (r.stderr or r.stdout)[-400:]}
+        except Exception as e:  # noqa: BLE001 - must never take the benchmark line down
+            return {"error": f"{type(e).__name__}: {e}"}
+
+    t0 = time.perf_counter()
+    e2e = run([])
+    if "error" in e2e:
+        if committed is not None:
+            committed["source"] = "committed (profiles/r02_e2e_learner_7b_fused_head.json) - the live run failed: " + e2e["error"][-200:]
+            return committed
+        return e2e
+    e2e["source"] = "measured in this run (scripts/e2e_learner_bench.py in a subprocess of bench.py)"
+    e2e["wall_s_including_model_init"] = time.perf_counter() - t0
+    # the same step with every layer's activations KEPT (no recompute in the backward): what the 288 GB of one MI355X allow
+    k = run(["--no-checkpointing"])
+    e2e["without_activation_recompute"] = k if "error" in k else {key: k[key] for key in ("s_per_step", "samples_per_s", "tokens_per_s", "peak_memory_GB", "loss")}
+    return e2e
+
+
+def _pick(d: dict | None, keys) -> dict | None:
+    return None if d is None else {k: d[k] for k in keys if k in d}
+
+
+def split_line(full: dict, detail_path: str) -> tuple[dict, dict]:
+    """(the ONE printed line, the detail file's content).  The line carries exactly the driver's contract - scalars where the contract
+    has scalars, `cpu_baseline.cores` an int, at most LINE_LIMIT_BYTES - and the path of the detail file; everything else that was measured
+    (per-kernel table, CPU legs, side measurements) is in the detail file only.  Pure function of `full`: tests/test_bench_line.py."""
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                       "vs_baseline", "dtype", "data", "config")}
+    r = full["roofline"]
+    line["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_us", "min_us",
+                                               "launches", "algorithmic_bytes_per_launch")}
+    if line["roofline"]["traffic_source"]:
+        line["roofline"]["traffic_source"] = line["roofline"]["traffic_source"][:200]
+    c = full.get("cpu_baseline")
+    if c is not None:
+        ref = c.get("reference") or {}
+        line["cpu_baseline"] = {
+            "value": c["value"], "unit": c["unit"], "cores": int(c["cores"]), "kind": c["kind"], "sample": c["sample"][:420],
+            # the reference's OWN functions cannot travel to the GPU box (/root/reference is in the build container only): a committed constant from
+            # that container's cores, quoted beside the port that was timed here
+            "reference_value": ref.get("samples_per_s_extrapolated"), "reference_cores": ref.get("threads"),
+            "reference_source": ref.get("source"),
+        }
+    else:
+        line["cpu_baseline"] = None
+    w = full.get("weight_sync")
+    line["weight_sync"] = _pick(w, ("metric", "transport", "median_ms", "min_ms", "gbytes", "tensors", "effective_GBps", "n_receivers",
+                                    "broadcast_ms", "scatter_allgather_ms", "full_update_verified", "error"))
+    if line["weight_sync"] and "error" in line["weight_sync"]:
+        line["weight_sync"]["error"] = str(line["weight_sync"]["error"])[:200]
+    o = full.get("value_skip_unlabelled")
+    line["value_skip_unlabelled"] = None if o is None else o["value"]
+    line["skip_unlabelled_steps"] = None if o is None else o["steps"]
+    # one number per timed kernel: fraction of the 8 TB/s peak on algorithmic bytes (the table behind them is in the detail file)
+    line["hbm_frac"] = {k: round(v["hbm_frac"], 4) for k, v in (full.get("kernels") or {}).items() if "hbm_frac" in v}
+    ar = (full.get("kernels") or {}).get("grad_allreduce")
+    if ar:
+        line["grad_allreduce"] = {"avg_ms": ar["avg_us"] / 1e3, "bytes": ar.get("bytes"), "busbw_GBps": ar.get("busbw_GBps")}
+    line["loss"] = full.get("loss")
+    if full.get("skipped"):
+        line["skipped"] = {k: v[:120] for k, v in full["skipped"].items()}
+    line["wall_s"] = full.get("wall_s")
+    line["detail"] = detail_path
+    size = len(json.dumps(line))
+    assert size <= LINE_LIMIT_BYTES, f"the bench line is {size} bytes (limit {LINE_LIMIT_BYTES}): move something to the detail file"
+    return line, full
+
+
 def main():
     args = parse_args()
     if args.cpu_baseline_threads:
@@ -991,7 +1075,7 @@ def main():
     del setup, setup_batches
     torch.cuda.synchronize()
 
-    timer = EventTimer()
+    main_timer = EventTimer()
     grad_buckets = []
     if world > 1 and not args.no_grad_allreduce and args.backend == "nccl":
         left = args.grad_bytes
@@ -1000,8 +1084,10 @@ def main():
             grad_buckets.append(torch.zeros(n // 2, dtype=torch.bfloat16, device=dev))
             left -= n
 
-    def one_step(timed: bool):
-        step = HotPathStep(cfg, eos_token_id=2, current_step=0, max_step=10)
+    def one_step(timed: bool, skip_unlabelled: bool = False, timer=None):
+        # `value` is timed on the reference's behaviour: EVERY row of the logits is read, so that `isfinite(new_logprobs)` holds
+        # over every position (rl/__init__.py:213); the opt-out that leaves unlabelled rows unread is timed afterwards, separately
+        step = HotPathStep(cfg, eos_token_id=2, current_step=0, max_step=10, skip_unlabelled=skip_unlabelled)
         if timed:
             with timer.time("preprocess_K5_K6"):  # incl. the host planning (numpy plan + three small uploads)
                 step.preprocess(rag, micro_batches, timer=timer)  # + event pairs around K5 and the K6 kernel alone
@@ -1041,7 +1127,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, stats = one_step(True)
+        loss, stats = one_step(True, timer=main_timer)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -1053,27 +1139,55 @@ def main():
     assert np.isfinite(stats_host[0]), "non-finite loss in the benchmark step"
     assert int(stats_host[2]) == bs, f"step covered {int(stats_host[2])} sequences, expected {bs}"
 
-    kernels = timer.summary()
+    kernels = main_timer.summary()
     V4 = vocab * 4
-    # rows whose next token is unlabelled (the prompts) are not read by the fused kernel, only their gradient row is
-    # zeroed: they count V*4 bytes, not 2*V*4 (the average over this rank's launches; one sequence per launch)
     labelled = int((rag.labels != -100).sum().item())
     live_frac = labelled / float(tokens_per_rank)
-    algo = {
-        # algorithmic bytes per launch
-        "fused_logits_loss": seq_length * ((1.0 + live_frac) * V4 + 56),  # logits of labelled rows read once + d logits written once
-        "grpo_loss_step": tokens_per_rank * 52,                   # 56 B/token minus the unwritten 4 B gradient
-        "preprocess_K5_K6": tokens_per_rank * (84 + 8),           # K6 16 B read + 68 B written; K5 scan 8 B read
-        "pack_collate_kernel": tokens_per_rank * 84,              # the K6 kernel alone
-        "group_advantages_K5": tokens_per_rank * 8,               # the K5 scan (+ O(S) group arithmetic), host planning + upload included
-        "group_advantages_K5_kernels": tokens_per_rank * 8,       # the two K5 launches alone
-    }
-    for name, k in kernels.items():
-        if name in algo:
-            k["algorithmic_bytes"] = algo[name]
-            k["GBps"] = algo[name] / (k["avg_us"] * 1e-6) / 1e9
-            k["hbm_frac"] = k["GBps"] / HBM_PEAK_GBS
+
+    def algorithmic_bytes(skip_unlabelled: bool) -> dict:
+        """Algorithmic bytes per launch.  With every row read (the reference's behaviour) a row costs V*4 read + V*4
+        written; with the opt-out the rows whose next token is unlabelled are not read, only their gradient row is zeroed."""
+        read_frac = live_frac if skip_unlabelled else 1.0
+        return {
+            "fused_logits_loss": seq_length * ((1.0 + read_frac) * V4 + 56),  # logits read once + d logits written once
+            "grpo_loss_step": tokens_per_rank * 52,                   # 56 B/token minus the unwritten 4 B gradient
+            "preprocess_K5_K6": tokens_per_rank * (84 + 8),           # K6 16 B read + 68 B written; K5 scan 8 B read
+            "pack_collate_kernel": tokens_per_rank * 84,              # the K6 kernel alone
+            "group_advantages_K5": tokens_per_rank * 8,               # the K5 scan (+ O(S) group arithmetic), host planning + upload included
+            "group_advantages_K5_kernels": tokens_per_rank * 8,       # the two K5 launches alone
+        }
+
+    def price(table: dict, algo: dict) -> None:
+        for name, k in table.items():
+            if name in algo:
+                k["algorithmic_bytes"] = algo[name]
+                k["GBps"] = algo[name] / (k["avg_us"] * 1e-6) / 1e9
+                k["hbm_frac"] = k["GBps"] / HBM_PEAK_GBS
+
+    price(kernels, algorithmic_bytes(False))
     dom = "fused_logits_loss" if "fused_logits_loss" in kernels else max(kernels, key=lambda n: kernels[n]["avg_us"] * kernels[n]["launches"])
+
+    # ---- the opt-out (HotPathStep's default, skip_unlabelled=True), timed separately on a few steps: never `value` ----
+    optout = None
+    if args.skip_unlabelled_steps > 0:
+        t_opt = EventTimer()
+        one_step(False, skip_unlabelled=True)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.skip_unlabelled_steps):
+            one_step(True, skip_unlabelled=True, timer=t_opt)
+        barrier()
+        dt_opt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt_opt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_opt = t.item()
+        k_opt = t_opt.summary()
+        price(k_opt, algorithmic_bytes(True))
+        optout = {"value": bs / (dt_opt / args.skip_unlabelled_steps), "steps": args.skip_unlabelled_steps, "ms_per_step": 1e3 * dt_opt / args.skip_unlabelled_steps,
+                  "what": "HotPathStep(skip_unlabelled=True): rows whose next token carries no label are not read (no isfinite check there)",
+                  "kernel": {k: k_opt[dom].get(k) for k in ("avg_us", "launches", "algorithmic_bytes", "GBps", "hbm_frac")} if dom in k_opt else None}
+
     traffic = None
     traffic_source = None
     pmc = ROOT / "profiles" / "pmc_traffic.json"
@@ -1081,8 +1195,7 @@ def main():
         try:
             table = json.loads(pmc.read_text())
             traffic = table.get(dom, {}).get("hbm_bytes_per_launch")
-            traffic_source = ("profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over scripts/kernel_sweep.py, "
-                              "fused-kernel entry re-measured on the round-2 tree; committed, NOT measured in this run)")
+            traffic_source = "committed: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; every row read)"
             # per-token PMC figures of the two step-scale kernels, scaled to this launch
             if "grpo_loss_step" in kernels and "hbm_bytes_per_token" in table.get("grpo_loss_step", {}):
                 kernels["grpo_loss_step"]["traffic"] = table["grpo_loss_step"]["hbm_bytes_per_token"] * tokens_per_rank
@@ -1090,24 +1203,59 @@ def main():
                 kernels["preprocess_K5_K6"]["pack_write_traffic"] = table["pack_collate"]["write_kb"] * 1024 / table["pack_collate"]["tokens"] * tokens_per_rank
         except Exception:
             traffic = None
+    skipped: dict[str, str] = {}
+
+    def fits(name: str, estimate_s: float) -> bool:
+        """Optional legs of a DEFAULT run stay inside --budget-s (the driver's lease is shared with the tests and the smoke)."""
+        if args.detail or time.perf_counter() - T_START + estimate_s <= args.budget_s:
+            return True
+        skipped[name] = f"not run: {time.perf_counter() - T_START:.0f} s spent, ~{estimate_s:.0f} s needed, budget {args.budget_s:.0f} s (--detail or --budget-s lifts it)"
+        return False
+
+    cpu_base = None if (args.no_cpu_baseline or world != 1) else cpu_baseline(seq_length, vocab)
+
+    # The weight-sync probe creates its own RCCL communicator; a hang there must not cost the
+    # benchmark line, so a watchdog prints the line without it and ends the process.
+    full: dict = {}
+
+    def release_step_buffers():
+        nonlocal logits, grad_logits
+        logits = grad_logits = None
+        torch.cuda.empty_cache()
+
+    wsync = None
+    if world == 1 and not args.no_weight_sync and os.environ.get("PRL_BENCH_WSYNC", "1") != "0" and fits("weight_sync", 35 if param_set != "32b" else 120):
+        # one GPU: the only trainer -> actor layout is colocated; hand the 7B / 0.5B parameter set to a
+        # second process on this GPU over HIP IPC (request-to-ack of send_weight_update, median of 5)
+        release_step_buffers()
+        try:
+            from pipelinerl_amd.weight_sync_probe import colocated_probe
+
+            wsync = colocated_probe(param_set, iters=5, rehome=True, ready_timeout=240.0 if param_set != "32b" else 600.0)
+            wsync = {"transport": "hip_ipc_colocated", **wsync,
+                     "transport_note": "ONE GPU: trainer and inference worker share it, the bytes never touch a link - this figure says nothing about xGMI; the RCCL "
+                                       "broadcast BASELINE's metric names needs >= 2 GPUs (`bench.py --gpus N` reports it under the same keys, transport rccl_xgmi)"}
+        except Exception as e:  # noqa: BLE001 - the probe must never take the benchmark line down
+            wsync = {"error": f"{type(e).__name__}: {e}"}
+
     if (rank == 0 and world == 1 and dom == "fused_logits_loss" and (seq_length, vocab) == (8192, 152064) and not args.no_live_pmc
-            and os.environ.get("PRL_BENCH_LIVE_PMC", "1") != "0"):
+            and os.environ.get("PRL_BENCH_LIVE_PMC", "1") != "0" and fits("live_pmc", 60)):
+        release_step_buffers()
         try:
             live = live_pmc_traffic()
         except Exception:  # noqa: BLE001 - must never take the benchmark line down
             live = None
         if live is not None:
             traffic = live["hbm_bytes_per_launch"]
-            traffic_source = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) over "
-                              f"scripts/kernel_sweep.py --quick, {live['launches']} launches of the same kernel on the same micro-batch shape with every "
-                              f"row labelled; FETCH_SIZE {live['fetch_kb']:.0f} KB doubled per MI355X_MICROARCH.md + WRITE_SIZE {live['write_kb']:.0f} KB")
+            traffic_source = (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel trace only) over scripts/kernel_sweep.py --quick, "
+                              f"{live['launches']} launches, every row read; FETCH_SIZE {live['fetch_kb']:.0f} KB x2 (gfx950) + WRITE_SIZE {live['write_kb']:.0f} KB")
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": kernels[dom]["hbm_frac"], "traffic": traffic, "traffic_source": traffic_source,
-        # what `achieved` is made of, so that the trimmed line is self-sufficient: algorithmic bytes per launch / average launch duration
+        # what `achieved` is made of, so that the line is self-sufficient: algorithmic bytes per launch / average launch duration
         "avg_us": kernels[dom]["avg_us"], "min_us": kernels[dom]["min_us"], "launches": kernels[dom]["launches"],
         "algorithmic_bytes_per_launch": kernels[dom].get("algorithmic_bytes"),
-        "timing": "HIP events on torch's current stream (the stream the kernel is launched on), every launch of the timed region",
+        "timing": "HIP events on torch's current stream (where the kernel is launched), every launch of the timed region",
     }
     if grad_buckets and "grad_allreduce" in kernels:
         k = kernels["grad_allreduce"]
@@ -1115,96 +1263,38 @@ def main():
         k["algbw_GBps"] = k["bytes"] / (k["avg_us"] * 1e-6) / 1e9
         k["busbw_GBps"] = 2 * (world - 1) / world * k["algbw_GBps"]  # ring all-reduce: every byte crosses 2 (N - 1) / N links
 
-    cpu_base = None if (args.no_cpu_baseline or world != 1) else cpu_baseline(seq_length, vocab)
-
-    # ---- secondary objects (never part of `value`) ----
-    roofline_mfma = None
-    if world == 1 and not args.no_fused_head:
-        try:
-            del logits, grad_logits
-            torch.cuda.empty_cache()
-            roofline_mfma = fused_head_probe(dev, seq_length, vocab, hidden)
-        except Exception as e:  # noqa: BLE001 - must never take the benchmark line down
-            roofline_mfma = {"error": f"{type(e).__name__}: {e}"}
-        logits = grad_logits = None
-    e2e = None
-    if world == 1 and param_set == "7b" and vocab == 152064:
-        committed = _committed_json("profiles/r02_e2e_learner_7b_fused_head.json",
-                                    note="MODEL-IN-THE-LOOP step (random-init Qwen2.5-7B shape, stock PyTorch-ROCm forward/backward + AdamW on ONE MI355X, "
-                                         "bs 16 x 8192) measured separately with scripts/e2e_learner_bench.py and committed; `value` above is the post-model "
-                                         "hot path on resident logits, NOT learner throughput")
-        live = not args.no_e2e and os.environ.get("PRL_BENCH_E2E", "1") != "0"
-        if live:
-            # a live model-in-the-loop step in a fresh process (it needs ~80 GB of this GPU: everything of ours is released first)
-            import subprocess
-
-            logits = grad_logits = None
-            del rag
-            torch.cuda.empty_cache()
-            out = ROOT / "gpurun_out" / "bench_e2e_7b.json"
-            out.parent.mkdir(exist_ok=True)
-            if out.exists():
-                out.unlink()
-            t_e2e = time.perf_counter()
+    # ---- side measurements (--detail only; they go to the detail file, never to the printed line) ----
+    side: dict = {}
+    if args.detail:
+        release_step_buffers()
+        if world == 1 and not args.no_fused_head:
             try:
-                r = subprocess.run([sys.executable, str(ROOT / "scripts" / "e2e_learner_bench.py"), "--model", "7b", "--batch-size", "16", "--seq-len", "8192",
-                                    "--micro-batch", "1", "--fused", "--fused-head", "--steps", "1", "--warmup", "1", "--out", str(out)],
-                                   capture_output=True, text=True, timeout=float(os.environ.get("PRL_BENCH_E2E_TIMEOUT", 900)))
-                e2e = json.loads(out.read_text().splitlines()[0]) if r.returncode == 0 and out.exists() else {"error": (r.stderr or r.stdout)[-400:]}
+                side["roofline_mfma"] = fused_head_probe(dev, seq_length, vocab, hidden)
             except Exception as e:  # noqa: BLE001 - must never take the benchmark line down
-                e2e = {"error": f"{type(e).__name__}: {e}"}
-            if "error" not in e2e:
-                e2e["source"] = "measured in this run (scripts/e2e_learner_bench.py in a subprocess of bench.py)"
-                e2e["wall_s_including_model_init"] = time.perf_counter() - t_e2e
-                # the same step with every layer's activations KEPT (no recompute in the backward): what the 288 GB of one MI355X
-                # allow for 7B x 8192 tokens; the entry above keeps the reference's gradient checkpointing for comparability
-                try:
-                    out.unlink()
-                    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "e2e_learner_bench.py"), "--model", "7b", "--batch-size", "16", "--seq-len", "8192",
-                                        "--micro-batch", "1", "--fused", "--fused-head", "--no-checkpointing", "--steps", "1", "--warmup", "1", "--out", str(out)],
-                                       capture_output=True, text=True, timeout=float(os.environ.get("PRL_BENCH_E2E_TIMEOUT", 900)))
-                    if r.returncode == 0 and out.exists():
-                        k = json.loads(out.read_text().splitlines()[0])
-                        e2e["without_activation_recompute"] = {key: k[key] for key in ("s_per_step", "samples_per_s", "tokens_per_s", "peak_memory_GB", "loss")}
-                    else:
-                        e2e["without_activation_recompute"] = {"error": (r.stderr or r.stdout)[-300:]}
-                except Exception as e:  # noqa: BLE001
-                    e2e["without_activation_recompute"] = {"error": f"{type(e).__name__}: {e}"}
-            elif committed is not None:
-                committed["source"] = "committed (profiles/r02_e2e_learner_7b_fused_head.json) - the live run failed: " + e2e["error"][-200:]
-                e2e = committed
-        else:
-            e2e = committed
-            if e2e is not None:
-                e2e["source"] = "committed (profiles/r02_e2e_learner_7b_fused_head.json), NOT measured in this run"
-    ref_logprob = None
-    if not args.no_ref_logprob and not args.no_fused_head:  # every rank runs it (no collective inside), rank 0 reports
-        try:
-            logits = grad_logits = None
-            torch.cuda.empty_cache()
-            ref_logprob = ref_logprob_probe(dev, seq_length, vocab, hidden)
-        except Exception as e:  # noqa: BLE001
-            ref_logprob = {"error": f"{type(e).__name__}: {e}"}
-    preprocess_loop = None
-    if world == 1 and not args.no_preprocess_loop:
-        try:
-            preprocess_loop = preprocess_loop_probe(dev, seq_length, vocab, attempts)
-        except Exception as e:  # noqa: BLE001
-            preprocess_loop = {"error": f"{type(e).__name__}: {e}"}
-    pipeline = None
-    if world == 1 and not args.no_pipeline and os.environ.get("PRL_BENCH_PIPELINE", "1") != "0":
-        try:
-            logits = grad_logits = None
-            torch.cuda.empty_cache()
-            pipeline = pipeline_probe(args.pipeline_steps, tiny=args.workload == "tiny")
-        except Exception as e:  # noqa: BLE001 - must never take the benchmark line down
-            pipeline = {"error": f"{type(e).__name__}: {e}"}
-    transport = None
-    if rank == 0 and not args.no_transport:
-        try:
-            transport = transport_probe(seq_length, vocab)
-        except Exception as e:  # noqa: BLE001
-            transport = {"error": f"{type(e).__name__}: {e}"}
+                side["roofline_mfma"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and param_set == "7b" and vocab == 152064:
+            side["e2e"] = e2e_probe(live=not args.no_e2e and os.environ.get("PRL_BENCH_E2E", "1") != "0")
+        if not args.no_ref_logprob and not args.no_fused_head:  # every rank runs it (no collective inside), rank 0 reports
+            try:
+                side["ref_logprob"] = ref_logprob_probe(dev, seq_length, vocab, hidden)
+            except Exception as e:  # noqa: BLE001
+                side["ref_logprob"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_preprocess_loop:
+            try:
+                side["preprocess_loop"] = preprocess_loop_probe(dev, seq_length, vocab, attempts)
+            except Exception as e:  # noqa: BLE001
+                side["preprocess_loop"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_pipeline and os.environ.get("PRL_BENCH_PIPELINE", "1") != "0":
+            try:
+                torch.cuda.empty_cache()
+                side["pipeline"] = pipeline_probe(args.pipeline_steps, tiny=args.workload == "tiny")
+            except Exception as e:  # noqa: BLE001 - must never take the benchmark line down
+                side["pipeline"] = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0 and not args.no_transport:
+            try:
+                side["transport"] = transport_probe(seq_length, vocab)
+            except Exception as e:  # noqa: BLE001
+                side["transport"] = {"error": f"{type(e).__name__}: {e}"}
 
     label = {"7b_grpo_bs4096_seq8192": "7B GRPO bs=4096", "0p5b_grpo_bs512_seq2048": "0.5B GRPO bs=512 seq=2048",
              "32b_grpo_kl_bs4096_seq8192": "32B GRPO bs=4096, KL-to-ref on"}.get(args.workload, args.workload)
@@ -1212,12 +1302,10 @@ def main():
     def emit(wsync):
         if rank != 0:
             return
-        line = {
-            "metric": f"learner samples/sec, {label} (POST-MODEL hot path on resident fp32 logits: K5+K6 preprocess, fused logits->GRPO loss->dlogits, step stats; "
-                      "`value` EXCLUDES the transformer forward/backward - the model-in-the-loop rate is `value_e2e`, the pipelined configs[1] rate is "
-                      "`pipeline.samples_per_s`; trainer->actor weight-sync ms in weight_sync)",
+        full.update({
+            "metric": f"learner samples/sec, {label} (post-model hot path on resident fp32 logits: K5+K6 preprocess, fused logits->GRPO loss->dlogits, "
+                      "step stats; excludes the transformer forward/backward; trainer->actor weight-sync ms in weight_sync)",
             "value": bs / (elapsed / args.steps),
-            "value_e2e": (e2e or {}).get("samples_per_s"),
             "unit": "samples/s",
             "n_gpus": n_ranks,
             "steps": args.steps,
@@ -1230,45 +1318,35 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "global_batch": bs, "seq_len": seq_length, "vocab": vocab,
                        "tokens_per_step": bs * seq_length, "parallelism": f"dp{world}", "logits_mode": args.logits_mode,
-                       "policy_loss": "ppo", "kl_coef": kl_coef, "ref_logprobs": ("old + N(0, 0.05)" if kl_coef > 0 else "== old (KL off)"),
-                       "param_set": param_set, "head_hidden": hidden, "old_logprob_sigma": sigma, "labelled_token_fraction": live_frac,
+                       "policy_loss": "ppo", "kl_coef": kl_coef, "skip_unlabelled": False, "labelled_token_fraction": live_frac,
                        "grad_allreduce_bytes_per_step": sum(b.numel() * 2 for b in grad_buckets) if grad_buckets else 0,
-                       "torch_distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
-                                              "distinct_devices": distinct_devices, "rccl_comm_size": (wsync or {}).get("rccl_comm_size"),
-                                              "share_device_dry_run": share_device} if world > 1 else None),
-                       "h2d_ragged_input": {"bytes": h2d_bytes, "ms": 1e3 * t_h2d, "ms_pinned": 1e3 * t_h2d_pinned,
-                                            "note": "one step's ragged rollouts, pageable vs page-locked host memory; not part of value"}},
+                       "backend": dist.get_backend() if world > 1 else None, "distinct_devices": distinct_devices},
+            "config_detail": {"ref_logprobs": ("old + N(0, 0.05)" if kl_coef > 0 else "== old (KL off)"), "param_set": param_set, "head_hidden": hidden,
+                              "old_logprob_sigma": sigma,
+                              "torch_distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
+                                                     "distinct_devices": distinct_devices, "rccl_comm_size": (wsync or {}).get("rccl_comm_size"),
+                                                     "share_device_dry_run": share_device} if world > 1 else None),
+                              "h2d_ragged_input": {"bytes": h2d_bytes, "ms": 1e3 * t_h2d, "ms_pinned": 1e3 * t_h2d_pinned,
+                                                   "note": "one step's ragged rollouts, pageable vs page-locked host memory; not part of value"}},
             "roofline": roofline,
-            "roofline_mfma": roofline_mfma,
-            "ref_logprob": ref_logprob,
-            "preprocess_loop": preprocess_loop,
-            "pipeline": pipeline,
-            "e2e": e2e,
-            "transport": transport,
+            "value_skip_unlabelled": optout,
             "kernels": kernels,
             "cpu_baseline": cpu_base,
             "weight_sync": wsync,
+            "skipped": skipped,
             "loss": stats_host[0],
-        }
+            "wall_s": time.perf_counter() - T_START,
+            **side,
+        })
+        line, detail = split_line(full, args.detail_out)
+        out = ROOT / args.detail_out
+        try:
+            out.parent.mkdir(parents=True, exist_ok=True)
+            out.write_text(json.dumps(detail, indent=1) + "\n")
+        except OSError as e:  # a read-only tree must not cost the line
+            line["detail"] = f"not written: {e}"
         print(json.dumps(line), flush=True)
 
-    # The weight-sync probe creates its own RCCL communicator; a hang there must not cost the
-    # benchmark line, so a watchdog prints the line without it and ends the process.
-    wsync = None
-    if world == 1 and not args.no_weight_sync and os.environ.get("PRL_BENCH_WSYNC", "1") != "0":
-        # one GPU: the only trainer -> actor layout is colocated; hand the 7B / 0.5B parameter set to a
-        # second process on this GPU over HIP IPC (request-to-ack of send_weight_update, median of 5)
-        logits = grad_logits = None
-        torch.cuda.empty_cache()
-        try:
-            from pipelinerl_amd.weight_sync_probe import colocated_probe
-
-            wsync = colocated_probe(param_set, iters=5, rehome=True, ready_timeout=240.0 if param_set != "32b" else 600.0)
-            wsync = {"transport": "hip_ipc_colocated", **wsync,
-                     "transport_note": "ONE GPU: trainer and inference worker share it, the bytes never touch a link - this figure says nothing about xGMI; the RCCL "
-                                       "broadcast BASELINE's metric names needs >= 2 GPUs (`bench.py --gpus N` reports it under the same keys, transport rccl_xgmi)"}
-        except Exception as e:  # noqa: BLE001 - the probe must never take the benchmark line down
-            wsync = {"error": f"{type(e).__name__}: {e}"}
     force = os.environ.get("PRL_BENCH_FORCE_WSYNC") == "1"  # dry runs: exercise the probe's error handling under gloo
     if world > 1 and (args.backend == "nccl" or force) and not args.no_weight_sync and os.environ.get("PRL_BENCH_WSYNC", "1") != "0":
         import threading
@@ -1282,6 +1360,7 @@ def main():
                 os._exit(0)
 
         threading.Thread(target=watchdog, daemon=True).start()
+        release_step_buffers()
         weight_sync_probe(rank, world, dev, wsync)
         done.set()
     emit(wsync)

@@ -23,10 +23,11 @@ Backends
          like a file.  Non-batch records (trainer messages, stats dicts) travel as JSON bytes.  With
          `mirror_jsonl=True` (or a list of topics) every record is also appended to the files-backend
          location, so the run can be replayed with `backend: files` (`debug.streams_from`).
-  redis  NOT provided: the reference's Redis backend (streams.py:106-232) is a network service outside the hot path, and
-         this image ships neither the client package nor a server, so a restatement of it could not even be tested.
-         `backend: redis` raises with a pointer to `shm` (same log semantics - every reader from record 0, fan-out,
-         reopened writers - in shared memory, one node) and `files`.
+  redis  the reference's networked transport, wire-compatible (streams.py:106-232): XADD {index, data = pickle(record)} with
+         the writer's running index, XREAD from id 0 one entry at a time, `maxlen` 1 000 000 approximate.  Needs the `redis`
+         client package, imported lazily: `set_streams_backend("redis", host=, port=)` raises ImportError where it is absent
+         (this image ships neither client nor server; tests/test_streams.py runs both classes against an in-process stand-in
+         of the five client calls they make).  Multi-node runs use this; `shm` is one node, `files` needs a shared filesystem.
 """
 
 from __future__ import annotations
@@ -57,16 +58,22 @@ _backend: str | None = None
 _backend_options: dict[str, Any] = {}
 
 
-def set_streams_backend(backend: Literal["files", "shm"], **kwargs: Any) -> None:
+def set_streams_backend(backend: Literal["files", "shm", "redis"], **kwargs: Any) -> None:
     """Select the transport once per process (reference :33-43)."""
     global _backend, _backend_options
     if _backend is not None:
         raise ValueError("Backend already set. Cannot change it.")
     if backend == "redis":
-        raise NotImplementedError("streams backend 'redis' is not part of pipelinerl_amd (the reference's Redis transport is a network service "
-                                  "outside the hot path). Use backend 'shm' (the same log semantics in shared memory, one node) or 'files'.")
-    if backend not in ("files", "shm"):
-        raise ValueError(f"Invalid backend: {backend}. Only 'files' and 'shm' are supported.")
+        try:
+            import redis  # noqa: F401
+        except ImportError as e:
+            raise ImportError("streams backend 'redis' needs the `redis` client package (and a reachable server); it is not installed here. "
+                              "Single-node runs can use backend 'shm' (same log semantics in shared memory) or 'files'.") from e
+        unknown = set(kwargs) - {"host", "port"}
+        if unknown:  # the reference's RedisConfig(host, port) rejects nothing silently either (pydantic ignores, we say so)
+            raise ValueError(f"redis backend takes host and port only, got {sorted(unknown)}")
+    if backend not in ("files", "shm", "redis"):
+        raise ValueError(f"Invalid backend: {backend}. Only 'redis', 'files' and 'shm' are supported.")
     _backend, _backend_options = backend, dict(kwargs)
 
 
@@ -438,6 +445,104 @@ class ShmStreamReader(StreamReader):
 
 
 # ---------------------------------------------------------------------------------------------
+# redis backend (reference streams.py:106-192; needs the `redis` client package + a server)
+# ---------------------------------------------------------------------------------------------
+
+_REDIS_RETRY_DELAY = 5.0
+
+
+def _connect_to_redis():
+    """Connect with unlimited retries, as the reference does (:106-117)."""
+    import redis
+
+    host, port = _backend_options.get("host", "localhost"), int(_backend_options.get("port", 6379))
+    while True:
+        try:
+            client = redis.Redis(host=host, port=port)
+            client.ping()
+            return client
+        except (redis.exceptions.TimeoutError, redis.ConnectionError) as e:
+            logger.warning(f"Waiting for Redis server ({type(e)}). Retrying in {_REDIS_RETRY_DELAY:g} seconds.")
+            time.sleep(_REDIS_RETRY_DELAY)
+
+
+def _picklable(data: Any) -> Any:
+    """What the reference pickles: `model_dump()` of a pydantic record (:154-155) - tensors stay tensors.  Our batch type and the
+    SoA rollout record are not pydantic models; they take the same plain form (dict of tensors / the actor's list of dicts)."""
+    if isinstance(data, RaggedRollouts):
+        return data.to_entries()
+    if isinstance(data, (BaseModel, PipelineBatchEncoding)):
+        return data.model_dump()
+    return data
+
+
+class RedisStreamWriter(StreamWriter):
+    """XADD {index, data = pickle(record)} under the stream name `topic/instance/partition`, with the running index the
+    reference keeps: mode "a" continues after the last entry, mode "w" refuses a stream that already has data (:120-158)."""
+
+    def __init__(self, stream: SingleStreamSpec, mode: Literal["w", "a"] = "a"):
+        if mode not in ("w", "a"):
+            raise ValueError(f"Invalid mode: {mode}. Only 'w' and 'a' are supported.")
+        self.stream = stream
+        self._stream_name = str(stream)
+        self._redis = _connect_to_redis()
+        last = self._redis.xrevrange(self._stream_name, count=1)
+        if mode == "w" and last:
+            raise ValueError(f"Stream {self.stream} already exists. Cannot overwrite it.")
+        self._index = int(last[0][1][b"index"].decode()) + 1 if last else 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        self._redis.close()
+
+    def write(self, data, partition: int | None = None):
+        import pickle
+
+        if partition is not None:
+            raise ValueError()
+        self._redis.xadd(self._stream_name, {"index": self._index, "data": pickle.dumps(_picklable(data))}, maxlen=1000000, approximate=True)
+        self._index += 1
+
+
+class RedisStreamReader(StreamReader):
+    """XREAD from id 0, one entry per call, blocking `_REREAD_DELAY` at the tail; every entry's index must be the next one
+    (a trimmed or interleaved stream raises, :163-192)."""
+
+    def __init__(self, stream: SingleStreamSpec):
+        self.stream = stream
+        self._stream_name = str(stream)
+        self._redis = _connect_to_redis()
+        self._last_id: Any = 0
+        self._index = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        self._redis.close()
+
+    def read(self):
+        import pickle
+
+        block = int(_REREAD_DELAY * 1000)
+        while True:
+            response = self._redis.xread({self._stream_name: self._last_id}, count=1, block=block)
+            if not response:
+                continue
+            name, result = response[0]
+            assert (name.decode("utf-8") if isinstance(name, bytes) else name) == self._stream_name and len(result) == 1
+            entry_id, entry = result[0]
+            got = int(entry[b"index"].decode("utf-8"))
+            if got != self._index:
+                raise ValueError(f"Index mismatch: expected {self._index}, got {got}")
+            self._last_id = entry_id
+            self._index += 1
+            yield pickle.loads(entry[b"data"])
+
+
+# ---------------------------------------------------------------------------------------------
 # partitioned writer (reference :349-384)
 # ---------------------------------------------------------------------------------------------
 
@@ -477,7 +582,7 @@ def read_stream(stream: SingleStreamSpec) -> StreamReader:
     raise_if_backend_not_set()
     if not isinstance(stream, SingleStreamSpec):
         raise ValueError(f"Invalid stream spec: {stream}")
-    return {"files": FileStreamReader, "shm": ShmStreamReader}[_backend](stream)
+    return {"files": FileStreamReader, "shm": ShmStreamReader, "redis": RedisStreamReader}[_backend](stream)
 
 
 def write_to_streams(streams: StreamSpec, mode: Literal["w", "a"] = "a") -> StreamWriter:
@@ -485,7 +590,7 @@ def write_to_streams(streams: StreamSpec, mode: Literal["w", "a"] = "a") -> Stre
     raise_if_backend_not_set()
     if not isinstance(streams, (SingleStreamSpec, StreamRangeSpec)):
         raise ValueError(f"Invalid stream spec: {streams}")
-    writer_cls = {"files": FileStreamWriter, "shm": ShmStreamWriter}[_backend]
+    writer_cls = {"files": FileStreamWriter, "shm": ShmStreamWriter, "redis": RedisStreamWriter}[_backend]
     if isinstance(streams, SingleStreamSpec):
         return writer_cls(streams, mode)
     return PartitionedStreamWriter(streams, mode, writer_cls)

@@ -73,7 +73,7 @@ def bucket_nbytes(bucket: Sequence[tuple[ParamSpec, int]]) -> int:
 
 
 # `hipIpcOpenMemHandle` never returns for an allocation of 2 GiB or more on this stack (ROCm 7.0 / dmabuf IPC; measured with
-# scripts/exp/ipc_large_allocation_probe.py: 1.9 GiB opens in 0.2 ms, 2.0 GiB and above not within 40 s - the 7B-shaped
+# profiles/r05r_ipc_open_by_allocation_size.txt: 1.9 GiB opens in 0.2 ms, 2.0 GiB and above not within 40 s - the 7B-shaped
 # pipeline, whose fp32 output head is ONE 2.18 GB tensor, stalled there).  No exported bucket may reach it.
 IPC_MAX_ALLOCATION = (1 << 31) - (1 << 20)
 _ROWS = "#rows"

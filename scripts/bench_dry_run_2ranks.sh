@@ -9,5 +9,5 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp PRL_BENCH_SHARE_DEVICE=1 PRL_BENCH_FORCE_WSYNC=1 PRL_BENCH_WSYNC_TIMEOUT=60
 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 1 --warmup 0 \
-  --backend gloo --workload $WL --no-fused-head > $OUT/dry_run.log 2> $OUT/dry_run.err
+  --backend gloo --workload $WL --detail-out $OUT/dry_run_detail.json > $OUT/dry_run.log 2> $OUT/dry_run.err
 echo "exit $?"; grep '^{' $OUT/dry_run.log | head -1 | cut -c1-1500; tail -3 $OUT/dry_run.err

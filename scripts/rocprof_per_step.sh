@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-weight-sync --no-e2e --no-transport --no-live-pmc --no-fused-head --no-preprocess-loop --no-ref-logprob > $OUT/bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-weight-sync --no-live-pmc --skip-unlabelled-steps 0 > $OUT/bench.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - "$OUT" <<'PY'
 import csv, glob, json, sys

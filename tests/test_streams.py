@@ -50,10 +50,13 @@ def test_backend_must_be_set_once(streams, tmp_path):
     with pytest.raises(ValueError):
         streams.set_streams_backend("files")
     streams.reset_streams_backend()
-    # the reference's Redis transport is not part of this package: asking for it fails loudly, naming the two backends that exist,
+    # `redis` is the reference's own wire format and needs the redis client: without it the choice fails loudly (ImportError)
     # instead of being served by another transport
-    with pytest.raises(NotImplementedError, match="shm"):
-        streams.set_streams_backend("redis", host="localhost", port=6379)
+    try:
+        import redis  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="redis"):
+            streams.set_streams_backend("redis", host="localhost", port=6379)
     streams.reset_streams_backend()
     with pytest.raises(ValueError):
         streams.set_streams_backend("carrier-pigeon")
@@ -347,3 +350,182 @@ def test_packed_step_record_recipe_equals_the_generic_encoding():
     dev_like = packed[1]
     nb_, pb = batch_codec.describe_batch(dev_like, packed.block.data_ptr(), packed.block.numel(), inline_b)
     assert na == nb_
+
+
+# ---------------------------------------------------------------------------------------------
+# redis backend against an in-process stand-in of the client calls it makes (the image has neither client nor server)
+# ---------------------------------------------------------------------------------------------
+
+
+class _FakeRedisServer:
+    """The stream commands of one server: XADD (auto ids `<ms>-<seq>`, field names and values come back as bytes, like redis-py
+    without decode_responses), XREVRANGE count=1, XREAD {name: last_id} count=1 block=ms."""
+
+    def __init__(self):
+        self.streams: dict[str, list] = {}
+        self.cond = threading.Condition()
+        self.refuse_first_pings = 0
+
+    def client_module(self):
+        import types
+
+        server = self
+
+        class ConnectionError(Exception):  # noqa: A001 - the name redis-py uses
+            pass
+
+        class TimeoutError(Exception):  # noqa: A001
+            pass
+
+        class Redis:
+            def __init__(self, host="localhost", port=6379):
+                self.host, self.port, self.closed = host, port, False
+
+            def ping(self):
+                if server.refuse_first_pings > 0:
+                    server.refuse_first_pings -= 1
+                    raise ConnectionError("connection refused")
+                return True
+
+            def close(self):
+                self.closed = True
+
+            def xadd(self, name, fields, maxlen=None, approximate=True):
+                assert maxlen == 1000000 and approximate is True  # the reference's retention (streams.py:157)
+                with server.cond:
+                    entries = server.streams.setdefault(name, [])
+                    eid = (len(entries) + 1, 0)
+                    enc = lambda v: v if isinstance(v, bytes) else str(v).encode()  # noqa: E731
+                    entries.append((eid, {k.encode(): enc(v) for k, v in fields.items()}))
+                    server.cond.notify_all()
+                return f"{eid[0]}-{eid[1]}".encode()
+
+            def xrevrange(self, name, count=None):
+                with server.cond:
+                    entries = server.streams.get(name, [])
+                    return [(f"{e[0][0]}-{e[0][1]}".encode(), e[1]) for e in reversed(entries)][:count]
+
+            def xread(self, streams, count=None, block=None):
+                (name, last), = streams.items()
+                if isinstance(last, bytes):
+                    last = tuple(int(x) for x in last.decode().split("-"))
+                elif last == 0:
+                    last = (0, 0)
+                with server.cond:
+                    def newer():
+                        return [e for e in server.streams.get(name, []) if e[0] > last]
+                    if not newer() and block:
+                        server.cond.wait(block / 1000.0)
+                    got = newer()[:count]
+                return [[name.encode(), [(f"{e[0][0]}-{e[0][1]}".encode(), e[1]) for e in got]]] if got else []
+
+        mod = types.ModuleType("redis")
+        mod.Redis, mod.ConnectionError = Redis, ConnectionError
+        mod.exceptions = types.SimpleNamespace(TimeoutError=TimeoutError, ConnectionError=ConnectionError)
+        return mod
+
+
+@pytest.fixture()
+def fake_redis(monkeypatch, streams):
+    import sys
+
+    server = _FakeRedisServer()
+    monkeypatch.setitem(sys.modules, "redis", server.client_module())
+    monkeypatch.setattr(streams, "_REDIS_RETRY_DELAY", 0.01)
+    streams.set_streams_backend("redis", host="redis.example", port=6380)
+    return server
+
+
+def test_redis_wire_format_is_the_references(streams, fake_redis, tmp_path):
+    """Stream name `topic/instance/partition`, fields {index, data}, data = pickle of the record's plain form (streams.py:120-158)."""
+    import pickle
+
+    from pipelinerl_amd.finetune_loop import SamplesProcessed
+
+    batch, want = _batch()
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="training_data", partition=3)
+    with streams.write_to_streams(spec) as w:
+        assert isinstance(w, streams.RedisStreamWriter)
+        w.write(batch)
+        w.write(SamplesProcessed(samples_processed=7))
+        with pytest.raises(ValueError):
+            w.write({}, partition=0)
+    entries = fake_redis.streams["training_data/0/3"]
+    assert [int(e[1][b"index"]) for e in entries] == [0, 1] and set(entries[0][1]) == {b"index", b"data"}
+    first, second = (pickle.loads(e[1][b"data"]) for e in entries)
+    assert isinstance(first, dict) and isinstance(first["input_ids"], torch.Tensor)  # model_dump(): tensors stay tensors in the pickle
+    _same(first, want)
+    assert second["kind"] == "samples_processed" and second["samples_processed"] == 7
+    with streams.read_stream(spec) as r:
+        it = r.read()
+        _same(next(it), want)
+        assert next(it)["samples_processed"] == 7
+
+
+def test_redis_append_continues_the_index_and_w_refuses_existing_data(streams, fake_redis, tmp_path):
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="trainer")
+    for k in range(3):  # the trainer topic is reopened for every weight update (finetune_loop.py:244)
+        with streams.write_to_streams(spec) as w:
+            w.write({"k": k})
+    assert [int(e[1][b"index"]) for e in fake_redis.streams["trainer/0/0"]] == [0, 1, 2]
+    with pytest.raises(ValueError, match="already exists"):
+        streams.write_to_streams(spec, mode="w")
+    with pytest.raises(ValueError, match="Invalid mode"):
+        streams.write_to_streams(spec, mode="x")
+    fresh = streams.SingleStreamSpec(exp_path=tmp_path, topic="fresh")
+    with streams.write_to_streams(fresh, mode="w") as w:
+        w.write({"a": 1})
+    # two independent readers each see every record from the first one (fan-out: TrainerState in three processes)
+    for _ in range(2):
+        with streams.read_stream(spec) as r:
+            it = r.read()
+            assert [next(it)["k"] for _ in range(3)] == [0, 1, 2]
+
+
+def test_redis_reader_blocks_for_new_entries_and_checks_the_running_index(streams, fake_redis, tmp_path):
+    spec = streams.SingleStreamSpec(exp_path=tmp_path, topic="actor")
+    got = []
+
+    def consume():
+        with streams.read_stream(spec) as r:
+            for rec in r.read():
+                got.append(rec)
+                if len(got) == 2:
+                    return
+
+    t = threading.Thread(target=consume)
+    t.start()
+    with streams.write_to_streams(spec) as w:  # the reader polls an empty / absent stream until entries arrive
+        w.write([{"reward": 1.0}])
+        w.write([{"reward": 0.0}])
+    t.join(10)
+    assert not t.is_alive() and got == [[{"reward": 1.0}], [{"reward": 0.0}]]
+    # a stream that lost its head (maxlen trimming) or has a foreign writer: the index check raises, as in the reference (:185-186)
+    fake_redis.streams["actor/0/0"].pop(0)
+    with streams.read_stream(spec) as r, pytest.raises(ValueError, match="Index mismatch"):
+        next(r.read())
+
+
+def test_redis_partitioned_writer_and_connection_retry(streams, fake_redis, tmp_path):
+    fake_redis.refuse_first_pings = 2  # the server is not up yet: unlimited retries (:106-117)
+    rng = streams.StreamRangeSpec(exp_path=tmp_path, topic="training_data", partition_range=(0, 3))
+    with streams.write_to_streams(rng) as w:
+        for k in range(4):
+            w.write({"k": k})          # round robin
+        w.write({"k": 99}, partition=2)
+        with pytest.raises(ValueError):
+            w.write({}, partition=3)
+    assert fake_redis.refuse_first_pings == 0
+    import pickle
+
+    by_part = {p: [pickle.loads(e[1][b"data"])["k"] for e in fake_redis.streams[f"training_data/0/{p}"]] for p in range(3)}
+    assert by_part == {0: [0, 3], 1: [1], 2: [2, 99]}
+
+
+def test_redis_options_are_host_and_port_only(streams, monkeypatch):
+    import sys
+    import types
+
+    monkeypatch.setitem(sys.modules, "redis", types.ModuleType("redis"))
+    with pytest.raises(ValueError, match="host and port"):
+        streams.set_streams_backend("redis", host="h", segment_bytes=1)

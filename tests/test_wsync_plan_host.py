@@ -59,7 +59,7 @@ def test_small_buckets_leave_trailing_slices_empty(plan):
 
 
 def test_ipc_transport_cuts_tensors_too_large_for_one_exportable_allocation(monkeypatch):
-    """`hipIpcOpenMemHandle` does not return for allocations of 2 GiB and more on this stack (scripts/exp/ipc_large_allocation_probe.py):
+    """`hipIpcOpenMemHandle` does not return for allocations of 2 GiB and more on this stack (profiles/r05r_ipc_open_by_allocation_size.txt):
     the IPC transport turns such a tensor into row ranges on both sides (same arithmetic from `parameters_info`), no bucket reaches the
     limit, and a receiver without a registered destination gets the tensor back in one piece."""
     import torch
