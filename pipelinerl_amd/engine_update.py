@@ -75,9 +75,13 @@ class ScriptedEngine:
     def __init__(self, workers: Sequence[Any], generate_step: Callable[[], Any] | None = None):
         self.workers = list(workers)
         self.generate_step = generate_step
-        self._run = threading.Event()
-        self._run.set()
-        self._parked = threading.Event()
+        # ONE lock guards both facts - "generation may run" and "a quantum is running": the loop decides to start a quantum and
+        # marks it under the lock, so a pause that has cleared `_want_run` under the same lock sees either a quantum to wait for or
+        # none that can still start.  (Two independent events left a window: a pause right after a resume saw the previous
+        # park and returned while the loop thread was already past its check.)
+        self._cond = threading.Condition()
+        self._want_run = True
+        self._in_quantum = False
         self._stop = False
         self.quanta = 0
         self.quanta_by_version: dict[Any, int] = {}
@@ -86,29 +90,41 @@ class ScriptedEngine:
         if generate_step is not None:
             self._thread = threading.Thread(target=self._loop, name="scripted-engine", daemon=True)
             self._thread.start()
-        else:
-            self._parked.set()
 
     def _loop(self) -> None:
-        while not self._stop:
-            if not self._run.is_set():
-                self._parked.set()
-                self._run.wait(0.05)
-                continue
-            self._parked.clear()
-            self.generate_step()
-            self.quanta += 1
-            self.quanta_by_version[self.current_version] = self.quanta_by_version.get(self.current_version, 0) + 1
+        while True:
+            with self._cond:
+                while not self._want_run and not self._stop:
+                    self._cond.wait(0.05)
+                if self._stop:
+                    return
+                self._in_quantum = True
+            try:
+                self.generate_step()
+            finally:
+                with self._cond:
+                    self._in_quantum = False
+                    self.quanta += 1
+                    self.quanta_by_version[self.current_version] = self.quanta_by_version.get(self.current_version, 0) + 1
+                    self._cond.notify_all()
+
+    def generating(self) -> bool:
+        """True while a generation quantum is executing (what a weight copy must never overlap)."""
+        with self._cond:
+            return self._in_quantum
 
     async def pause_generation(self, mode: str = "keep", clear_cache: bool = False) -> None:
         if mode != "keep":
             raise ValueError("the in-flight update pauses with mode='keep' (vllm1.py:164)")
-        self._run.clear()
-        while self._thread is not None and not self._parked.is_set():
+        with self._cond:
+            self._want_run = False
+        while self.generating():
             await asyncio.sleep(0.0005)
 
     async def resume_generation(self) -> None:
-        self._run.set()
+        with self._cond:
+            self._want_run = True
+            self._cond.notify_all()
 
     async def collective_rpc(self, method: str, args: tuple = ()) -> list:
         loop = asyncio.get_running_loop()
@@ -121,8 +137,9 @@ class ScriptedEngine:
         return out
 
     def shutdown(self) -> None:
-        self._stop = True
-        self._run.set()
+        with self._cond:
+            self._stop = True
+            self._cond.notify_all()
         if self._thread is not None:
             self._thread.join(timeout=5)
 

@@ -19,6 +19,7 @@ Differences, all inside the contract:
 
 from __future__ import annotations
 
+import collections
 import contextlib
 import logging
 import threading
@@ -81,6 +82,9 @@ class WeightUpdateRequest(BaseModel):
     bucket_bytes: int = 1 << 30
     ipc_handles: list[str] = Field(default_factory=list)
     ipc_nbytes: list[int] = Field(default_factory=list)
+    # the sender's IPC allocation cap: with bucket_bytes it fixes the row-range piece list (`weight_sync.split_for_ipc`), which
+    # the receiver must derive identically - it travels with the request instead of being a constructor default on both sides
+    ipc_max_allocation: int | None = None
     tp_size: int = 1
 
 
@@ -438,6 +442,7 @@ class WeightUpdateManager:
                         self._sender = ColocatedSender(params[0][1].device, self.bucket_bytes)
                     desc = self._sender.publish(params)
                 message.ipc_handles, message.ipc_nbytes = desc["ipc_handles"], desc["ipc_nbytes"]
+                message.ipc_max_allocation = desc["ipc_max_allocation"]
             futures = self.request_weight_updates(message)
         if self.transport == "ipc":
             # the POST returns when the worker has copied the buckets.  The other trainer ranks of a SHARDED
@@ -724,9 +729,15 @@ class StreamedLearnerStep(LearnerStep):
             inner = inner.module
         if getattr(inner, "_prl_fused_head", None) is None:
             raise TypeError("StreamedLearnerStep drives a model prepared with pipelinerl_amd.fused_head.install_fused_head")
+        if self.seq_parallel != 1 or self.seq_parallel_group is not None:
+            # the model's own forward (`model(rl_batch=...)`) has no sequence-parallel reduction: slices would be trained as if they
+            # were whole sequences, silently.  `LearnerStep` (rl_step with seq_parallel_group) is the sequence-parallel path.
+            raise ValueError("StreamedLearnerStep does not implement sequence parallelism (seq_parallel must be 1 and seq_parallel_group None); "
+                             "use LearnerStep for seq_parallel > 1")
         self._stats_dev: list[torch.Tensor] = []
         self._input_sizes: list[int] = []
-        self.lag_samples: list[int] = []  # per real micro-batch: samples trained so far - the batch's model version
+        # per real micro-batch: samples trained so far - the batch's model version; the most recent 4096 (a run is unbounded)
+        self.lag_samples: collections.deque[int] = collections.deque(maxlen=4096)
 
     def step(self, batch: PipelineBatchEncoding) -> dict[str, Any]:
         from .finetune.rl import VALUE_STAT_KEYS, check_finite, make_loss_config, stats_to_dict

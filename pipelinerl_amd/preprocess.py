@@ -580,6 +580,11 @@ class PreprocessorLoop:
         self.host_chunks: dict[int, dict] = {}  # compact wire: per chunk, the host arrays its records are gathered from
 
         self.cfg = cfg
+        # a bare "cuda" means the process's CURRENT device, once and for all: the native publisher thread binds to an index
+        # (hipSetDevice) and must wait on / copy from the device the loop's kernels run on, not device 0
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
         self.stager = self.down_stager = None
         if batched_transfers and torch.device(device).type == "cuda":
@@ -842,8 +847,9 @@ class PreprocessorLoop:
         piece_arr = np.array([(src, off, nb, kind, 0) for kind, src, off, nb in pieces], dtype=_PUB_PIECE_DT)
         ready = None
         if block is not None:
-            ready = torch.cuda.Event()
-            ready.record()  # K6 (and the reference-policy annotation) of this drain are complete once this event has fired
+            with torch.cuda.device(self.device):  # the event belongs to the loop's device, whatever the caller's current device is
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(self.device))  # K6 (and the reference-policy annotation) of this drain are complete once it has fired
         inline_c = (ctypes.c_char * len(inline)).from_buffer(inline) if inline else None
         ticket = ctypes.c_uint64()
         _lib.check(lib.prl_publisher_submit(self._pub, block_ptr or None, block_nbytes, ready.cuda_event if ready is not None else None,
@@ -910,8 +916,7 @@ class PreprocessorLoop:
         if not parts or any(getattr(w, "_mirror", None) is not None or getattr(w, "_log", None) is None for w in parts):
             return
         h = ctypes.c_void_p()
-        dev = torch.device(self.device)
-        _lib.check(_lib.load().prl_publisher_create(dev.index or 0, ctypes.byref(h)))
+        _lib.check(_lib.load().prl_publisher_create(int(self.device.index), ctypes.byref(h)))
         self._pub, self._pub_logs = h, [getattr(w._log._h, "value", w._log._h) for w in parts]
 
     def _stop_publisher(self) -> None:

@@ -104,7 +104,7 @@ class WorkerExtension:
             if getattr(self, "_ipc_receiver", None) is None:
                 self._ipc_receiver = ColocatedReceiver(self.device, request.bucket_bytes)
             self._ipc_receiver.receive([i.model_dump() for i in request.parameters_info], request.ipc_handles, request.ipc_nbytes, load,
-                                       destinations=self._weight_destinations())
+                                       destinations=self._weight_destinations(), max_allocation=request.ipc_max_allocation)
         elif request.transport == "sharded":
             from .tp_shard import TpShard
             from .weight_sync import ParamSpec, plan_shard_buckets

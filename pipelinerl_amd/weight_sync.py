@@ -593,13 +593,16 @@ class ColocatedSender:
     def _pieces(self, params: list[tuple[str, torch.Tensor]]) -> list[tuple[str, torch.Tensor]]:
         """`params` with every tensor too large for one exportable allocation replaced by views of its row ranges (`split_for_ipc`)."""
         tensors = dict(params)
+        dense: dict[str, torch.Tensor] = {}  # a non-contiguous base tensor is made contiguous ONCE, not once per piece
         out = []
         for sp in split_for_ipc([ParamSpec(n, tuple(p.shape), p.dtype) for n, p in params], self.bucket_bytes, self.max_allocation):
             piece = rows_piece(sp.name)
             if piece is not None and sp.name not in tensors:
                 base, a, b = piece
-                t = tensors[base]
-                out.append((sp.name, (t if t.is_contiguous() else t.contiguous())[a:b]))
+                if base not in dense:
+                    t = tensors[base]
+                    dense[base] = t if t.is_contiguous() else t.contiguous()
+                out.append((sp.name, dense[base][a:b]))
             else:
                 out.append((sp.name, tensors[sp.name]))
         return out
@@ -647,7 +650,7 @@ class ColocatedSender:
             if moving:
                 gather_into_bucket(dev_bucket.tensor(), moving, tensors)
         torch.cuda.synchronize(self.device)
-        return {"ipc_handles": [b.handle().hex() for b in self._buckets], "ipc_nbytes": sizes}
+        return {"ipc_handles": [b.handle().hex() for b in self._buckets], "ipc_nbytes": sizes, "ipc_max_allocation": self.max_allocation}
 
     def close(self) -> None:
         for b in self._buckets:
@@ -667,16 +670,23 @@ class ColocatedReceiver:
 
     def receive(self, parameters_info: Sequence[dict | ParamSpec], ipc_handles: Sequence[str], ipc_nbytes: Sequence[int],
                 load_weights: Callable[[list[tuple[str, torch.Tensor]]], Any] | None,
-                destinations: dict[str, torch.Tensor] | None = None) -> int:
+                destinations: dict[str, torch.Tensor] | None = None, max_allocation: int | None = None) -> int:
+        """`max_allocation`: the SENDER's cap as announced in the request (`WeightUpdateRequest.ipc_max_allocation`); the piece
+        list is derived with it so that both ends cut a large tensor into the same row ranges.  None (a request that predates
+        the field) falls back to this receiver's own setting; a mismatch that survives is caught by the size check below."""
         specs = [
             p if isinstance(p, ParamSpec) else ParamSpec(p["name"], tuple(p["shape"]), string_to_dtype(p["dtype"]))
             for p in parameters_info
         ]
         full = {sp.name: sp for sp in specs}
-        specs = split_for_ipc(specs, self.bucket_bytes, self.max_allocation)
+        specs = split_for_ipc(specs, self.bucket_bytes, self.max_allocation if max_allocation is None else int(max_allocation))
         plan = plan_buckets(specs, self.bucket_bytes)
         if len(plan) != len(ipc_handles):
             raise ValueError(f"{len(ipc_handles)} IPC buckets announced, the parameter list implies {len(plan)}")
+        implied = [bucket_nbytes(b) for b in plan]
+        if list(ipc_nbytes) != implied:  # same bucket count, different cuts: the weights would be scattered to the wrong rows
+            raise ValueError(f"IPC bucket sizes {list(ipc_nbytes)[:4]}... announced, the parameter list implies {implied[:4]}... "
+                             "(sender and receiver disagree on bucket_bytes / ipc_max_allocation)")
         # row ranges of a tensor that travelled in pieces: straight into the rows of its destination when one is registered,
         # otherwise collected and handed to `load_weights` as ONE tensor once every piece is there
         pieces = {sp.name: rows_piece(sp.name) for sp in specs if sp.name not in full}

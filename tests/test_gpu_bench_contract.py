@@ -36,7 +36,7 @@ def test_bench_json_contract(libprl, cuda_device, tmp_path):
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] / 1e3)) <= 1e-6 * d["value"]
     # `value` is timed on the reference's behaviour (every row read, rl/__init__.py:213); the opt-out is a separate, labelled number
-    assert d["config"]["skip_unlabelled"] is False and d["value_skip_unlabelled"] > 0 and d["skip_unlabelled_steps"] == 2
+    assert d["config"]["skip_unlabelled"] is False and d["value_skip_unlabelled"] > 0 and d["skip_unlabelled_steps"] == 1
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r and "traffic_source" in r

@@ -87,7 +87,8 @@ def _cut_worker(req_q, ack_q, bucket_bytes, max_allocation):
 
     device = torch.device("cuda:0")
     torch.cuda.set_device(device)
-    rx = ColocatedReceiver(device, bucket_bytes, max_allocation)
+    # max_allocation None: the receiver is built like vllm_worker builds it (bucket_bytes only) and takes the sender's cap from the request
+    rx = ColocatedReceiver(device, bucket_bytes, max_allocation) if max_allocation is not None else ColocatedReceiver(device, bucket_bytes)
     ack_q.put("ready")
     while True:
         msg = req_q.get()
@@ -97,14 +98,17 @@ def _cut_worker(req_q, ack_q, bucket_bytes, max_allocation):
         # `big.direct` has a registered destination (its row ranges are scattered straight into it), `big.loaded` comes back whole
         dest = {n: torch.zeros(tuple(s), dtype=getattr(torch, dt), device=device) for n, s, dt in msg["info"] if n in ("big.direct", "small")}
         loaded = {}
-        n = rx.receive(info, msg["handles"], msg["nbytes"], lambda views: loaded.update({k: v.clone() for k, v in views}), dest)
+        n = rx.receive(info, msg["handles"], msg["nbytes"], lambda views: loaded.update({k: v.clone() for k, v in views}), dest,
+                       max_allocation=msg.get("max_allocation"))
         out = {k: v.double().sum().item() for k, v in {**dest, **loaded}.items()}
         ack_q.put((n, out, sorted(loaded)))
     rx.close()
 
 
-def test_ipc_hand_off_of_tensors_cut_into_row_ranges(cuda_device):
-    """Tensors too large for one exportable allocation (`weight_sync.IPC_MAX_ALLOCATION`; small limits here) cross in row ranges:
+@pytest.mark.parametrize("cap_from", ["constructor", "request"])
+def test_ipc_hand_off_of_tensors_cut_into_row_ranges(cuda_device, cap_from):
+    """(`cap_from` = request: the receiver knows only `bucket_bytes`, the allocation cap that fixes the piece list travels with the
+    update - `WeightUpdateRequest.ipc_max_allocation`.)  Tensors too large for one exportable allocation (`weight_sync.IPC_MAX_ALLOCATION`; small limits here) cross in row ranges:
     the sender keeps such a tensor where it is and copies its ranges per update, every other parameter is rehomed; the receiver
     scatters ranges into a registered destination or reassembles the tensor for `load_weights`."""
     from pipelinerl_amd.weight_sync import ColocatedSender
@@ -115,7 +119,7 @@ def test_ipc_hand_off_of_tensors_cut_into_row_ranges(cuda_device):
               (("small", (7, 9), torch.float32), ("big.direct", (300, 16), torch.float32), ("mid", (40, 8), torch.bfloat16), ("big.loaded", (257, 24), torch.bfloat16))]
     ctx = mp.get_context("spawn")
     req_q, ack_q = ctx.Queue(), ctx.Queue()
-    proc = ctx.Process(target=_cut_worker, args=(req_q, ack_q, bucket_bytes, max_allocation), daemon=True)
+    proc = ctx.Process(target=_cut_worker, args=(req_q, ack_q, bucket_bytes, max_allocation if cap_from == "constructor" else None), daemon=True)
     proc.start()
     tx = ColocatedSender(cuda_device, bucket_bytes, max_allocation)
     try:
@@ -130,7 +134,8 @@ def test_ipc_hand_off_of_tensors_cut_into_row_ranges(cuda_device):
                     p.data.mul_(0.5).add_(1.0)
             pub = tx.publish([(n, p.data) for n, p in params])
             assert max(pub["ipc_nbytes"]) < max_allocation and len(pub["ipc_handles"]) > 4
-            req_q.put({"info": [(n, list(p.shape), str(p.dtype).replace("torch.", "")) for n, p in params], "handles": pub["ipc_handles"], "nbytes": pub["ipc_nbytes"]})
+            req_q.put({"info": [(n, list(p.shape), str(p.dtype).replace("torch.", "")) for n, p in params], "handles": pub["ipc_handles"], "nbytes": pub["ipc_nbytes"],
+                       "max_allocation": pub["ipc_max_allocation"] if cap_from == "request" else None})
             n, sums, loaded = ack_q.get(timeout=120)
             assert n == 4 and loaded == ["big.loaded", "mid"]
             assert sums == pytest.approx({k: p.data.double().sum().item() for k, p in params}, rel=0, abs=0)

@@ -188,6 +188,45 @@ def test_inflight_update_pauses_updates_resumes_and_serialises(tmp_path):
         server.close()
 
 
+def test_pause_right_after_resume_still_waits_for_the_quantum():
+    """Back-to-back updates (a second one queued on the manager's lock pauses immediately after the first one's resume): `pause_generation`
+    must not return on the strength of the PREVIOUS park while the loop thread is already past its check - no generation quantum may
+    overlap the window between pause and resume."""
+    import asyncio
+
+    from pipelinerl_amd.engine_update import ScriptedEngine
+
+    copying = threading.Event()
+    overlaps = []
+
+    def generate_step():
+        if copying.is_set():
+            overlaps.append("started inside the window")
+        time.sleep(0.0002)
+        if copying.is_set():
+            overlaps.append("ran into the window")
+
+    engine = ScriptedEngine([], generate_step)
+
+    async def hammer():
+        for _ in range(400):
+            await engine.pause_generation()
+            assert not engine.generating()
+            copying.set()
+            await asyncio.sleep(0.0003)   # the weight copy
+            copying.clear()
+            await engine.resume_generation()  # ... and the next update pauses right away
+
+    try:
+        asyncio.run(hammer())
+        assert not overlaps, overlaps[:3]
+        q = engine.quanta
+        time.sleep(0.05)
+        assert engine.quanta > q  # left running
+    finally:
+        engine.shutdown()
+
+
 def test_pause_mode_other_than_keep_is_refused():
     import asyncio
 
@@ -277,7 +316,7 @@ def test_streamed_learner_step_defers_statistics_to_the_boundary(tmp_path):
         step.step(annotate_host_batch(_packed(5, 4, version=0)))
         r = step.step(annotate_host_batch(_packed(1, 4, version=6)))
         assert r["did_optimizer_step"] and step.metrics.samples == 12
-        assert step.lag_samples == [0, 0, 0, 6, 0]
+        assert list(step.lag_samples) == [0, 0, 0, 6, 0] and step.lag_samples.maxlen == 4096
         # a non-finite value is reported at the END of its step, by the reference's assert text
         step2 = StreamedLearnerStep(_FakeFusedModel(), opt, RLConfig(), train_batch_size=1, gradient_accumulation_passes=2, max_train_steps=4)
         bad = annotate_host_batch(_packed(1, 5))

@@ -102,7 +102,7 @@ def test_per_tensor_protocol_is_the_reference_traffic(g, tmp_path):
         body.pop("timestamp")
         want = g["posts"][0]["json"]
         assert {k: body[k] for k in want} == want
-        assert body["transport"] == "per_tensor" and set(body) - set(want) <= {"transport", "bucket_bytes", "ipc_handles", "ipc_nbytes", "tp_size"}
+        assert body["transport"] == "per_tensor" and set(body) - set(want) <= {"transport", "bucket_bytes", "ipc_handles", "ipc_nbytes", "ipc_max_allocation", "tp_size"}
     # stream: WeightUpdateSuccess after the broadcasts
     for r in records:
         r.pop("timestamp")

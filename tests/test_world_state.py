@@ -86,7 +86,7 @@ def test_trainer_messages_and_state_match_reference(tmp_path):
     assert fl.TRAINER_TOPIC == g["topic"]
     # (a) every reference dump parses into the same-kind model, and our dump carries the reference's
     # fields with equal values (extra keys are the MI355X transport extensions with defaults)
-    extensions = {"transport", "bucket_bytes", "ipc_handles", "ipc_nbytes", "tp_size"}
+    extensions = {"transport", "bucket_bytes", "ipc_handles", "ipc_nbytes", "ipc_max_allocation", "tp_size"}
     for want in g["dumps"]:
         msg = fl.parse_trainer_message(want)
         got = msg.model_dump()

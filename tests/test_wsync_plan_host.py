@@ -101,3 +101,31 @@ def test_ipc_transport_cuts_tensors_too_large_for_one_exportable_allocation(monk
     assert n == 3 and set(got) == set(tensors) and all(torch.equal(got[k], tensors[k]) for k in tensors)
     with pytest.raises(ValueError, match="IPC buckets announced"):
         rx.receive(info, ["00"], [1], lambda v: None)
+
+
+def test_receiver_refuses_an_update_cut_with_another_allocation_cap():
+    """Sender and receiver derive the row-range piece list from (bucket_bytes, ipc_max_allocation).  A receiver that does not use the
+    sender's cap either gets another bucket COUNT or - worse - the same count with other cuts; both are refused before any byte is
+    mapped (no GPU needed to get that far), and the cap announced in the request makes the lists agree."""
+    import torch
+
+    from pipelinerl_amd.weight_sync import ColocatedReceiver, ParamSpec, bucket_nbytes, plan_buckets, split_for_ipc
+
+    info = [ParamSpec("small", (7, 9), torch.float32), ParamSpec("big", (300, 16), torch.float32), ParamSpec("tail", (40, 8), torch.bfloat16)]
+    bucket_bytes, sender_cap = 4096, 8192
+    sender_plan = plan_buckets(split_for_ipc(info, bucket_bytes, sender_cap), bucket_bytes)
+    handles, sizes = ["00"] * len(sender_plan), [bucket_nbytes(b) for b in sender_plan]
+    rx = ColocatedReceiver(torch.device("cpu"), bucket_bytes)  # built like vllm_worker builds it: the default cap (2 GiB - 1 MiB)
+    with pytest.raises(ValueError, match="IPC buckets announced|disagree"):
+        rx.receive(info, handles, sizes, None)
+    # same NUMBER of buckets, other cuts inside them (one large bucket; 124-row vs 89-row pieces): the case that would scatter rows wrongly
+    wide = 1 << 20
+    plan_a, plan_b = (plan_buckets(split_for_ipc(info, wide, cap), wide) for cap in (8192, 6000))
+    assert len(plan_a) == len(plan_b) == 1 and [sp.name for sp, _ in plan_a[0]] != [sp.name for sp, _ in plan_b[0]]
+    rx_wide = ColocatedReceiver(torch.device("cpu"), wide)
+    with pytest.raises(ValueError, match="disagree"):
+        rx_wide.receive(info, ["00"], [bucket_nbytes(plan_a[0])], None, max_allocation=6000)
+    # with the sender's cap the plan matches and the receiver goes on to map the first bucket (which needs the library + a device)
+    with pytest.raises(Exception) as e:
+        rx.receive(info, handles, sizes, None, max_allocation=sender_cap)
+    assert "announced" not in str(e.value) and "disagree" not in str(e.value)
