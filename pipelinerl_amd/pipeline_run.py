@@ -16,6 +16,15 @@ actor.py:510-557 / 648-652, vllm1.py:137-186):
                   reference's update manager (pause(keep) -> collective_rpc -> resume, vllm1.py:137-186) and its one HTTP
                   route; optionally a scripted "generation" load on the GPU that the pause really stops
 
+The same stages run as **N learners x M engines** (BASELINE configs[2] / [3]: 2 + 2 and 4 + 4; `PipelineSpec(n_learners=, n_engines=,
+weight_transport=)`): the preprocessor publishes to `training_data/0/{rank}` for N lead trainers with the per-step quota and the
+sentinel rule (preprocess.py:462-481, 596-662), the N learner ranks form one torch.distributed group (DDP; RCCL when every rank has
+its own GPU, gloo when they share one) and keep the reference's per-rank sample accounting (finetune_loop.py:627-646, 709), every rank
+calls `send_weight_update` and rank 0 sends (finetune_loop.py:205-292) - to a weight-update group of M + 1 members over RCCL
+(`weight_transport="rccl"`, one GPU per member), over gloo (`"gloo"`: the same group and protocol where RCCL cannot run) or through HIP
+IPC handles every colocated engine maps (`"ipc"`) - and every engine acknowledges before `WeightUpdateSuccess` is published.  GPU
+placement follows world.py:143-192 (inference GPUs first, learners after them) unless `share_device` puts every stage on one GPU.
+
 Every stage writes a report (`<exp_path>/reports/<stage>.json`: wall / busy seconds, queue gauges, per-update timings);
 `run_pipeline` merges them into one object (bench.py `pipeline`, scripts/pipeline_cfg1.py).  Nothing here is measured
 against the oracle or uses it: the parity of a pipelined step is tests/test_gpu_pipeline_procs.py.
@@ -73,7 +82,60 @@ class PipelineSpec:
     stage_timeout_s: float = 900.0
     stacks_after_s: float = 0.0        # diagnosis: every stage still alive after this many seconds dumps its threads' Python stacks
     device: int = 0
+    n_learners: int = 1                # data-parallel learner ranks (lead trainers; seq_parallel = 1)
+    n_engines: int = 1                 # inference engines, one GPU (one weight-group member) each
+    weight_transport: str = "ipc"      # "ipc" (HIP IPC handles, engines colocated with learner 0) | "rccl" | "gloo" (group of n_engines + 1)
+    grad_backend: str | None = None    # learners' process group: default "nccl" with one GPU per learner, "gloo" when they share a device / on CPU
+    share_device: bool = True          # every stage on `device`; False: engines on GPUs [device, device + M), learners on the N after them (world.py:143-192)
+    platform: str = "cuda"             # "cpu": host tensors - topology tests; needs `hooks` (the loss and preprocessing kernels have no CPU path)
+    hooks: str | None = None           # module with optional `build_policy(spec, device, seed)`, `rl_step_fn`, `preprocessor_stage(spec)` replacements
+    sys_path: list = field(default_factory=list)  # prepended to sys.path in every stage process (where `hooks` lives)
+    learner_port: int = 0              # rendezvous ports on 127.0.0.1, chosen by run_pipeline
+    wsync_port: int = 0
     extra: dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        if self.n_learners < 1 or self.n_engines < 1:
+            raise ValueError("a pipeline has at least one learner and one engine")
+        if self.global_batch % self.n_learners:
+            raise ValueError(f"global_batch {self.global_batch} does not split into {self.n_learners} equal per-learner quotas "
+                             "(the launcher rounds gradient_accumulation_passes up to a multiple of the learner count, launch.py:631-640)")
+        if self.weight_transport not in ("ipc", "rccl", "gloo"):
+            raise ValueError(f"weight_transport {self.weight_transport!r}: 'ipc', 'rccl' or 'gloo'")
+        if self.weight_transport == "ipc" and not self.share_device:
+            raise ValueError("weight_transport 'ipc' hands HIP IPC handles to engines on the learner's own GPU: it needs share_device=True")
+        if self.weight_transport == "rccl" and self.share_device:
+            raise ValueError("weight_transport 'rccl' needs one GPU per member of the weight-update group (RCCL refuses two ranks on one device): "
+                             "share_device=False, or 'gloo' / 'ipc' on a shared device")
+        if self.platform not in ("cuda", "cpu"):
+            raise ValueError(f"platform {self.platform!r}")
+        if self.platform == "cpu" and (self.weight_transport != "gloo" or not self.hooks):
+            raise ValueError("platform 'cpu' runs the topology with host tensors: weight_transport='gloo' and a `hooks` module are required")
+
+    @property
+    def learner_backend(self) -> str:
+        if self.grad_backend:
+            return self.grad_backend
+        return "nccl" if (self.platform == "cuda" and not self.share_device) else "gloo"
+
+    def device_of(self, stage: str, index: int = 0):
+        """The torch device of a stage process.  Not shared: inference GPUs first, learner GPUs after them - the order in which the
+        reference's WorldMap hands out a node's GPUs (world.py:143-192); the preprocessor computes on the first learner's GPU."""
+        import torch
+
+        if self.platform == "cpu":
+            return torch.device("cpu")
+        if self.share_device:
+            return torch.device("cuda", self.device)
+        if stage == "engine":
+            return torch.device("cuda", self.device + index)
+        return torch.device("cuda", self.device + self.n_engines + (index if stage == "learner" else 0))
+
+    def stage_names(self) -> list[str]:
+        """Report names, start order: engines, learners, preprocessor, actor.  A single learner / engine keeps the bare name."""
+        eng = ["engine"] if self.n_engines == 1 else [f"engine{e}" for e in range(self.n_engines)]
+        lrn = ["learner"] if self.n_learners == 1 else [f"learner{r}" for r in range(self.n_learners)]
+        return eng + lrn + ["preprocessor", "actor"]
 
     @property
     def shape(self) -> dict:
@@ -120,13 +182,30 @@ def _report(spec: PipelineSpec, stage: str, data: dict) -> None:
     tmp.rename(d / f"{stage}.json")
 
 
-def _stage(fn):
-    """Stage entry point: spec dict in, a report out - an error report (with the traceback) when the stage dies."""
+def _hook(spec: PipelineSpec, name: str, default=None):
+    """`spec.hooks` is a module name; an attribute of that module replaces the default piece (tests: a CPU policy, a torch loss)."""
+    if not spec.hooks:
+        return default
+    import importlib
 
-    def main(spec_dict: dict) -> None:
+    return getattr(importlib.import_module(spec.hooks), name, default)
+
+
+def _stage(fn):
+    """Stage entry point: spec dict (+ the stage's index among its kind) in, a report out - an error report (with the traceback)
+    when the stage dies."""
+
+    def main(spec_dict: dict, index: int = 0) -> None:
+        import sys
+
         spec = PipelineSpec(**spec_dict)
-        logging.basicConfig(level=os.environ.get("PRL_PIPELINE_LOG", "WARNING"), format=f"%(asctime)s {fn.__name__} %(levelname)s %(message)s")
-        name = fn.__name__.replace("_stage", "")
+        for d in reversed(spec.sys_path):
+            if d not in sys.path:
+                sys.path.insert(0, d)
+        kind = fn.__name__.replace("_stage", "")
+        count = {"learner": spec.n_learners, "engine": spec.n_engines}.get(kind, 1)
+        name = kind if count == 1 else f"{kind}{index}"
+        logging.basicConfig(level=os.environ.get("PRL_PIPELINE_LOG", "WARNING"), format=f"%(asctime)s {name} %(levelname)s %(message)s")
         if spec.stacks_after_s:  # a stage that is still running then leaves the Python stacks of all its threads behind
             import faulthandler
 
@@ -134,9 +213,12 @@ def _stage(fn):
             d.mkdir(parents=True, exist_ok=True)
             faulthandler.dump_traceback_later(spec.stacks_after_s, repeat=False, file=open(d / f"{name}.stacks", "w"), exit=False)
         try:
-            fn(spec)
+            if kind in ("learner", "engine"):
+                fn(spec, index, name)
+            else:
+                fn(spec)
         except BaseException:  # noqa: BLE001 - the orchestrator reads it
-            _report(spec, fn.__name__.replace("_stage", ""), {"error": traceback.format_exc()})
+            _report(spec, name, {"error": traceback.format_exc()})
             raise
 
     main.__name__ = fn.__name__
@@ -208,9 +290,10 @@ def actor_stage(spec: PipelineSpec) -> None:
         "dataset_loader_params": {"n_problems": spec.n_problems, "seed": spec.seed},
         "train_dataset_names": ["synthetic"],
     }
-    llm = SyntheticLLM(spec.shape["vocab"], spec.seq_length, dense=spec.dense, prompt_max=min(512, max(8, spec.seq_length // 4)),
-                       prompt_min=min(64, max(2, spec.seq_length // 32)))
-    harness = ActorHarness(cfg, [llm], spec.exp_path, trainer_state=state, scheduler_name="actor0", wire="ragged", shuffle_seed=spec.seed)
+    # one scripted llm per engine: the harness sends a group to the least busy one (actor.py:247-262)
+    llms = [SyntheticLLM(spec.shape["vocab"], spec.seq_length, dense=spec.dense, prompt_max=min(512, max(8, spec.seq_length // 4)),
+                         prompt_min=min(64, max(2, spec.seq_length // 32))) for _ in range(spec.n_engines)]
+    harness = ActorHarness(cfg, llms, spec.exp_path, trainer_state=state, scheduler_name="actor0", wire="ragged", shuffle_seed=spec.seed)
     versions: list[int] = []
     t0 = time.perf_counter()
     n = harness.run_paced(samples_target=spec.steps * spec.global_batch, train_batch_size=1, gradient_accumulation_passes=spec.global_batch,
@@ -222,7 +305,8 @@ def actor_stage(spec: PipelineSpec) -> None:
         hist[v] = hist.get(v, 0) + 1
     _report(spec, "actor", {"published_samples": n, "published_groups": harness.published_groups, "wall_s": time.perf_counter() - t0,
                             "busy_s": t["busy_s"], "blocked_by_lag_s": t["blocked_by_lag_s"], "busy_frac": t["busy_s"] / max(t["wall_s"], 1e-9),
-                            "groups_per_model_version": {str(k): v for k, v in sorted(hist.items())}, "llm_calls": llm.calls,
+                            "groups_per_model_version": {str(k): v for k, v in sorted(hist.items())}, "llm_calls": sum(l.calls for l in llms),
+                            "llm_calls_per_engine": [l.calls for l in llms],
                             "pacing": {"max_lag_samples": spec.lag, "weight_update_interval": spec.weight_update_interval,
                                        "budget": ActorHarness.submission_budget(spec.attempts, 1, spec.global_batch, spec.weight_update_interval, spec.lag)}})
 
@@ -235,12 +319,13 @@ def preprocessor_stage(spec: PipelineSpec) -> None:
     from .state import TrainerState
 
     _set_backend(spec)
-    dev = torch.device("cuda", spec.device)
+    dev = spec.device_of("preprocessor")
     torch.cuda.set_device(dev)
     state = TrainerState(Path(spec.exp_path))
     state.start_listening()
     state.wait_for_processed_samples()  # the trainer's first message (finetune_loop.py:462-465)
-    cfg = PreprocessorConfig(exp_path=Path(spec.exp_path), num_trainers=1, train_batch_size=1, gradient_accumulation_passes=spec.global_batch,
+    # N lead trainers: `training_data/0/{rank}`, per-step quota global_batch / N each, sentinels for the ranks that are full (preprocess.py:462-481, 596-662)
+    cfg = PreprocessorConfig(exp_path=Path(spec.exp_path), num_trainers=spec.n_learners, train_batch_size=1, gradient_accumulation_passes=spec.global_batch,
                              seq_length=spec.budget, attempts=spec.attempts, rl=rl_config_of(spec), eos_token_id=2, chunk_n_groups=spec.chunk_n_groups,
                              max_lag=spec.lag, samples_target=spec.steps * spec.global_batch,
                              ring_buffer_size=max(128, 2 * spec.global_batch), max_ready_samples_per_lead=max(64, spec.global_batch))
@@ -267,7 +352,7 @@ def preprocessor_stage(spec: PipelineSpec) -> None:
 
 
 @_stage
-def engine_stage(spec: PipelineSpec) -> None:
+def engine_stage(spec: PipelineSpec, index: int = 0, name: str = "engine") -> None:
     import torch
 
     from .engine_update import InflightUpdateManager, ScriptedEngine, UpdateServer
@@ -275,11 +360,13 @@ def engine_stage(spec: PipelineSpec) -> None:
     from .vllm_worker import StandaloneWeightReceiver
 
     _set_backend(spec)
-    dev = torch.device("cuda", spec.device)
-    torch.cuda.set_device(dev)
-    _trace(spec, "engine", "building the policy")
-    model = build_policy(spec, dev, seed=spec.seed + 999)  # different values than the trainer's: an update must really land
-    _trace(spec, "engine", "policy built")
+    dev = spec.device_of("engine", index)
+    cuda = dev.type == "cuda"
+    if cuda:
+        torch.cuda.set_device(dev)
+    _trace(spec, name, "building the policy")
+    model = _hook(spec, "build_policy", build_policy)(spec, dev, seed=spec.seed + 999 + index)  # different values than the trainer's: an update must really land
+    _trace(spec, name, "policy built")
     model.eval()
     for p in model.parameters():
         p.requires_grad_(False)
@@ -289,15 +376,23 @@ def engine_stage(spec: PipelineSpec) -> None:
 
     def generate_step():
         with torch.no_grad():
-            model.model(input_ids=ids)
-        torch.cuda.synchronize(dev)
+            (model.model if hasattr(model, "model") else model)(input_ids=ids)
+        if cuda:
+            torch.cuda.synchronize(dev)
 
     engine = ScriptedEngine([worker], generate_step if spec.engine_load else None)
     manager = InflightUpdateManager(engine)
     server = UpdateServer(manager)
     (Path(spec.exp_path) / "reports").mkdir(parents=True, exist_ok=True)
-    (Path(spec.exp_path) / "reports" / "engine_url.txt").write_text(server.url)
-    _trace(spec, "engine", "serving " + server.url)
+    tmp = Path(spec.exp_path) / "reports" / f".engine_url_{index}.tmp"
+    tmp.write_text(server.url)
+    tmp.rename(Path(spec.exp_path) / "reports" / f"engine_url_{index}.txt")
+    _trace(spec, name, "serving " + server.url)
+    if spec.weight_transport != "ipc":
+        # the weight-update group: trainer rank 0 + every engine GPU, this engine is rank 1 + index (vllm1.py:64-108, world.py:192);
+        # blocks until the trainer and the other engines have joined
+        worker.init_actor_update_group(index, 1, f"tcp://127.0.0.1:{spec.wsync_port}", spec.n_engines + 1, backend=spec.weight_transport)
+        _trace(spec, name, f"joined the weight-update group as rank {worker.pg_rank} of {spec.n_engines + 1} ({spec.weight_transport})")
     state = TrainerState(Path(spec.exp_path))
     state.start_listening()
     t0 = time.perf_counter()
@@ -307,19 +402,22 @@ def engine_stage(spec: PipelineSpec) -> None:
     probe = _param_probe(model.named_parameters())
     tm = manager.timings
     med = lambda k: sorted(t[k] for t in tm)[len(tm) // 2] if tm else None  # noqa: E731
-    _report(spec, "engine", {"updates": len(tm), "wall_s": wall, "last_version": tm[-1]["version"] if tm else None, "param_probe": probe,
-                             "pause_ms_median": 1e3 * med("pause_s") if tm else None, "update_ms_median": 1e3 * med("update_s") if tm else None,
-                             "resume_ms_median": 1e3 * med("resume_s") if tm else None, "per_update": tm,
-                             "busy_s": sum(t["total_s"] for t in tm), "busy_frac": sum(t["total_s"] for t in tm) / max(wall, 1e-9),
-                             "generation_quanta": engine.quanta, "generation_quanta_by_version": {str(k): v for k, v in engine.quanta_by_version.items()},
-                             "engine_load": spec.engine_load})
+    grp = getattr(worker, "model_update_group", None)
+    _report(spec, name, {"updates": len(tm), "wall_s": wall, "last_version": tm[-1]["version"] if tm else None, "param_probe": probe,
+                         "pause_ms_median": 1e3 * med("pause_s") if tm else None, "update_ms_median": 1e3 * med("update_s") if tm else None,
+                         "resume_ms_median": 1e3 * med("resume_s") if tm else None, "per_update": tm,
+                         "busy_s": sum(t["total_s"] for t in tm), "busy_frac": sum(t["total_s"] for t in tm) / max(wall, 1e-9),
+                         "generation_quanta": engine.quanta, "generation_quanta_by_version": {str(k): v for k, v in engine.quanta_by_version.items()},
+                         "engine_load": spec.engine_load, "device": str(dev), "weight_transport": spec.weight_transport,
+                         "weight_group": ({"rank": worker.pg_rank, "size": grp.comm_size()[0], "bytes_received": getattr(grp, "bytes_moved", None)}
+                                          if grp is not None else None)})
     engine.shutdown()
     worker.close_communicator()
     server.close()
 
 
 @_stage
-def learner_stage(spec: PipelineSpec) -> None:
+def learner_stage(spec: PipelineSpec, rank: int = 0, name: str = "learner") -> None:
     import queue
     import threading
 
@@ -327,50 +425,86 @@ def learner_stage(spec: PipelineSpec) -> None:
 
     from . import streams
     from .finetune_loop import (TRAINER_TOPIC, LearnerStep, SamplesProcessed, StreamedLearnerStep, WeightUpdateManager, run_data_loader)
-    from .fused_head import install_fused_head, rl_step_fused_head
-    from .weight_sync import ColocatedSender
 
     _set_backend(spec)
-    dev = torch.device("cuda", spec.device)
-    torch.cuda.set_device(dev)
+    dev = spec.device_of("learner", rank)
+    cuda = dev.type == "cuda"
+    world, main = spec.n_learners, rank == 0
+    if cuda:
+        torch.cuda.set_device(dev)
     t_init = time.perf_counter()
-    _trace(spec, "learner", "building the policy")
-    model = build_policy(spec, dev, seed=spec.seed)
-    _trace(spec, "learner", "policy built")
-    install_fused_head(model)
+    if world > 1:
+        # the learners' own group (gradients, sample accounting, the barrier that ends an update); the weight-update group is separate
+        import torch.distributed as dist
+
+        backend = spec.learner_backend
+        _trace(spec, name, f"joining the learner group: rank {rank} of {world} over {backend}")
+        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{spec.learner_port}", rank=rank, world_size=world,
+                                **({"device_id": dev} if backend == "nccl" else {}))
+    _trace(spec, name, "building the policy")
+    model = _hook(spec, "build_policy", build_policy)(spec, dev, seed=spec.seed)  # the same seed on every rank: replicas start equal
+    _trace(spec, name, "policy built")
+    rl_step_fn = _hook(spec, "rl_step_fn")
+    if rl_step_fn is None:
+        from .fused_head import install_fused_head, rl_step_fused_head
+
+        install_fused_head(model)
+        rl_step_fn = rl_step_fused_head
+    elif spec.learner == "streamed":
+        raise ValueError("a hooked loss function drives LearnerStep: learner='dropin'")
     if spec.gradient_checkpointing:
         model.gradient_checkpointing_enable()
     model.train()
     n_params = sum(p.numel() for p in model.parameters())
     param_bytes = sum(p.numel() * p.element_size() for p in model.parameters())
-    # wait for the inference server like the reference does (finetune_loop.py:470)
-    url_file = Path(spec.exp_path) / "reports" / "engine_url.txt"
-    deadline = time.time() + spec.stage_timeout_s
-    while not url_file.exists():
-        if time.time() > deadline:
-            raise TimeoutError("the engine never announced its url")
-        time.sleep(0.05)
-    url = url_file.read_text().strip()
-    _trace(spec, "learner", "engine found at " + url)
     topic = streams.SingleStreamSpec(exp_path=Path(spec.exp_path), topic=TRAINER_TOPIC)
-    mgr = WeightUpdateManager(llm_urls=[url], accelerated_model=model, update_stream=topic, actor_update_group=None, transport="ipc")
-    mgr._sender = ColocatedSender(dev, mgr.bucket_bytes)
-    mgr._sender.rehome(model.named_parameters())  # the parameters LIVE in the exported buckets: publishing an update copies nothing
-    _trace(spec, "learner", "parameters rehomed into the exported buckets")
+    urls: list[str] = []
+    group = None
+    if main:
+        # wait for every inference server like the reference does (finetune_loop.py:470)
+        deadline = time.time() + spec.stage_timeout_s
+        for e in range(spec.n_engines):
+            url_file = Path(spec.exp_path) / "reports" / f"engine_url_{e}.txt"
+            while not url_file.exists():
+                if time.time() > deadline:
+                    raise TimeoutError(f"engine {e} never announced its url")
+                time.sleep(0.05)
+            urls.append(url_file.read_text().strip())
+        _trace(spec, name, "engines found at " + ", ".join(urls))
+        if spec.weight_transport != "ipc":
+            from .weight_sync import weight_sync_group
+
+            group = weight_sync_group(spec.weight_transport, f"tcp://127.0.0.1:{spec.wsync_port}", 0, spec.n_engines + 1, dev, timeout_s=spec.stage_timeout_s)
+            _trace(spec, name, f"weight-update group of {group.comm_size()[0]} formed over {spec.weight_transport}")
+    transport = "ipc" if spec.weight_transport == "ipc" else "bucketed"
+    # every rank owns a manager and calls send_weight_update (the call ends in a barrier among the learners); rank 0 sends (finetune_loop.py:205-292)
+    mgr = WeightUpdateManager(llm_urls=urls, accelerated_model=model, update_stream=topic if main else None, actor_update_group=group,
+                              is_main_process=main, transport=transport, bucket_bytes=int(spec.extra.get("bucket_bytes", 1 << 30)))
+    if main and transport == "ipc":
+        from .weight_sync import ColocatedSender
+
+        mgr._sender = ColocatedSender(dev, mgr.bucket_bytes)
+        mgr._sender.rehome(model.named_parameters())  # the parameters LIVE in the exported buckets: publishing an update copies nothing
+        _trace(spec, name, "parameters rehomed into the exported buckets")
+    train_model = model
+    if world > 1:
+        # (wrapped AFTER the rehoming: DDP's reducer keeps the parameters it was given)
+        train_model = torch.nn.parallel.DistributedDataParallel(model, **({"device_ids": [dev.index]} if cuda and spec.learner_backend == "nccl" else {}))
     if spec.optimizer == "sgd":
-        opt = torch.optim.SGD(model.parameters(), lr=spec.lr)
+        opt = torch.optim.SGD(train_model.parameters(), lr=spec.lr)
     else:
-        opt = torch.optim.AdamW(model.parameters(), lr=spec.lr, fused=True)
+        opt = torch.optim.AdamW(train_model.parameters(), lr=spec.lr, fused=cuda)
     rl = rl_config_of(spec)
     common = dict(train_batch_size=1, gradient_accumulation_passes=spec.global_batch, max_train_steps=spec.steps, weight_update_manager=mgr,
                   weight_update_interval=spec.weight_update_interval, trainer_stream=topic, max_lag=spec.lag)
     if spec.learner == "streamed":
-        step = StreamedLearnerStep(model, opt, rl, **common)
+        step = StreamedLearnerStep(train_model, opt, rl, **common)
     else:
-        step = LearnerStep(model, opt, rl, rl_step_fn=rl_step_fused_head, **common)
+        step = LearnerStep(train_model, opt, rl, rl_step_fn=rl_step_fn, **common)
+    assert step.samples_per_step == spec.global_batch and step.samples_per_lead_per_step == spec.global_batch // world
     init_s = time.perf_counter() - t_init
 
-    capture = Path(spec.capture_step0) if spec.capture_step0 else None
+    capture = (Path(spec.capture_step0) if world == 1 else Path(spec.capture_step0) / f"rank{rank}") if spec.capture_step0 else None
     if capture is not None:
         capture.mkdir(parents=True, exist_ok=True)
         torch.save({n: p.detach().cpu().clone() for n, p in model.named_parameters()}, capture / "params_before.pt")
@@ -388,16 +522,16 @@ def learner_stage(spec: PipelineSpec) -> None:
     step.publish(SamplesProcessed(samples_processed=step.metrics.samples))
     sync_ms: list[float] = []
     t0 = time.perf_counter()
-    _trace(spec, "learner", "sending weight version 0")
+    _trace(spec, name, "sending weight version 0")
     mgr.send_weight_update(step.metrics.samples)
     first_sync_ms = 1e3 * (time.perf_counter() - t0)
-    _trace(spec, "learner", f"weight version 0 acknowledged after {first_sync_ms:.0f} ms")
+    _trace(spec, name, f"weight version 0 acknowledged after {first_sync_ms:.0f} ms")
     probes = {str(step.metrics.samples): _param_probe(model.named_parameters())}
 
     q: queue.Queue = queue.Queue(maxsize=8)
     stop = threading.Event()
-    data_spec = streams.SingleStreamSpec(exp_path=Path(spec.exp_path), topic="training_data", partition=0)
-    threading.Thread(target=run_data_loader, args=(data_spec, q, dev, stop), kwargs={"annotate": spec.learner == "streamed"},
+    data_spec = streams.SingleStreamSpec(exp_path=Path(spec.exp_path), topic="training_data", partition=rank)  # this lead trainer's partition
+    threading.Thread(target=run_data_loader, args=(data_spec, q, dev if cuda else None, stop), kwargs={"annotate": spec.learner == "streamed"},
                      name="learner-loader", daemon=True).start()
 
     wait_s = 0.0
@@ -435,11 +569,13 @@ def learner_stage(spec: PipelineSpec) -> None:
         if res["did_optimizer_step"]:
             last_loss = res["metrics"].get("rl/loss")
             if capture is not None and step.metrics.completed_steps == 1:
-                torch.cuda.synchronize(dev)
+                if cuda:
+                    torch.cuda.synchronize(dev)
                 torch.save(captured, capture / "step0_batches.pt")
                 torch.save({n: p.detach().cpu().clone() for n, p in model.named_parameters()}, capture / "params_after.pt")
                 (capture / "step0_metrics.json").write_text(json.dumps(res["metrics"]))
-            torch.cuda.synchronize(dev)
+            if cuda:
+                torch.cuda.synchronize(dev)
             t_opt = time.perf_counter()
             t1 = time.perf_counter()
             sent = step.maybe_send_weights()
@@ -450,7 +586,8 @@ def learner_stage(spec: PipelineSpec) -> None:
             step_marks.append({"step": step.metrics.completed_steps, "wall_s": now - t_step, "waiting_for_data_s": wait_step,
                                "weight_sync_ms": sync_ms[-1] if sent else None, "compute_s": t_opt - t_step - wait_step, "loss": last_loss})
             t_step, wait_step = now, 0.0
-    torch.cuda.synchronize(dev)
+    if cuda:
+        torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t_loop
     stop.set()
     step.finish()
@@ -461,14 +598,17 @@ def learner_stage(spec: PipelineSpec) -> None:
         hist[k] = hist.get(k, 0) + 1
     steady = step_marks[1:] if len(step_marks) > 1 else step_marks
     sync_sorted = sorted(sync_ms)
-    _report(spec, "learner", {
-        "completed_steps": step.metrics.completed_steps, "samples": step.metrics.samples, "micro_batches": micro_batches, "tokens": tokens,
+    wire_label = {"ipc": "hip_ipc_colocated", "rccl": "rccl_xgmi", "gloo": "gloo_host_staged"}[spec.weight_transport]
+    _report(spec, name, {
+        "rank": rank, "world": world, "device": str(dev), "grad_backend": spec.learner_backend if world > 1 else None,
+        "weight_group": ({"size": group.comm_size()[0], "bytes_sent": getattr(group, "bytes_moved", None)} if group is not None else None),
+        "completed_steps": step.metrics.completed_steps, "samples": step.metrics.samples, "local_samples": step.local_samples, "micro_batches": micro_batches, "tokens": tokens,
         "wall_s": wall, "waiting_for_data_s": wait_s, "busy_s": wall - wait_s, "busy_frac": (wall - wait_s) / max(wall, 1e-9),
         "init_s": init_s, "params": n_params, "param_bytes": param_bytes,
         "steady_state": {"steps": len(steady), "s_per_step": sum(m["wall_s"] for m in steady) / max(len(steady), 1),
                          "samples_per_s": spec.global_batch * len(steady) / max(sum(m["wall_s"] for m in steady), 1e-9)},
         "per_step": step_marks,
-        "weight_sync": {"transport": "hip_ipc_colocated", "first_ms": first_sync_ms, "under_load_ms": sync_ms,
+        "weight_sync": {"transport": wire_label, "engines": spec.n_engines, "first_ms": first_sync_ms, "under_load_ms": sync_ms,
                         "median_ms": sync_sorted[len(sync_sorted) // 2] if sync_sorted else None, "max_ms": sync_sorted[-1] if sync_sorted else None,
                         "what": "send_weight_update request -> engine paused, weights copied, resumed -> HTTP ack -> WeightUpdateSuccess, while the "
                                 "preprocessor's kernels and the loader's copies keep running on the same GPU"},
@@ -476,8 +616,15 @@ def learner_stage(spec: PipelineSpec) -> None:
         "lag_optimizer_steps_histogram": {str(k): v for k, v in sorted(hist.items())},
         "lag_what": "per micro-batch: (samples trained when it is consumed - model_version stamped on its oldest rollout) // samples per step",
         "samples_too_old_to_train": step.metrics.samples_too_old_to_train, "param_probes": probes, "final_loss": last_loss, "learner": spec.learner,
-        "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9})
+        "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9 if cuda else None})
     # (the exported buckets are not freed here: the engine may still have them mapped - they go with the process)
+    if group is not None:
+        group.close()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -487,10 +634,36 @@ def learner_stage(spec: PipelineSpec) -> None:
 STAGES = {"engine": engine_stage, "learner": learner_stage, "preprocessor": preprocessor_stage, "actor": actor_stage}
 
 
+def _hooked_stage(spec_dict: dict, hook: str) -> None:
+    """A stage body supplied by `spec.hooks` (tests: a host preprocessor); same contract as the built-in stages."""
+    import sys
+
+    spec = PipelineSpec(**spec_dict)
+    for d in reversed(spec.sys_path):
+        if d not in sys.path:
+            sys.path.insert(0, d)
+    name = hook.replace("_stage", "")
+    try:
+        _hook(spec, hook)(spec)
+    except BaseException:  # noqa: BLE001 - the orchestrator reads it
+        _report(spec, name, {"error": traceback.format_exc()})
+        raise
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def run_pipeline(spec: PipelineSpec, timeout_s: float | None = None) -> dict:
-    """Run the four stages as processes until the learner has done `spec.steps` optimizer steps; returns the merged report."""
+    """Run the stages as processes - M engines, N learner ranks, the preprocessor, the actor - until the learners have done `spec.steps`
+    optimizer steps; returns the merged report."""
     import multiprocessing as mp
     import shutil
+    import sys
 
     from . import streams
 
@@ -498,6 +671,20 @@ def run_pipeline(spec: PipelineSpec, timeout_s: float | None = None) -> dict:
     if (exp / "reports").exists():
         shutil.rmtree(exp / "reports")
     exp.mkdir(parents=True, exist_ok=True)
+    if spec.platform == "cuda" and not spec.share_device:
+        import torch
+
+        need, have = spec.device + spec.n_engines + spec.n_learners, torch.cuda.device_count()
+        if have < need:
+            raise RuntimeError(f"{spec.n_engines} engine + {spec.n_learners} learner GPUs from device {spec.device} on need {need} devices, {have} visible "
+                               "(share_device=True runs the same topology on one GPU, with weight_transport 'ipc' or 'gloo')")
+    if not spec.learner_port:
+        spec.learner_port = _free_port()
+    if not spec.wsync_port:
+        spec.wsync_port = _free_port()
+    for d in reversed(spec.sys_path):
+        if d not in sys.path:
+            sys.path.insert(0, d)
     was = (streams._backend, dict(streams._backend_options))
     _set_backend(spec, owner=True)
     streams.begin_run(exp)
@@ -505,9 +692,16 @@ def run_pipeline(spec: PipelineSpec, timeout_s: float | None = None) -> dict:
     procs = {}
     t0 = time.perf_counter()
     timeout_s = timeout_s or spec.stage_timeout_s
+    names = spec.stage_names()
     try:
-        for name in ("engine", "learner", "preprocessor", "actor"):
-            procs[name] = ctx.Process(target=STAGES[name], args=(asdict(spec),), name=f"prl-{name}", daemon=True)
+        for name in names:
+            kind = name.rstrip("0123456789")
+            index = int(name[len(kind):] or 0)
+            if _hook(spec, f"{kind}_stage") is not None:
+                target, args = _hooked_stage, (asdict(spec), f"{kind}_stage")
+            else:
+                target, args = STAGES[kind], ((asdict(spec), index) if kind in ("learner", "engine") else (asdict(spec),))
+            procs[name] = ctx.Process(target=target, args=args, name=f"prl-{name}", daemon=True)
             procs[name].start()
         failed = None
         while time.perf_counter() - t0 < timeout_s:
@@ -530,7 +724,7 @@ def run_pipeline(spec: PipelineSpec, timeout_s: float | None = None) -> dict:
             if p.is_alive():
                 p.kill()
     reports = {}
-    for name in STAGES:
+    for name in names:
         f = exp / "reports" / f"{name}.json"
         reports[name] = json.loads(f.read_text()) if f.exists() else {"error": "no report"}
     streams.clean_shm_streams(exp)
@@ -541,13 +735,13 @@ def run_pipeline(spec: PipelineSpec, timeout_s: float | None = None) -> dict:
     out: dict[str, Any] = {"spec": {k: v for k, v in asdict(spec).items() if k not in ("extra",)}, "wall_s_incl_start_up": wall, "stages": reports}
     if failed or timed_out or errors:
         traces = {}
-        for name in STAGES:
+        for name in names:
             f = exp / "reports" / f"{name}.trace"
             if f.exists():
                 lines = f.read_text().splitlines()
                 t0 = float(lines[0].split()[0]) if lines else 0.0
                 traces[name] = [f"+{float(x.split()[0]) - t0:.1f}s {' '.join(x.split()[1:])}" for x in lines]
-        stacks = {n: (exp / "reports" / f"{n}.stacks").read_text()[-6000:] for n in STAGES if (exp / "reports" / f"{n}.stacks").exists()
+        stacks = {n: (exp / "reports" / f"{n}.stacks").read_text()[-6000:] for n in names if (exp / "reports" / f"{n}.stacks").exists()
                   and (exp / "reports" / f"{n}.stacks").stat().st_size}
         out["error"] = {"failed_stage": failed, "timed_out": timed_out, "stage_errors": {n: e[-1500:] for n, e in errors.items()}, "start_up_traces": traces,
                         "stacks": stacks}
@@ -557,19 +751,22 @@ def run_pipeline(spec: PipelineSpec, timeout_s: float | None = None) -> dict:
 
 
 def summarize(spec: PipelineSpec, r: dict) -> dict:
-    """The numbers the bench line quotes: steady-state samples/s, who was busy, what waited, weight sync under load, lag."""
-    L, P, A, E = r["learner"], r["preprocessor"], r["actor"], r["engine"]
+    """The numbers the bench line quotes: steady-state samples/s, who was busy, what waited, weight sync under load, lag.  With N
+    learners the step clock and the weight sync are rank 0's (the sender); with M engines the update timings are per engine."""
+    eng = [n for n in r if n.startswith("engine")]
+    lrn = [n for n in r if n.startswith("learner")]
+    L, P, A, E = r[lrn[0]], r["preprocessor"], r["actor"], r[eng[0]]
     steps = max(L["completed_steps"], 1)
-    busy_per_step = {"actor_s": A["busy_s"] / steps, "preprocessor_s": P["busy_s"] / steps, "learner_s": L["busy_s"] / steps,
-                     "engine_s": E["busy_s"] / max(E["updates"], 1)}
-    probes_agree = None
+    busy_per_step = {"actor_s": A["busy_s"] / steps, "preprocessor_s": P["busy_s"] / steps, "learner_s": max(r[n]["busy_s"] for n in lrn) / steps,
+                     "engine_s": max(r[n]["busy_s"] / max(r[n]["updates"], 1) for n in eng)}
     last = str(E.get("last_version"))
-    if last in L.get("param_probes", {}):
-        probes_agree = L["param_probes"][last] == E["param_probe"]
-    return {
+    probes_agree = None
+    if last in L.get("param_probes", {}):  # EVERY engine holds the trainer's weights of the last version it acknowledged
+        probes_agree = all(str(r[n].get("last_version")) == last and L["param_probes"][last] == r[n]["param_probe"] for n in eng)
+    out = {
         "samples_per_s": L["steady_state"]["samples_per_s"], "s_per_step": L["steady_state"]["s_per_step"], "steady_state_steps": L["steady_state"]["steps"],
-        "tokens_per_s": L["tokens"] / max(L["wall_s"], 1e-9), "optimizer_steps": L["completed_steps"],
-        "busy_frac": {"actor": A["busy_frac"], "preprocessor": P["busy_frac"], "learner": L["busy_frac"], "engine": E["busy_frac"]},
+        "tokens_per_s": sum(r[n]["tokens"] for n in lrn) / max(L["wall_s"], 1e-9), "optimizer_steps": L["completed_steps"],
+        "busy_frac": {"actor": A["busy_frac"], "preprocessor": P["busy_frac"], **{n: r[n]["busy_frac"] for n in lrn}, **{n: r[n]["busy_frac"] for n in eng}},
         "stage_busy_s_per_step": busy_per_step,
         "sum_of_stage_busy_s_per_step": sum(busy_per_step.values()),
         "overlap": {"pipelined_s_per_step": L["wall_s"] / steps, "stages_back_to_back_s_per_step": sum(busy_per_step.values()),
@@ -577,9 +774,15 @@ def summarize(spec: PipelineSpec, r: dict) -> dict:
                             "ran one after the other) next to the wall time of a step with the stages overlapping"},
         "queue_depth": {"preprocessor": P["queue_depth"], "learner_batch_queue": L["batch_queue_depth"]},
         "weight_sync_under_load_ms": {"median": L["weight_sync"]["median_ms"], "max": L["weight_sync"]["max_ms"], "first": L["weight_sync"]["first_ms"],
-                                       "updates": len(L["weight_sync"]["under_load_ms"]), "transport": "hip_ipc_colocated",
+                                       "updates": len(L["weight_sync"]["under_load_ms"]), "transport": L["weight_sync"]["transport"],
                                        "engine_pause_update_resume_ms": [E["pause_ms_median"], E["update_ms_median"], E["resume_ms_median"]]},
         "lag_optimizer_steps_histogram": L["lag_optimizer_steps_histogram"],
         "actor_blocked_by_lag_s": A["blocked_by_lag_s"], "preprocessor_backpressure_waits": P["backpressure_waits"],
         "engine_weights_equal_trainer_at_last_version": probes_agree, "final_loss": L["final_loss"], "learner_peak_memory_GB": L["peak_memory_GB"],
     }
+    if len(lrn) > 1 or len(eng) > 1:
+        out["topology"] = {"learners": len(lrn), "engines": len(eng), "grad_backend": L.get("grad_backend"), "weight_transport": L["weight_sync"]["transport"],
+                           "devices": {n: r[n].get("device") for n in lrn + eng},
+                           "micro_batches_per_learner": {n: r[n]["micro_batches"] for n in lrn}, "samples_per_learner": {n: r[n].get("local_samples") for n in lrn},
+                           "updates_per_engine": {n: r[n]["updates"] for n in eng}}
+    return out

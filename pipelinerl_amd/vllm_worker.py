@@ -38,7 +38,7 @@ class WorkerExtension:
         invalidates its fp32 lm_head cache here, vllm1.py:126)."""
 
     def init_actor_update_group(self, actor_idx: int, actor_ngpus: int, weight_update_group_init_method: str,
-                                weight_update_group_world_size: int, tp_sharded: bool = False) -> None:
+                                weight_update_group_world_size: int, tp_sharded: bool = False, backend: str = "rccl") -> None:
         """`tp_sharded`: join the communicator of THIS worker's tensor-parallel rank (trainer + the same TP rank of every
         engine) instead of the one spanning all workers: updates then arrive as this rank's slices only
         (`transport: sharded`, tp_shard.py).  The engine's TP degree is `actor_ngpus`."""
@@ -47,14 +47,17 @@ class WorkerExtension:
         logger.info(f"[INIT_ACTOR_UPDATE_GROUP]: actor {actor_idx}, ngpus {actor_ngpus}, rank {self.rank}, pg_rank {self.pg_rank}, "
                     f"init {weight_update_group_init_method}, world {weight_update_group_world_size}, tp_sharded {tp_sharded}")
         if tp_sharded:
+            if backend != "rccl":
+                raise ValueError("the tensor-parallel update groups are RCCL communicators")
             self.model_update_group = WeightSyncGroup.tp_shard_groups(
                 weight_update_group_init_method, rank=self.pg_rank, world_size=weight_update_group_world_size, tp_size=actor_ngpus,
                 device=self.device)[0]
             self.tp_rank, self.tp_size = self.rank, actor_ngpus
         else:
-            self.model_update_group = WeightSyncGroup.from_init_method(
-                weight_update_group_init_method, rank=self.pg_rank, world_size=weight_update_group_world_size, device=self.device
-            )
+            from .weight_sync import weight_sync_group
+
+            # backend "gloo": the same group without RCCL (hosts with one GPU, CPU tensors) - pipeline_run's weight_transport="gloo"
+            self.model_update_group = weight_sync_group(backend, weight_update_group_init_method, self.pg_rank, weight_update_group_world_size, self.device)
         self._receiver = None
 
     def _load_weight_shards(self, shards):

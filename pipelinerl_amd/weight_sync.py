@@ -253,6 +253,71 @@ class WeightSyncGroup:
             self._h = ctypes.c_void_p()
 
 
+class GlooWeightSyncGroup:
+    """The weight-update group over gloo: the same rank layout (trainer 0, inference workers 1..) and the same `tcp://host:port`
+    rendezvous as `WeightSyncGroup.from_init_method`, for hosts without a second GPU and for CPU tensors - `pipeline_run` uses it
+    (`weight_transport="gloo"`) to run the N-learner x M-engine topology where RCCL cannot (RCCL refuses two ranks on one device).
+    A STATELESS group like the reference's `stateless_init_process_group` (torch_utils.py:70-94): its own store and its own
+    ProcessGroupGloo, independent of the process's default group (the learners' data-parallel group).  Device buffers are staged
+    through host memory; this is a correctness transport, not a fast one."""
+
+    def __init__(self, pg: Any, store: Any, rank: int, world_size: int, device: torch.device):
+        self._pg, self._store = pg, store
+        self.rank, self.world_size, self.device = rank, world_size, torch.device(device)
+        self.bytes_moved = 0
+
+    @classmethod
+    def from_init_method(cls, init_method: str, rank: int, world_size: int, device: torch.device, timeout_s: float = 300.0) -> "GlooWeightSyncGroup":
+        import torch.distributed as dist
+
+        u = urlparse(init_method)
+        timeout = datetime.timedelta(seconds=timeout_s)
+        store = dist.TCPStore(u.hostname or "127.0.0.1", u.port or 9000, world_size, is_master=(rank == 0), timeout=timeout, wait_for_workers=False)
+        pg = dist.ProcessGroupGloo(dist.PrefixStore("prl_wsync_gloo", store), rank, world_size, timeout)
+        return cls(pg, store, rank, world_size, device)
+
+    def comm_size(self) -> tuple[int, int]:
+        return self._pg.size(), self._pg.rank()
+
+    def _bcast(self, t: torch.Tensor, src: int) -> None:
+        import torch.distributed as dist
+
+        opts = dist.BroadcastOptions()
+        opts.rootRank, opts.rootTensor = src, 0
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()  # the bucket was filled on this stream
+            host = t.cpu()
+            self._pg.broadcast([host], opts).wait()
+            if self.rank != src:
+                t.copy_(host)
+        else:
+            self._pg.broadcast([t], opts).wait()
+        self.bytes_moved += t.numel() * t.element_size()
+
+    def broadcast_bucket(self, bucket: torch.Tensor, mode: str = "scatter_allgather", src: int = 0) -> None:
+        """`mode` is accepted for interface parity; gloo has one broadcast."""
+        assert bucket.is_contiguous()
+        self._bcast(bucket, src)
+
+    def broadcast(self, tensor: torch.Tensor, src: int = 0, stream: Any = None) -> None:
+        t = tensor if tensor.is_contiguous() else tensor.contiguous()
+        self._bcast(t, src)
+        if t is not tensor and self.rank != src:
+            tensor.copy_(t)
+
+    def close(self) -> None:
+        self._pg = None
+
+
+def weight_sync_group(backend: str, init_method: str, rank: int, world_size: int, device: torch.device, timeout_s: float = 300.0):
+    """`rccl` -> `WeightSyncGroup` (RCCL over xGMI, one device per rank), `gloo` -> `GlooWeightSyncGroup`."""
+    if backend == "rccl":
+        return WeightSyncGroup.from_init_method(init_method, rank, world_size, device, timeout_s)
+    if backend == "gloo":
+        return GlooWeightSyncGroup.from_init_method(init_method, rank, world_size, device, timeout_s)
+    raise ValueError(f"weight-update group backend {backend!r}: 'rccl' or 'gloo'")
+
+
 _DTYPE_NAMES = {
     torch.bfloat16: ("bfloat16", "bf16"),
     torch.float32: ("float32", "fp32", "float"),
