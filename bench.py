@@ -805,6 +805,20 @@ def weight_sync_probe(rank: int, world: int, dev: torch.device, out: dict) -> di
     return out
 
 
+def grad_bucket_sizes(total_bytes: int, bucket_bytes: int = 1 << 30) -> list[int]:
+    """Byte sizes of the bf16 gradient buckets a data-parallel learner all-reduces per step: `bucket_bytes` each, the remainder last;
+    every size even (whole bf16 elements).  A ring all-reduce is bound by the slowest xGMI link at 2 (N - 1) / N of the bytes, so the
+    bucket count - not N - sets the number of collectives: 15 for the 7B set, 62 for 32B."""
+    if total_bytes < 0 or total_bytes % 2:
+        raise ValueError(f"{total_bytes} bytes is not a whole number of bf16 gradients")
+    out, left = [], total_bytes
+    while left > 0:
+        n = min(left, bucket_bytes)
+        out.append(n)
+        left -= n
+    return out
+
+
 def self_launch(n: int, share_device: bool) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this same command under torch.distributed.run (one process per
     GPU, rendezvous on 127.0.0.1) and return their exit code.  Refuses when the node has fewer than N devices, unless the dry-run mode
@@ -1078,11 +1092,7 @@ def main():
     main_timer = EventTimer()
     grad_buckets = []
     if world > 1 and not args.no_grad_allreduce and args.backend == "nccl":
-        left = args.grad_bytes
-        while left > 0:
-            n = min(left, 1 << 30)
-            grad_buckets.append(torch.zeros(n // 2, dtype=torch.bfloat16, device=dev))
-            left -= n
+        grad_buckets = [torch.zeros(n // 2, dtype=torch.bfloat16, device=dev) for n in grad_bucket_sizes(args.grad_bytes)]
 
     def one_step(timed: bool, skip_unlabelled: bool = False, timer=None):
         # `value` is timed on the reference's behaviour: EVERY row of the logits is read, so that `isfinite(new_logprobs)` holds

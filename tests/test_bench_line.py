@@ -112,3 +112,22 @@ def test_an_oversized_line_is_refused_not_printed():
     full["config"]["workload"] = "w" * 5000
     with pytest.raises(AssertionError, match="bytes"):
         bench.split_line(full, "x.json")
+
+
+def test_gradient_buckets_of_the_baseline_models():
+    """N > 1: the data-parallel exchange step all-reduces the model's bf16 gradients in 1 GiB buckets - sized here, for every
+    BASELINE workload, without a GPU."""
+    import bench
+
+    for name, (_, _, _, nbytes) in bench.WORKLOAD_MODEL.items():
+        sizes = bench.grad_bucket_sizes(nbytes)
+        assert sum(sizes) == nbytes and all(0 < n <= 1 << 30 and n % 2 == 0 for n in sizes) and all(n == 1 << 30 for n in sizes[:-1]), name
+    assert len(bench.grad_bucket_sizes(bench.WORKLOAD_MODEL["7b_grpo_bs4096_seq8192"][3])) == 15
+    assert len(bench.grad_bucket_sizes(bench.WORKLOAD_MODEL["32b_grpo_kl_bs4096_seq8192"][3])) == 62
+    assert bench.grad_bucket_sizes(0) == []
+    with pytest.raises(ValueError):
+        bench.grad_bucket_sizes(3)
+    # every BASELINE batch splits into whole groups per rank at 1, 2, 4 and 8 ranks
+    for name, (bs, _, _, attempts) in bench.WORKLOADS.items():
+        for world in (1, 2, 4, 8):
+            assert bs % (attempts * world) == 0, (name, world)

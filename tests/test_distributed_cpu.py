@@ -436,3 +436,37 @@ def test_fsdp_source_drops_the_tied_head_and_dispatch_picks_the_source():
     else:
         assert isinstance(parameter_source_for(engine), Zero3Parameters)
     assert isinstance(parameter_source_for(types.SimpleNamespace(zero_optimization_stage=lambda: 2, named_parameters=lambda: [])), PlainParameters)
+
+
+def _reduce_stats_rank(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    from pipelinerl_amd import _lib
+    from pipelinerl_amd.hotpath import _MAX_LANES, _MIN_LANES, HotPathStep
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    step = HotPathStep.__new__(HotPathStep)  # the reduction needs no device state
+    step.group = None
+    g = torch.Generator().manual_seed(100 + rank)
+    mine = torch.randn(_lib.PRL_NUM_STATS, dtype=torch.float64, generator=g)
+    got = step.reduce_stats(mine.clone())
+    everyone = torch.stack([torch.randn(_lib.PRL_NUM_STATS, dtype=torch.float64, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)])
+    want = everyone.sum(0)
+    want[_MAX_LANES] = everyone[:, _MAX_LANES].max(0).values
+    want[_MIN_LANES] = everyone[:, _MIN_LANES].min(0).values
+    Path(out_dir, f"stats{rank}.json").write_text(json.dumps({"equal": bool(torch.equal(got, want)), "n": int(got.numel())}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_step_statistics_all_gather_at_world_8(tmp_path, world):
+    """The ONE data-path collective of the sharded benchmark step (`HotPathStep.reduce_stats`, bench.py --gpus N): every rank ends with
+    the same vector - sums of the additive lanes in rank order, max / min of the extrema lanes - at the 8 ranks the driver's scaling run uses."""
+    port = _free_port()
+    mp.spawn(_reduce_stats_rank, args=(world, port, tmp_path), nprocs=world, join=True)
+    for r in range(world):
+        d = json.loads((tmp_path / f"stats{r}.json").read_text())
+        assert d["equal"] and d["n"] == 32, (r, d)

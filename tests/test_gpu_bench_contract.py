@@ -103,14 +103,16 @@ def test_bench_detail_side_measurements(libprl, cuda_device, tmp_path):
     assert pl["overlap"]["pipelined_s_per_step"] > 0 and sum(pl["lag_optimizer_steps_histogram"].values()) > 0
 
 
-def test_bare_multi_gpu_invocation_becomes_n_ranks(libprl, cuda_device):
-    """`python bench.py --gpus 2` with no launcher re-executes itself as 2 ranks (here both on this GPU over gloo, the dry-run mode)
-    and the line's `n_gpus` comes from the process group, not from argv."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bare_multi_gpu_invocation_becomes_n_ranks(libprl, cuda_device, world):
+    """`python bench.py --gpus N` with no launcher re-executes itself as N ranks (here all on this GPU over gloo, the dry-run mode)
+    and the line's `n_gpus` comes from the process group, not from argv.  N = 8 is the driver's scaling run: the batch splits into
+    whole groups per rank, every rank shards / packs / runs its share, the statistics all-gather closes the step."""
     import os
 
     env = {**os.environ, "PRL_BENCH_SHARE_DEVICE": "1"}
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
-    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "tiny", "--steps", "1", "--warmup", "0",
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--backend", "gloo", "--workload", "tiny", "--steps", "1", "--warmup", "0",
                           "--no-weight-sync", "--detail-out", "gpurun_out/bench_detail_2ranks.json"], capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -118,5 +120,5 @@ def test_bare_multi_gpu_invocation_becomes_n_ranks(libprl, cuda_device):
     d = json.loads(lines[0])
     assert len(lines[0]) < 4096
     td = json.loads((ROOT / "gpurun_out" / "bench_detail_2ranks.json").read_text())["config_detail"]["torch_distributed"]
-    assert d["n_gpus"] == 2 and td["world_size"] == 2 and td["backend"] == "gloo" and td["share_device_dry_run"] is True and td["distinct_devices"] == 1
-    assert d["config"]["parallelism"] == "dp2" and d["config"]["backend"] == "gloo" and d["config"]["distinct_devices"] == 1 and d["cpu_baseline"] is None
+    assert d["n_gpus"] == world and td["world_size"] == world and td["backend"] == "gloo" and td["share_device_dry_run"] is True and td["distinct_devices"] == 1
+    assert d["config"]["parallelism"] == f"dp{world}" and d["config"]["backend"] == "gloo" and d["config"]["distinct_devices"] == 1 and d["cpu_baseline"] is None

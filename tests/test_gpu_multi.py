@@ -17,6 +17,8 @@ from __future__ import annotations
 
 import multiprocessing as mp
 import socket
+import time
+from pathlib import Path
 
 import pytest
 import torch
@@ -24,6 +26,32 @@ import torch
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs at least 2 GPUs")]
 
 SIZES = [1, 255, 4099, (1 << 30) + 3]
+DIAG = Path(__file__).resolve().parent.parent / "gpurun_out" / "multi_gpu_diag.jsonl"
+
+
+def _diag(record: dict) -> None:
+    """The first run of these tests on a multi-GPU node is also the first time the code moves bytes between two devices: every test leaves
+    what it did - transport, world size, bytes, seconds, bus bandwidth, which RCCL path - on stdout (pytest -rA / -s) and in
+    gpurun_out/multi_gpu_diag.jsonl, so that a failure (or a slow link) can be read without re-running."""
+    import json
+
+    line = json.dumps(record)
+    print("[multi-gpu diag]", line, flush=True)
+    try:
+        DIAG.parent.mkdir(parents=True, exist_ok=True)
+        with open(DIAG, "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+def _env_diag() -> dict:
+    import os
+
+    props = [torch.cuda.get_device_properties(i) for i in range(torch.cuda.device_count())]
+    return {"devices": len(props), "names": sorted({p.name for p in props}), "gcn": sorted({getattr(p, "gcnArchName", "?") for p in props}),
+            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "NCCL_DEBUG": os.environ.get("NCCL_DEBUG"),
+            "torch": torch.__version__, "hip": torch.version.hip}
 
 
 def _free_port() -> int:
@@ -46,13 +74,17 @@ def _wsync_worker(rank: int, world: int, port: int, out_q, which: str = "7b") ->
         torch.cuda.set_device(dev)
         grp = WeightSyncGroup.from_init_method(f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device=dev, timeout_s=120)
         errs = []
+        diag = {"rank": rank, "device": torch.cuda.get_device_name(dev), "rccl_comm": list(grp.comm_size()), "buckets": {}}
         # ---- raw buckets, both modes, awkward sizes
         for mode in ("broadcast", "scatter_allgather"):
             for k, n in enumerate(SIZES):
                 want = _pattern(n, 1000 + k, dev)
                 buf = want.clone() if rank == 0 else torch.full((n,), 0xAA, dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
                 grp.broadcast_bucket(buf, mode=mode)
                 torch.cuda.synchronize()
+                diag["buckets"][f"{mode}:{n}"] = round(1e3 * (time.perf_counter() - t0), 3)
                 if not torch.equal(buf, want):
                     bad = int((buf != want).sum())
                     errs.append(f"{mode} {n} bytes: {bad} bytes differ on rank {rank}")
@@ -62,13 +94,23 @@ def _wsync_worker(rank: int, world: int, port: int, out_q, which: str = "7b") ->
         shapes = qwen25_shapes(which)
         gen = torch.Generator(device=dev).manual_seed(77)
         params = [(n, torch.empty(s, dtype=torch.bfloat16, device=dev).normal_(generator=gen)) for n, s in shapes]
+        nbytes = sum(t.numel() * 2 for _, t in params)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         if rank == 0:
             BucketedSender(grp, 1 << 30).send(params)
+            torch.cuda.synchronize()
         else:
             dest = {n: torch.zeros_like(t) for n, t in params}
             info = [ParamSpec(n, tuple(s), torch.bfloat16) for n, s in shapes]
+            t0 = time.perf_counter()
             got = BucketedReceiver(grp, 1 << 30).receive(info, None, destinations=dest)
             torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # first update of a fresh communicator (channel set-up included): a lower bound on the steady-state rate, which bench.py --gpus N measures
+        diag["full_update"] = {"tensors": len(shapes), "gbytes": round(nbytes / 1e9, 3), "ms_first": round(1e3 * dt, 1), "GBps_first": round(nbytes / dt / 1e9, 1),
+                               "mode": "scatter_allgather (default)", "per_link_peak_GBps": 153}
+        if rank != 0:
             if got != len(shapes):
                 errs.append(f"received {got} of {len(shapes)} tensors")
             wrong = [n for n, t in params if not torch.equal(dest[n], t)]
@@ -76,14 +118,42 @@ def _wsync_worker(rank: int, world: int, port: int, out_q, which: str = "7b") ->
                 errs.append(f"{len(wrong)} tensors differ, first {wrong[:3]}")
         torch.cuda.synchronize()
         grp.close()
-        out_q.put((rank, errs))
+        out_q.put((rank, errs, diag))
     except Exception as e:  # noqa: BLE001
         import traceback
 
-        out_q.put((rank, [f"{type(e).__name__}: {e}", traceback.format_exc()]))
+        out_q.put((rank, [f"{type(e).__name__}: {e}", traceback.format_exc()], {"rank": rank, "died": True}))
 
 
-@pytest.mark.parametrize("world,which", [(2, "7b"), (4, "7b"), (3, "32b")], ids=["2_gpus_7b", "4_gpus_7b", "3_gpus_32b_65GB"])
+def _collect(procs, q, world, timeout=600):
+    """(errors per rank, diagnostics per rank); a rank that never reports is named instead of a bare queue.Empty."""
+    import queue
+
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        deadline = time.time() + timeout
+        while len(got) < world and time.time() < deadline:
+            try:
+                r = q.get(timeout=5)
+                got[r[0]] = r[1:]
+            except queue.Empty:
+                if all(not p.is_alive() for p in procs):
+                    break
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    missing = [r for r in range(world) if r not in got]
+    errs = {r: got[r][0] for r in got}
+    for r in missing:
+        errs[r] = [f"rank {r} never reported (exit code {procs[r].exitcode}): a hang in the rendezvous or in a collective - rerun with NCCL_DEBUG=INFO"]
+    return errs, {r: (got[r][1] if len(got[r]) > 1 else None) for r in got}
+
+
+@pytest.mark.parametrize("world,which", [(2, "7b"), (4, "7b"), (8, "7b"), (3, "32b")], ids=["2_gpus_7b", "4_gpus_7b", "8_gpus_7b", "3_gpus_32b_65GB"])
 def test_rccl_weight_broadcast_is_byte_exact(libprl, world, which):
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs {world} GPUs")
@@ -91,15 +161,8 @@ def test_rccl_weight_broadcast_is_byte_exact(libprl, world, which):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_wsync_worker, args=(r, world, port, q, which), daemon=True) for r in range(world)]
-    for p in procs:
-        p.start()
-    try:
-        results = dict(q.get(timeout=600) for _ in range(world))
-    finally:
-        for p in procs:
-            p.join(timeout=30)
-            if p.is_alive():
-                p.kill()
+    results, diags = _collect(procs, q, world)
+    _diag({"test": "rccl_weight_broadcast", "transport": "rccl_xgmi", "world": world, "params": which, "env": _env_diag(), "ranks": diags})
     for r in range(world):
         assert not results[r], (r, results[r])
 
@@ -143,7 +206,8 @@ def _tp_shard_worker(rank: int, world: int, port: int, tp: int, out_q, which: st
                 errs.append(f"{len(wrong)} slices differ on rank {rank} (TP rank {t}), first {wrong[:3]}")
         for g in groups:
             g.close()
-        out_q.put((rank, errs))
+        out_q.put((rank, errs, {"rank": rank, "role": "trainer" if rank == 0 else f"engine {(rank - 1) // tp} tp {(rank - 1) % tp}",
+                                "bytes_sent_per_tp_rank": getattr(locals().get("sender"), "bytes_sent", None)}))
     except Exception as e:  # noqa: BLE001
         import traceback
 
@@ -163,15 +227,9 @@ def test_tp_aware_update_over_rccl(libprl, engines, tp, which):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_tp_shard_worker, args=(r, world, port, tp, q, which), daemon=True) for r in range(world)]
-    for p in procs:
-        p.start()
-    try:
-        results = dict(q.get(timeout=600) for _ in range(world))
-    finally:
-        for p in procs:
-            p.join(timeout=30)
-            if p.is_alive():
-                p.kill()
+    results, diags = _collect(procs, q, world)
+    _diag({"test": "tp_aware_update", "transport": "rccl_xgmi, one communicator per TP rank", "world": world, "engines": engines, "tp": tp, "params": which,
+           "env": _env_diag(), "ranks": diags})
     for r in range(world):
         assert not results[r], (r, results[r])
 
@@ -180,3 +238,33 @@ def test_native_learner_step_under_ddp_over_rccl(libprl, cuda_device, tmp_path):
     from test_gpu_native_ddp import run_two_rank_check
 
     run_two_rank_check(cuda_device, tmp_path, backend="nccl", own_gpu=True)
+
+
+@pytest.mark.parametrize("n_learners,n_engines", [(1, 1), (2, 2), (4, 4)], ids=["1+1", "configs2_2+2", "configs3_4+4"])
+def test_pipeline_learners_and_engines_on_their_own_gpus_over_rccl(libprl, tmp_path, n_learners, n_engines):
+    """BASELINE configs[2] / [3] as they are meant to run: every engine and every learner rank on its OWN GPU (engines first, world.py:143-192),
+    gradients over RCCL, trainer rank 0 -> the weight-update group of M + 1 over RCCL / xGMI after every optimizer step.  The same
+    `run_pipeline` the 1-GPU tests drive with gloo / HIP IPC (tests/test_gpu_pipeline_procs.py, tests/test_pipeline_topology_cpu.py)."""
+    import json
+
+    from pipelinerl_amd.pipeline_run import PipelineSpec, run_pipeline
+
+    need = n_learners + n_engines
+    if torch.cuda.device_count() < need:
+        pytest.skip(f"needs {need} GPUs")
+    bs, steps = 32, 3
+    spec = PipelineSpec(exp_path=str(tmp_path / "exp"), model="tiny", global_batch=bs, seq_length=128, attempts=4, steps=steps, n_problems=5, concurrent_groups=2,
+                        stage_timeout_s=600.0, n_learners=n_learners, n_engines=n_engines, weight_transport="rccl", share_device=False, stacks_after_s=300.0)
+    res = run_pipeline(spec)
+    s = res.get("summary") or {}
+    _diag({"test": "pipeline_rccl", "learners": n_learners, "engines": n_engines, "env": _env_diag(), "error": res.get("error"),
+           "topology": s.get("topology"), "weight_sync_under_load_ms": s.get("weight_sync_under_load_ms"), "samples_per_s": s.get("samples_per_s")})
+    assert "error" not in res, json.dumps(res.get("error"), indent=1)[:6000]
+    st = res["stages"]
+    eng = [n for n in st if n.startswith("engine")]
+    lrn = [n for n in st if n.startswith("learner")]
+    assert len({st[n]["device"] for n in eng + lrn}) == need, "one GPU per engine and per learner rank"
+    assert all(st[n]["completed_steps"] == steps and st[n]["local_samples"] == steps * bs // n_learners for n in lrn)
+    assert all(st[n]["updates"] == steps + 1 and st[n]["weight_group"]["size"] == n_engines + 1 for n in eng)
+    assert s["engine_weights_equal_trainer_at_last_version"] is True
+    assert s["weight_sync_under_load_ms"]["transport"] == "rccl_xgmi"

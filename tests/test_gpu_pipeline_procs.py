@@ -133,3 +133,63 @@ def test_four_process_pipeline_and_step0_vs_oracle(libprl, cuda_device, tmp_path
         assert not torch.equal(after[n], before[n]), f"{n} did not move"
     bad = {n: e for n, e in worst.items() if e > 1e-4}
     assert not bad, "gradients of step 0, relative 2-norm error per tensor: " + json.dumps(dict(sorted(worst.items(), key=lambda kv: -kv[1])[:12]), indent=1)
+
+
+@pytest.mark.parametrize("weights,learner", [("ipc", "streamed"), ("gloo", "dropin")])
+def test_two_learners_two_engines_on_one_gpu_match_one_learner(libprl, cuda_device, tmp_path, weights, learner):
+    """BASELINE configs[2]'s topology (2 learner ranks + 2 engines) with every stage on this ONE GPU: six processes, the real HIP preprocessor
+    and the real fused-head loss on both learner ranks, gradients all-reduced over gloo (RCCL refuses two ranks on one device), weights
+    handed to BOTH engines - as HIP IPC handles each engine maps, or through the weight-update group of 3 over gloo - after every
+    optimizer step.  Step 0 equals the single-learner pipeline on the same rollouts: the ranks' partial losses add up to its loss, the
+    aggregated statistics agree, and the SGD update is its update / 2 (DDP averages the ranks' gradients like the reference's engines do;
+    the loss normaliser is the global samples_per_step on every rank, finetune_loop.py:644-646).  Dense rollouts: one sequence per
+    micro-batch on either side, so the two runs differ in WHO trains a sequence, not in how it is packed."""
+    from pipelinerl_amd.pipeline_run import PipelineSpec, run_pipeline
+
+    bs, seq, lr, steps = 16, 96, 0.05, 3
+    runs = {}
+    for tag, n, m in (("two", 2, 2), ("one", 1, 1)):
+        exp, cap = tmp_path / tag / "exp", tmp_path / tag / "cap"
+        spec = PipelineSpec(exp_path=str(exp), model="tiny", global_batch=bs, seq_length=seq, attempts=4, steps=steps, optimizer="sgd", lr=lr, param_dtype="fp32",
+                            capture_step0=str(cap), n_problems=5, concurrent_groups=2, stage_timeout_s=600.0, learner=learner, dense=True,
+                            n_learners=n, n_engines=m, weight_transport=weights if n > 1 else "ipc", share_device=True, extra={"bucket_bytes": 1 << 16})
+        res = run_pipeline(spec)
+        assert "error" not in res, json.dumps(res.get("error"), indent=1)[:6000]
+        runs[tag] = (res, cap)
+    res, cap2 = runs["two"]
+    st, s = res["stages"], res["summary"]
+    assert s["topology"]["learners"] == 2 and s["topology"]["engines"] == 2 and s["topology"]["grad_backend"] == "gloo"
+    assert s["topology"]["weight_transport"] == {"ipc": "hip_ipc_colocated", "gloo": "gloo_host_staged"}[weights]
+    assert set(s["topology"]["devices"].values()) == {"cuda:0"}
+    l0, l1 = st["learner0"], st["learner1"]
+    assert l0["completed_steps"] == l1["completed_steps"] == steps and l0["local_samples"] == l1["local_samples"] == steps * bs // 2
+    assert l0["micro_batches"] == l1["micro_batches"]
+    for e in ("engine0", "engine1"):
+        assert st[e]["updates"] == steps + 1 and st[e]["last_version"] == steps * bs
+        if weights == "gloo":
+            assert st[e]["weight_group"]["size"] == 3 and st[e]["weight_group"]["bytes_received"] == l0["weight_group"]["bytes_sent"] > 0
+    assert s["engine_weights_equal_trainer_at_last_version"] is True and st["engine0"]["param_probe"] == st["engine1"]["param_probe"]
+    assert st["preprocessor"]["published_samples"] >= steps * bs
+    a0, a1 = torch.load(cap2 / "rank0" / "params_after.pt"), torch.load(cap2 / "rank1" / "params_after.pt")
+    assert all(torch.equal(a0[n], a1[n]) for n in a0), "DDP kept the replicas identical"
+    # ---- against the single-learner pipeline
+    _, cap1 = runs["one"]
+    b1, b2 = torch.load(cap1 / "params_before.pt"), torch.load(cap2 / "rank0" / "params_before.pt")
+    assert all(torch.equal(b1[n], b2[n]) for n in b1)
+    ids = lambda captured: sorted(tuple(b["input_ids"].flatten().tolist()) for b in captured if not b["sentinel"])  # noqa: E731
+    assert ids(torch.load(cap1 / "step0_batches.pt")) == ids(torch.load(cap2 / "rank0" / "step0_batches.pt") + torch.load(cap2 / "rank1" / "step0_batches.pt"))
+    m1, m2 = json.loads((cap1 / "step0_metrics.json").read_text()), json.loads((cap2 / "rank0" / "step0_metrics.json").read_text())
+    assert m2["rl/loss"] == pytest.approx(m1["rl/loss"], rel=1e-4, abs=1e-7)
+    for k, w in m1.items():
+        if k.startswith("rl/"):
+            assert m2[k] == pytest.approx(w, rel=1e-4, abs=1e-6), k
+    after1 = torch.load(cap1 / "params_after.pt")
+    g1, g2 = torch.load(cap1 / "grads_step0.pt"), torch.load(cap2 / "rank0" / "grads_step0.pt")
+    worst = {}
+    for n in g1:
+        want, got = 0.5 * g1[n].double(), g2[n].double()
+        worst[n] = float((got - want).norm() / max(float(want.norm()), 1e-30))
+        d1, d2 = (after1[n] - b1[n]).double(), (a0[n] - b2[n]).double()
+        assert float((d2 - 0.5 * d1).abs().max()) <= 1e-3 * float(d1.abs().max()) + 1e-9, f"{n}: update of the 2-rank run = update of the 1-rank run / 2"
+    bad = {n: e for n, e in worst.items() if e > 1e-4}
+    assert not bad, "averaged gradients of step 0 vs half the single-learner gradients, relative 2-norm error: " + json.dumps(bad, indent=1)
