@@ -171,27 +171,34 @@ def encode_rollouts(rollouts) -> bytearray:
     return _frame(MAGIC_ROLLOUTS, {"group_ids": list(rollouts.group_ids)}, tensors)
 
 
-_COMPACT_FIELDS = ("tokens", "labels", "logprobs", "ref_logprobs", "seq_off", "lp_off", "seq_scalars")
+_COMPACT_FIELDS = ("tokens", "labels", "logprobs", "ref_logprobs", "seq_off", "lp_off", "seq_scalars", "ref_column")
 
 
-def compact_layout(n: int, nc: int, m: int, has_ref: bool, model_version: int, padding: int, eos_token_id: int):
+def compact_layout(n: int, nc: int, m: int, has_ref: bool, model_version: int, padding: int, eos_token_id: int,
+                   slice_index: int = 0, num_slices: int = 1, ref_column_tokens: int = 0):
     """(header bytes incl. magic and length, offset of the first tensor, {name: (offset from there, nbytes)}, record size) of the
     compact record of a micro-batch of `n` tokens / `nc` completion tokens / `m` sequences.  One definition for the generic
     encoder (`encode_compact`) and for the preprocessor's gather recipe (the native publisher copies every column's per-sequence
     slices straight from the decoded `actor` records).  The header text is formatted by hand - the preprocessor builds one per
-    micro-batch - and is the text `json.dumps` produces for the same structure (tests/test_compact_wire_host.py)."""
+    micro-batch - and is the text `json.dumps` produces for the same structure (tests/test_compact_wire_host.py).
+    `num_slices` > 1 (sequence parallelism): the record names the token slice its reader keeps after expansion (`slice`, `slices`
+    scalars; absent otherwise, so the records of the common case are unchanged).  `ref_column_tokens` > 0 (a reference policy in the
+    preprocessor, KL on): one more fp32 column of that many entries - the expanded batch's `ref_logprobs`, token for token."""
     shapes = [("tokens", "int32", f"[{n}]", 4 * n), ("labels", "int32", f"[{n}]", 4 * n), ("logprobs", "float32", f"[{nc}]", 4 * nc)]
     if has_ref:
         shapes.append(("ref_logprobs", "float32", f"[{nc}]", 4 * nc))
     shapes += [("seq_off", "int64", f"[{m + 1}]", 8 * (m + 1)), ("lp_off", "int64", f"[{m + 1}]", 8 * (m + 1)), ("seq_scalars", "float32", f"[5, {m}]", 20 * m)]
+    if ref_column_tokens:
+        shapes.append(("ref_column", "float32", f"[{ref_column_tokens}]", 4 * ref_column_tokens))
     offset, tensors, where = 0, [], {}
     for name, dt, shape, nb in shapes:
         offset += (-offset) % _ALIGN
         tensors.append(f'["{name}", "{dt}", {shape}, {offset}, {nb}]')
         where[name] = (offset, nb)
         offset += nb
-    header = ('{"scalars": {"model_version": %d, "padding": %d, "eos_token_id": %d}, "tensors": [%s]}'
-              % (int(model_version), int(padding), int(eos_token_id), ", ".join(tensors))).encode("utf-8")
+    sliced = ', "slice": %d, "slices": %d' % (int(slice_index), int(num_slices)) if num_slices > 1 else ""
+    header = ('{"scalars": {"model_version": %d, "padding": %d, "eos_token_id": %d%s}, "tensors": [%s]}'
+              % (int(model_version), int(padding), int(eos_token_id), sliced, ", ".join(tensors))).encode("utf-8")
     head = MAGIC_COMPACT + struct.pack("<I", len(header)) + header
     base = len(head) + (-len(head)) % _ALIGN
     return head, base, where, base + offset
@@ -201,7 +208,10 @@ def encode_compact(cb) -> bytearray:
     """`finetune.data.CompactBatch` -> one record (the generic path: every column copied once into a record buffer)."""
     t = torch.from_numpy
     tensors = [(k, t(np.ascontiguousarray(getattr(cb, k)))) for k in _COMPACT_FIELDS if getattr(cb, k) is not None]
-    return _frame(MAGIC_COMPACT, {"model_version": int(cb.model_version), "padding": int(cb.padding), "eos_token_id": int(cb.eos_token_id)}, tensors)
+    scalars = {"model_version": int(cb.model_version), "padding": int(cb.padding), "eos_token_id": int(cb.eos_token_id)}
+    if cb.num_slices > 1:
+        scalars.update(slice=int(cb.slice_index), slices=int(cb.num_slices))
+    return _frame(MAGIC_COMPACT, scalars, tensors)
 
 
 def encode_batch(batch: PipelineBatchEncoding) -> bytearray:
@@ -239,7 +249,8 @@ def decode(record: "bytes | bytearray") -> Any:
         from .finetune.data import CompactBatch
 
         return CompactBatch(**{k: (out[k].numpy() if k in out else None) for k in _COMPACT_FIELDS},
-                            model_version=out["model_version"], padding=out["padding"], eos_token_id=out["eos_token_id"])
+                            model_version=out["model_version"], padding=out["padding"], eos_token_id=out["eos_token_id"],
+                            slice_index=out.get("slice", 0), num_slices=out.get("slices", 1))
     if magic == MAGIC_ROLLOUTS:
         from .ragged import RaggedRollouts
 

@@ -314,8 +314,11 @@ class CompactBatch:
     lp_off: np.ndarray               # int64 [m + 1]
     seq_scalars: np.ndarray          # fp32 [5, m]: rewards, advantages, group_tokens, num_labels, overflow per sequence
     model_version: int = 0
-    padding: int = 0                 # sequence-parallel filler tokens appended by the pack kernel (0 on this wire today)
+    padding: int = 0                 # sequence-parallel filler tokens appended by the pack kernel ((-n) % seq_parallel)
     eos_token_id: int = 0
+    ref_column: np.ndarray | None = None  # fp32 [n + padding]: the EXPANDED batch's `ref_logprobs`, written by a reference policy in the preprocessor (KL on)
+    slice_index: int = 0             # sequence parallelism: every rank of the group receives the whole record and keeps token slice
+    num_slices: int = 1              # `slice_index` of `num_slices` after expansion (types.py:145-180 `make_slices`)
 
     @property
     def n_tokens(self) -> int:
@@ -332,8 +335,13 @@ class CompactBatch:
         lab = self.labels.copy()
         first = self.seq_off[1:-1]
         lab[first[first < len(lab)]] = MASKED_TOKEN_ID
+        total = self.n_tokens + int(self.padding)
+        if self.num_slices > 1:  # the facts of THIS rank's slice, as `annotate_host_batch` finds them on the sliced batch (filler tokens carry no label)
+            lab = np.concatenate([lab, np.full(int(self.padding), MASKED_TOKEN_ID, dtype=lab.dtype)])
+            lo, hi = self.slice_index * total // self.num_slices, (self.slice_index + 1) * total // self.num_slices
+            lab, total = lab[lo:hi], hi - lo
         live = np.flatnonzero(lab[1:] != MASKED_TOKEN_ID)
-        return {"tokens": self.n_tokens + int(self.padding), "labelled_rows": torch.from_numpy(live.astype(np.int64))}
+        return {"tokens": total, "labelled_rows": torch.from_numpy(live.astype(np.int64))}
 
     def to_batch(self, device: torch.device | str, stager: Any = None) -> PipelineBatchEncoding:
         """Upload (ONE copy through `stager`, a `staging.PinnedStager`, when given) + one K6 launch on `device`'s current
@@ -346,12 +354,22 @@ class CompactBatch:
         # the launch plan of ONE micro-batch whose sequences already lie in packing order: source = segment = 0 .. m - 1, destination
         # offsets = the sequence offsets themselves - it rides along with the columns (one copy), nothing is planned
         order = np.arange(m, dtype=np.int32)
-        cols = [self.tokens, self.labels, self.logprobs, self.ref_logprobs, seq_off, self.lp_off, self.seq_scalars, order]
+        cols = [self.tokens, self.labels, self.logprobs, self.ref_logprobs, seq_off, self.lp_off, self.seq_scalars, order, self.ref_column]
         if stager is not None:
             up = stager.upload(cols)
         else:
             up = [None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True) for a in cols]
-        tokens, labels, lp, ref, d_off, lp_off, sc, d_order = up
+        tokens, labels, lp, ref, d_off, lp_off, sc, d_order, ref_column = up
+
+        def finish(batch: PipelineBatchEncoding) -> PipelineBatchEncoding:
+            if ref_column is not None:  # the column a reference policy wrote in the preprocessor replaces what the pack kernel derived from the rollouts
+                if ref_column.numel() != batch.input_ids.numel():
+                    raise ValueError(f"ref_column has {ref_column.numel()} entries, the expanded batch {batch.input_ids.numel()} tokens")
+                batch.ref_logprobs = ref_column.unsqueeze(0)
+            if self.num_slices > 1:
+                batch = batch.make_slices(self.num_slices)[self.slice_index]
+            return batch
+
         if self.padding:  # sequence-parallel filler: the general planner knows how to append it
             none = torch.empty(0, device=dev)
             rag = RaggedRollouts(
@@ -361,7 +379,7 @@ class CompactBatch:
             )
             prep = PreparedRollouts(rollouts=rag, reward32=sc[0], advantage=sc[1], group_tokens=sc[2], num_labels=sc[3], overflow=sc[4],
                                     advantage64=none, group_tokens64=none)
-            return pack_prepared(prep, [range(m)], self.eos_token_id, sentinel_pad=[int(self.padding)], stager=stager)[0]
+            return finish(pack_prepared(prep, [range(m)], self.eos_token_id, sentinel_pad=[int(self.padding)], stager=stager)[0])
         out = _alloc_outputs(n, dev, packed=True)
         out.pop("__block__")
         if m and n:
@@ -372,8 +390,8 @@ class CompactBatch:
                     p(sc[3]), p(sc[4]), 0, int(self.eos_token_id), p(out["input_ids"]), p(out["labels"]), p(out["attention_mask"]), p(out["position_ids"]),
                     p(out["segment_ids"]), p(out["rewards"]), p(out["advantages"]), p(out["ref_logprobs"]), p(out["old_logprobs"]), p(out["group_tokens"]),
                     p(out["num_labels"]), p(out["overflow"]), _lib.current_stream_ptr(dev)))
-        return PipelineBatchEncoding(**{k: v.unsqueeze(0) for k, v in out.items()}, model_version=int(self.model_version), is_packed=True,
-                                     seq_boundaries=torch.from_numpy(seq_off.astype(np.int32)), padding=0)
+        return finish(PipelineBatchEncoding(**{k: v.unsqueeze(0) for k, v in out.items()}, model_version=int(self.model_version), is_packed=True,
+                                            seq_boundaries=torch.from_numpy(seq_off.astype(np.int32)), padding=0))
 
 
 def compact_micro_batch(host_chunks: Sequence[RaggedRollouts], seq_scalars: Sequence[np.ndarray], members: Sequence[tuple[int, int]],
