@@ -74,6 +74,7 @@ class PipelineSpec:
     learner: str = "streamed"          # "streamed" (StreamedLearnerStep) or "dropin" (LearnerStep + rl_step_fused_head)
     optimizer: str = "adamw"           # "adamw" | "sgd" (parity tests)
     param_dtype: str = "bf16"          # "bf16" (the reference's training dtype) | "fp32" (parity tests: tight parameter deltas)
+    kl_coef: float = 0.0               # > 0 (configs[4]: 0.001): KL-to-reference on - the preprocessor holds the frozen reference policy (the initial policy) and writes `ref_logprobs`
     wire: str = "full"                 # `training_data` records: "full" (the reference's expanded batch) | "compact" (ragged columns; K6 on the learner's GPU)
     mirror_jsonl: bool = False         # JSONL mirrors of `actor` and `training_data` (replay / parity tests; compact wire: `actor` only)
     retain_streams: bool = False       # keep consumed segments of the bulk topics (isolated-stage reruns read them again)
@@ -230,7 +231,7 @@ def rl_config_of(spec: PipelineSpec):
     """conf/finetune/grpo.yaml over base.yaml:100-114."""
     from .finetune.rl import RLConfig
 
-    return RLConfig(policy_loss="ppo", epsilon_low=0.02, epsilon_high=0.02, kl_coef=0.0, final_kl_coef=0.0, clamp_log_ratio_ref_new_value=5,
+    return RLConfig(policy_loss="ppo", epsilon_low=0.02, epsilon_high=0.02, kl_coef=spec.kl_coef, final_kl_coef=spec.kl_coef, clamp_log_ratio_ref_new_value=5,
                     temperature=1.0, divide_advantage_by_std=False, group_normalization=False, batch_size=spec.global_batch)
 
 
@@ -329,7 +330,14 @@ def preprocessor_stage(spec: PipelineSpec) -> None:
                              seq_length=spec.budget, attempts=spec.attempts, rl=rl_config_of(spec), eos_token_id=2, chunk_n_groups=spec.chunk_n_groups,
                              max_lag=spec.lag, samples_target=spec.steps * spec.global_batch,
                              ring_buffer_size=max(128, 2 * spec.global_batch), max_ready_samples_per_lead=max(64, spec.global_batch))
-    loop = PreprocessorLoop(cfg, dev, trainer_state=state, profile=True, wire=spec.wire)
+    ref_model = None
+    if spec.kl_coef > 0:
+        # the reference policy = the policy the run starts from, frozen, on the preprocessor's GPU: its log-probs replace the reference's
+        # HTTP round trips to a second inference server (preprocess.py:86-104, llm.py:606-648)
+        ref_model = build_policy(spec, dev, seed=spec.seed).eval()
+        for p in ref_model.parameters():
+            p.requires_grad_(False)
+    loop = PreprocessorLoop(cfg, dev, trainer_state=state, profile=True, wire=spec.wire, ref_model=ref_model)
     t0 = time.perf_counter()
     n = loop.run(idle_timeout=spec.stage_timeout_s)
     wall = time.perf_counter() - t0

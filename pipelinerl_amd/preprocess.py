@@ -476,20 +476,28 @@ def compact_sources(rollouts: RaggedRollouts, k5_out32: np.ndarray) -> dict:
                 has_ref=r.ref_logprobs is not None, seq_off=r.host_seq_off, lp_off=r.host_lp_off)
 
 
-def describe_compact(members: Sequence[tuple[dict, int]], model_version: int, eos_token_id: int, inline: bytearray, pieces: list) -> int:
-    """The PRLCMP01 record of the micro-batch whose sequences are `members` = (chunk sources, index in that chunk) in packing
+def describe_compact(members: Sequence[tuple[dict, int]], model_version: int, eos_token_id: int, inline: bytearray, pieces: list,
+                     padding: int = 0, slice_index: int = 0, num_slices: int = 1, ref_block: tuple[int, int] | None = None) -> int:
+    """(`padding`, `slice_index` / `num_slices`: the sequence-parallel form - the record names the filler the pack kernel appends and the
+    token slice its reader keeps.  `ref_block` = (byte offset, nbytes) of the micro-batch's `ref_logprobs` column inside the job's
+    device block: one PRL_PUB_FROM_BLOCK piece, the column a reference policy wrote in the preprocessor.)  The PRLCMP01 record of the micro-batch whose sequences are `members` = (chunk sources, index in that chunk) in packing
     order, as a recipe for the native publisher: appends `prl_pub_piece` rows (src, offset in the record, nbytes, kind, 0) to
     `pieces` - one PRL_PUB_FROM_HOST piece per sequence and per-token column, header and per-sequence arrays PRL_PUB_INLINE in
     `inline` - and returns the record size.  Byte for byte `batch_codec.encode_compact(finetune.data.compact_micro_batch(...))`."""
     from . import _lib, batch_codec
 
-    FROM_HOST, INLINE = _lib.PRL_PUB_FROM_HOST, _lib.PRL_PUB_INLINE
+    FROM_HOST, INLINE, FROM_BLOCK = _lib.PRL_PUB_FROM_HOST, _lib.PRL_PUB_INLINE, _lib.PRL_PUB_FROM_BLOCK
     spans = [(int(hc["seq_off"][i]), int(hc["seq_off"][i + 1]), int(hc["lp_off"][i]), int(hc["lp_off"][i + 1])) for hc, i in members]
     lens = [b - a for a, b, _, _ in spans]
     lp_lens = [lb - la for _, _, la, lb in spans]
     m = len(members)
     has_ref = any(hc["has_ref"] for hc, _ in members)
-    head, base, where, total = batch_codec.compact_layout(sum(lens), sum(lp_lens), m, has_ref, model_version, 0, eos_token_id)
+    head, base, where, total = batch_codec.compact_layout(sum(lens), sum(lp_lens), m, has_ref, model_version, padding, eos_token_id,
+                                                          slice_index, num_slices, (ref_block[1] // 4) if ref_block else 0)
+    if ref_block is not None:
+        if ref_block[1] != 4 * (sum(lens) + padding):
+            raise ValueError(f"ref column of {ref_block[1]} bytes for a micro-batch of {sum(lens)} + {padding} tokens")
+        pieces.append((ref_block[0], base + where["ref_column"][0], ref_block[1], FROM_BLOCK, 0))
     at = len(inline)
     inline += head
     pieces.append((at, 0, len(head), INLINE, 0))
@@ -562,18 +570,21 @@ class PreprocessorLoop:
         its sequences, gathered by the publisher straight from the decoded `actor` records on the host, + the five per-sequence
         scalars (K5's outputs: 16 bytes per SEQUENCE come back from the device); K6 then runs on the learner's GPU
         (`finetune.data.CompactBatch.to_batch`, called by `finetune_loop.run_data_loader`) and produces the identical batch.
-        Needs the shm backend, packing, seq_parallel = 1, and no stage that rewrites per-token data on this GPU (`ref_model`,
-        `oov_patcher`).
+        Needs the shm backend and packing.  Sequence parallelism: every rank of an SP group gets the whole record (with the filler
+        count) and keeps its `make_slices` slice after expansion (types.py:145-180).  A reference policy here (`ref_model`, KL on):
+        K6 and its forward run on THIS GPU as on the full wire, and of the packed block only the `ref_logprobs` column - 4 bytes per
+        token - comes back and rides in the record (`ref_column`).  `oov_patcher` rewrites token ids on the device, which the
+        host-gathered columns would not see: refused.
         `profile`: accumulate host wall time per phase in `self.prof` (seconds; `perf_counter` pairs, no device sync)."""
         from .streams import SingleStreamSpec, StreamRangeSpec
 
         if wire not in ("full", "compact"):
             raise ValueError(f"wire must be 'full' or 'compact', not {wire!r}")
         if wire == "compact":
-            if not cfg.seq_packing or cfg.seq_parallel != 1:
-                raise ValueError("the compact wire carries packed micro-batches of one sequence-parallel rank (seq_packing=True, seq_parallel=1)")
-            if ref_model is not None or oov_patcher is not None:
-                raise ValueError("the compact wire gathers per-token data from the host records: ref_model / oov_patcher rewrite it on the device - use wire='full'")
+            if not cfg.seq_packing:
+                raise ValueError("the compact wire carries packed micro-batches (seq_packing=True)")
+            if oov_patcher is not None:
+                raise ValueError("the compact wire gathers token ids from the host records: oov_patcher rewrites them on the device - use wire='full'")
             if torch.device(device).type != "cuda":
                 raise RuntimeError("the preprocessor's kernels need a HIP device; there is no CPU fallback")
         self.wire = wire
@@ -735,7 +746,31 @@ class PreprocessorLoop:
         packed: Any = None
         merged = base = None
         if self.wire == "compact":
-            self._submit_compact(mbs)
+            ref_cols = None
+            if self.ref_model is not None and real:
+                # KL on: the reference policy needs the packed micro-batches on this GPU (K6 + its forward, as on the full wire); only
+                # the column it writes goes back to the host
+                from .finetune.rl import annotate_ref_logprobs
+
+                used = sorted({s.chunk for mb in real for s in mb.samples})
+                merged = concat_prepared([self.chunks[c] for c in used])
+                base, acc = {}, 0
+                for c in used:
+                    base[c] = acc
+                    acc += self.chunks[c].rollouts.n_seqs
+                pads = [(-sum(s.length for s in mb.samples)) % sp for mb in real] if sp > 1 else None
+                with self._kernels("K6"):
+                    packed = pack_prepared(merged, [[base[s.chunk] + s.index for s in mb.samples] for mb in real], self.cfg.eos_token_id,
+                                           sentinel_pad=pads, stager=self.stager)
+                t = self._tick("k6_plan_launch", t)
+                for k in range(len(packed)):
+                    b = packed[k]
+                    annotate_ref_logprobs(self.ref_model, b, self.cfg.rl.temperature)
+                    t0_, t1_ = int(packed.token_off[k]), int(packed.token_off[k + 1])
+                    packed.flat["ref_logprobs"][t0_:t1_].copy_(b.ref_logprobs.reshape(-1))
+                ref_cols = (packed.flat["ref_logprobs"], [int(x) for x in packed.token_off], packed)
+                t = self._tick("ref_logprobs", t)
+            self._submit_compact(mbs, ref_cols)
             t = self._tick("publish_submit", t)
             self._prune_chunks()
             self._tick("schedule", t)
@@ -869,9 +904,12 @@ class PreprocessorLoop:
             hc.update(compact_sources(hc["rollouts"], k5))
         return hc
 
-    def _submit_compact(self, mbs: list) -> None:
+    def _submit_compact(self, mbs: list, ref_cols: tuple | None = None) -> None:
         """One drain on the compact wire: per micro-batch a PRLCMP01 record whose per-token columns the publisher copies from
-        the chunks' host arrays (PRL_PUB_FROM_HOST pieces, one per sequence and column), header and per-sequence arrays inline."""
+        the chunks' host arrays (PRL_PUB_FROM_HOST pieces, one per sequence and column), header and per-sequence arrays inline.
+        Sequence parallelism: the record goes to every partition of the lead trainer's SP group, each copy naming its slice.
+        `ref_cols` = (flat fp32 device column, token offsets of the drain's real micro-batches, owner): the job's device block; every
+        record takes its micro-batch's range of it as `ref_column`."""
         import ctypes
 
         from . import _lib, batch_codec
@@ -880,26 +918,50 @@ class PreprocessorLoop:
         if not mbs:
             return
         lib = _lib.load()
+        sp = self.cfg.seq_parallel
         inline = bytearray()
         recs, pieces, keep = [], [], []
+        k = 0
         for mb in mbs:
-            first = len(pieces)
             if mb.sentinel:
                 s_batch = create_sentinel_batch(None, tokenizer=type("T", (), {"eos_token_id": self.cfg.eos_token_id})(), model_version=self.max_model_version)
-                nbytes, ps = batch_codec.describe_batch(s_batch, 0, 0, inline)
-                pieces += [(src, off, nb, kind, 0) for kind, src, off, nb in ps]
-            else:
-                members = [(self._chunk_sources(s.chunk), s.index) for s in mb.samples]
-                nbytes = describe_compact(members, min(s.model_version for s in mb.samples), self.cfg.eos_token_id, inline, pieces)
-                keep += [hc["rollouts"] for hc, _ in members]
-            recs.append((self._pub_logs[mb.trainer_id], nbytes, first, len(pieces) - first))
+                for off, piece in enumerate(s_batch.make_slices(sp) if sp > 1 else [s_batch]):
+                    first = len(pieces)
+                    nbytes, ps = batch_codec.describe_batch(piece, 0, 0, inline)
+                    pieces += [(src, o, nb, kind, 0) for kind, src, o, nb in ps]
+                    recs.append((self._pub_logs[mb.trainer_id + off], nbytes, first, len(pieces) - first))
+                continue
+            members = [(self._chunk_sources(s.chunk), s.index) for s in mb.samples]
+            keep += [hc["rollouts"] for hc, _ in members]
+            n = sum(s.length for s in mb.samples)
+            pad = (-n) % sp if sp > 1 else 0
+            ref_block = None
+            if ref_cols is not None:
+                t0_, t1_ = ref_cols[1][k], ref_cols[1][k + 1]
+                assert t1_ - t0_ == n + pad, "the packed micro-batch and its compact record disagree on the token count"
+                ref_block = (4 * t0_, 4 * (t1_ - t0_))
+            k += 1
+            version = min(s.model_version for s in mb.samples)
+            for off in range(sp):
+                first = len(pieces)
+                nbytes = describe_compact(members, version, self.cfg.eos_token_id, inline, pieces, padding=pad, slice_index=off, num_slices=sp, ref_block=ref_block)
+                recs.append((self._pub_logs[mb.trainer_id + off], nbytes, first, len(pieces) - first))
         rec_arr = np.array(recs, dtype=_PUB_RECORD_DT)
         piece_arr = np.array(pieces, dtype=_PUB_PIECE_DT)
         inline_c = (ctypes.c_char * len(inline)).from_buffer(inline) if inline else None
+        block_ptr, block_nbytes, ready = None, 0, None
+        if ref_cols is not None:
+            col = ref_cols[0]
+            block_ptr, block_nbytes = col.data_ptr(), col.numel() * col.element_size()
+            with torch.cuda.device(self.device):
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(self.device))  # K6 and the reference policy's forward of this drain are complete once it has fired
+            keep.append(ref_cols)
         ticket = ctypes.c_uint64()
-        _lib.check(lib.prl_publisher_submit(self._pub, None, 0, None, rec_arr.ctypes.data, len(recs), piece_arr.ctypes.data, len(pieces),
+        _lib.check(lib.prl_publisher_submit(self._pub, block_ptr, block_nbytes, ready.cuda_event if ready is not None else None,
+                                            rec_arr.ctypes.data, len(recs), piece_arr.ctypes.data, len(pieces),
                                             inline_c, len(inline), ctypes.byref(ticket)))
-        self._pub_inflight.append((ticket.value, keep, None))  # the host arrays stay alive until the publisher has copied them
+        self._pub_inflight.append((ticket.value, keep, ready))  # host arrays and the device column stay alive until the publisher has copied them
         done = ctypes.c_uint64()
         _lib.check(lib.prl_publisher_completed(self._pub, ctypes.byref(done)))
         while self._pub_inflight and self._pub_inflight[0][0] <= done.value:

@@ -119,6 +119,49 @@ def test_publisher_recipe_is_the_generic_record_byte_for_byte():
         Log.unlink_name(name)
 
 
+def test_sequence_parallel_and_reference_column_records():
+    """The two extensions of the record: `slice` / `slices` + `padding` (every rank of an SP group gets the record and keeps its slice)
+    and `ref_column` (the expanded batch's ref_logprobs when a reference policy ran in the preprocessor).  Round trip, header text =
+    the generic encoder's, and records WITHOUT them are byte-identical to what they were (no new scalar, no new tensor)."""
+    rng = np.random.default_rng(4)
+    r, k5 = _chunk(rng, 4, False)
+    src = compact_sources(r, k5)
+    members = [(0, 2), (0, 0), (0, 3)]
+    plain = compact_micro_batch([r], [src["scalars"]], members, eos_token_id=5)
+    n = plain.n_tokens
+    pad = (-n) % 4
+    ref = rng.normal(size=n + pad).astype(np.float32)
+    for k in range(4):
+        cb = compact_micro_batch([r], [src["scalars"]], members, eos_token_id=5, padding=pad)
+        cb.slice_index, cb.num_slices, cb.ref_column = k, 4, ref
+        rec = batch_codec.encode_compact(cb)
+        head, base, where, total = batch_codec.compact_layout(n, len(cb.logprobs), 3, False, cb.model_version, pad, 5, k, 4, n + pad)
+        assert len(rec) == total and bytes(rec[:len(head)]) == head and where["ref_column"][1] == 4 * (n + pad)
+        back = batch_codec.decode(rec)
+        assert (back.slice_index, back.num_slices, back.padding) == (k, 4, pad)
+        np.testing.assert_array_equal(back.ref_column, ref)
+        np.testing.assert_array_equal(back.tokens, plain.tokens)
+        facts = back.host_facts()
+        assert facts["tokens"] == (n + pad) // 4
+        # the slice's labelled rows are those of the packed labels cut to the slice (the slice's last row has no successor inside it)
+        lab = plain.labels.copy()
+        lab[plain.seq_off[1:-1]] = -100
+        lab = np.concatenate([lab, np.full(pad, -100, dtype=lab.dtype)])[k * (n + pad) // 4: (k + 1) * (n + pad) // 4]
+        assert facts["labelled_rows"].tolist() == np.flatnonzero(lab[1:] != -100).tolist()
+    # the recipe of the preprocessor's publisher writes the same header and puts the column where the layout says
+    inline, pieces = bytearray(), []
+    nbytes = describe_compact([(src, i) for _, i in members], plain.model_version, 5, inline, pieces, padding=pad, slice_index=1, num_slices=4, ref_block=(128, 4 * (n + pad)))
+    head, base, where, total = batch_codec.compact_layout(n, len(plain.logprobs), 3, False, plain.model_version, pad, 5, 1, 4, n + pad)
+    assert nbytes == total and bytes(inline[:len(head)]) == head
+    blocks = [p for p in pieces if p[3] == _lib.PRL_PUB_FROM_BLOCK]
+    assert blocks == [(128, base + where["ref_column"][0], 4 * (n + pad), _lib.PRL_PUB_FROM_BLOCK, 0)]
+    with pytest.raises(ValueError, match="ref column"):
+        describe_compact([(src, i) for _, i in members], 0, 5, bytearray(), [], padding=pad, ref_block=(0, 4 * n + 4 * pad + 4))
+    # unchanged records for the common case
+    old_head = batch_codec.compact_layout(n, len(plain.logprobs), 3, False, plain.model_version, 0, 5)[0]
+    assert b"slice" not in old_head and b"ref_column" not in old_head and bytes(batch_codec.encode_compact(plain)[:len(old_head)]) == old_head
+
+
 def test_compact_wire_refusals():
     """The compact wire is a choice with preconditions, not a fallback: wrong combinations fail at construction; expansion
     without a HIP device fails loudly."""
@@ -132,12 +175,14 @@ def test_compact_wire_refusals():
 
     with pytest.raises(ValueError, match="wire must be"):
         PreprocessorLoop(cfg(), "cpu", wire="tiny")
-    with pytest.raises(ValueError, match="seq_parallel"):
-        PreprocessorLoop(cfg(seq_parallel=2), "cpu", wire="compact")
     with pytest.raises(ValueError, match="seq_packing"):
         PreprocessorLoop(cfg(seq_packing=False), "cpu", wire="compact")
-    with pytest.raises(ValueError, match="ref_model"):
-        PreprocessorLoop(cfg(), "cpu", wire="compact", ref_model=object())
+    with pytest.raises(ValueError, match="oov_patcher"):
+        PreprocessorLoop(cfg(), "cpu", wire="compact", oov_patcher=object())
+    # sequence parallelism and a reference policy are served by the compact wire (tests/test_gpu_compact_wire.py); it still needs a device
+    for kw in (dict(), dict(seq_parallel=2, num_trainers=2)):
+        with pytest.raises(RuntimeError, match="HIP device"):
+            PreprocessorLoop(cfg(**kw), "cpu", wire="compact", ref_model=object() if kw else None)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         PreprocessorLoop(cfg(), "cpu", wire="compact")
     cb = CompactBatch(tokens=np.zeros(2, np.int32), labels=np.zeros(2, np.int32), logprobs=np.zeros(1, np.float32), ref_logprobs=None,

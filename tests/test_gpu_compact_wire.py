@@ -61,8 +61,27 @@ def test_expansion_on_the_consumer_equals_the_preprocessors_pack(libprl, cuda_de
         assert facts["tokens"] == on_host.model_extra["tokens"] and torch.equal(facts["labelled_rows"], on_host.model_extra["labelled_rows"])
 
 
-@pytest.mark.parametrize("trainers", [1, 2])
-def test_compact_wire_delivers_the_full_wires_batches(libprl, cuda_device, tmp_path, trainers):
+class _RefPolicy(torch.nn.Module):
+    """A frozen reference policy that only exposes `.logits` (the K1 path of `annotate_ref_logprobs`)."""
+
+    def __init__(self, vocab: int, dim: int = 32):
+        super().__init__()
+        torch.manual_seed(11)
+        self.emb = torch.nn.Embedding(vocab, dim)
+        self.out = torch.nn.Linear(dim, vocab)
+
+    def forward(self, input_ids=None, **kw):
+        import types
+
+        return types.SimpleNamespace(logits=self.out(torch.tanh(self.emb(input_ids))).float())
+
+
+@pytest.mark.parametrize("trainers,sp,kl", [(1, 1, False), (2, 1, False), (2, 2, False), (1, 1, True), (2, 2, True), (4, 2, True)],
+                         ids=["1_trainer", "2_trainers", "seq_parallel_2", "kl", "seq_parallel_2+kl", "2_leads_x_seq_parallel_2+kl"])
+def test_compact_wire_delivers_the_full_wires_batches(libprl, cuda_device, tmp_path, trainers, sp, kl):
+    """Every combination the full wire serves: data-parallel partitions, sequence-parallel slices (types.py:145-180: every rank of the
+    group expands the record and keeps its slice, filler included) and a reference policy in the preprocessor (preprocess.py:86-104's
+    role: the `ref_logprobs` column comes from its forward, 4 bytes per token cross the bus and ride in the record)."""
     from pipelinerl_amd import streams
     from pipelinerl_amd.finetune.rl import RLConfig
     from pipelinerl_amd.synthetic import make_entries
@@ -75,7 +94,8 @@ def test_compact_wire_delivers_the_full_wires_batches(libprl, cuda_device, tmp_p
         for i, e in enumerate(raw):
             e.setdefault("metadata", {})["model_version"] = i // 8  # versions move inside the stream
         cfg_kw = dict(num_trainers=trainers, train_batch_size=2, gradient_accumulation_passes=4, seq_length=256, attempts=attempts,
-                      rl=RLConfig(), eos_token_id=2, chunk_n_groups=2)
+                      rl=RLConfig(kl_coef=0.05 if kl else 0.0), eos_token_id=2, chunk_n_groups=2, seq_parallel=sp)
+        ref_model = _RefPolicy(300).to(cuda_device).eval() if kl else None
         from pipelinerl_amd.ring import Log
         from pipelinerl_amd.streams import ring_name
 
@@ -83,8 +103,8 @@ def test_compact_wire_delivers_the_full_wires_batches(libprl, cuda_device, tmp_p
             return [Log(ring_name(streams.SingleStreamSpec(exp_path=exp, topic="training_data", partition=p)), reader=True).stats()["records"] for p in range(trainers)]
 
         # publish everything first, then read exactly as many records as each partition's log holds
-        full_pub, full, full_bytes, _ = _run_loop_then_read(streams, tmp_path, cuda_device, "full", n_groups, attempts, raw, cfg_kw, counts)
-        cmp_pub, cmp, cmp_bytes, loop = _run_loop_then_read(streams, tmp_path, cuda_device, "compact", n_groups, attempts, raw, cfg_kw, counts)
+        full_pub, full, full_bytes, _ = _run_loop_then_read(streams, tmp_path, cuda_device, "full", n_groups, attempts, raw, cfg_kw, counts, ref_model)
+        cmp_pub, cmp, cmp_bytes, loop = _run_loop_then_read(streams, tmp_path, cuda_device, "compact", n_groups, attempts, raw, cfg_kw, counts, ref_model)
         assert full_pub == cmp_pub == n_groups * attempts
         n_real = 0
         for part in range(trainers):
@@ -101,13 +121,26 @@ def test_compact_wire_delivers_the_full_wires_batches(libprl, cuda_device, tmp_p
                     assert a.model_extra["tokens"] == b.model_extra["tokens"]
                     assert torch.equal(a.model_extra["labelled_rows"].cpu(), b.model_extra["labelled_rows"].cpu())
         assert n_real >= 4
-        assert cmp_bytes * 3 < full_bytes, (cmp_bytes, full_bytes)  # 12-16 bytes per token + headers against 68
-        assert "k6_plan_launch" not in loop.prof and loop.prof.get("publish_submit", 0) > 0  # the preprocessor never packed
+        if kl:
+            assert any(bool((b.ref_logprobs != b.old_logprobs).any()) for part in cmp for b in part if not b.sentinel), "the reference policy's column arrived"
+        if sp > 1:  # the slices of one micro-batch sit side by side in the partitions of its SP group and add up to the padded length
+            for lead in range(0, trainers, sp):
+                for group in zip(*[cmp[lead + k] for k in range(sp)]):
+                    assert len({b.input_ids.shape[1] for b in group}) == 1 and len({b.sentinel for b in group}) == 1
+                    assert all(torch.equal(group[0].seq_boundaries, b.seq_boundaries) for b in group)
+        # bytes in the logs: 12-16 per token (+ 4 with the reference column) per COPY of the record against 68 per token of the expanded batch
+        # spread over the slices - an SP group of 2 holds each compact record twice
+        assert cmp_bytes * (3 if sp == 1 and not kl else 1.5) < full_bytes * (sp if sp > 1 else 1), (cmp_bytes, full_bytes)
+        if kl:
+            assert loop.prof.get("ref_logprobs", 0) > 0 and loop.prof.get("k6_plan_launch", 0) > 0  # K6 + the policy's forward ran here; only the column left the GPU
+        else:
+            assert "k6_plan_launch" not in loop.prof  # the preprocessor never packed
+        assert loop.prof.get("publish_submit", 0) > 0
     finally:
         streams.reset_streams_backend()
 
 
-def _run_loop_then_read(streams, tmp_path, cuda_device, wire, n_groups, attempts, raw, cfg_kw, counts):
+def _run_loop_then_read(streams, tmp_path, cuda_device, wire, n_groups, attempts, raw, cfg_kw, counts, ref_model=None):
     from pipelinerl_amd.preprocess import PreprocessorConfig, PreprocessorLoop
     from pipelinerl_amd.ragged import RaggedRollouts
 
@@ -116,7 +149,7 @@ def _run_loop_then_read(streams, tmp_path, cuda_device, wire, n_groups, attempts
     with streams.write_to_streams(streams.SingleStreamSpec(exp_path=exp, topic="actor")) as w:
         for g in range(n_groups):
             w.write(RaggedRollouts.from_entries(raw[g * attempts:(g + 1) * attempts]))
-    loop = PreprocessorLoop(PreprocessorConfig(exp_path=exp, **cfg_kw), cuda_device, wire=wire, profile=True)
+    loop = PreprocessorLoop(PreprocessorConfig(exp_path=exp, **cfg_kw), cuda_device, wire=wire, profile=True, ref_model=ref_model)
     published = loop.run(max_published_samples=n_groups * attempts, idle_timeout=2.0)
     n = counts(exp)
     from pipelinerl_amd.finetune_loop import run_data_loader

@@ -195,3 +195,36 @@ def test_two_learners_two_engines_on_one_gpu_match_one_learner(libprl, cuda_devi
         assert bool(((d2 - 0.5 * d1).abs() <= 1.5 * ulp + 1e-3 * float(d1.abs().max())).all()), f"{n}: update of the 2-rank run = update of the 1-rank run / 2"
     bad = {n: e for n, e in worst.items() if e > 1e-4}
     assert not bad, "averaged gradients of step 0 vs half the single-learner gradients, relative 2-norm error: " + json.dumps(bad, indent=1)
+
+
+def test_pipeline_with_reference_policy_compact_wire_equals_full_wire(libprl, cuda_device, tmp_path):
+    """BASELINE configs[4]'s loss configuration (KL-to-reference on, kl_coef 0.001) through the pipeline on BOTH wires: the preprocessor holds the
+    frozen reference policy and writes `ref_logprobs`; on the compact wire that column is the only per-token data that leaves its GPU (4 B/token,
+    `ref_column`).  Step 0's micro-batches are identical on the two wires - every column bit for bit, the reference column different from the
+    rollout log-probs - and so are the loss and the KL statistics."""
+    from pipelinerl_amd.pipeline_run import PipelineSpec, run_pipeline
+
+    bs, seq, steps = 16, 96, 2
+    got = {}
+    for wire in ("full", "compact"):
+        exp, cap = tmp_path / wire / "exp", tmp_path / wire / "cap"
+        spec = PipelineSpec(exp_path=str(exp), model="tiny", global_batch=bs, seq_length=seq, attempts=4, steps=steps, optimizer="sgd", lr=0.05, param_dtype="fp32",
+                            capture_step0=str(cap), n_problems=5, concurrent_groups=2, stage_timeout_s=600.0, learner="streamed", wire=wire, kl_coef=0.001)
+        res = run_pipeline(spec)
+        assert "error" not in res, json.dumps(res.get("error"), indent=1)[:6000]
+        assert res["summary"]["optimizer_steps"] == steps and res["summary"]["engine_weights_equal_trainer_at_last_version"] is True
+        assert res["stages"]["preprocessor"]["host_phase_s"].get("ref_logprobs", 0) > 0, "the reference policy ran in the preprocessor"
+        got[wire] = (torch.load(cap / "step0_batches.pt"), json.loads((cap / "step0_metrics.json").read_text()))
+    (fb, fm), (cb, cm) = got["full"], got["compact"]
+    assert len(fb) == len(cb) > 0
+    for a, b in zip(fb, cb):
+        assert a.keys() == b.keys()
+        for k in a:
+            if torch.is_tensor(a[k]):
+                assert torch.equal(a[k], b[k]), k
+            else:
+                assert a[k] == b[k], k
+        if not a["sentinel"]:
+            lab = a["labels"] != -100
+            assert bool((a["ref_logprobs"][lab] != a["old_logprobs"][lab]).any()) and bool((a["ref_logprobs"][~lab] == 0).all())
+    assert fm["rl/loss"] == cm["rl/loss"] and fm["rl/kl"] == cm["rl/kl"] and abs(fm["rl/kl"]) > 0
