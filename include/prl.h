@@ -26,6 +26,8 @@
  *                                 pipelinerl/finetune/rl/utils.py:26-92
  *   prl_fused_logits_loss         the two above in one pass (no reference analogue)
  *   prl_segment_sums              pipelinerl/finetune/rl/utils.py:106-208
+ *   prl_gspo_segment_sums / prl_gspo_expand
+ *                                 pipelinerl/finetune/rl/__init__.py:310-352 (the per-token ends of the sequence-level term)
  *   prl_value_head_fwd_bwd        pipelinerl/finetune/rl/__init__.py:265-272, 367-381, 441-448
  *                                 (models of pipelinerl/finetune/value_model.py)
  *   prl_seq_scan / prl_group_advantages
@@ -55,7 +57,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 11
+#define PRL_ABI_VERSION 12
 
 #define PRL_OK 0
 #define PRL_EINVAL (-22)   /* bad argument                                  */
@@ -275,6 +277,25 @@ int prl_segment_sums(int64_t cols, int32_t n_segments, const int64_t* segment_id
                      const int64_t* labels, const float* a, const float* b,
                      double* a_sum, double* b_sum, double* count,
                      prl_stream_t stream);
+
+/*
+ * GSPO (sequence-level policy term, rl/__init__.py:310-352 + rl/utils.py:106-208) on one packed micro-batch or one
+ * sequence-parallel slice of it, the two per-token ends of it:
+ *   prl_gspo_segment_sums  the four per-segment masked sums in ONE pass, sums = float64 [4, n_segments] in the order
+ *       sum(new_logprobs - old_logprobs) [fp32 difference], sum(advantages), token count, sum(token weight) - the weight as in
+ *       prl_grpo_loss_fwd_bwd (cfg->group_normalization, token_weight, overlong_filtering).  Columns float32 [1, cols],
+ *       token-aligned; segment_ids / labels as for prl_segment_sums (non-decreasing ids; unsorted or out-of-range ids -> NaN).
+ *       Fixed-order reduction, bitwise reproducible.
+ *   prl_gspo_expand        per-segment float32 [n_segments] -> per-token float32 [1, cols]: token_grad[u] = coef[segment_ids[u]]
+ *       and token_indicator[u] = indicator[segment_ids[u] - segment_ids[0]] (the j-th sequence starting or continuing in the
+ *       slice takes the value of global segment j, rl/__init__.py:347-350), indices clamped to [0, n_segments).
+ */
+int prl_gspo_segment_sums(const prl_loss_config* cfg, int64_t cols, int32_t n_segments, const int64_t* segment_ids,
+                          const int64_t* labels, const float* new_logprobs, const float* old_logprobs,
+                          const float* advantages, const float* group_tokens, const float* overflow,
+                          double* sums, prl_stream_t stream);
+int prl_gspo_expand(int64_t cols, int32_t n_segments, const int64_t* segment_ids, const float* coef,
+                    const float* indicator, float* token_grad, float* token_indicator, prl_stream_t stream);
 
 /*
  * Value-head (actor-critic) branch of rl_step (rl/__init__.py:162, 265-272, 367-381, 441-448) for models

@@ -684,7 +684,125 @@ __global__ __launch_bounds__(kBlock) void segment_order_check_kernel(int64_t col
   }
 }
 
+// GSPO (rl/__init__.py:310-352): the four per-segment sums of one micro-batch in ONE pass - log(new/old), advantages, token
+// count, token weight - with the per-token columns computed in the loop's prologue (new - old; 1 / group_tokens or the batch
+// weight, x (1 - overflow)): what `gspo_segment_terms` used to materialise as [1, T] tensors with eager launches before two
+// calls of segment_sums_kernel.  Same run search, same fixed-order fp64 reduction.
+__global__ __launch_bounds__(kBlock) void gspo_segment_sums_kernel(prl_loss_config cfg, int64_t cols, int32_t n_segments,
+                                                                   const int64_t* __restrict__ seg, const int64_t* __restrict__ labels,
+                                                                   const float* __restrict__ new_lp, const float* __restrict__ old_lp,
+                                                                   const float* __restrict__ adv, const float* __restrict__ group_tokens,
+                                                                   const float* __restrict__ overflow, double* sums /* [4, n_segments] */) {
+  __shared__ double red[4][kBlock / prl::kWave];
+  const int64_t s = blockIdx.x;
+  auto bound = [&](int64_t key) {
+    int64_t lo = 1, hi = cols;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (seg[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const int64_t u0 = bound(s), u1 = bound(s + 1);
+  double c = 0.0, sl = 0.0, sa = 0.0, sw = 0.0;
+  for (int64_t u = u0 + threadIdx.x; u < u1; u += kBlock) {
+    if (labels[u] == -100) continue;
+    float w = cfg.group_normalization ? (1.0f / group_tokens[u]) : cfg.token_weight;  // (:245-255), as prl_token_eval
+    if (cfg.overlong_filtering) w = w * (1.0f - overflow[u]);
+    c += 1.0;
+    sl += (double)(new_lp[u] - old_lp[u]);  // fp32 difference, like the reference's log_ratio_new_old (:257)
+    sa += (double)adv[u];
+    sw += (double)w;
+  }
+  c = prl::wave_sum(c);
+  sl = prl::wave_sum(sl);
+  sa = prl::wave_sum(sa);
+  sw = prl::wave_sum(sw);
+  const int lane = threadIdx.x & (prl::kWave - 1), wid = threadIdx.x / prl::kWave;
+  if (lane == 0) {
+    red[0][wid] = sl;
+    red[1][wid] = sa;
+    red[2][wid] = c;
+    red[3][wid] = sw;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0.0;
+    for (int w = 0; w < kBlock / prl::kWave; ++w) t += red[threadIdx.x][w];
+    sums[(int64_t)threadIdx.x * n_segments + s] = t;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gspo_order_check_kernel(int64_t cols, int32_t n_segments, const int64_t* __restrict__ seg,
+                                                                  const int64_t* __restrict__ labels, double* sums) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int64_t u = 1 + threadIdx.x; u < cols; u += kBlock) {
+    if (u + 1 < cols && seg[u] > seg[u + 1]) mine = 1;
+    if (labels[u] != -100 && (seg[u] < 0 || seg[u] >= n_segments)) mine = 1;
+  }
+  if (mine) atomicOr(&bad, 1);
+  __syncthreads();
+  if (bad) {
+    const double nan = __builtin_nan("");
+    for (int i = threadIdx.x; i < 4 * n_segments; i += kBlock) sums[i] = nan;
+  }
+}
+
+// The way back: every token takes its segment's gradient coefficient, and the clip indicator of the j-th sequence starting or
+// continuing in this (slice of a) batch (rl/__init__.py:347-350: zip(local segments, per-segment values)).
+__global__ __launch_bounds__(kBlock) void gspo_expand_kernel(int64_t cols, int32_t n_segments, const int64_t* __restrict__ seg,
+                                                             const float* __restrict__ coef, const float* __restrict__ indicator,
+                                                             float* __restrict__ token_grad, float* __restrict__ token_indicator) {
+  const int64_t first = seg[0];
+  const int64_t top = n_segments > 0 ? n_segments - 1 : 0;
+  for (int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x; u < cols; u += (int64_t)gridDim.x * kBlock) {
+    int64_t g = seg[u];
+    g = g < 0 ? 0 : (g > top ? top : g);
+    int64_t l = seg[u] - first;
+    l = l < 0 ? 0 : (l > top ? top : l);
+    token_grad[u] = coef[g];
+    token_indicator[u] = indicator[l];
+  }
+}
+
 }  // namespace
+
+extern "C" int prl_gspo_segment_sums(const prl_loss_config* cfg, int64_t cols, int32_t n_segments, const int64_t* segment_ids,
+                                     const int64_t* labels, const float* new_logprobs, const float* old_logprobs,
+                                     const float* advantages, const float* group_tokens, const float* overflow,
+                                     double* sums, prl_stream_t stream) {
+  PRL_CHECK_ARG(cfg != nullptr, "null config");
+  PRL_CHECK_ARG(cols >= 0 && n_segments >= 0, "negative shape");
+  PRL_CHECK_ARG(segment_ids && labels && new_logprobs && old_logprobs && advantages && group_tokens && overflow && sums, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_segments == 0) return PRL_OK;
+  if (cols <= 1) {
+    PRL_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 4 * n_segments, s));
+    return PRL_OK;
+  }
+  hipLaunchKernelGGL(gspo_segment_sums_kernel, dim3(n_segments), dim3(kBlock), 0, s, *cfg, cols, n_segments, segment_ids, labels,
+                     new_logprobs, old_logprobs, advantages, group_tokens, overflow, sums);
+  PRL_LAUNCH_CHECK("gspo_segment_sums_kernel");
+  hipLaunchKernelGGL(gspo_order_check_kernel, dim3(1), dim3(kBlock), 0, s, cols, n_segments, segment_ids, labels, sums);
+  PRL_LAUNCH_CHECK("gspo_order_check_kernel");
+  return PRL_OK;
+}
+
+extern "C" int prl_gspo_expand(int64_t cols, int32_t n_segments, const int64_t* segment_ids, const float* coef,
+                               const float* indicator, float* token_grad, float* token_indicator, prl_stream_t stream) {
+  PRL_CHECK_ARG(cols >= 0 && n_segments >= 1, "bad shape");
+  PRL_CHECK_ARG(segment_ids && coef && indicator && token_grad && token_indicator, "null pointer");
+  if (cols == 0) return PRL_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t blocks = (cols + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(gspo_expand_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(kBlock), 0, s, cols, n_segments, segment_ids,
+                     coef, indicator, token_grad, token_indicator);
+  PRL_LAUNCH_CHECK("gspo_expand_kernel");
+  return PRL_OK;
+}
 
 extern "C" int prl_segment_sums(int64_t cols, int32_t n_segments, const int64_t* segment_ids,
                                 const int64_t* labels, const float* a, const float* b,

@@ -265,19 +265,21 @@ def gspo_segment_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, new_log
             top = _group_all_reduce(top, seq_parallel_group, dist.ReduceOp.MAX)
         n_seg = int(top.item()) + 1
     f32 = torch.float32
-    lrno = new_logprobs - batch.old_logprobs
-    if cfg.group_normalization:
-        w = 1.0 / batch.group_tokens
-    else:
-        w = torch.full_like(batch.group_tokens, cfg.token_weight)
-    if cfg.overlong_filtering:
-        w = w * (1 - batch.overflow)
-    lrn_sum, adv_sum, cnt = segment_sums(seg_ids, batch.labels, lrno, batch.advantages, n_seg)
-    w_sum, _, _ = segment_sums(seg_ids, batch.labels, w, torch.zeros_like(w), n_seg)
+    # the four per-segment sums in ONE launch: new - old and the token weight are formed in the kernel's loop, not as [1, T] tensors
+    lib = _lib.load()
+    dev = new_logprobs.device
+    cont = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
+    sums = torch.empty((4, max(n_seg, 0)), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.prl_gspo_segment_sums(ctypes.byref(cfg), new_logprobs.shape[-1], n_seg, _lib.ptr(cont(seg_ids)), _lib.ptr(cont(batch.labels)),
+                                             _lib.ptr(cont(new_logprobs)), _lib.ptr(cont(batch.old_logprobs)), _lib.ptr(cont(batch.advantages)),
+                                             _lib.ptr(cont(batch.group_tokens)), _lib.ptr(cont(batch.overflow)), _lib.ptr(sums),
+                                             _lib.current_stream_ptr(dev)))
     grad_scale = 1.0
     if sp:
-        lrn_sum, adv_sum, cnt, w_sum = _group_all_reduce(torch.stack([lrn_sum, adv_sum, cnt, w_sum]), seq_parallel_group, dist.ReduceOp.SUM)
+        sums = _group_all_reduce(sums, seq_parallel_group, dist.ReduceOp.SUM)
         grad_scale = float(dist.get_world_size(seq_parallel_group))
+    lrn_sum, adv_sum, cnt, w_sum = sums[0], sums[1], sums[2], sums[3]
     cnt32 = cnt.to(f32)
     den = cnt32.clamp(min=1e-6)
     ratio = torch.exp(lrn_sum.to(f32) / den)
@@ -298,14 +300,18 @@ def gspo_segment_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, new_log
     coef = -(w_sum * valid.to(f32)) * dmin * ratio / den * grad_scale
     if batch.sentinel:
         coef = torch.zeros_like(coef)
-    idx = seg_ids.reshape(-1).clamp(0, max(n_seg - 1, 0))
-    ext_g = coef[idx].reshape(new_logprobs.shape).contiguous()
-    # The reference expands the clip indicator with zip(local segments, per-segment values)
-    # (rl/__init__.py:347-350): the j-th sequence STARTING OR CONTINUING in this slice takes the
-    # value of global segment j.  Identical to indexing by segment id when the slice starts at 0.
-    first = seg_ids.reshape(-1)[:1] if seg_ids.numel() else seg_ids.reshape(-1)
-    local_idx = (seg_ids.reshape(-1) - first).clamp(0, max(n_seg - 1, 0)) if seg_ids.numel() else idx
-    ext_c = indicator.to(f32)[local_idx].reshape(new_logprobs.shape).contiguous()
+    # back to the tokens in one launch: the segment's coefficient, and the clip indicator of the j-th sequence STARTING OR CONTINUING in
+    # this slice (the reference zips local segments with per-segment values, rl/__init__.py:347-350; identical to indexing by segment
+    # id when the slice starts at segment 0)
+    ext_g = torch.empty(new_logprobs.shape, dtype=f32, device=dev)
+    ext_c = torch.empty_like(ext_g)
+    if n_seg > 0 and ext_g.numel():
+        with torch.cuda.device(dev):
+            _lib.check(lib.prl_gspo_expand(ext_g.shape[-1], n_seg, _lib.ptr(cont(seg_ids)), _lib.ptr(coef.to(f32).contiguous()),
+                                           _lib.ptr(indicator.to(f32).contiguous()), _lib.ptr(ext_g), _lib.ptr(ext_c), _lib.current_stream_ptr(dev)))
+    else:
+        ext_g.zero_()
+        ext_c.zero_()
     return loss, ext_g, ext_c
 
 

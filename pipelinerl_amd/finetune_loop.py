@@ -857,14 +857,13 @@ class NativeLearnerStep:
         `equalize_micro_batches`: pad with sentinel micro-batches up to the largest count over the ranks
         (needed by ZeRO / FSDP; plain DDP only needs every rank to run at least one).
         `skip_unlabelled`: see `HotPathStep` - False keeps the reference's finiteness assert over every logits row (rl/__init__.py:213).
-        An actor-critic model (`.value_head`, finetune/value_model.py) is refused: this step reads `.logits` only - the value
-        branch of `rl_step` (rl/__init__.py:162, 265-272, 367-381) lives in `rl_step` / `rl_step_fused_head` / `StreamedLearnerStep`;
-        training such a model here would silently drop the value loss and use the stored advantages."""
+        An actor-critic model (`.value_head`, finetune/value_model.py; its forward also returns `.value` [B, L]) takes the value branch
+        of `rl_step` per micro-batch (rl/__init__.py:162, 265-272, 367-381, 441-448; one `prl_value_head_fwd_bwd` launch): the advantages
+        column of the step batch becomes rewards - V before the logits kernel reads it, the value loss's closed-form gradient goes
+        back through `.value` next to d logits, and the five value statistics are accumulated over the step (`stats_dict`)."""
         import torch.distributed as dist
 
-        if getattr(getattr(model, "module", model), "value_head", None) is not None:
-            raise NotImplementedError("NativeLearnerStep has no value-head branch (rewards - V advantages, value loss, value_* statistics): drive an "
-                                      "actor-critic model through LearnerStep with rl_step / rl_step_fused_head, or StreamedLearnerStep")
+        self.has_value_head = getattr(_unwrap(model), "value_head", None) is not None
         self.skip_unlabelled = bool(skip_unlabelled)
 
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
@@ -913,8 +912,11 @@ class NativeLearnerStep:
         from .finetune.utils import create_sentinel_batch
 
         b = create_sentinel_batch(device, tokenizer=type("T", (), {"eos_token_id": self.eos_token_id})(), model_version=0)
-        logits = self.model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits
-        logits.backward(torch.zeros_like(logits))
+        out = self.model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids)
+        if self.has_value_head:  # the critic's parameters take part in the reduction too
+            torch.autograd.backward([out.logits, out.value], [torch.zeros_like(out.logits), torch.zeros_like(out.value)])
+        else:
+            out.logits.backward(torch.zeros_like(out.logits))
 
     def step(self, rollouts, micro_batches) -> dict[str, Any]:
         """`rollouts`: THIS rank's share of the step (ragged, on the device); `micro_batches`: its packing plan."""
@@ -927,6 +929,7 @@ class NativeLearnerStep:
         n_max, n_samples = self._share_counts(n, rollouts.n_seqs, rollouts.device)
         assert n_samples == self.samples_per_step, f"the ranks' shares hold {n_samples} samples, a step takes {self.samples_per_step}"
         n_passes = max(n_max, 1) if self.equalize else max(n, 1)
+        vacc = None  # actor-critic: [value_mean, value_max, value_min, value_loss, value_mse] of the step so far (device, fp64)
         for j in range(n_passes):
             last = j == n_passes - 1
             ctx = self.model.no_sync() if (hasattr(self.model, "no_sync") and not last) else contextlib.nullcontext()
@@ -951,13 +954,35 @@ class NativeLearnerStep:
                     hp.annotate_ref_logprobs(j, ref_logits)
                     del ref_logits
             with ctx:
-                logits = self.model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids).logits
+                out = self.model(input_ids=b.input_ids, attention_mask=b.attention_mask, position_ids=b.position_ids)
+                logits = out.logits
+                g_val = None
+                if self.has_value_head:
+                    from .finetune.rl import value_head_terms
+
+                    values = out.value
+                    _, adv, vstats, g_val = value_head_terms(hp.cfg, b, values.detach(), want_grad=True)
+                    # advantages := rewards - V (rl/__init__.py:272), IN the step batch: the logits kernel below and the step's ONE
+                    # statistics launch (`finish`) read this column
+                    b.advantages.copy_(adv.reshape(b.advantages.shape))
+                    if vacc is None:
+                        vacc = vstats.clone()
+                    else:
+                        vacc = torch.stack([vacc[0] + vstats[0], torch.maximum(vacc[1], vstats[1]), torch.minimum(vacc[2], vstats[2]),
+                                            vacc[3] + vstats[3], vacc[4] + vstats[4]])
                 lg = logits.detach()
                 if lg.dtype not in (torch.float32, torch.bfloat16) or not lg.is_contiguous():
                     lg = lg.float().contiguous()
                 dlogits = hp.logits_backward(j, lg)
-                logits.backward(dlogits.to(logits.dtype))
+                if g_val is not None:  # final_loss = policy_loss + value_loss_coef * value_loss (:381): both roots in one backward
+                    torch.autograd.backward([logits, values], [dlogits.to(logits.dtype), (self.rl_config.value_loss_coef * g_val).to(values.dtype)])
+                else:
+                    logits.backward(dlogits.to(logits.dtype))
         loss, stats = hp.finish()
+        value_stats = None
+        if self.has_value_head:
+            value_stats = self._reduce_value_stats(vacc if vacc is not None else torch.zeros(5, dtype=torch.float64, device=rollouts.device))
+            loss = loss + self.rl_config.value_loss_coef * value_stats[3].to(loss.dtype)
         if self.gradient_clipping_threshold is not None:
             self.metrics.grad_norm = float(torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.gradient_clipping_threshold))
         self.optimizer.step()
@@ -970,8 +995,21 @@ class NativeLearnerStep:
         m.samples += self.samples_per_step
         m.tokens += int(hp.offsets[-1]) * self.world
         self.publish(SamplesProcessed(samples_processed=m.samples))
-        self._last = hp
-        return {"loss": loss, "stats": stats, "micro_batches": n, "did_optimizer_step": True, "sentinel_passes": n_passes - n}
+        self._last, self._last_value_stats = hp, value_stats
+        return {"loss": loss, "stats": stats, "value_stats": value_stats, "micro_batches": n, "did_optimizer_step": True, "sentinel_passes": n_passes - n}
+
+    def _reduce_value_stats(self, v: torch.Tensor) -> torch.Tensor:
+        """The five value statistics over the data-parallel ranks: sums for the additive ones, max / min for the extrema."""
+        if not self.distributed or self.world == 1:
+            return v
+        import torch.distributed as dist
+
+        dev = v.device
+        mine = v.cpu() if dist.get_backend(self.group) == "gloo" else v
+        everyone = torch.empty((self.world, 5), dtype=v.dtype, device=mine.device)
+        dist.all_gather_into_tensor(everyone, mine.unsqueeze(0).contiguous(), group=self.group)
+        everyone = everyone.to(dev)
+        return torch.stack([everyone[:, 0].sum(), everyone[:, 1].max(), everyone[:, 2].min(), everyone[:, 3].sum(), everyone[:, 4].sum()])
 
     def maybe_send_weights(self) -> bool:
         """After `step()`: broadcast when enough samples were trained since the last broadcast
@@ -993,4 +1031,15 @@ class NativeLearnerStep:
             self._writer_cm = self._writer = None
 
     def stats_dict(self, stats: torch.Tensor) -> dict[str, float]:
-        return self._last.stats_dict(stats)
+        """The step's statistics as the reference's dict; for an actor-critic model the reported loss is the combined one and the five
+        value keys close the dict (rl/__init__.py:381-386, 441-448)."""
+        out = self._last.stats_dict(stats)
+        v = getattr(self, "_last_value_stats", None)
+        if v is not None:
+            from .finetune.rl import VALUE_STAT_KEYS
+
+            vs = [float(np.float32(x)) for x in v.cpu().tolist()]
+            combined = float(np.float32(out["loss"]) + np.float32(self.rl_config.value_loss_coef * np.float32(vs[VALUE_STAT_KEYS.index("value_loss")])))
+            out["loss"] = out["max_loss"] = out["min_loss"] = combined
+            out.update(dict(zip(VALUE_STAT_KEYS, vs)))
+        return out

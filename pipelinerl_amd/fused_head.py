@@ -28,7 +28,7 @@ from typing import Any
 import torch
 
 from . import _lib
-from .finetune.rl import RLConfig, _ValueLossFn, _with_advantages, grpo_loss_from_logprobs, host_stats, make_loss_config
+from .finetune.rl import RLConfig, _ValueLossFn, _with_advantages, grpo_loss_from_logprobs, gspo_segment_terms, host_stats, make_loss_config
 from .finetune.types import PipelineBatchEncoding
 from ._lib import STAT_INDEX
 
@@ -244,7 +244,7 @@ class _FusedHeadLossFn(torch.autograd.Function):
     cost.  The kernels are the same ones; only which rows they are handed changes (one `nonzero()` = one host sync)."""
 
     @staticmethod
-    def forward(ctx, hidden, weight, head: FusedLmHead, batch, cfg, temperature, chunk_rows):  # type: ignore[override]
+    def forward(ctx, hidden, weight, head: FusedLmHead, batch, cfg, temperature, chunk_rows, sp_group=None):  # type: ignore[override]
         rows = None
         if head.skip_unlabelled and not batch.sentinel:
             _lib.require_device(hidden, batch.labels)
@@ -296,7 +296,15 @@ class _FusedHeadLossFn(torch.autograd.Function):
             ent = torch.zeros_like(nlp)
             nlp.view(-1).index_copy_(0, idx + 1, nlp_c[0, 1:])  # token-aligned: the value for token u = q + 1
             ent.view(-1).index_copy_(0, idx + 1, ent_c[0, 1:])
-        loss, stats, g_nlp, g_ent = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=need_grad)
+        if cfg.policy_loss == _lib.PRL_POLICY_GSPO:
+            # sequence-level term (rl/__init__.py:310-352) on the head's log-probs: per-segment sums -> clipped sequence ratio -> a
+            # per-token gradient coefficient that joins the token kernel's own terms (KL, entropy) on the way into the head's backward
+            seg_loss, ext_g, ext_c = gspo_segment_terms(cfg, batch, nlp, sp_group)
+            _, stats, g_nlp, g_ent = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=need_grad, ext_token_grad=ext_g, ext_clamp_indicator=ext_c)
+            loss = seg_loss
+            stats[STAT_INDEX["loss"]] = seg_loss.double()
+        else:
+            loss, stats, g_nlp, g_ent = grpo_loss_from_logprobs(cfg, batch, nlp, ent, want_grad=need_grad)
         if idx is not None:
             # The reference asserts isfinite(new_logprobs) over EVERY position (rl/__init__.py:213).  Rows that were not handed
             # to the head cannot show up in the kernel's counter, so the check moves to their inputs: a non-finite hidden state
@@ -328,7 +336,7 @@ class _FusedHeadLossFn(torch.autograd.Function):
             hs, hd, ws_, wd, dev = ctx.shapes
             gh = torch.zeros(hs, dtype=hd, device=dev) if ctx.needs_input_grad[0] else None
             gw = torch.zeros(ws_, dtype=wd, device=dev) if ctx.needs_input_grad[1] else None
-            return gh, gw, None, None, None, None, None
+            return gh, gw, None, None, None, None, None, None
         h, ids, lse2, ent, g_nlp, g_ent, idx, kept = ctx.saved_tensors
         head: FusedLmHead = ctx.head
         want_h, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -348,7 +356,7 @@ class _FusedHeadLossFn(torch.autograd.Function):
             gh = gh.to(ctx.hidden_dtype)
         if gw is not None and gw.dtype != ctx.weight_dtype:
             gw = gw.to(ctx.weight_dtype)
-        return gh, gw, None, None, None, None, None
+        return gh, gw, None, None, None, None, None, None
 
 
 def _host_stats(stats_dev: torch.Tensor, batch: PipelineBatchEncoding, kl_coef: float, ent_coef: float, value_loss_coef: float = 0.0):
@@ -356,16 +364,16 @@ def _host_stats(stats_dev: torch.Tensor, batch: PipelineBatchEncoding, kl_coef: 
 
 
 def fused_head_loss(hidden: torch.Tensor, weight: torch.Tensor, head: FusedLmHead, batch: PipelineBatchEncoding,
-                    config: RLConfig, current_step: int, max_step: int, chunk_rows: int | None = None, values: torch.Tensor | None = None):
+                    config: RLConfig, current_step: int, max_step: int, chunk_rows: int | None = None, values: torch.Tensor | None = None,
+                    seq_parallel_group: Any = None):
     """Loss + stats from last hidden states and the head weight; same return contract as `rl_step`.
-    `values`: the value head's predictions [B, L] for an actor-critic model (rl/__init__.py:265-272, 367-381, 441-448)."""
-    if config.policy_loss == "gspo":
-        raise NotImplementedError("the fused head covers ppo / reinforce; gspo goes through rl_step")
+    `values`: the value head's predictions [B, L] for an actor-critic model (rl/__init__.py:265-272, 367-381, 441-448).
+    `seq_parallel_group`: GSPO on a sequence-parallel slice adds its per-segment sums over the group (rl/utils.py:194-206)."""
     cfg, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
     if values is not None:
         value_loss, value_advantages, vstats_dev = _ValueLossFn.apply(values, batch, cfg)
         batch = _with_advantages(batch, value_advantages)
-    loss, stats_dev = _FusedHeadLossFn.apply(hidden, weight, head, batch, cfg, config.temperature, chunk_rows)
+    loss, stats_dev = _FusedHeadLossFn.apply(hidden, weight, head, batch, cfg, config.temperature, chunk_rows, seq_parallel_group)
     if values is not None:
         loss = loss + config.value_loss_coef * value_loss
         stats_dev = torch.cat([stats_dev, vstats_dev])
@@ -457,11 +465,9 @@ def install_fused_head(model: Any, chunk_rows: int = 8192, hidden_grad_terms: in
     original = model.forward
 
     def forward(*args, rl_batch: PipelineBatchEncoding | None = None, rl_config: RLConfig | None = None,
-                current_step: int = 0, max_step: int = 1, **kwargs):
+                current_step: int = 0, max_step: int = 1, seq_parallel_group: Any = None, **kwargs):
         if rl_batch is None:
             return original(*args, **kwargs)
-        if rl_config.policy_loss == "gspo":
-            raise NotImplementedError("the fused head covers ppo / reinforce; gspo goes through rl_step")
         body, lm_head = _body_and_head(_lm_of(model))
         hidden = _hidden_states(body, rl_batch)
         w = lm_head.weight
@@ -472,7 +478,7 @@ def install_fused_head(model: Any, chunk_rows: int = 8192, hidden_grad_terms: in
             value_loss, value_advantages, vstats_dev = _ValueLossFn.apply(value_head(hidden), rl_batch, cfg)
             rl_batch = _with_advantages(rl_batch, value_advantages)
         loss, stats_dev = _FusedHeadLossFn.apply(hidden, w, _head_for(lm_head, w, opts["chunk_rows"], opts["hidden_grad_terms"], opts["keep_logits"]),
-                                                 rl_batch, cfg, rl_config.temperature, opts["chunk_rows"])
+                                                 rl_batch, cfg, rl_config.temperature, opts["chunk_rows"], seq_parallel_group)
         if value_head is not None:
             loss = loss + rl_config.value_loss_coef * value_loss
             stats_dev = torch.cat([stats_dev, vstats_dev])
@@ -500,7 +506,8 @@ def rl_step_fused_head(model: Any, batch: PipelineBatchEncoding, current_step: i
         inner = inner.module
     if getattr(inner, "_prl_fused_head", None) is not None:
         _, kl_coef, ent_coef = make_loss_config(config, current_step, max_step)
-        loss, stats_dev = model(rl_batch=batch, rl_config=config, current_step=current_step, max_step=max_step)
+        loss, stats_dev = model(rl_batch=batch, rl_config=config, current_step=current_step, max_step=max_step,
+                                **({"seq_parallel_group": seq_parallel_group} if seq_parallel_group is not None else {}))
         return loss, _host_stats(stats_dev, batch, kl_coef, ent_coef, config.value_loss_coef)
     # an actor-critic wrapper (finetune/value_model.py:54-116): the LM is `.pretrained_model`, the critic reads the same hidden states
     value_head = getattr(model, "value_head", None)
@@ -512,7 +519,7 @@ def rl_step_fused_head(model: Any, batch: PipelineBatchEncoding, current_step: i
     chunk_rows = int(chunk_rows or getattr(config, "fused_head_chunk_rows", 8192) or 8192)
     keep = keep_logits if keep_logits is not None else getattr(config, "fused_head_keep_logits", None)
     return fused_head_loss(hidden, w, _head_for(lm_head, w, chunk_rows, keep_logits=keep), batch, config, current_step, max_step, chunk_rows,
-                           values=values)
+                           values=values, seq_parallel_group=seq_parallel_group)
 
 
 # -- reference log-probabilities ---------------------------------------------------------

@@ -494,10 +494,8 @@ def describe_compact(members: Sequence[tuple[dict, int]], model_version: int, eo
     has_ref = any(hc["has_ref"] for hc, _ in members)
     head, base, where, total = batch_codec.compact_layout(sum(lens), sum(lp_lens), m, has_ref, model_version, padding, eos_token_id,
                                                           slice_index, num_slices, (ref_block[1] // 4) if ref_block else 0)
-    if ref_block is not None:
-        if ref_block[1] != 4 * (sum(lens) + padding):
-            raise ValueError(f"ref column of {ref_block[1]} bytes for a micro-batch of {sum(lens)} + {padding} tokens")
-        pieces.append((ref_block[0], base + where["ref_column"][0], ref_block[1], FROM_BLOCK, 0))
+    if ref_block is not None and ref_block[1] != 4 * (sum(lens) + padding):
+        raise ValueError(f"ref column of {ref_block[1]} bytes for a micro-batch of {sum(lens)} + {padding} tokens")
     at = len(inline)
     inline += head
     pieces.append((at, 0, len(head), INLINE, 0))
@@ -524,6 +522,8 @@ def describe_compact(members: Sequence[tuple[dict, int]], model_version: int, eo
             at = len(inline)
             inline += raw
             pieces.append((at, base + where[col][0], len(raw), INLINE, 0))
+    if ref_block is not None:  # the last column of the record (the log gathers a record's pieces in ascending offset)
+        pieces.append((ref_block[0], base + where["ref_column"][0], ref_block[1], FROM_BLOCK, 0))
     return total
 
 
@@ -797,6 +797,9 @@ class PreprocessorLoop:
                         annotate_ref_logprobs(self.ref_model, b, self.cfg.rl.temperature)
                         t0_, t1_ = int(packed.token_off[k]), int(packed.token_off[k + 1])
                         packed.flat["ref_logprobs"][t0_:t1_].copy_(b.ref_logprobs.reshape(-1))
+                        # the cached batch object must keep VIEWING the block: its fields are located inside it when the record is described
+                        # (sequence-parallel slices go through `describe_batch`, which refuses a tensor that lives elsewhere)
+                        b.ref_logprobs = packed.flat["ref_logprobs"][t0_:t1_].reshape(1, -1)
                     t = self._tick("ref_logprobs", t)
         job = {"mbs": mbs, "packed": packed, "merged": merged, "base": base, "max_model_version": self.max_model_version}
         if self._pub is not None:

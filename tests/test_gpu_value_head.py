@@ -227,3 +227,64 @@ def test_actor_critic_model_through_rl_step_and_the_fused_head(libprl, cuda_devi
     h = model.pretrained_model.model(input_ids=batch.input_ids).last_hidden_state.detach().float()[0].double().cpu().numpy()
     want_gw = want["g_value"][0].astype(np.float64) @ h
     np.testing.assert_allclose(g0["value_head.output.weight"].cpu().numpy()[0], want_gw, rtol=1e-3, atol=1e-6 * np.abs(want_gw).max())
+
+
+def test_native_step_with_a_value_head_equals_per_micro_batch_rl_step(libprl, cuda_device):
+    """`NativeLearnerStep` with an actor-critic model: one K6 launch, per micro-batch the value kernel (advantages := rewards - V written INTO
+    the step batch, value-loss gradient) + the fused logits kernel, ONE statistics launch - against the drop-in loop of `rl_step` (which the
+    c18-c23 goldens pin to the reference) over the same micro-batches: parameter gradients of the critic, the head and the embedding,
+    the combined loss, the 32 statistics and the five value statistics."""
+    import copy
+
+    from pipelinerl_amd.finetune.rl import VALUE_STAT_KEYS, RLConfig, rl_step
+    from pipelinerl_amd.finetune_loop import NativeLearnerStep
+    from pipelinerl_amd.hotpath import HotPathStep, dense_micro_batches
+    from pipelinerl_amd.synthetic import make_ragged
+
+    V = 256
+    rag_h, _ = make_ragged(4, attempts=4, seq_length=48, vocab=V, seed=7, prompt_min=3, prompt_max=9, with_ref=True)
+    rag = rag_h.to(cuda_device)
+    mbs = dense_micro_batches(rag_h, 120)
+    assert len(mbs) >= 3
+    rl = RLConfig(policy_loss="ppo", epsilon_low=0.2, epsilon_high=0.2, kl_coef=0.05, final_kl_coef=0.05, divide_advantage_by_std=False,
+                  clamp_log_ratio_ref_new_value=5, value_loss_coef=0.25, group_normalization=True, overlong_filtering=True)
+    torch.manual_seed(1)
+    model_a = TinyActorCritic(V, 64).to(cuda_device)
+    torch.nn.init.normal_(model_a.value_head.output.weight, std=0.3)
+    model_b = copy.deepcopy(model_a)
+
+    captured = {}
+    opt_a = torch.optim.SGD(model_a.parameters(), lr=0.0)
+    orig_zero = opt_a.zero_grad
+    opt_a.zero_grad = lambda *a, **k: captured.update(g={n: p.grad.detach().clone() for n, p in model_a.named_parameters()}) or orig_zero(*a, **k)
+    native = NativeLearnerStep(model_a, opt_a, rl, eos_token_id=2, samples_per_step=16, max_train_steps=10, skip_unlabelled=False)
+    assert native.has_value_head
+    res = native.step(rag, mbs)
+    stats_a = native.stats_dict(res["stats"])
+    assert list(stats_a)[-5:] == list(VALUE_STAT_KEYS) and len(stats_a) == 37
+
+    cfg_b = rl.model_copy()
+    cfg_b.batch_size = 16
+    hp = HotPathStep(cfg_b, 2, 0, 10)
+    batches = hp.preprocess(rag, mbs)
+    agg, total = {}, 0.0
+    for b in batches:
+        loss, st = rl_step(model_b, b, 0, 10, cfg_b)
+        loss.backward()
+        total += loss.item()
+        for k, v in st.items():
+            agg.setdefault(k, []).append(v)
+    for n, pb in model_b.named_parameters():
+        ga = captured["g"][n]
+        assert pb.grad is not None and float(pb.grad.abs().max()) > 0, n
+        assert torch.allclose(ga, pb.grad, rtol=2e-4, atol=1e-6 * float(pb.grad.abs().max())), n
+    assert abs(res["loss"].item() - total) <= FP_TOL * max(1.0, abs(total))
+    assert abs(stats_a["loss"] - sum(agg["loss"])) <= FP_TOL * max(1.0, abs(sum(agg["loss"])))
+    for k in ("reward", "kl", "ratio_new_old", "advantage", "token_weight", "value_mean", "value_loss", "value_mse"):
+        assert abs(stats_a[k] - sum(agg[k])) <= FP_TOL * max(1.0, abs(sum(agg[k]))), k
+    for k in ("max_advantage", "value_max"):
+        assert abs(stats_a[k] - max(agg[k])) <= 1e-6 * max(1.0, abs(max(agg[k]))), k
+    for k in ("min_advantage", "value_min"):
+        assert abs(stats_a[k] - min(agg[k])) <= 1e-6 * max(1.0, abs(min(agg[k]))), k
+    # the advantages the policy term used are rewards - V, not the column the preprocessor wrote
+    assert abs(stats_a["advantage"] - sum(agg["advantage"])) <= FP_TOL and stats_a["value_loss"] > 0

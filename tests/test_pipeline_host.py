@@ -379,9 +379,10 @@ def test_bench_refuses_to_run_n_gpus_as_one_rank():
     assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
-def test_native_learner_step_refuses_an_actor_critic_model():
-    """rl_step's value-head branch (rl/__init__.py:162, 265-272, 367-381) is not part of NativeLearnerStep, which reads `.logits` only:
-    a model with a `value_head` must not train silently as plain GRPO."""
+def test_native_learner_step_recognises_an_actor_critic_model():
+    """rl_step's value-head branch (rl/__init__.py:162, 265-272, 367-381) is part of NativeLearnerStep: a model with a `value_head`, bare or
+    behind a `.module` wrapper, is detected at construction (its step then routes `outputs.value` through the value kernel -
+    tests/test_gpu_value_head.py); a plain causal LM is not."""
     from pipelinerl_amd.finetune.rl import RLConfig
     from pipelinerl_amd.finetune_loop import NativeLearnerStep
 
@@ -392,13 +393,12 @@ def test_native_learner_step_refuses_an_actor_critic_model():
             self.value_head = torch.nn.Linear(2, 1)
 
     m = ActorCritic()
-    with pytest.raises(NotImplementedError, match="value-head"):
-        NativeLearnerStep(m, torch.optim.SGD(m.parameters(), lr=0.1), RLConfig(), eos_token_id=2, samples_per_step=8, max_train_steps=2)
+    kw = dict(eos_token_id=2, samples_per_step=8, max_train_steps=2)
+    assert NativeLearnerStep(m, torch.optim.SGD(m.parameters(), lr=0.1), RLConfig(), **kw).has_value_head is True
     wrapped = types.SimpleNamespace(module=m, parameters=m.parameters)
-    with pytest.raises(NotImplementedError):
-        NativeLearnerStep(wrapped, torch.optim.SGD(m.parameters(), lr=0.1), RLConfig(), eos_token_id=2, samples_per_step=8, max_train_steps=2)
+    assert NativeLearnerStep(wrapped, torch.optim.SGD(m.parameters(), lr=0.1), RLConfig(), **kw).has_value_head is True
     plain = torch.nn.Linear(2, 2)
-    NativeLearnerStep(plain, torch.optim.SGD(plain.parameters(), lr=0.1), RLConfig(), eos_token_id=2, samples_per_step=8, max_train_steps=2)
+    assert NativeLearnerStep(plain, torch.optim.SGD(plain.parameters(), lr=0.1), RLConfig(), **kw).has_value_head is False
 
 
 def test_summary_of_a_recorded_pipeline_run_recomputes():
