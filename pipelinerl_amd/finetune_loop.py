@@ -964,7 +964,9 @@ class NativeLearnerStep:
                     _, adv, vstats, g_val = value_head_terms(hp.cfg, b, values.detach(), want_grad=True)
                     # advantages := rewards - V (rl/__init__.py:272), IN the step batch: the logits kernel below and the step's ONE
                     # statistics launch (`finish`) read this column
-                    b.advantages.copy_(adv.reshape(b.advantages.shape))
+                    # (`.data`: every column of the step batch is a view of ONE block, so an in-place write through the tensor itself would
+                    # bump the version counter the model's saved `input_ids` share with it and autograd would refuse the backward)
+                    b.advantages.data.copy_(adv.reshape(b.advantages.shape))
                     if vacc is None:
                         vacc = vstats.clone()
                     else:

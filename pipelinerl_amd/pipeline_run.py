@@ -75,6 +75,7 @@ class PipelineSpec:
     optimizer: str = "adamw"           # "adamw" | "sgd" (parity tests)
     param_dtype: str = "bf16"          # "bf16" (the reference's training dtype) | "fp32" (parity tests: tight parameter deltas)
     kl_coef: float = 0.0               # > 0 (configs[4]: 0.001): KL-to-reference on - the preprocessor holds the frozen reference policy (the initial policy) and writes `ref_logprobs`
+    ref_seed: int | None = None        # seed of the reference policy (default: `seed`, i.e. the policy the run starts from)
     wire: str = "full"                 # `training_data` records: "full" (the reference's expanded batch) | "compact" (ragged columns; K6 on the learner's GPU)
     mirror_jsonl: bool = False         # JSONL mirrors of `actor` and `training_data` (replay / parity tests; compact wire: `actor` only)
     retain_streams: bool = False       # keep consumed segments of the bulk topics (isolated-stage reruns read them again)
@@ -334,7 +335,7 @@ def preprocessor_stage(spec: PipelineSpec) -> None:
     if spec.kl_coef > 0:
         # the reference policy = the policy the run starts from, frozen, on the preprocessor's GPU: its log-probs replace the reference's
         # HTTP round trips to a second inference server (preprocess.py:86-104, llm.py:606-648)
-        ref_model = build_policy(spec, dev, seed=spec.seed).eval()
+        ref_model = build_policy(spec, dev, seed=spec.seed if spec.ref_seed is None else spec.ref_seed).eval()
         for p in ref_model.parameters():
             p.requires_grad_(False)
     loop = PreprocessorLoop(cfg, dev, trainer_state=state, profile=True, wire=spec.wire, ref_model=ref_model)

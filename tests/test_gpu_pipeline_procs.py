@@ -209,7 +209,8 @@ def test_pipeline_with_reference_policy_compact_wire_equals_full_wire(libprl, cu
     for wire in ("full", "compact"):
         exp, cap = tmp_path / wire / "exp", tmp_path / wire / "cap"
         spec = PipelineSpec(exp_path=str(exp), model="tiny", global_batch=bs, seq_length=seq, attempts=4, steps=steps, optimizer="sgd", lr=0.05, param_dtype="fp32",
-                            capture_step0=str(cap), n_problems=5, concurrent_groups=2, stage_timeout_s=600.0, learner="streamed", wire=wire, kl_coef=0.001)
+                            capture_step0=str(cap), n_problems=5, concurrent_groups=2, stage_timeout_s=600.0, learner="streamed", wire=wire, kl_coef=0.001,
+                            ref_seed=4242)  # (a reference policy that differs from the initial policy: the KL term is non-zero from step 0 on)
         res = run_pipeline(spec)
         assert "error" not in res, json.dumps(res.get("error"), indent=1)[:6000]
         assert res["summary"]["optimizer_steps"] == steps and res["summary"]["engine_weights_equal_trainer_at_last_version"] is True
