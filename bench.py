@@ -1164,7 +1164,7 @@ def main():
             "preprocess_K5_K6": tokens_per_rank * (84 + 8),           # K6 16 B read + 68 B written; K5 scan 8 B read
             "pack_collate_kernel": tokens_per_rank * 84,              # the K6 kernel alone
             "group_advantages_K5": tokens_per_rank * 8,               # the K5 scan (+ O(S) group arithmetic), host planning + upload included
-            "group_advantages_K5_kernels": tokens_per_rank * 8,       # the two K5 launches alone
+            "group_advantages_K5_kernels": tokens_per_rank * 8,       # the K5 scan launch alone (the O(S) group launch is timed next to it)
         }
 
     def price(table: dict, algo: dict) -> None:

@@ -625,6 +625,9 @@ def _csr(keys: np.ndarray) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
     return off, order, sorted_keys[starts]
 
 
+_NP_TORCH = {"int64": torch.int64, "int32": torch.int32, "float32": torch.float32, "float64": torch.float64, "uint8": torch.uint8}
+
+
 def plan_groups(group_index: np.ndarray, step_index: np.ndarray, rollout_index: np.ndarray):
     """Host-side O(S) planning for K5: CSR membership of (group, step) keys and of groups, plus
     the number of distinct rollouts per group (reference groupby keys, rl/__init__.py:464-486)."""
@@ -651,10 +654,6 @@ def populate_rl_data_ragged(rollouts: RaggedRollouts, eos_token_id: int, config:
     _lib.require_device(r.tokens)
     dev = r.device
     S = r.n_seqs
-    if plan is None:
-        plan = [torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
-                for a in plan_groups(r.host_group_index, r.host_step_index, r.host_rollout_index)]
-    key_off, group_off = plan[0], plan[2]
     # the six per-sequence outputs live in one allocation (8-byte columns first)
     out64 = torch.empty((2, S), dtype=torch.float64, device=dev)
     out32 = torch.empty((4, S), dtype=torch.float32, device=dev)
@@ -662,22 +661,38 @@ def populate_rl_data_ragged(rollouts: RaggedRollouts, eos_token_id: int, config:
     num_labels, overflow, adv32, gt32 = out32[0], out32[1], out32[2], out32[3]
     import contextlib
 
-    # `timer` (bench.py's EventTimer): HIP events around the two launches alone, next to the all-in figure of the caller
-    with torch.cuda.device(dev), (timer.time("group_advantages_K5_kernels") if timer is not None else contextlib.nullcontext()):
+    # `timer` (bench.py's EventTimer): HIP events around each launch alone, next to the all-in figure of the caller
+    with torch.cuda.device(dev):
         stream = _lib.current_stream_ptr(dev)
-        _lib.check(
-            lib.prl_seq_scan(
-                S, _lib.ptr(r.tokens), _lib.ptr(r.labels), _lib.ptr(r.seq_off), _lib.ptr(r.finish_code),
-                _lib.ptr(r.finished), int(eos_token_id), _lib.ptr(num_labels), _lib.ptr(overflow), stream,
+        # the scan needs no plan: it goes first, and the O(S) host planning below + its ONE upload overlap with it
+        with (timer.time("group_advantages_K5_kernels") if timer is not None else contextlib.nullcontext()):
+            _lib.check(
+                lib.prl_seq_scan(
+                    S, _lib.ptr(r.tokens), _lib.ptr(r.labels), _lib.ptr(r.seq_off), _lib.ptr(r.finish_code),
+                    _lib.ptr(r.finished), int(eos_token_id), _lib.ptr(num_labels), _lib.ptr(overflow), stream,
+                )
             )
-        )
-        _lib.check(
-            lib.prl_group_advantages(
-                S, len(key_off) - 1, len(group_off) - 1, *[_lib.ptr(p) for p in plan], _lib.ptr(r.reward),
-                _lib.ptr(r.seq_off), int(config.divide_advantage_by_std), _lib.ptr(adv64), _lib.ptr(gt64),
-                _lib.ptr(adv32), _lib.ptr(gt32), stream,
+        if plan is None:
+            host = [np.ascontiguousarray(a) for a in plan_groups(r.host_group_index, r.host_step_index, r.host_rollout_index)]
+            offs, total = [], 0
+            for a in host:
+                total += (-total) % 8
+                offs.append(total)
+                total += a.nbytes
+            packed = np.empty(total, dtype=np.uint8)
+            for a, o in zip(host, offs):
+                packed[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+            on_dev = torch.from_numpy(packed).to(dev, non_blocking=True)  # five small arrays, one copy
+            plan = [on_dev[o:o + a.nbytes].view(_NP_TORCH[a.dtype.name]).view(a.shape) for a, o in zip(host, offs)]
+        key_off, group_off = plan[0], plan[2]
+        with (timer.time("group_advantages_K5_group_launch") if timer is not None else contextlib.nullcontext()):
+            _lib.check(
+                lib.prl_group_advantages(
+                    S, len(key_off) - 1, len(group_off) - 1, *[_lib.ptr(p) for p in plan], _lib.ptr(r.reward),
+                    _lib.ptr(r.seq_off), int(config.divide_advantage_by_std), _lib.ptr(adv64), _lib.ptr(gt64),
+                    _lib.ptr(adv32), _lib.ptr(gt32), stream,
+                )
             )
-        )
     return PreparedRollouts(
         rollouts=r, reward32=r.reward.to(torch.float32), advantage=adv32, group_tokens=gt32,
         num_labels=num_labels, overflow=overflow, advantage64=adv64, group_tokens64=gt64, k5_out32=out32,

@@ -60,6 +60,11 @@ class HotPathStep:
         so nothing changes numerically and ~3-30 % of the logits traffic goes away; the price is that a non-finite logit in
         such a row passes unnoticed, where the reference asserts `isfinite(new_logprobs)` over EVERY position
         (rl/__init__.py:213).  `False` keeps that assert: every row is read, `stats_dict()` raises for a NaN / inf anywhere."""
+        if config.policy_loss == "gspo":
+            # the sequence-level term needs every token's log-prob of a sequence before any token's gradient exists (rl/__init__.py:310-352):
+            # it cannot live in the one-pass logits kernel this step is built around
+            raise ValueError("HotPathStep / NativeLearnerStep fuse the per-token losses (ppo, reinforce); gspo is served by rl_step and "
+                             "rl_step_fused_head (LearnerStep, StreamedLearnerStep)")
         self.config = config
         self.eos_token_id = eos_token_id
         self.cfg, self.kl_coef, self.ent_coef = make_loss_config(config, current_step, max_step)

@@ -1,7 +1,11 @@
-"""BASELINE `configs[1]` as the pipeline it is: actor -> preprocessor -> learner -> engine, four processes on ONE MI355X
-(pipelinerl_amd/pipeline_run.py).  Prints one JSON object (the merged stage reports + summary).
+"""The hot path as the pipeline it is (pipelinerl_amd/pipeline_run.py): actor -> preprocessor -> N learner ranks -> M engines as OS processes.
+Prints one JSON object (the merged stage reports + summary).  Defaults = BASELINE `configs[1]` (four processes on ONE MI355X).
 
     python scripts/pipeline_cfg1.py [--steps 5] [--model 0p5b] [--global-batch 512] [--seq-length 2048] [--engine-load] [--out f.json]
+    # configs[2] topology on ONE GPU (gloo gradients, HIP IPC to both engines):
+    python scripts/pipeline_cfg1.py --learners 2 --engines 2 --weights ipc
+    # configs[2] / [3] on their own GPUs (engines first, learners after them; RCCL gradients and weight-update group):
+    python scripts/pipeline_cfg1.py --model 7b --global-batch 4096 --seq-length 8192 --learners 2 --engines 2 --weights rccl --own-gpus --gradient-checkpointing
 """
 
 import argparse
@@ -28,6 +32,11 @@ def main():
     ap.add_argument("--gradient-checkpointing", action="store_true")
     ap.add_argument("--learner", default="streamed", choices=["streamed", "dropin"])
     ap.add_argument("--wire", default="full", choices=["full", "compact"], help="training_data records: the expanded batch, or the ragged columns (K6 on the learner's GPU)")
+    ap.add_argument("--learners", type=int, default=1, help="data-parallel learner ranks (lead trainers)")
+    ap.add_argument("--engines", type=int, default=1, help="inference engines (weight-update group = engines + 1)")
+    ap.add_argument("--weights", default="ipc", choices=["ipc", "rccl", "gloo"], help="trainer -> engines transport")
+    ap.add_argument("--own-gpus", action="store_true", help="one GPU per engine and per learner rank (engines first); default: every stage on GPU 0")
+    ap.add_argument("--kl-coef", type=float, default=0.0, help="> 0: KL-to-reference on, the preprocessor holds the frozen reference policy (configs[4]: 0.001)")
     ap.add_argument("--stacks-after", type=float, default=0.0, help="diagnosis: stages still alive after this many seconds dump their Python stacks")
     ap.add_argument("--timeout", type=float, default=900.0)
     ap.add_argument("--exp-path", default=None)
@@ -39,7 +48,8 @@ def main():
     exp = a.exp_path or tempfile.mkdtemp(prefix="prl_pipeline_")
     spec = PipelineSpec(exp_path=exp, model=a.model, global_batch=a.global_batch, seq_length=a.seq_length, pack_budget=a.pack_budget, attempts=a.attempts, steps=a.steps,
                         max_lag=a.max_lag, weight_update_interval=a.weight_update_interval, dense=a.dense, engine_load=a.engine_load,
-                        gradient_checkpointing=a.gradient_checkpointing, learner=a.learner, wire=a.wire, stage_timeout_s=a.timeout, stacks_after_s=a.stacks_after)
+                        gradient_checkpointing=a.gradient_checkpointing, learner=a.learner, wire=a.wire, stage_timeout_s=a.timeout, stacks_after_s=a.stacks_after,
+                        n_learners=a.learners, n_engines=a.engines, weight_transport=a.weights, share_device=not a.own_gpus, kl_coef=a.kl_coef)
     res = run_pipeline(spec)
     line = json.dumps(res)
     print(line)

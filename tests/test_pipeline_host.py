@@ -419,3 +419,11 @@ def test_summary_of_a_recorded_pipeline_run_recomputes():
     assert sum(s["lag_optimizer_steps_histogram"].values()) == rec["stages"]["learner"]["micro_batches"]
     assert s["overlap"]["stages_back_to_back_s_per_step"] == pytest.approx(sum(s["stage_busy_s_per_step"].values()))
     assert s["weight_sync_under_load_ms"]["updates"] == s["optimizer_steps"] == 3 and s["engine_weights_equal_trainer_at_last_version"] is True
+
+
+def test_step_granular_loop_names_where_gspo_lives():
+    from pipelinerl_amd.finetune.rl import RLConfig
+    from pipelinerl_amd.hotpath import HotPathStep
+
+    with pytest.raises(ValueError, match="rl_step_fused_head"):
+        HotPathStep(RLConfig(policy_loss="gspo"), eos_token_id=2)

@@ -140,7 +140,7 @@ def test_pg_rank_arithmetic_and_dtype_table(g, monkeypatch):
 
     calls = []
     monkeypatch.setattr(vllm_worker.WeightSyncGroup, "from_init_method",
-                        classmethod(lambda cls, init_method, rank, world_size, device: calls.append(
+                        classmethod(lambda cls, init_method, rank, world_size, device, timeout_s=300.0: calls.append(
                             {"init_method": str(init_method), "rank": str(rank), "world_size": str(world_size), "device": str(device)}) or "group"))
     for rec in g["pg_ranks"]:
         eng = _engine(set(), Loopback(), [])
