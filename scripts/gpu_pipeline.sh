@@ -1,21 +1,28 @@
 #!/bin/bash
-# One GPU-box session for the process pipeline: the parity test (tiny shape, four processes) and BASELINE configs[1] as a pipeline.
-# usage: /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash scripts/gpu_pipeline.sh r05a [steps]'
+# The pipeline at BASELINE configs[1]'s shape (Qwen2.5-0.5B, bs 512 x seq 2048) on ONE MI355X in three topologies:
+# 1 learner + 1 engine, 2 + 2 with HIP-IPC weights, 2 + 2 with the gloo weight-update group (the configs[2] topology where RCCL cannot run).
+# usage: gpurun --timeout 1800 -- 'bash scripts/gpu_pipeline.sh r06g [steps]'
 set -u
-TAG=${1:-pipe}
-STEPS=${2:-4}
+TAG=${1:-pipeline}
+STEPS=${2:-3}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-(rocminfo | grep -E "Marketing Name|gfx" | head -4; nproc; grep -m1 "model name" /proc/cpuinfo; free -g | head -2; df -h /dev/shm | tail -1) > $OUT/env.log 2>&1
-timeout 900 python -m pytest tests/test_gpu_pipeline_procs.py -m gpu -q -x --timeout 800 -p no:cacheprovider > $OUT/pytest_pipeline.log 2>&1
-echo "pytest exit $?" | tee -a $OUT/pytest_pipeline.log
-tail -40 $OUT/pytest_pipeline.log
-( time timeout 900 python scripts/pipeline_cfg1.py --steps $STEPS --out $OUT/pipeline_cfg1.json ) > $OUT/pipeline_cfg1.log 2> $OUT/pipeline_cfg1.err
-echo "pipeline exit $?"
-tail -5 $OUT/pipeline_cfg1.err
-python - "$OUT" <<'PY'
+for cfg in "1 1 ipc" "2 2 ipc" "2 2 gloo"; do
+  set -- $cfg
+  name=pipeline_0p5b_${1}x${2}_$3
+  ( time timeout 900 python scripts/pipeline_cfg1.py --steps $STEPS --learners $1 --engines $2 --weights $3 --stacks-after 600 --out $OUT/$name.json ) > $OUT/$name.log 2> $OUT/$name.err
+  echo "$name exit $?"
+  python - "$OUT/$name.json" <<'PY'
 import json, sys
-d = json.loads(open(sys.argv[1] + "/pipeline_cfg1.json").read())
-print(json.dumps(d.get("summary") or d.get("error"), indent=1)[:6000])
+try:
+    d = json.loads(open(sys.argv[1]).read())
+except Exception as e:
+    print(" no result", e); sys.exit(0)
+if "error" in d:
+    print(" ERROR", json.dumps(d["error"])[:1500]); sys.exit(0)
+s = d["summary"]
+print(" samples/s", round(s["samples_per_s"], 2), "s/step", round(s["s_per_step"], 2), "busy", {k: round(v, 3) for k, v in s["busy_frac"].items()},
+      "wsync under load ms", s["weight_sync_under_load_ms"], "topology", s.get("topology"), "engines equal trainer", s["engine_weights_equal_trainer_at_last_version"])
 PY
+done
