@@ -585,7 +585,10 @@ class LearnerStep:
             return value
         import torch.distributed as dist
 
-        t = torch.tensor([value], dtype=torch.int64, device=self._counter_device)
+        # (a gloo group reduces host memory: a device tensor would be staged through the host behind a stream synchronisation,
+        # i.e. drain the GPU once per micro-batch; only RCCL needs the counter on the device)
+        device = "cpu" if dist.get_backend(self.group) == "gloo" else self._counter_device
+        t = torch.tensor([value], dtype=torch.int64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return int(t.item())
 

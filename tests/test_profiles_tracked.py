@@ -89,3 +89,36 @@ def test_the_final_bench_line_recomputes_from_its_own_fields():
     assert p["samples_per_s"] == pytest.approx(512 / p["s_per_step"], rel=1e-6) and p["engine_weights_equal_trainer_at_last_version"] is True
     m = d["roofline_mfma"]
     assert m["bound"] == "mfma" and m["peak"] == 2500.0 and m["frac"] == pytest.approx(m["achieved"] / m["peak"], rel=1e-9)
+
+
+def test_the_round_6_driver_line_is_small_recomputes_and_agrees_with_rocprofv3():
+    """profiles/r06f_bench_default.json is the line `python3 bench.py --gpus 1 --steps 20 --warmup 5` printed on an MI355X: under 4 KB, scalar
+    `cpu_baseline.cores`, value = samples / step time ON THE REFERENCE'S BEHAVIOUR (every logits row read: algorithmic bytes 2 V 4 + 56 per row),
+    roofline = algorithmic bytes / HIP-event average / peak, the rocprofv3 average of the same kernel within a few per cent, live PMC traffic
+    above the algorithmic bytes; the detail file written by the same run carries the per-kernel table and the CPU legs."""
+    import json
+
+    text = (ROOT / "profiles" / "r06f_bench_default.json").read_text().strip()
+    assert len(text.encode()) < 4096 and "\n" not in text
+    d = json.loads(text)
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True and d["dtype"] == "f32"
+    assert d["value"] == pytest.approx(4096 / (d["ms_per_step"] * 1e-3), rel=1e-6) and d["config"]["skip_unlabelled"] is False
+    assert d["value_skip_unlabelled"] > d["value"]  # the opt-out reads 3.5 % fewer rows
+    r = d["roofline"]
+    V, T = d["config"]["vocab"], d["config"]["seq_len"]
+    assert r["algorithmic_bytes_per_launch"] == T * (2 * V * 4 + 56) and r["launches"] == 4096 * d["steps"]
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9, rel=1e-6)
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9) and 0.6 < r["frac"] < 0.8 and r["peak"] == 8000.0
+    assert r["traffic_source"].startswith("live") and 1.0 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.25
+    rows = [l for l in (ROOT / "profiles" / "r06f_bench_kernel_stats.csv").read_text().splitlines() if l.startswith('"fused_logits_loss_keep_kernel')]
+    assert len(rows) == 1
+    avg_ns = float(rows[0].split('",')[1].split(",")[2])
+    assert abs(avg_ns * 1e-3 - r["avg_us"]) / r["avg_us"] < 0.03
+    c = d["cpu_baseline"]
+    assert type(c["cores"]) is int and c["kind"] == "port" and c["value"] > c["reference_value"] > 0 and c["reference_cores"] == 8
+    w = d["weight_sync"]
+    assert w["transport"] == "hip_ipc_colocated" and w["gbytes"] > 15 and 0 < w["median_ms"] < 50
+    assert d["wall_s"] < 270 and "skipped" not in d
+    full = json.loads((ROOT / "profiles" / "r06f_bench_default_detail.json").read_text())
+    assert full["value"] == d["value"] and set(d["hbm_frac"]) == {k for k, v in full["kernels"].items() if "hbm_frac" in v}
+    assert full["cpu_baseline"]["legs"]["logprob_fwd_bwd_closed_form"]["us_per_token"] > 0
