@@ -26,3 +26,24 @@ print(" samples/s", round(s["samples_per_s"], 2), "s/step", round(s["s_per_step"
       "wsync under load ms", s["weight_sync_under_load_ms"], "topology", s.get("topology"), "engines equal trainer", s["engine_weights_equal_trainer_at_last_version"])
 PY
 done
+
+if [ "${3:-}" == "7b" ]; then
+  # BASELINE configs[2]'s topology AT THE 7B SHAPE on one GPU (reduced batch: a 4096-sample step would take half an hour): two 7.6 B-parameter
+  # learners (bf16 body, fp32 head, AdamW, gradient checkpointing) + two engines holding their own 16.3 GB copies, HIP-IPC hand-off to both
+  name=pipeline_7b_2x2_ipc_bs16_seq8192
+  ( time timeout 1500 python scripts/pipeline_cfg1.py --model 7b --global-batch 16 --seq-length 8192 --steps 3 --gradient-checkpointing --learners 2 --engines 2 \
+      --weights ipc --stacks-after 1200 --timeout 1400 --out $OUT/$name.json ) > $OUT/$name.log 2> $OUT/$name.err
+  echo "$name exit $?"
+  python - "$OUT/$name.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read())
+except Exception as e:
+    print(" no result", e); sys.exit(0)
+if "error" in d:
+    print(" ERROR", json.dumps(d["error"])[:3000]); sys.exit(0)
+s = d["summary"]
+print(" samples/s", round(s["samples_per_s"], 3), "s/step", round(s["s_per_step"], 2), "busy", {k: round(v, 3) for k, v in s["busy_frac"].items()},
+      "wsync under load ms", s["weight_sync_under_load_ms"], "peak GB", s["learner_peak_memory_GB"], "engines equal trainer", s["engine_weights_equal_trainer_at_last_version"])
+PY
+fi

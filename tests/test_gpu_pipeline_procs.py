@@ -135,7 +135,7 @@ def test_four_process_pipeline_and_step0_vs_oracle(libprl, cuda_device, tmp_path
     assert not bad, "gradients of step 0, relative 2-norm error per tensor: " + json.dumps(dict(sorted(worst.items(), key=lambda kv: -kv[1])[:12]), indent=1)
 
 
-@pytest.mark.parametrize("weights,learner", [("ipc", "streamed"), ("gloo", "dropin")])
+@pytest.mark.parametrize("weights,learner", [("ipc", "streamed"), ("gloo", "dropin"), ("ipc", "streamed+compact_wire")])
 def test_two_learners_two_engines_on_one_gpu_match_one_learner(libprl, cuda_device, tmp_path, weights, learner):
     """BASELINE configs[2]'s topology (2 learner ranks + 2 engines) with every stage on this ONE GPU: six processes, the real HIP preprocessor
     and the real fused-head loss on both learner ranks, gradients all-reduced over gloo (RCCL refuses two ranks on one device), weights
@@ -146,12 +146,14 @@ def test_two_learners_two_engines_on_one_gpu_match_one_learner(libprl, cuda_devi
     micro-batch on either side, so the two runs differ in WHO trains a sequence, not in how it is packed."""
     from pipelinerl_amd.pipeline_run import PipelineSpec, run_pipeline
 
+    learner, _, wire = learner.partition("+")
+    wire = "compact" if wire else "full"  # compact: each rank's loader expands its own partition's records on the shared GPU
     bs, seq, lr, steps = 16, 96, 0.05, 3
     runs = {}
     for tag, n, m in (("two", 2, 2), ("one", 1, 1)):
         exp, cap = tmp_path / tag / "exp", tmp_path / tag / "cap"
         spec = PipelineSpec(exp_path=str(exp), model="tiny", global_batch=bs, seq_length=seq, attempts=4, steps=steps, optimizer="sgd", lr=lr, param_dtype="fp32",
-                            capture_step0=str(cap), n_problems=5, concurrent_groups=2, stage_timeout_s=600.0, learner=learner, dense=True,
+                            capture_step0=str(cap), n_problems=5, concurrent_groups=2, stage_timeout_s=600.0, learner=learner, dense=True, wire=wire,
                             n_learners=n, n_engines=m, weight_transport=weights if n > 1 else "ipc", share_device=True, extra={"bucket_bytes": 1 << 16})
         res = run_pipeline(spec)
         assert "error" not in res, json.dumps(res.get("error"), indent=1)[:6000]
