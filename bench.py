@@ -1014,6 +1014,28 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    if world > 1:
+        # preflight: ONE tiny collective under a watchdog, so that a fabric / rendezvous problem of the first multi-GPU run ends with a message
+        # that names the rank and the stage instead of a silent hang until the driver's limit (the timed region has no watchdog by design)
+        import threading
+
+        ok = threading.Event()
+        limit = float(os.environ.get("PRL_BENCH_PREFLIGHT_TIMEOUT", 300))
+
+        def preflight_watchdog():
+            if not ok.wait(limit):
+                print(f"bench.py: rank {rank}/{world} ({args.backend}, device {local_rank}): the first all-reduce did not complete in {limit:.0f} s - the process "
+                      f"group formed but a collective hangs (HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, "
+                      f"NCCL_DEBUG={os.environ.get('NCCL_DEBUG')}; rerun with NCCL_DEBUG=INFO)", file=sys.stderr, flush=True)
+                os._exit(3)
+
+        threading.Thread(target=preflight_watchdog, daemon=True).start()
+        probe = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(probe)
+        if args.backend == "nccl":
+            torch.cuda.synchronize()
+        assert int(probe.item()) == world, f"all-reduce of ones over {world} ranks gave {probe.item()}"
+        ok.set()
     # what the process group itself says (never argv): ranks, and how many DISTINCT devices they sit on
     n_ranks, distinct_devices = 1, 1
     if world > 1:

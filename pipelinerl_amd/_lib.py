@@ -225,6 +225,14 @@ def load() -> ctypes.CDLL:
     # torch first: its bundled HIP runtime / RCCL must be the ones the process uses.
     import torch  # noqa: F401
 
+    # ONE RCCL per process: the weight-sync entry points dlopen RCCL at first use (`PRL_RCCL_LIB`, then the loader's search path).
+    # torch ships its own librccl.so next to libtorch; name it, so that a search-path hit on another copy (/opt/rocm/lib) cannot
+    # put a second RCCL runtime beside the one torch.distributed's "nccl" backend already initialised.
+    if "PRL_RCCL_LIB" not in os.environ:
+        bundled = Path(torch.__file__).resolve().parent / "lib" / "librccl.so"
+        if bundled.exists():
+            os.environ["PRL_RCCL_LIB"] = str(bundled)
+
     lib = ctypes.CDLL(str(path), mode=ctypes.RTLD_GLOBAL)
     for name, (restype, argtypes) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
