@@ -573,8 +573,8 @@ class PreprocessorLoop:
         Needs the shm backend and packing.  Sequence parallelism: every rank of an SP group gets the whole record (with the filler
         count) and keeps its `make_slices` slice after expansion (types.py:145-180).  A reference policy here (`ref_model`, KL on):
         K6 and its forward run on THIS GPU as on the full wire, and of the packed block only the `ref_logprobs` column - 4 bytes per
-        token - comes back and rides in the record (`ref_column`).  `oov_patcher` rewrites token ids on the device, which the
-        host-gathered columns would not see: refused.
+        token - comes back and rides in the record (`ref_column`).  `oov_patcher` rewrites token ids on the device: the chunk's patched
+        ids are copied back into its host record (4 bytes per token) before anything is gathered from it.
         `profile`: accumulate host wall time per phase in `self.prof` (seconds; `perf_counter` pairs, no device sync)."""
         from .streams import SingleStreamSpec, StreamRangeSpec
 
@@ -583,8 +583,6 @@ class PreprocessorLoop:
         if wire == "compact":
             if not cfg.seq_packing:
                 raise ValueError("the compact wire carries packed micro-batches (seq_packing=True)")
-            if oov_patcher is not None:
-                raise ValueError("the compact wire gathers token ids from the host records: oov_patcher rewrites them on the device - use wire='full'")
             if torch.device(device).type != "cuda":
                 raise RuntimeError("the preprocessor's kernels need a HIP device; there is no CPU fallback")
         self.wire = wire
@@ -713,6 +711,11 @@ class PreprocessorLoop:
             t = self._tick("h2d", t)
         if self.oov_patcher is not None:
             self.oov_patcher.apply(rag)
+            if self.wire == "compact" and not host.tokens.is_cuda:
+                # the compact records are gathered from the HOST copy of the chunk: bring the patched ids back (4 bytes per token of
+                # this chunk, one copy) so that both wires publish the same tokens
+                host.tokens.copy_(self.down_stager.download(rag.tokens))
+                t = self._tick("oov_d2h", t)
         with self._kernels("K5"):
             prep = populate_rl_data_ragged(rag, self.cfg.eos_token_id, self.cfg.rl, plan=plan_dev)
         t = self._tick("k5_launch", t)

@@ -177,9 +177,7 @@ def test_compact_wire_refusals():
         PreprocessorLoop(cfg(), "cpu", wire="tiny")
     with pytest.raises(ValueError, match="seq_packing"):
         PreprocessorLoop(cfg(seq_packing=False), "cpu", wire="compact")
-    with pytest.raises(ValueError, match="oov_patcher"):
-        PreprocessorLoop(cfg(), "cpu", wire="compact", oov_patcher=object())
-    # sequence parallelism and a reference policy are served by the compact wire (tests/test_gpu_compact_wire.py); it still needs a device
+    # sequence parallelism, a reference policy and the OOV patch are served by the compact wire (tests/test_gpu_compact_wire.py); it still needs a device
     for kw in (dict(), dict(seq_parallel=2, num_trainers=2)):
         with pytest.raises(RuntimeError, match="HIP device"):
             PreprocessorLoop(cfg(**kw), "cpu", wire="compact", ref_model=object() if kw else None)

@@ -76,9 +76,10 @@ class _RefPolicy(torch.nn.Module):
         return types.SimpleNamespace(logits=self.out(torch.tanh(self.emb(input_ids))).float())
 
 
-@pytest.mark.parametrize("trainers,sp,kl", [(1, 1, False), (2, 1, False), (2, 2, False), (1, 1, True), (2, 2, True), (4, 2, True)],
-                         ids=["1_trainer", "2_trainers", "seq_parallel_2", "kl", "seq_parallel_2+kl", "2_leads_x_seq_parallel_2+kl"])
-def test_compact_wire_delivers_the_full_wires_batches(libprl, cuda_device, tmp_path, trainers, sp, kl):
+@pytest.mark.parametrize("trainers,sp,kl,oov", [(1, 1, False, False), (2, 1, False, False), (2, 2, False, False), (1, 1, True, False), (2, 2, True, False),
+                                                (4, 2, True, False), (2, 1, False, True), (2, 2, True, True)],
+                         ids=["1_trainer", "2_trainers", "seq_parallel_2", "kl", "seq_parallel_2+kl", "2_leads_x_seq_parallel_2+kl", "oov_patch", "seq_parallel_2+kl+oov_patch"])
+def test_compact_wire_delivers_the_full_wires_batches(libprl, cuda_device, tmp_path, trainers, sp, kl, oov):
     """Every combination the full wire serves: data-parallel partitions, sequence-parallel slices (types.py:145-180: every rank of the
     group expands the record and keeps its slice, filler included) and a reference policy in the preprocessor (preprocess.py:86-104's
     role: the `ref_logprobs` column comes from its forward, 4 bytes per token cross the bus and ride in the record)."""
@@ -96,6 +97,12 @@ def test_compact_wire_delivers_the_full_wires_batches(libprl, cuda_device, tmp_p
         cfg_kw = dict(num_trainers=trainers, train_batch_size=2, gradient_accumulation_passes=4, seq_length=256, attempts=attempts,
                       rl=RLConfig(kl_coef=0.05 if kl else 0.0), eos_token_id=2, chunk_n_groups=2, seq_parallel=sp)
         ref_model = _RefPolicy(300).to(cuda_device).eval() if kl else None
+        if oov:  # ids 280..299 are not in the tokenizer's vocabulary: replaced by "the" (id 5) on the device (preprocess.py:107-141), on both wires
+            from pipelinerl_amd.preprocess import OovPatcher
+
+            make_patcher = lambda: OovPatcher(range(280), 5, cuda_device)  # noqa: E731
+        else:
+            make_patcher = lambda: None  # noqa: E731
         from pipelinerl_amd.ring import Log
         from pipelinerl_amd.streams import ring_name
 
@@ -103,8 +110,8 @@ def test_compact_wire_delivers_the_full_wires_batches(libprl, cuda_device, tmp_p
             return [Log(ring_name(streams.SingleStreamSpec(exp_path=exp, topic="training_data", partition=p)), reader=True).stats()["records"] for p in range(trainers)]
 
         # publish everything first, then read exactly as many records as each partition's log holds
-        full_pub, full, full_bytes, _ = _run_loop_then_read(streams, tmp_path, cuda_device, "full", n_groups, attempts, raw, cfg_kw, counts, ref_model)
-        cmp_pub, cmp, cmp_bytes, loop = _run_loop_then_read(streams, tmp_path, cuda_device, "compact", n_groups, attempts, raw, cfg_kw, counts, ref_model)
+        full_pub, full, full_bytes, _ = _run_loop_then_read(streams, tmp_path, cuda_device, "full", n_groups, attempts, raw, cfg_kw, counts, ref_model, make_patcher())
+        cmp_pub, cmp, cmp_bytes, loop = _run_loop_then_read(streams, tmp_path, cuda_device, "compact", n_groups, attempts, raw, cfg_kw, counts, ref_model, make_patcher())
         assert full_pub == cmp_pub == n_groups * attempts
         n_real = 0
         for part in range(trainers):
@@ -121,6 +128,9 @@ def test_compact_wire_delivers_the_full_wires_batches(libprl, cuda_device, tmp_p
                     assert a.model_extra["tokens"] == b.model_extra["tokens"]
                     assert torch.equal(a.model_extra["labelled_rows"].cpu(), b.model_extra["labelled_rows"].cpu())
         assert n_real >= 4
+        if oov:
+            ids = torch.cat([b.input_ids.flatten().cpu() for part in cmp for b in part if not b.sentinel])
+            assert int(ids.max()) < 280 and int((ids == 5).sum()) > 0, "out-of-vocabulary ids were patched before the records were gathered"
         if kl:
             assert any(bool((b.ref_logprobs != b.old_logprobs).any()) for part in cmp for b in part if not b.sentinel), "the reference policy's column arrived"
         if sp > 1:  # the slices of one micro-batch sit side by side in the partitions of its SP group and add up to the padded length
@@ -140,7 +150,7 @@ def test_compact_wire_delivers_the_full_wires_batches(libprl, cuda_device, tmp_p
         streams.reset_streams_backend()
 
 
-def _run_loop_then_read(streams, tmp_path, cuda_device, wire, n_groups, attempts, raw, cfg_kw, counts, ref_model=None):
+def _run_loop_then_read(streams, tmp_path, cuda_device, wire, n_groups, attempts, raw, cfg_kw, counts, ref_model=None, oov_patcher=None):
     from pipelinerl_amd.preprocess import PreprocessorConfig, PreprocessorLoop
     from pipelinerl_amd.ragged import RaggedRollouts
 
@@ -149,7 +159,7 @@ def _run_loop_then_read(streams, tmp_path, cuda_device, wire, n_groups, attempts
     with streams.write_to_streams(streams.SingleStreamSpec(exp_path=exp, topic="actor")) as w:
         for g in range(n_groups):
             w.write(RaggedRollouts.from_entries(raw[g * attempts:(g + 1) * attempts]))
-    loop = PreprocessorLoop(PreprocessorConfig(exp_path=exp, **cfg_kw), cuda_device, wire=wire, profile=True, ref_model=ref_model)
+    loop = PreprocessorLoop(PreprocessorConfig(exp_path=exp, **cfg_kw), cuda_device, wire=wire, profile=True, ref_model=ref_model, oov_patcher=oov_patcher)
     published = loop.run(max_published_samples=n_groups * attempts, idle_timeout=2.0)
     n = counts(exp)
     from pipelinerl_amd.finetune_loop import run_data_loader
