@@ -732,11 +732,10 @@ class StreamedLearnerStep(LearnerStep):
             inner = inner.module
         if getattr(inner, "_prl_fused_head", None) is None:
             raise TypeError("StreamedLearnerStep drives a model prepared with pipelinerl_amd.fused_head.install_fused_head")
-        if self.seq_parallel != 1 or self.seq_parallel_group is not None:
-            # the model's own forward (`model(rl_batch=...)`) has no sequence-parallel reduction: slices would be trained as if they
-            # were whole sequences, silently.  `LearnerStep` (rl_step with seq_parallel_group) is the sequence-parallel path.
-            raise ValueError("StreamedLearnerStep does not implement sequence parallelism (seq_parallel must be 1 and seq_parallel_group None); "
-                             "use LearnerStep for seq_parallel > 1")
+        if self.seq_parallel != 1 and self.seq_parallel_group is None:
+            # slices of a packed sequence (types.py:145-180) trained without their group would silently drop the sequence-parallel
+            # reduction of the sequence-level sums (rl/utils.py:194-206); the group is forwarded to the model's forward in `step`
+            raise ValueError("StreamedLearnerStep with seq_parallel > 1 needs seq_parallel_group (the ranks that hold the slices of one sequence)")
         self._stats_dev: list[torch.Tensor] = []
         self._input_sizes: list[int] = []
         # per real micro-batch: samples trained so far - the batch's model version; the most recent 4096 (a run is unbounded)
@@ -768,7 +767,8 @@ class StreamedLearnerStep(LearnerStep):
         do_optimizer_step = self.total_samples == self.target_samples
 
         with self._sync_context(do_optimizer_step):
-            loss, stats_dev = self.model(rl_batch=batch, rl_config=self.rl_config, current_step=m.completed_steps, max_step=self.max_train_steps)
+            sp = {"seq_parallel_group": self.seq_parallel_group} if self.seq_parallel_group is not None else {}  # (finetune_loop.py:768-775)
+            loss, stats_dev = self.model(rl_batch=batch, rl_config=self.rl_config, current_step=m.completed_steps, max_step=self.max_train_steps, **sp)
             if is_sentinel:
                 loss = loss * 0.0
             else:
