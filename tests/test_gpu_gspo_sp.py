@@ -161,7 +161,7 @@ def _streamed_worker(rank: int, world: int, port: int, out_q) -> None:
             step.metrics.completed_steps = case["steps"][0]
             res = step.step(batch)
             errs = []
-            n_seq = len(case["batch"]["seq_boundaries"]) - 1
+            n_seq = len(case["batch"]["seq_boundaries"]) - 1 - (1 if case["batch"].get("padding") else 0)  # the SP filler is not a sample
             if res["did_optimizer_step"] or res["stats"] is not None or step.total_samples != n_seq:
                 errs.append(f"accounting: {res['did_optimizer_step']}, {step.total_samples} samples for {n_seq} sequences on 2 SP ranks")
             loss = float(res["loss"].item())
