@@ -578,6 +578,13 @@ class LearnerStep:
             self._writer_cm = write_to_streams(trainer_stream)
             self._writer = self._writer_cm.__enter__()
         self._counter_device = next(model.parameters()).device if any(True for _ in model.parameters()) else torch.device("cpu")
+        # The per-micro-batch sample counter (finetune_loop.py:709) is summed over the ranks on the HOST.  Under RCCL a device tensor + `.item()`
+        # would drain the GPU's queue once per micro-batch - the synchronisation `StreamedLearnerStep` exists to avoid - so the default
+        # group gets a gloo companion for these 8 bytes (every rank constructs its step, so every rank takes part in creating it); a
+        # caller-supplied subgroup keeps its own backend.
+        self._counter_group = process_group
+        if self.distributed and self.world > 1 and process_group is None and dist.get_backend() == "nccl":
+            self._counter_group = dist.new_group(backend="gloo")
 
     # -- helpers --------------------------------------------------------------------------------
     def _sum_over_ranks(self, value: int) -> int:
@@ -587,9 +594,9 @@ class LearnerStep:
 
         # (a gloo group reduces host memory: a device tensor would be staged through the host behind a stream synchronisation,
         # i.e. drain the GPU once per micro-batch; only RCCL needs the counter on the device)
-        device = "cpu" if dist.get_backend(self.group) == "gloo" else self._counter_device
+        device = "cpu" if dist.get_backend(self._counter_group) == "gloo" else self._counter_device
         t = torch.tensor([value], dtype=torch.int64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._counter_group)
         return int(t.item())
 
     @contextlib.contextmanager
