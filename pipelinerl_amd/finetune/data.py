@@ -261,9 +261,9 @@ def pack_prepared(
     if stager is not None:  # the three plan arrays in one page-locked copy
         d_src, d_dst, d_seg = stager.upload([pk_src, pk_dst, pk_seg])
     else:
-        d_src = torch.from_numpy(pk_src).to(dev, non_blocking=True)
-        d_dst = torch.from_numpy(pk_dst).to(dev, non_blocking=True)
-        d_seg = torch.from_numpy(pk_seg).to(dev, non_blocking=True)
+        from .rl import upload_packed
+
+        d_src, d_dst, d_seg = upload_packed([pk_src, pk_dst, pk_seg], dev)  # one copy
     if m and total:
         # `timer` (bench.py's EventTimer): HIP events around the kernel alone, so that the host planning
         # above (O(#sequences) numpy + three small uploads) is not charged to the kernel's bandwidth

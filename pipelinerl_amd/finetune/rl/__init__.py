@@ -628,6 +628,22 @@ def _csr(keys: np.ndarray) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
 _NP_TORCH = {"int64": torch.int64, "int32": torch.int32, "float32": torch.float32, "float64": torch.float64, "uint8": torch.uint8}
 
 
+def upload_packed(arrays: Sequence[np.ndarray], device) -> list[torch.Tensor]:
+    """Several small host arrays -> device tensors of the same dtype and shape, views into ONE allocation filled by ONE copy
+    (8-byte aligned; a planning table of a few KB costs a copy's fixed latency, not its bandwidth)."""
+    host = [np.ascontiguousarray(a) for a in arrays]
+    offs, total = [], 0
+    for a in host:
+        total += (-total) % 8
+        offs.append(total)
+        total += a.nbytes
+    packed = np.empty(total, dtype=np.uint8)
+    for a, o in zip(host, offs):
+        packed[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+    on_dev = torch.from_numpy(packed).to(device, non_blocking=True)
+    return [on_dev[o:o + a.nbytes].view(_NP_TORCH[a.dtype.name]).view(a.shape) for a, o in zip(host, offs)]
+
+
 def plan_groups(group_index: np.ndarray, step_index: np.ndarray, rollout_index: np.ndarray):
     """Host-side O(S) planning for K5: CSR membership of (group, step) keys and of groups, plus
     the number of distinct rollouts per group (reference groupby keys, rl/__init__.py:464-486)."""
@@ -673,17 +689,7 @@ def populate_rl_data_ragged(rollouts: RaggedRollouts, eos_token_id: int, config:
                 )
             )
         if plan is None:
-            host = [np.ascontiguousarray(a) for a in plan_groups(r.host_group_index, r.host_step_index, r.host_rollout_index)]
-            offs, total = [], 0
-            for a in host:
-                total += (-total) % 8
-                offs.append(total)
-                total += a.nbytes
-            packed = np.empty(total, dtype=np.uint8)
-            for a, o in zip(host, offs):
-                packed[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
-            on_dev = torch.from_numpy(packed).to(dev, non_blocking=True)  # five small arrays, one copy
-            plan = [on_dev[o:o + a.nbytes].view(_NP_TORCH[a.dtype.name]).view(a.shape) for a, o in zip(host, offs)]
+            plan = upload_packed(plan_groups(r.host_group_index, r.host_step_index, r.host_rollout_index), dev)  # five small arrays, one copy
         key_off, group_off = plan[0], plan[2]
         with (timer.time("group_advantages_K5_group_launch") if timer is not None else contextlib.nullcontext()):
             _lib.check(

@@ -155,6 +155,27 @@ class PipelineSpec:
         return self.global_batch if self.max_lag is None else int(self.max_lag)
 
 
+def baseline_spec(config: int, exp_path: str, **overrides: Any) -> PipelineSpec:
+    """BASELINE.json `configs[config]` as a PipelineSpec.  [1]: Qwen2.5-0.5B, one GPU, actor + learner colocated, bs 512 x seq 2048.
+    [2] / [3]: Qwen2.5-7B, bs 4096 x seq 8192 on a node of 4 / 8 GPUs split by the reference's arithmetic (`world.split_gpus`, default
+    fractions 4 : 0 : 4 -> 2 + 2 / 4 + 4), RCCL weight broadcast to the inference GPUs, in-flight updates.  `overrides` replace fields
+    (a reduced `global_batch`, `share_device=True` + `weight_transport="ipc"` to run the topology on one GPU, ...)."""
+    from .world import split_gpus
+
+    if config == 1:
+        kw: dict[str, Any] = {}
+    elif config in (2, 3):
+        part = split_gpus({2: 4, 3: 8}[config])
+        kw = dict(model="7b", global_batch=4096, seq_length=8192, n_learners=part.total_finetune_gpus, n_engines=part.total_actor_llms,
+                  weight_transport="rccl", share_device=False, gradient_checkpointing=True)
+        assert part.weight_update_group_size == kw["n_engines"] + 1
+    else:
+        raise ValueError("configs[1], [2] and [3] are pipeline topologies of this harness ([0] is the CPU plumbing case; [4]'s TP = 2 engines are "
+                         "covered by the TP-aware weight update, tests/test_gpu_multi.py, and its KL loss by PipelineSpec(kl_coef=))")
+    kw.update(overrides)
+    return PipelineSpec(exp_path=exp_path, **kw)
+
+
 def _set_backend(spec: PipelineSpec, owner: bool = False) -> None:
     from . import streams
 

@@ -19,8 +19,11 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3],
+                    help="BASELINE.json configs[k] as given (pipeline_run.baseline_spec): [2] = 7B, 2 + 2 GPUs, RCCL; [3] = 4 + 4; other flags are ignored "
+                         "except --steps / --global-batch / --timeout / --exp-path / --out")
     ap.add_argument("--model", default="0p5b", choices=["0p5b", "7b", "tiny"])
-    ap.add_argument("--global-batch", type=int, default=512)
+    ap.add_argument("--global-batch", type=int, default=None, help="default: 512, or the config's")
     ap.add_argument("--seq-length", type=int, default=2048)
     ap.add_argument("--pack-budget", type=int, default=None, help="tokens per packed micro-batch (default: --seq-length)")
     ap.add_argument("--attempts", type=int, default=8)
@@ -46,10 +49,15 @@ def main():
     from pipelinerl_amd.pipeline_run import PipelineSpec, run_pipeline
 
     exp = a.exp_path or tempfile.mkdtemp(prefix="prl_pipeline_")
-    spec = PipelineSpec(exp_path=exp, model=a.model, global_batch=a.global_batch, seq_length=a.seq_length, pack_budget=a.pack_budget, attempts=a.attempts, steps=a.steps,
-                        max_lag=a.max_lag, weight_update_interval=a.weight_update_interval, dense=a.dense, engine_load=a.engine_load,
-                        gradient_checkpointing=a.gradient_checkpointing, learner=a.learner, wire=a.wire, stage_timeout_s=a.timeout, stacks_after_s=a.stacks_after,
-                        n_learners=a.learners, n_engines=a.engines, weight_transport=a.weights, share_device=not a.own_gpus, kl_coef=a.kl_coef)
+    if a.config is not None:
+        from pipelinerl_amd.pipeline_run import baseline_spec
+
+        over = {"steps": a.steps, "stage_timeout_s": a.timeout, "stacks_after_s": a.stacks_after}
+        if a.global_batch:
+            over["global_batch"] = a.global_batch
+        spec = baseline_spec(a.config, exp, **over)
+    else:
+        spec = _spec_from_flags(a, exp, PipelineSpec)
     res = run_pipeline(spec)
     line = json.dumps(res)
     print(line)
@@ -57,6 +65,13 @@ def main():
         Path(a.out).parent.mkdir(parents=True, exist_ok=True)
         Path(a.out).write_text(line + "\n")
     return 1 if "error" in res else 0
+
+
+def _spec_from_flags(a, exp, PipelineSpec):
+    return PipelineSpec(exp_path=exp, model=a.model, global_batch=a.global_batch or 512, seq_length=a.seq_length, pack_budget=a.pack_budget, attempts=a.attempts, steps=a.steps,
+                        max_lag=a.max_lag, weight_update_interval=a.weight_update_interval, dense=a.dense, engine_load=a.engine_load,
+                        gradient_checkpointing=a.gradient_checkpointing, learner=a.learner, wire=a.wire, stage_timeout_s=a.timeout, stacks_after_s=a.stacks_after,
+                        n_learners=a.learners, n_engines=a.engines, weight_transport=a.weights, share_device=not a.own_gpus, kl_coef=a.kl_coef)
 
 
 if __name__ == "__main__":

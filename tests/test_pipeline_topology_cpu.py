@@ -133,3 +133,19 @@ def test_spec_refuses_impossible_topologies():
     assert s.learner_backend == "nccl" and s.stage_names() == ["engine0", "engine1", "learner0", "learner1", "preprocessor", "actor"]
     s = PipelineSpec(exp_path="x", model="7b", global_batch=4096, seq_length=8192, n_learners=4, n_engines=4, weight_transport="rccl", share_device=False)
     assert str(s.device_of("learner", 3)) == "cuda:7" and str(s.device_of("preprocessor")) == "cuda:4"
+
+
+def test_baseline_configs_as_specs():
+    """BASELINE.json configs[1..3] through `baseline_spec`: the GPU split is the reference's arithmetic (world.py:143-192, fractions 4 : 0 : 4)."""
+    from pipelinerl_amd.pipeline_run import baseline_spec
+
+    c1, c2, c3 = (baseline_spec(k, "x") for k in (1, 2, 3))
+    assert (c1.model, c1.global_batch, c1.seq_length, c1.n_learners, c1.n_engines, c1.share_device, c1.weight_transport) == ("0p5b", 512, 2048, 1, 1, True, "ipc")
+    assert (c2.model, c2.global_batch, c2.seq_length, c2.n_learners, c2.n_engines, c2.share_device, c2.weight_transport) == ("7b", 4096, 8192, 2, 2, False, "rccl")
+    assert (c3.n_learners, c3.n_engines) == (4, 4) and c3.learner_backend == "nccl"
+    assert [str(c3.device_of("engine", e)) for e in range(4)] == [f"cuda:{e}" for e in range(4)]
+    assert [str(c3.device_of("learner", r)) for r in range(4)] == [f"cuda:{4 + r}" for r in range(4)]
+    one_gpu = baseline_spec(2, "x", global_batch=16, share_device=True, weight_transport="ipc")  # the topology on one GPU, reduced batch
+    assert one_gpu.n_learners == 2 and one_gpu.learner_backend == "gloo" and str(one_gpu.device_of("learner", 1)) == "cuda:0"
+    with pytest.raises(ValueError, match="configs"):
+        baseline_spec(4, "x")
