@@ -128,7 +128,9 @@ class ScriptedEngine:
 
     async def collective_rpc(self, method: str, args: tuple = ()) -> list:
         loop = asyncio.get_running_loop()
-        out = [await loop.run_in_executor(None, lambda w=w: getattr(w, method)(*args)) for w in self.workers]
+        # every worker at once, like an engine's collective_rpc to its tensor-parallel worker processes: the TP ranks of a sharded update
+        # each wait in a collective with the trainer, one after the other they would wait for each other
+        out = list(await asyncio.gather(*[loop.run_in_executor(None, lambda w=w: getattr(w, method)(*args)) for w in self.workers]))
         if method == "receive_weight_update":
             try:
                 self.current_version = json.loads(args[0]).get("version", self.current_version)

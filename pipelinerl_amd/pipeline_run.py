@@ -47,6 +47,7 @@ MODEL_SHAPES = {
     # name: vocab, hidden, intermediate, layers, heads, kv heads, tied embeddings   (Qwen2.5 model cards; weight_sync_probe.qwen25_shapes)
     "0p5b": dict(vocab=151936, hidden=896, inter=4864, layers=24, heads=14, kv=2, tied=True),
     "7b": dict(vocab=152064, hidden=3584, inter=18944, layers=28, heads=28, kv=4, tied=False),
+    "32b": dict(vocab=152064, hidden=5120, inter=27648, layers=64, heads=40, kv=8, tied=False),
     "tiny": dict(vocab=512, hidden=64, inter=128, layers=2, heads=4, kv=2, tied=True),
 }
 
@@ -85,7 +86,8 @@ class PipelineSpec:
     stacks_after_s: float = 0.0        # diagnosis: every stage still alive after this many seconds dumps its threads' Python stacks
     device: int = 0
     n_learners: int = 1                # data-parallel learner ranks (lead trainers; seq_parallel = 1)
-    n_engines: int = 1                 # inference engines, one GPU (one weight-group member) each
+    n_engines: int = 1                 # inference engines, `engine_tp` GPUs (weight-group members) each
+    engine_tp: int = 1                 # tensor-parallel degree of an engine: > 1 = every TP rank receives only ITS slices (`transport: sharded`, tp_shard.py)
     weight_transport: str = "ipc"      # "ipc" (HIP IPC handles, engines colocated with learner 0) | "rccl" | "gloo" (group of n_engines + 1)
     grad_backend: str | None = None    # learners' process group: default "nccl" with one GPU per learner, "gloo" when they share a device / on CPU
     share_device: bool = True          # every stage on `device`; False: engines on GPUs [device, device + M), learners on the N after them (world.py:143-192)
@@ -109,6 +111,8 @@ class PipelineSpec:
         if self.weight_transport == "rccl" and self.share_device:
             raise ValueError("weight_transport 'rccl' needs one GPU per member of the weight-update group (RCCL refuses two ranks on one device): "
                              "share_device=False, or 'gloo' / 'ipc' on a shared device")
+        if self.engine_tp < 1 or (self.engine_tp > 1 and self.weight_transport == "ipc"):
+            raise ValueError("engine_tp > 1 is the sharded update over a per-TP-rank group: weight_transport 'rccl' or 'gloo'")
         if self.platform not in ("cuda", "cpu"):
             raise ValueError(f"platform {self.platform!r}")
         if self.platform == "cpu" and (self.weight_transport != "gloo" or not self.hooks):
@@ -120,9 +124,10 @@ class PipelineSpec:
             return self.grad_backend
         return "nccl" if (self.platform == "cuda" and not self.share_device) else "gloo"
 
-    def device_of(self, stage: str, index: int = 0):
-        """The torch device of a stage process.  Not shared: inference GPUs first, learner GPUs after them - the order in which the
-        reference's WorldMap hands out a node's GPUs (world.py:143-192); the preprocessor computes on the first learner's GPU."""
+    def device_of(self, stage: str, index: int = 0, tp_rank: int = 0):
+        """The torch device of a stage process (of TP rank `tp_rank` of engine `index`).  Not shared: inference GPUs first (engine e, TP
+        rank t on GPU e * engine_tp + t), learner GPUs after them - the order in which the reference's WorldMap hands out a node's GPUs
+        (world.py:143-192); the preprocessor computes on the first learner's GPU."""
         import torch
 
         if self.platform == "cpu":
@@ -130,8 +135,13 @@ class PipelineSpec:
         if self.share_device:
             return torch.device("cuda", self.device)
         if stage == "engine":
-            return torch.device("cuda", self.device + index)
-        return torch.device("cuda", self.device + self.n_engines + (index if stage == "learner" else 0))
+            return torch.device("cuda", self.device + index * self.engine_tp + tp_rank)
+        return torch.device("cuda", self.device + self.n_engines * self.engine_tp + (index if stage == "learner" else 0))
+
+    @property
+    def weight_group_size(self) -> int:
+        """Trainer rank 0 + every inference-worker GPU (world.py:192)."""
+        return 1 + self.n_engines * self.engine_tp
 
     def stage_names(self) -> list[str]:
         """Report names, start order: engines, learners, preprocessor, actor.  A single learner / engine keeps the bare name."""
@@ -158,7 +168,8 @@ class PipelineSpec:
 def baseline_spec(config: int, exp_path: str, **overrides: Any) -> PipelineSpec:
     """BASELINE.json `configs[config]` as a PipelineSpec.  [1]: Qwen2.5-0.5B, one GPU, actor + learner colocated, bs 512 x seq 2048.
     [2] / [3]: Qwen2.5-7B, bs 4096 x seq 8192 on a node of 4 / 8 GPUs split by the reference's arithmetic (`world.split_gpus`, default
-    fractions 4 : 0 : 4 -> 2 + 2 / 4 + 4), RCCL weight broadcast to the inference GPUs, in-flight updates.  `overrides` replace fields
+    fractions 4 : 0 : 4 -> 2 + 2 / 4 + 4), RCCL weight broadcast to the inference GPUs, in-flight updates.  [4]: Qwen2.5-32B, two TP = 2
+    engines + 4 learners on 8 GPUs, KL-to-reference on, every TP rank receiving only its slices.  `overrides` replace fields
     (a reduced `global_batch`, `share_device=True` + `weight_transport="ipc"` to run the topology on one GPU, ...)."""
     from .world import split_gpus
 
@@ -169,9 +180,14 @@ def baseline_spec(config: int, exp_path: str, **overrides: Any) -> PipelineSpec:
         kw = dict(model="7b", global_batch=4096, seq_length=8192, n_learners=part.total_finetune_gpus, n_engines=part.total_actor_llms,
                   weight_transport="rccl", share_device=False, gradient_checkpointing=True)
         assert part.weight_update_group_size == kw["n_engines"] + 1
+    elif config == 4:
+        # Qwen2.5-32B, TP = 2 inference x 2 actors + 4 learner GPUs, KL-to-reference on (kl_coef: conf/deepscaler15b.yaml:34)
+        part = split_gpus(8, tensor_parallel_size=2)
+        kw = dict(model="32b", global_batch=4096, seq_length=8192, n_learners=part.total_finetune_gpus, n_engines=part.total_actor_llms, engine_tp=part.gpus_per_llm,
+                  weight_transport="rccl", share_device=False, gradient_checkpointing=True, kl_coef=0.001)
+        assert part.weight_update_group_size == 1 + kw["n_engines"] * kw["engine_tp"]
     else:
-        raise ValueError("configs[1], [2] and [3] are pipeline topologies of this harness ([0] is the CPU plumbing case; [4]'s TP = 2 engines are "
-                         "covered by the TP-aware weight update, tests/test_gpu_multi.py, and its KL loss by PipelineSpec(kl_coef=))")
+        raise ValueError("configs[1] .. [4] are the pipeline topologies ([0] is the reference's CPU plumbing case)")
     kw.update(overrides)
     return PipelineSpec(exp_path=exp_path, **kw)
 
@@ -394,23 +410,38 @@ def engine_stage(spec: PipelineSpec, index: int = 0, name: str = "engine") -> No
     cuda = dev.type == "cuda"
     if cuda:
         torch.cuda.set_device(dev)
-    _trace(spec, name, "building the policy")
-    model = _hook(spec, "build_policy", build_policy)(spec, dev, seed=spec.seed + 999 + index)  # different values than the trainer's: an update must really land
-    _trace(spec, name, "policy built")
-    model.eval()
-    for p in model.parameters():
-        p.requires_grad_(False)
-    worker = StandaloneWeightReceiver(model, dev)
-    gen_tokens = min(256, spec.seq_length)
-    ids = torch.randint(3, spec.shape["vocab"], (4, gen_tokens), device=dev)
+    tp = spec.engine_tp
+    if tp > 1:
+        # a tensor-parallel engine: `tp` workers, each holding ITS slices of every parameter in vLLM's stacked layout (qkv_proj, gate_up_proj);
+        # they start at zero, so an update must really land.  Shapes / dtypes come from the policy class on the meta device: no weights here.
+        from .vllm_worker import StackedShardReceiver
 
-    def generate_step():
-        with torch.no_grad():
-            (model.model if hasattr(model, "model") else model)(input_ids=ids)
-        if cuda:
-            torch.cuda.synchronize(dev)
+        meta = _hook(spec, "build_policy", build_policy)(spec, torch.device("meta"), seed=spec.seed)
+        named = [(n, tuple(p.shape)) for n, p in meta.named_parameters()]
+        dtypes = {n: p.dtype for n, p in meta.named_parameters()}
+        devs = [spec.device_of("engine", index, t) for t in range(tp)]
+        workers = [StackedShardReceiver(named, dtypes.__getitem__, devs[t], t, tp, kv_heads=spec.shape["kv"]) for t in range(tp)]
+        model, worker = None, workers[0]
+        engine = ScriptedEngine(workers, None)
+    else:
+        _trace(spec, name, "building the policy")
+        model = _hook(spec, "build_policy", build_policy)(spec, dev, seed=spec.seed + 999 + index)  # different values than the trainer's: an update must really land
+        _trace(spec, name, "policy built")
+        model.eval()
+        for p in model.parameters():
+            p.requires_grad_(False)
+        worker = StandaloneWeightReceiver(model, dev)
+        workers = [worker]
+        gen_tokens = min(256, spec.seq_length)
+        ids = torch.randint(3, spec.shape["vocab"], (4, gen_tokens), device=dev)
 
-    engine = ScriptedEngine([worker], generate_step if spec.engine_load else None)
+        def generate_step():
+            with torch.no_grad():
+                (model.model if hasattr(model, "model") else model)(input_ids=ids)
+            if cuda:
+                torch.cuda.synchronize(dev)
+
+        engine = ScriptedEngine(workers, generate_step if spec.engine_load else None)
     manager = InflightUpdateManager(engine)
     server = UpdateServer(manager)
     (Path(spec.exp_path) / "reports").mkdir(parents=True, exist_ok=True)
@@ -419,17 +450,39 @@ def engine_stage(spec: PipelineSpec, index: int = 0, name: str = "engine") -> No
     tmp.rename(Path(spec.exp_path) / "reports" / f"engine_url_{index}.txt")
     _trace(spec, name, "serving " + server.url)
     if spec.weight_transport != "ipc":
-        # the weight-update group: trainer rank 0 + every engine GPU, this engine is rank 1 + index (vllm1.py:64-108, world.py:192);
-        # blocks until the trainer and the other engines have joined
-        worker.init_actor_update_group(index, 1, f"tcp://127.0.0.1:{spec.wsync_port}", spec.n_engines + 1, backend=spec.weight_transport)
-        _trace(spec, name, f"joined the weight-update group as rank {worker.pg_rank} of {spec.n_engines + 1} ({spec.weight_transport})")
+        # the weight-update group: trainer rank 0 + every engine GPU, worker (engine e, TP rank t) is rank 1 + e * tp + t (vllm1.py:64-108,
+        # world.py:192); with tp > 1 a worker joins the group of ITS TP rank only.  Blocks until the trainer and the other members have joined.
+        import threading
+
+        init = f"tcp://127.0.0.1:{spec.wsync_port}"
+        errors: list = []
+
+        def join(w):
+            try:
+                if cuda:
+                    torch.cuda.set_device(w.device)
+                w.init_actor_update_group(index, tp, init, spec.weight_group_size, tp_sharded=tp > 1, backend=spec.weight_transport)
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=join, args=(w,)) for w in workers]
+        for t_ in threads:
+            t_.start()
+        for t_ in threads:
+            t_.join()
+        if errors:
+            raise errors[0]
+        _trace(spec, name, f"joined the weight-update group as rank(s) {[w.pg_rank for w in workers]} of {spec.weight_group_size} ({spec.weight_transport})")
     state = TrainerState(Path(spec.exp_path))
     state.start_listening()
     t0 = time.perf_counter()
     state.wait_for_training_done(timeout=spec.stage_timeout_s)
     wall = time.perf_counter() - t0
     time.sleep(0.2)  # a POST that raced the TrainingDone message finishes
-    probe = _param_probe(model.named_parameters())
+    if tp > 1:  # per TP rank: the fingerprint of ITS slices (trainer-side names -> views of the stacked storage)
+        probe = [_param_probe(w._weight_shard_destinations().items()) for w in workers]
+    else:
+        probe = _param_probe(model.named_parameters())
     tm = manager.timings
     med = lambda k: sorted(t[k] for t in tm)[len(tm) // 2] if tm else None  # noqa: E731
     grp = getattr(worker, "model_update_group", None)
@@ -439,10 +492,14 @@ def engine_stage(spec: PipelineSpec, index: int = 0, name: str = "engine") -> No
                          "busy_s": sum(t["total_s"] for t in tm), "busy_frac": sum(t["total_s"] for t in tm) / max(wall, 1e-9),
                          "generation_quanta": engine.quanta, "generation_quanta_by_version": {str(k): v for k, v in engine.quanta_by_version.items()},
                          "engine_load": spec.engine_load, "device": str(dev), "weight_transport": spec.weight_transport,
-                         "weight_group": ({"rank": worker.pg_rank, "size": grp.comm_size()[0], "bytes_received": getattr(grp, "bytes_moved", None)}
+                         "engine_tp": tp,
+                         "weight_group": ({"rank": worker.pg_rank, "size": grp.comm_size()[0], "bytes_received": getattr(grp, "bytes_moved", None),
+                                           "ranks": [w.pg_rank for w in workers],
+                                           "bytes_received_per_tp_rank": [getattr(w.model_update_group, "bytes_moved", None) for w in workers]}
                                           if grp is not None else None)})
     engine.shutdown()
-    worker.close_communicator()
+    for w in workers:
+        w.close_communicator()
     server.close()
 
 
@@ -489,7 +546,7 @@ def learner_stage(spec: PipelineSpec, rank: int = 0, name: str = "learner") -> N
     param_bytes = sum(p.numel() * p.element_size() for p in model.parameters())
     topic = streams.SingleStreamSpec(exp_path=Path(spec.exp_path), topic=TRAINER_TOPIC)
     urls: list[str] = []
-    group = None
+    group = groups = None
     if main:
         # wait for every inference server like the reference does (finetune_loop.py:470)
         deadline = time.time() + spec.stage_timeout_s
@@ -501,15 +558,26 @@ def learner_stage(spec: PipelineSpec, rank: int = 0, name: str = "learner") -> N
                 time.sleep(0.05)
             urls.append(url_file.read_text().strip())
         _trace(spec, name, "engines found at " + ", ".join(urls))
-        if spec.weight_transport != "ipc":
+        if spec.weight_transport != "ipc" and spec.engine_tp > 1:
+            from .weight_sync import weight_sync_tp_groups
+
+            # one group per tensor-parallel rank: the trainer + that TP rank of every engine; each carries only that rank's slices
+            groups = weight_sync_tp_groups(spec.weight_transport, f"tcp://127.0.0.1:{spec.wsync_port}", 0, spec.weight_group_size, spec.engine_tp, dev,
+                                           timeout_s=spec.stage_timeout_s)
+            group = groups[0]
+            _trace(spec, name, f"{len(groups)} weight-update groups (one per TP rank) of {group.comm_size()[0]} formed over {spec.weight_transport}")
+        elif spec.weight_transport != "ipc":
             from .weight_sync import weight_sync_group
 
-            group = weight_sync_group(spec.weight_transport, f"tcp://127.0.0.1:{spec.wsync_port}", 0, spec.n_engines + 1, dev, timeout_s=spec.stage_timeout_s)
+            group = weight_sync_group(spec.weight_transport, f"tcp://127.0.0.1:{spec.wsync_port}", 0, spec.weight_group_size, dev, timeout_s=spec.stage_timeout_s)
             _trace(spec, name, f"weight-update group of {group.comm_size()[0]} formed over {spec.weight_transport}")
-    transport = "ipc" if spec.weight_transport == "ipc" else "bucketed"
+    transport = "ipc" if spec.weight_transport == "ipc" else ("sharded" if spec.engine_tp > 1 else "bucketed")
     # every rank owns a manager and calls send_weight_update (the call ends in a barrier among the learners); rank 0 sends (finetune_loop.py:205-292)
-    mgr = WeightUpdateManager(llm_urls=urls, accelerated_model=model, update_stream=topic if main else None, actor_update_group=group,
-                              is_main_process=main, transport=transport, bucket_bytes=int(spec.extra.get("bucket_bytes", 1 << 30)))
+    sharded = transport == "sharded"
+    mgr = WeightUpdateManager(llm_urls=urls, accelerated_model=model, update_stream=topic if main else None,
+                              actor_update_group=(groups if main else [None] * spec.engine_tp) if sharded else group,
+                              is_main_process=main, transport=transport, bucket_bytes=int(spec.extra.get("bucket_bytes", 1 << 30)),
+                              kv_heads=spec.shape["kv"] if sharded else None)
     if main and transport == "ipc":
         from .weight_sync import ColocatedSender
 
@@ -556,7 +624,19 @@ def learner_stage(spec: PipelineSpec, rank: int = 0, name: str = "learner") -> N
     mgr.send_weight_update(step.metrics.samples)
     first_sync_ms = 1e3 * (time.perf_counter() - t0)
     _trace(spec, name, f"weight version 0 acknowledged after {first_sync_ms:.0f} ms")
-    probes = {str(step.metrics.samples): _param_probe(model.named_parameters())}
+    def fingerprints():
+        """The trainer's weights as the engines must hold them: whole, and - for tensor-parallel engines - every TP rank's slices."""
+        full = _param_probe(model.named_parameters())
+        if spec.engine_tp == 1:
+            return full, None
+        from .tp_shard import plan_tp_shards, shard_view
+
+        named = list(model.named_parameters())
+        cuts = plan_tp_shards([(n, tuple(p.shape)) for n, p in named], spec.engine_tp, spec.shape["kv"])
+        return full, [_param_probe((n, shard_view(p.detach(), cuts[n], t, spec.engine_tp)) for n, p in named) for t in range(spec.engine_tp)]
+
+    probes, tp_probes = {}, {}
+    probes[str(step.metrics.samples)], tp_probes[str(step.metrics.samples)] = fingerprints()
 
     q: queue.Queue = queue.Queue(maxsize=8)
     stop = threading.Event()
@@ -611,7 +691,7 @@ def learner_stage(spec: PipelineSpec, rank: int = 0, name: str = "learner") -> N
             sent = step.maybe_send_weights()
             if sent:
                 sync_ms.append(1e3 * (time.perf_counter() - t1))
-                probes[str(step.metrics.samples)] = _param_probe(model.named_parameters())
+                probes[str(step.metrics.samples)], tp_probes[str(step.metrics.samples)] = fingerprints()
             now = time.perf_counter()
             step_marks.append({"step": step.metrics.completed_steps, "wall_s": now - t_step, "waiting_for_data_s": wait_step,
                                "weight_sync_ms": sync_ms[-1] if sent else None, "compute_s": t_opt - t_step - wait_step, "loss": last_loss})
@@ -631,7 +711,9 @@ def learner_stage(spec: PipelineSpec, rank: int = 0, name: str = "learner") -> N
     wire_label = {"ipc": "hip_ipc_colocated", "rccl": "rccl_xgmi", "gloo": "gloo_host_staged"}[spec.weight_transport]
     _report(spec, name, {
         "rank": rank, "world": world, "device": str(dev), "grad_backend": spec.learner_backend if world > 1 else None,
-        "weight_group": ({"size": group.comm_size()[0], "bytes_sent": getattr(group, "bytes_moved", None)} if group is not None else None),
+        "weight_group": ({"size": group.comm_size()[0], "bytes_sent": getattr(group, "bytes_moved", None),
+                          "bytes_sent_per_tp_rank": [getattr(g, "bytes_moved", None) for g in groups] if groups else None,
+                          "param_bytes": param_bytes} if group is not None else None),
         "completed_steps": step.metrics.completed_steps, "samples": step.metrics.samples, "local_samples": step.local_samples, "micro_batches": micro_batches, "tokens": tokens,
         "wall_s": wall, "waiting_for_data_s": wait_s, "busy_s": wall - wait_s, "busy_frac": (wall - wait_s) / max(wall, 1e-9),
         "init_s": init_s, "params": n_params, "param_bytes": param_bytes,
@@ -645,11 +727,11 @@ def learner_stage(spec: PipelineSpec, rank: int = 0, name: str = "learner") -> N
         "batch_queue_depth": {"median": sorted(depth)[len(depth) // 2] if depth else 0, "max": max(depth) if depth else 0, "maxsize": 8},
         "lag_optimizer_steps_histogram": {str(k): v for k, v in sorted(hist.items())},
         "lag_what": "per micro-batch: (samples trained when it is consumed - model_version stamped on its oldest rollout) // samples per step",
-        "samples_too_old_to_train": step.metrics.samples_too_old_to_train, "param_probes": probes, "final_loss": last_loss, "learner": spec.learner,
+        "samples_too_old_to_train": step.metrics.samples_too_old_to_train, "param_probes": probes, "param_probes_per_tp_rank": tp_probes, "final_loss": last_loss, "learner": spec.learner,
         "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9 if cuda else None})
     # (the exported buckets are not freed here: the engine may still have them mapped - they go with the process)
-    if group is not None:
-        group.close()
+    for g in (groups or ([group] if group is not None else [])):
+        g.close()
     if world > 1:
         import torch.distributed as dist
 
@@ -704,7 +786,7 @@ def run_pipeline(spec: PipelineSpec, timeout_s: float | None = None) -> dict:
     if spec.platform == "cuda" and not spec.share_device:
         import torch
 
-        need, have = spec.device + spec.n_engines + spec.n_learners, torch.cuda.device_count()
+        need, have = spec.device + spec.n_engines * spec.engine_tp + spec.n_learners, torch.cuda.device_count()
         if have < need:
             raise RuntimeError(f"{spec.n_engines} engine + {spec.n_learners} learner GPUs from device {spec.device} on need {need} devices, {have} visible "
                                "(share_device=True runs the same topology on one GPU, with weight_transport 'ipc' or 'gloo')")
@@ -792,7 +874,8 @@ def summarize(spec: PipelineSpec, r: dict) -> dict:
     last = str(E.get("last_version"))
     probes_agree = None
     if last in L.get("param_probes", {}):  # EVERY engine holds the trainer's weights of the last version it acknowledged
-        probes_agree = all(str(r[n].get("last_version")) == last and L["param_probes"][last] == r[n]["param_probe"] for n in eng)
+        want = L["param_probes"][last] if spec.engine_tp == 1 else L["param_probes_per_tp_rank"][last]  # tp > 1: every TP rank ITS slices
+        probes_agree = all(str(r[n].get("last_version")) == last and want == r[n]["param_probe"] for n in eng)
     out = {
         "samples_per_s": L["steady_state"]["samples_per_s"], "s_per_step": L["steady_state"]["s_per_step"], "steady_state_steps": L["steady_state"]["steps"],
         "tokens_per_s": sum(r[n]["tokens"] for n in lrn) / max(L["wall_s"], 1e-9), "optimizer_steps": L["completed_steps"],
@@ -810,8 +893,8 @@ def summarize(spec: PipelineSpec, r: dict) -> dict:
         "actor_blocked_by_lag_s": A["blocked_by_lag_s"], "preprocessor_backpressure_waits": P["backpressure_waits"],
         "engine_weights_equal_trainer_at_last_version": probes_agree, "final_loss": L["final_loss"], "learner_peak_memory_GB": L["peak_memory_GB"],
     }
-    if len(lrn) > 1 or len(eng) > 1:
-        out["topology"] = {"learners": len(lrn), "engines": len(eng), "grad_backend": L.get("grad_backend"), "weight_transport": L["weight_sync"]["transport"],
+    if len(lrn) > 1 or len(eng) > 1 or spec.engine_tp > 1:
+        out["topology"] = {"learners": len(lrn), "engines": len(eng), "engine_tp": spec.engine_tp, "grad_backend": L.get("grad_backend"), "weight_transport": L["weight_sync"]["transport"],
                            "devices": {n: r[n].get("device") for n in lrn + eng},
                            "micro_batches_per_learner": {n: r[n]["micro_batches"] for n in lrn}, "samples_per_learner": {n: r[n].get("local_samples") for n in lrn},
                            "updates_per_engine": {n: r[n]["updates"] for n in eng}}

@@ -47,11 +47,10 @@ class WorkerExtension:
         logger.info(f"[INIT_ACTOR_UPDATE_GROUP]: actor {actor_idx}, ngpus {actor_ngpus}, rank {self.rank}, pg_rank {self.pg_rank}, "
                     f"init {weight_update_group_init_method}, world {weight_update_group_world_size}, tp_sharded {tp_sharded}")
         if tp_sharded:
-            if backend != "rccl":
-                raise ValueError("the tensor-parallel update groups are RCCL communicators")
-            self.model_update_group = WeightSyncGroup.tp_shard_groups(
-                weight_update_group_init_method, rank=self.pg_rank, world_size=weight_update_group_world_size, tp_size=actor_ngpus,
-                device=self.device)[0]
+            from .weight_sync import weight_sync_tp_groups
+
+            self.model_update_group = weight_sync_tp_groups(backend, weight_update_group_init_method, self.pg_rank, weight_update_group_world_size,
+                                                            actor_ngpus, self.device)[0]
             self.tp_rank, self.tp_size = self.rank, actor_ngpus
         else:
             from .weight_sync import weight_sync_group

@@ -276,6 +276,30 @@ class GlooWeightSyncGroup:
         pg = dist.ProcessGroupGloo(dist.PrefixStore("prl_wsync_gloo", store), rank, world_size, timeout)
         return cls(pg, store, rank, world_size, device)
 
+    @classmethod
+    def tp_shard_groups(cls, init_method: str, rank: int, world_size: int, tp_size: int, device: torch.device,
+                        timeout_s: float = 300.0) -> list["GlooWeightSyncGroup"]:
+        """The groups of the TP-aware update over gloo, same layout as `WeightSyncGroup.tp_shard_groups`: one group per tensor-parallel
+        rank t = the trainer (rank 0 in each) + the workers that hold TP rank t of their engine (global rank r >= 1 is TP rank
+        (r - 1) % tp_size of engine (r - 1) // tp_size, vllm1.py:71).  The trainer gets all `tp_size` groups, a worker a one-element list."""
+        import torch.distributed as dist
+
+        if (world_size - 1) % tp_size:
+            raise ValueError(f"{world_size - 1} workers do not form engines of {tp_size} TP ranks")
+        n_engines = (world_size - 1) // tp_size
+        u = urlparse(init_method)
+        timeout = datetime.timedelta(seconds=timeout_s)
+        store = dist.TCPStore(u.hostname or "127.0.0.1", u.port or 9000, world_size, is_master=(rank == 0), timeout=timeout, wait_for_workers=False)
+
+        def group(t: int, r: int) -> "GlooWeightSyncGroup":
+            pg = dist.ProcessGroupGloo(dist.PrefixStore(f"prl_wsync_gloo/tp{t}", store), r, 1 + n_engines, timeout)
+            return cls(pg, store, r, 1 + n_engines, device)
+
+        if rank == 0:
+            return [group(t, 0) for t in range(tp_size)]  # group t completes when its workers have joined
+        t, engine = (rank - 1) % tp_size, (rank - 1) // tp_size
+        return [group(t, 1 + engine)]
+
     def comm_size(self) -> tuple[int, int]:
         return self._pg.size(), self._pg.rank()
 
@@ -315,6 +339,15 @@ def weight_sync_group(backend: str, init_method: str, rank: int, world_size: int
         return WeightSyncGroup.from_init_method(init_method, rank, world_size, device, timeout_s)
     if backend == "gloo":
         return GlooWeightSyncGroup.from_init_method(init_method, rank, world_size, device, timeout_s)
+    raise ValueError(f"weight-update group backend {backend!r}: 'rccl' or 'gloo'")
+
+
+def weight_sync_tp_groups(backend: str, init_method: str, rank: int, world_size: int, tp_size: int, device: torch.device, timeout_s: float = 300.0) -> list:
+    """The per-TP-rank groups of the sharded update (`transport: sharded`) over `rccl` or `gloo`."""
+    if backend == "rccl":
+        return WeightSyncGroup.tp_shard_groups(init_method, rank, world_size, tp_size, device, timeout_s)
+    if backend == "gloo":
+        return GlooWeightSyncGroup.tp_shard_groups(init_method, rank, world_size, tp_size, device, timeout_s)
     raise ValueError(f"weight-update group backend {backend!r}: 'rccl' or 'gloo'")
 
 

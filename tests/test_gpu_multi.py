@@ -240,8 +240,9 @@ def test_native_learner_step_under_ddp_over_rccl(libprl, cuda_device, tmp_path):
     run_two_rank_check(cuda_device, tmp_path, backend="nccl", own_gpu=True)
 
 
-@pytest.mark.parametrize("n_learners,n_engines", [(1, 1), (2, 2), (4, 4)], ids=["1+1", "configs2_2+2", "configs3_4+4"])
-def test_pipeline_learners_and_engines_on_their_own_gpus_over_rccl(libprl, tmp_path, n_learners, n_engines):
+@pytest.mark.parametrize("n_learners,n_engines,tp", [(1, 1, 1), (2, 2, 1), (4, 4, 1), (1, 1, 2), (4, 2, 2)],
+                         ids=["1+1", "configs2_2+2", "configs3_4+4", "1+1xTP2", "configs4_4+2xTP2"])
+def test_pipeline_learners_and_engines_on_their_own_gpus_over_rccl(libprl, tmp_path, n_learners, n_engines, tp):
     """BASELINE configs[2] / [3] as they are meant to run: every engine and every learner rank on its OWN GPU (engines first, world.py:143-192),
     gradients over RCCL, trainer rank 0 -> the weight-update group of M + 1 over RCCL / xGMI after every optimizer step.  The same
     `run_pipeline` the 1-GPU tests drive with gloo / HIP IPC (tests/test_gpu_pipeline_procs.py, tests/test_pipeline_topology_cpu.py)."""
@@ -249,22 +250,24 @@ def test_pipeline_learners_and_engines_on_their_own_gpus_over_rccl(libprl, tmp_p
 
     from pipelinerl_amd.pipeline_run import PipelineSpec, run_pipeline
 
-    need = n_learners + n_engines
+    need = n_learners + n_engines * tp
     if torch.cuda.device_count() < need:
         pytest.skip(f"needs {need} GPUs")
     bs, steps = 32, 3
     spec = PipelineSpec(exp_path=str(tmp_path / "exp"), model="tiny", global_batch=bs, seq_length=128, attempts=4, steps=steps, n_problems=5, concurrent_groups=2,
-                        stage_timeout_s=600.0, n_learners=n_learners, n_engines=n_engines, weight_transport="rccl", share_device=False, stacks_after_s=300.0)
+                        stage_timeout_s=600.0, n_learners=n_learners, n_engines=n_engines, engine_tp=tp, weight_transport="rccl", share_device=False, stacks_after_s=300.0,
+                        kl_coef=0.001 if tp > 1 else 0.0)
     res = run_pipeline(spec)
     s = res.get("summary") or {}
-    _diag({"test": "pipeline_rccl", "learners": n_learners, "engines": n_engines, "env": _env_diag(), "error": res.get("error"),
+    _diag({"test": "pipeline_rccl", "learners": n_learners, "engines": n_engines, "engine_tp": tp, "env": _env_diag(), "error": res.get("error"),
            "topology": s.get("topology"), "weight_sync_under_load_ms": s.get("weight_sync_under_load_ms"), "samples_per_s": s.get("samples_per_s")})
     assert "error" not in res, json.dumps(res.get("error"), indent=1)[:6000]
     st = res["stages"]
     eng = [n for n in st if n.startswith("engine")]
     lrn = [n for n in st if n.startswith("learner")]
-    assert len({st[n]["device"] for n in eng + lrn}) == need, "one GPU per engine and per learner rank"
+    assert len({st[n]["device"] for n in eng + lrn}) == n_learners + n_engines, "one (first) GPU per engine and per learner rank"
     assert all(st[n]["completed_steps"] == steps and st[n]["local_samples"] == steps * bs // n_learners for n in lrn)
-    assert all(st[n]["updates"] == steps + 1 and st[n]["weight_group"]["size"] == n_engines + 1 for n in eng)
+    assert all(st[n]["updates"] == steps + 1 and st[n]["weight_group"]["size"] == n_engines + 1 for n in eng)  # (tp > 1: the size of ONE TP rank's group)
+    assert sorted(r for n in eng for r in st[n]["weight_group"]["ranks"]) == list(range(1, 1 + n_engines * tp))
     assert s["engine_weights_equal_trainer_at_last_version"] is True
     assert s["weight_sync_under_load_ms"]["transport"] == "rccl_xgmi"

@@ -231,3 +231,28 @@ def test_pipeline_with_reference_policy_compact_wire_equals_full_wire(libprl, cu
             lab = a["labels"] != -100
             assert bool((a["ref_logprobs"][lab] != a["old_logprobs"][lab]).any()) and bool((a["ref_logprobs"][~lab] == 0).all())
     assert fm["rl/loss"] == cm["rl/loss"] and fm["rl/kl"] == cm["rl/kl"] and abs(fm["rl/kl"]) > 0
+
+
+def test_pipeline_with_a_tensor_parallel_engine_on_one_gpu(libprl, cuda_device, tmp_path):
+    """BASELINE configs[4]'s engine layout in the pipeline, on this one GPU: two learner ranks, one TP = 2 engine (two inference workers holding
+    vLLM-style stacked slices: qkv_proj, gate_up_proj, row-cut o_proj / down_proj, vocabulary-cut embeddings), KL-to-reference on.  After every
+    optimizer step each TP rank receives ITS slices through the group of its rank (gloo here; `weight_transport="rccl"` on real GPUs) -
+    about half of the parameter bytes - and ends with exactly the trainer's slices."""
+    from pipelinerl_amd.pipeline_run import PipelineSpec, run_pipeline
+
+    bs, steps = 16, 2
+    spec = PipelineSpec(exp_path=str(tmp_path / "exp"), model="tiny", global_batch=bs, seq_length=96, attempts=4, steps=steps, n_problems=5, concurrent_groups=2,
+                        stage_timeout_s=600.0, learner="streamed", n_learners=2, n_engines=1, engine_tp=2, weight_transport="gloo", share_device=True,
+                        kl_coef=0.001, extra={"bucket_bytes": 1 << 16})
+    res = run_pipeline(spec)
+    assert "error" not in res, json.dumps(res.get("error"), indent=1)[:6000]
+    st, s = res["stages"], res["summary"]
+    assert s["topology"]["engine_tp"] == 2 and s["optimizer_steps"] == steps and s["engine_weights_equal_trainer_at_last_version"] is True
+    e, l0 = st["engine"], st["learner0"]
+    assert e["updates"] == steps + 1 and e["weight_group"]["ranks"] == [1, 2] and e["weight_group"]["size"] == 2
+    sent = l0["weight_group"]["bytes_sent_per_tp_rank"]
+    total = l0["weight_group"]["param_bytes"] * (steps + 1)
+    assert e["weight_group"]["bytes_received_per_tp_rank"] == sent and all(0.45 * total < b < 0.65 * total for b in sent), (sent, total)
+    want = l0["param_probes_per_tp_rank"][str(steps * bs)]
+    assert e["param_probe"] == want and want[0] != want[1] and len(want[0]) == 3  # final norm (replicated), q_proj rows, embedding rows
+    assert st["preprocessor"]["host_phase_s"].get("ref_logprobs", 0) > 0

@@ -116,6 +116,29 @@ def test_four_learners_three_engines_topology(tmp_path):
     assert s["engine_weights_equal_trainer_at_last_version"] is True
 
 
+def test_tensor_parallel_engines_receive_only_their_slices(tmp_path):
+    """BASELINE configs[4]'s receiver layout: two TP = 2 engines (four inference workers) + the trainer form one weight-update group PER TP
+    RANK (vllm1.py:71 rank layout); every worker receives the slices `tp_shard.plan_tp_shards` assigns to its rank - about half of the
+    parameter bytes - into vLLM-style stacked storage, and ends with exactly the trainer's slices."""
+    if str(HERE) not in sys.path:
+        sys.path.insert(0, str(HERE))
+    spec, res, _ = _run(tmp_path, "n2m2tp2", 2, 2, steps=2, engine_tp=2)
+    st, s = res["stages"], res["summary"]
+    assert s["topology"]["engine_tp"] == 2 and s["engine_weights_equal_trainer_at_last_version"] is True
+    l0 = st["learner0"]
+    sent = l0["weight_group"]["bytes_sent_per_tp_rank"]
+    assert l0["weight_group"]["size"] == 3 and len(sent) == 2  # each TP group: the trainer + that TP rank of both engines
+    total = l0["weight_group"]["param_bytes"] * (spec.steps + 1)
+    assert all(0.45 * total < b < 0.62 * total for b in sent), (sent, total)  # half of the sharded tensors + the replicated norms, per update
+    ranks = sorted(r for e in ("engine0", "engine1") for r in st[e]["weight_group"]["ranks"])
+    assert ranks == [1, 2, 3, 4]
+    for e in ("engine0", "engine1"):
+        assert st[e]["engine_tp"] == 2 and st[e]["updates"] == spec.steps + 1
+        assert st[e]["weight_group"]["bytes_received_per_tp_rank"] == sent
+        assert len(st[e]["param_probe"]) == 2 and st[e]["param_probe"][0] != st[e]["param_probe"][1]  # two ranks, two different halves
+    assert st["engine0"]["param_probe"] == st["engine1"]["param_probe"] == l0["param_probes_per_tp_rank"][str(spec.steps * spec.global_batch)]
+
+
 def test_spec_refuses_impossible_topologies():
     from pipelinerl_amd.pipeline_run import PipelineSpec
 
@@ -147,5 +170,11 @@ def test_baseline_configs_as_specs():
     assert [str(c3.device_of("learner", r)) for r in range(4)] == [f"cuda:{4 + r}" for r in range(4)]
     one_gpu = baseline_spec(2, "x", global_batch=16, share_device=True, weight_transport="ipc")  # the topology on one GPU, reduced batch
     assert one_gpu.n_learners == 2 and one_gpu.learner_backend == "gloo" and str(one_gpu.device_of("learner", 1)) == "cuda:0"
+    c4 = baseline_spec(4, "x")  # Qwen2.5-32B: two TP = 2 engines on GPUs 0-3, four learners on 4-7, KL on, weight-update group of 5
+    assert (c4.model, c4.n_learners, c4.n_engines, c4.engine_tp, c4.kl_coef, c4.weight_group_size) == ("32b", 4, 2, 2, 0.001, 5)
+    assert [str(c4.device_of("engine", e, t)) for e in range(2) for t in range(2)] == ["cuda:0", "cuda:1", "cuda:2", "cuda:3"]
+    assert str(c4.device_of("learner", 0)) == "cuda:4" and c4.shape["kv"] == 8
     with pytest.raises(ValueError, match="configs"):
-        baseline_spec(4, "x")
+        baseline_spec(5, "x")
+    with pytest.raises(ValueError, match="engine_tp"):
+        baseline_spec(1, "x", engine_tp=2)
