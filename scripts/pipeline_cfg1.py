@@ -19,7 +19,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3],
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
                     help="BASELINE.json configs[k] as given (pipeline_run.baseline_spec): [2] = 7B, 2 + 2 GPUs, RCCL; [3] = 4 + 4; other flags are ignored "
                          "except --steps / --global-batch / --timeout / --exp-path / --out")
     ap.add_argument("--model", default="0p5b", choices=["0p5b", "7b", "tiny"])
