@@ -1134,11 +1134,7 @@ def main():
                     step.logits_backward(j, logits, grad_logits)
             else:
                 step.logits_two_pass(j, logits, grad_logits)
-        if timed:
-            with timer.time("grpo_loss_step"):
-                loss, stats = step.finish()
-        else:
-            loss, stats = step.finish()
+        loss, stats = step.finish(timer=timer if timed else None)  # event pairs around the K2+K3 launch and around the cross-rank reduction
         if grad_buckets:  # the DP learner's exchange step: all-reduce of the gradients, bucket by bucket
             ctx = timer.time("grad_allreduce") if timed else None
             if ctx:

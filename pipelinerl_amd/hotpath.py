@@ -166,16 +166,23 @@ class HotPathStep:
         return grad
 
     # -- per step -----------------------------------------------------------------------------
-    def finish(self, sync: bool = True) -> tuple[torch.Tensor, torch.Tensor]:
+    def finish(self, sync: bool = True, timer: Any = None) -> tuple[torch.Tensor, torch.Tensor]:
         """One K2+K3 launch over the whole step (+ one all-gather across ranks).  Returns the
-        device loss scalar and the reduced stats vector (double[32], on device)."""
+        device loss scalar and the reduced stats vector (double[32], on device).
+        `timer` (bench.py's EventTimer): event pairs around the launch alone ("grpo_loss_step") and around the
+        cross-rank reduction ("stats_allgather"), so that a collective's wait is not charged to the kernel."""
+        import contextlib
+
+        timed = (lambda name: timer.time(name)) if timer is not None else (lambda name: contextlib.nullcontext())
         # the first token of every micro-batch is column 0 of ITS batch (no prediction exists for
         # it): flat_micro_batches makes the kernel skip positions with position_ids == 0
         flat_cfg = type(self.cfg).from_buffer_copy(self.cfg)
         flat_cfg.flat_micro_batches = 1
-        loss, stats, _, _ = grpo_loss_from_logprobs(flat_cfg, self.step_batch, self.buffers.new_logprobs,
-                                                   self.buffers.entropy, want_grad=False)
-        stats = self.reduce_stats(stats)
+        with timed("grpo_loss_step"):
+            loss, stats, _, _ = grpo_loss_from_logprobs(flat_cfg, self.step_batch, self.buffers.new_logprobs,
+                                                       self.buffers.entropy, want_grad=False)
+        with timed("stats_allgather"):
+            stats = self.reduce_stats(stats)
         return loss, stats
 
     def reduce_stats(self, stats: torch.Tensor) -> torch.Tensor:
