@@ -394,7 +394,7 @@ def live_pmc_traffic(kernel_substr: str = "fused_logits_loss_keep_kernel") -> di
                 r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", str(out), "-o", "pmc", "--",
                                     sys.executable, str(ROOT / "scripts" / "kernel_sweep.py"), "--quick"],
                                    cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True,
-                                   timeout=float(os.environ.get("PRL_BENCH_PMC_TIMEOUT", 240)))
+                                   timeout=float(os.environ.get("PRL_BENCH_PMC_TIMEOUT", 90)))
             except Exception:  # noqa: BLE001
                 return None
             files = glob.glob(str(out / "**" / "*counter_collection.csv"), recursive=True)
