@@ -1,4 +1,4 @@
-"""Benchmark of the learner hot path on MI355X (contract: see the round prompt / DESIGN.md §6).
+"""Benchmark of the learner hot path on MI355X (contract: see the round prompt / DESIGN.md §5).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -1173,7 +1173,7 @@ def main():
     live_frac = labelled / float(tokens_per_rank)
 
     def algorithmic_bytes(skip_unlabelled: bool) -> dict:
-        """Algorithmic bytes per launch (DESIGN.md §5).  With every row read (the reference's behaviour) a row costs V*4 read + V*4
+        """Algorithmic bytes per launch (DESIGN.md §3).  With every row read (the reference's behaviour) a row costs V*4 read + V*4
         written; with the opt-out the rows whose next token is unlabelled are not read, only their gradient row is zeroed."""
         read_frac = live_frac if skip_unlabelled else 1.0
         return {

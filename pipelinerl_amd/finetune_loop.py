@@ -827,7 +827,7 @@ class StreamedLearnerStep(LearnerStep):
 
 
 class NativeLearnerStep:
-    """The MI355X-native optimizer step (DESIGN.md §3): consumes a whole step's rollouts at once.
+    """The MI355X-native optimizer step (DESIGN.md §4): consumes a whole step's rollouts at once.
 
         K5 + ONE K6 launch  ->  per micro-batch: model forward, fused logits kernel (loss gradient
         straight into d logits), model backward  ->  ONE K2+K3 launch for loss + 32 statistics

@@ -1,4 +1,4 @@
-"""The learner hot path for one optimizer step, MI355X style (DESIGN.md §3):
+"""The learner hot path for one optimizer step, MI355X style (DESIGN.md §4):
 
     rollouts (ragged SoA, HBM) --K5--> advantages --K6 (ONE launch)--> all micro-batches of the step
     per micro-batch:  model -> logits --fused K1+grad+K1'--> d loss/d logits ; new_logprobs/entropy
