@@ -15,10 +15,13 @@ One "step" = one optimizer step's worth of the post-model hot path for the BASEL
     7B learner (15.2 GB of bf16 gradients in 1 GiB buckets over RCCL) - without it the sharded path has no
     exchange step and a scaling figure says nothing about a DP learner
 
-The transformer forward/backward itself is outside the path (stock PyTorch-ROCm); the line
-carries `e2e` (a model-in-the-loop step measured separately) so that `value` is not read as end-to-end
-learner throughput.  Scaling is STRONG: the global batch of 4096 sequences is fixed and sharded across ranks.
-Rank 0 prints ONE JSON line.
+`value` is timed with EVERY logits row read (the reference's finiteness assert covers all positions, rl/__init__.py:213); the
+opt-out that leaves unlabelled rows unread is timed on one step afterwards (`value_skip_unlabelled`).
+
+The transformer forward/backward itself is outside the path (stock PyTorch-ROCm); the metric string says so, and
+`--detail` measures a model-in-the-loop step separately.  Scaling is STRONG: the global batch of 4096 sequences is fixed and
+sharded across ranks.  Rank 0 prints ONE JSON line of < 4 KB (`split_line`: the driver's keys + roofline + cpu_baseline +
+weight_sync) and writes everything else it measured to `--detail-out` (default gpurun_out/bench_detail.json).
 """
 
 from __future__ import annotations
