@@ -94,8 +94,9 @@ class _SegmentSums(torch.autograd.Function):
         ctx.save_for_backward(seg_full, valid)
         ctx.grad_scale, ctx.shapes, ctx.dtypes = float(grad_scale), (a.shape, b.shape), (a.dtype, b.dtype)
         out_dt = a.dtype
+        cnt = cnt.to(out_dt)
         ctx.mark_non_differentiable(cnt)
-        return sa.to(out_dt), sb.to(out_dt), cnt.to(out_dt)
+        return sa.to(out_dt), sb.to(out_dt), cnt
 
     @staticmethod
     def backward(ctx, g_a, g_b, _g_cnt):  # type: ignore[override]
