@@ -577,6 +577,37 @@ class PartitionedStreamWriter(StreamWriter):
         self._writers[partition].write(data)
 
 
+# the reference's class names for the partitioned writers (:195-232, 349-384) and its Redis helpers (:25-30, 106-117)
+
+
+class RoundRobinFileStreamWriter(PartitionedStreamWriter):
+    def __init__(self, streams: StreamRangeSpec, mode: Literal["w", "a"] = "a"):
+        super().__init__(streams, mode, FileStreamWriter)
+
+
+class RoundRobinRedisStreamWriter(PartitionedStreamWriter):
+    def __init__(self, streams: StreamRangeSpec, mode: Literal["w", "a"] = "a"):
+        super().__init__(streams, mode, RedisStreamWriter)
+
+
+class RedisConfig(BaseModel):
+    host: str = "localhost"
+    port: int = 6379
+
+
+def connect_to_redis(config: "RedisConfig | None" = None):
+    """Connect (unlimited retries) to `config`'s server - default: the one `set_streams_backend("redis", host=, port=)` named."""
+    if config is None:
+        return _connect_to_redis()
+    saved = dict(_backend_options)
+    _backend_options.update(host=config.host, port=config.port)
+    try:
+        return _connect_to_redis()
+    finally:
+        _backend_options.clear()
+        _backend_options.update(saved)
+
+
 def read_stream(stream: SingleStreamSpec) -> StreamReader:
     """Start reading the stream from the beginning."""
     raise_if_backend_not_set()

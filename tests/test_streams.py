@@ -529,3 +529,19 @@ def test_redis_options_are_host_and_port_only(streams, monkeypatch):
     monkeypatch.setitem(sys.modules, "redis", types.ModuleType("redis"))
     with pytest.raises(ValueError, match="host and port"):
         streams.set_streams_backend("redis", host="h", segment_bytes=1)
+
+
+def test_reference_class_names_of_the_partitioned_writers(streams, fake_redis, tmp_path):
+    """`RoundRobinFileStreamWriter` / `RoundRobinRedisStreamWriter` / `RedisConfig` / `connect_to_redis` exist under the reference's names
+    (streams.py:25-30, 106-117, 195-232, 349-384)."""
+    rng = streams.StreamRangeSpec(exp_path=tmp_path, topic="t", partition_range=(0, 2))
+    with streams.RoundRobinRedisStreamWriter(rng) as w:
+        for k in range(3):
+            w.write({"k": k})
+    assert [len(fake_redis.streams[f"t/0/{p}"]) for p in range(2)] == [2, 1]
+    with streams.RoundRobinFileStreamWriter(rng, mode="w") as w:
+        w.write({"k": 0}, partition=1)
+    assert (tmp_path / "streams" / "t" / "0" / "1" / "0.jsonl").read_text() == '{"k":0}\n'
+    client = streams.connect_to_redis(streams.RedisConfig(host="other.example", port=1234))
+    assert (client.host, client.port) == ("other.example", 1234) and streams._backend_options["host"] == "redis.example"
+    assert streams.connect_to_redis().host == "redis.example"
