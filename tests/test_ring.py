@@ -134,3 +134,46 @@ def test_shared_memory_queue_matches_reference_trace(libprl):
     assert [r["result"] for r in mine[leak + 1 : leak + 4]] == ["ok", "ok", "Full"]
     assert [r["result"] for r in mine[leak + 4 :]] == [{"item": {"nested": {"k": [1.5, None, True]}}}, {"item": 9}, {"item": 10}, "Empty", "Empty"]
     assert mine[-1]["qsize"] == 0 and mine[-1]["full"] is False
+
+
+def test_shared_memory_array_follows_the_reference_trace():
+    """`SharedMemoryArray` (shared_memory_array.py:9-106) replayed against a trace of the reference class (tests/golden/make_array_golden.py):
+    items, `None` for an empty slot, the oversize / index errors with the reference's messages, `max_actual_entry_size` after every call."""
+    import json
+    import multiprocessing as mp
+    from multiprocessing.managers import SharedMemoryManager
+
+    from helpers import GOLDEN
+    from pipelinerl_amd.shared_memory_array import SharedMemoryArray
+
+    g = json.loads((GOLDEN / "array_trace.json").read_text())
+    for make in ("managed", "own_segment"):
+        with SharedMemoryManager() as smm:
+            arr = SharedMemoryArray(smm if make == "managed" else None, 4, 256)
+            assert len(arr) == g["len"] and arr.get_memory_size() >= g["memory_size_at_least"]
+            for (op, index, value), want in zip(g["script"], g["trace"]):
+                if op == "set" and isinstance(value, str) and want.get("pickled_size") == 255:
+                    value = bytes.fromhex(value)
+                try:
+                    if op == "set":
+                        arr[index] = value
+                        got = "ok"
+                    else:
+                        item = arr[index]
+                        got = {"item": item.hex() if isinstance(item, bytes) else item, "bytes": isinstance(item, bytes)}
+                except Exception as e:  # noqa: BLE001
+                    got = {"raises": type(e).__name__, "message": str(e)}
+                assert got == want["result"], (op, index)
+                assert arr.max_actual_entry_size() == want["max_actual_entry_size"], (op, index)
+            if make == "managed":  # a child process reads what the parent wrote (the object travels like the reference's)
+                arr[2] = {"from": "parent"}
+                ctx = mp.get_context("fork")
+                q = ctx.Queue()
+                p = ctx.Process(target=lambda a, out: out.put(a[2]), args=(arr, q))
+                p.start()
+                assert q.get(timeout=10) == {"from": "parent"}
+                p.join(5)
+            arr.close()
+    for name, args in (("zero_entries", (0, 16)), ("zero_size", (4, 0))):
+        with pytest.raises(ValueError, match=g["ctor_errors"][name]["message"]):
+            SharedMemoryArray(None, *args)
