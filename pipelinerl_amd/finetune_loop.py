@@ -127,6 +127,29 @@ def parse_trainer_message(record: dict) -> TrainerMessage:
 # ---------------------------------------------------------------------------------------------
 
 
+def gather_rl_metrics(rl_metrics: dict, group: Any = None) -> dict:
+    """{metric: [values of this rank's micro-batches]} -> the same over every rank of `group`, finite values only (reference :64-89: one
+    `all_gather_object` per optimizer step)."""
+    import torch.distributed as dist
+
+    parts: list = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, dict(rl_metrics), group=group)
+    merged: dict[str, list] = defaultdict(list)
+    for p in parts:
+        for k, v in p.items():
+            if v:
+                merged[k].extend(x for x in v if np.isfinite(x))
+    return merged
+
+
+def validate_packing_config(args: Any) -> None:
+    """Sequence packing needs an attention implementation that honours sequence boundaries (reference :315-323)."""
+    if getattr(args, "seq_packing", False) and not getattr(args, "use_flash_attention", False):
+        raise ValueError("Sequence packing requires flash attention. Either:\n"
+                         "- Enable flash attention (use_flash_attention=true), or\n"
+                         "- Disable sequence packing (seq_packing=false)")
+
+
 def get_batch_token_count(batch: PipelineBatchEncoding) -> int:
     """Real (non-padding) tokens of a batch."""
     return int(batch.attention_mask.sum().item())
@@ -678,15 +701,7 @@ class LearnerStep:
         """rl/* metrics of the finished step over all ranks (reference :908-922)."""
         gathered = dict(self._rl_metrics)
         if self.distributed and self.world > 1:
-            import torch.distributed as dist
-
-            parts: list = [None] * self.world
-            dist.all_gather_object(parts, gathered, group=self.group)
-            merged: dict[str, list] = defaultdict(list)
-            for p in parts:
-                for k, v in p.items():
-                    merged[k].extend(x for x in v if np.isfinite(x))
-            gathered = merged
+            gathered = gather_rl_metrics(gathered, self.group)
         if not gathered:
             return {}
         avg = aggregate_rl_stats(gathered, self.samples_per_step)

@@ -122,3 +122,14 @@ def test_trainer_messages_and_state_match_reference(tmp_path):
         assert st.wait_for_training_done(timeout=1.0) == g["wait_for_training_done"]
     finally:
         streams.reset_streams_backend()
+
+
+def test_validate_packing_config_like_the_reference():
+    import types
+
+    from pipelinerl_amd.finetune_loop import validate_packing_config
+
+    validate_packing_config(types.SimpleNamespace(seq_packing=False, use_flash_attention=False))
+    validate_packing_config(types.SimpleNamespace(seq_packing=True, use_flash_attention=True))
+    with pytest.raises(ValueError, match="Sequence packing requires flash attention"):
+        validate_packing_config(types.SimpleNamespace(seq_packing=True, use_flash_attention=False))
