@@ -470,3 +470,27 @@ def test_step_statistics_all_gather_at_world_8(tmp_path, world):
     for r in range(world):
         d = json.loads((tmp_path / f"stats{r}.json").read_text())
         assert d["equal"] and d["n"] == 32, (r, d)
+
+
+def _stateless_rank(rank, world, port, out_dir):
+    from pipelinerl_amd.torch_utils import stateless_init_process_group
+
+    grp = stateless_init_process_group(f"tcp://127.0.0.1:{port}", rank, world, "cpu", backend="gloo")
+    assert grp.comm_size() == (world, rank)
+    t = torch.arange(6, dtype=torch.float32).reshape(2, 3).t() * (rank == 0)  # non-contiguous on purpose
+    grp.broadcast(t, src=0)
+    bucket = torch.full((1000,), rank, dtype=torch.uint8)
+    grp.broadcast_bucket(bucket, mode="scatter_allgather")
+    Path(out_dir, f"stateless{rank}.json").write_text(json.dumps({"t": t.tolist(), "bucket": int(bucket.sum()), "moved": grp.bytes_moved}))
+    grp.close()
+
+
+def test_stateless_weight_group_over_gloo_three_ranks(tmp_path):
+    """`stateless_init_process_group(..., backend="gloo")` = `GlooWeightSyncGroup`: a group of its own (no default process group in these
+    processes), the reference's per-tensor `.broadcast` and the bucket form, trainer rank 0 -> two workers."""
+    port = _free_port()
+    mp.spawn(_stateless_rank, args=(3, port, tmp_path), nprocs=3, join=True)
+    want = (torch.arange(6, dtype=torch.float32).reshape(2, 3).t()).tolist()
+    for r in range(3):
+        d = json.loads((tmp_path / f"stateless{r}.json").read_text())
+        assert d["t"] == want and d["bucket"] == 0 and d["moved"] == 24 + 1000
