@@ -309,8 +309,11 @@ class GlooWeightSyncGroup:
         opts = dist.BroadcastOptions()
         opts.rootRank, opts.rootTensor = src, 0
         if t.is_cuda:
-            torch.cuda.current_stream(t.device).synchronize()  # the bucket was filled on this stream
-            host = t.cpu()
+            if self.rank == src:
+                torch.cuda.current_stream(t.device).synchronize()  # the bucket was filled on this stream
+                host = t.cpu()
+            else:
+                host = torch.empty(t.shape, dtype=t.dtype)  # nothing of the receiver's buffer needs to leave the device
             self._pg.broadcast([host], opts).wait()
             if self.rank != src:
                 t.copy_(host)
