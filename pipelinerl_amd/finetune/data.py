@@ -14,6 +14,7 @@ Two levels:
 from __future__ import annotations
 
 import contextlib
+import itertools
 
 import logging
 from dataclasses import dataclass
@@ -210,8 +211,9 @@ class PackedStep(Sequence):
 def plan_packing(lens: np.ndarray, micro_batches: Sequence[Sequence[int]], sentinel_pad: Sequence[int] | None):
     """Host-side O(#sequences) plan of one K6 launch, vectorised: (pk_src, pk_seg, pk_dst, mb_off)."""
     n_mb = len(micro_batches)
-    counts = np.fromiter((len(x) for x in micro_batches), dtype=np.int64, count=n_mb)
-    src = np.fromiter((int(s) for mb in micro_batches for s in mb), dtype=np.int64, count=int(counts.sum()))
+    # (C-level iteration: a generator expression over 4096 one-element lists cost more than the kernel's planning is worth)
+    counts = np.fromiter(map(len, micro_batches), dtype=np.int64, count=n_mb)
+    src = np.fromiter(itertools.chain.from_iterable(micro_batches), dtype=np.int64, count=int(counts.sum()))
     pads = None if sentinel_pad is None else np.asarray(sentinel_pad, dtype=np.int64)
     if pads is None or not pads.any():
         mb_off = np.zeros(n_mb + 1, dtype=np.int64)
@@ -286,11 +288,15 @@ def pack_prepared(
     mv = r.host_model_version
     n_mb = len(micro_batches)
     if n_mb:
+        big = np.iinfo(np.int64).max
         real = pk_src >= 0
-        mb_of = np.repeat(np.arange(n_mb), np.diff(mb_off))
-        versions = np.full(n_mb, np.iinfo(np.int64).max, dtype=np.int64)
-        np.minimum.at(versions, mb_of[real], mv[pk_src[real]])
-        versions[versions == np.iinfo(np.int64).max] = 0
+        if len(pk_src) and np.all(np.diff(mb_off) > 0):  # entries lie grouped by micro-batch: one segmented minimum (ufunc.at is ~20 x slower)
+            versions = np.minimum.reduceat(np.where(real, mv[np.maximum(pk_src, 0)], big), mb_off[:-1])
+        else:  # an empty micro-batch in the plan
+            mb_of = np.repeat(np.arange(n_mb), np.diff(mb_off))
+            versions = np.full(n_mb, big, dtype=np.int64)
+            np.minimum.at(versions, mb_of[real], mv[pk_src[real]])
+        versions[versions == big] = 0
     else:
         versions = np.zeros(0, dtype=np.int64)
     pads = None if sentinel_pad is None else np.asarray(sentinel_pad, dtype=np.int64)

@@ -649,8 +649,11 @@ def plan_groups(group_index: np.ndarray, step_index: np.ndarray, rollout_index: 
     the number of distinct rollouts per group (reference groupby keys, rl/__init__.py:464-486)."""
     g = group_index.astype(np.int64)
     n_steps = int(step_index.max()) + 1 if len(step_index) else 1
-    key_off, key_members, _ = _csr(g * n_steps + step_index.astype(np.int64))
     group_off, group_members, group_keys = _csr(g)
+    if n_steps == 1:  # single-step rollouts (every BASELINE config): the (group, step) keys ARE the groups
+        key_off, key_members = group_off, group_members
+    else:
+        key_off, key_members, _ = _csr(g * n_steps + step_index.astype(np.int64))
     n_roll = int(rollout_index.max()) + 1 if len(rollout_index) else 1
     pairs = np.unique(g * n_roll + rollout_index.astype(np.int64))
     pair_group = pairs // n_roll
