@@ -24,6 +24,9 @@ calls `send_weight_update` and rank 0 sends (finetune_loop.py:205-292) - to a we
 (`weight_transport="rccl"`, one GPU per member), over gloo (`"gloo"`: the same group and protocol where RCCL cannot run) or through HIP
 IPC handles every colocated engine maps (`"ipc"`) - and every engine acknowledges before `WeightUpdateSuccess` is published.  GPU
 placement follows world.py:143-192 (inference GPUs first, learners after them) unless `share_device` puts every stage on one GPU.
+`engine_tp > 1` (configs[4]: TP = 2 engines): an engine is `tp` inference workers holding vLLM-style stacked slices; the trainer forms
+one weight-update group PER TP RANK (rank layout vllm1.py:71) and every worker receives only its slices (`transport: sharded`,
+tp_shard.py).  `kl_coef > 0` puts the frozen reference policy into the preprocessor.  `baseline_spec(k)` builds configs[1..4].
 
 Every stage writes a report (`<exp_path>/reports/<stage>.json`: wall / busy seconds, queue gauges, per-update timings);
 `run_pipeline` merges them into one object (bench.py `pipeline`, scripts/pipeline_cfg1.py).  Nothing here is measured
