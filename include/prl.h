@@ -26,7 +26,7 @@
  *                                 pipelinerl/finetune/rl/utils.py:26-92
  *   prl_fused_logits_loss         the two above in one pass (no reference analogue)
  *   prl_segment_sums              pipelinerl/finetune/rl/utils.py:106-208
- *   prl_gspo_segment_sums / prl_gspo_expand
+ *   prl_gspo_segment_sums / prl_gspo_segment_terms / prl_gspo_expand
  *                                 pipelinerl/finetune/rl/__init__.py:310-352 (the per-token ends of the sequence-level term)
  *   prl_value_head_fwd_bwd        pipelinerl/finetune/rl/__init__.py:265-272, 367-381, 441-448
  *                                 (models of pipelinerl/finetune/value_model.py)
@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 12
+#define PRL_ABI_VERSION 13
 
 #define PRL_OK 0
 #define PRL_EINVAL (-22)   /* bad argument                                  */
@@ -286,6 +286,11 @@ int prl_segment_sums(int64_t cols, int32_t n_segments, const int64_t* segment_id
  *       prl_grpo_loss_fwd_bwd (cfg->group_normalization, token_weight, overlong_filtering).  Columns float32 [1, cols],
  *       token-aligned; segment_ids / labels as for prl_segment_sums (non-decreasing ids; unsorted or out-of-range ids -> NaN).
  *       Fixed-order reduction, bitwise reproducible.
+ *   prl_gspo_segment_terms the O(#segments) arithmetic between the two (rl/__init__.py:316-343) in one launch: from `sums` (after the
+ *       sequence-parallel all-reduce, if any) the clipped sequence ratio, coef[s] = d loss / d new_logprobs of every token of segment s
+ *       (times grad_scale: the SP group size, as a differentiable all-reduce would give), the clip indicator, and
+ *       loss = -sum_s min(r_s A_s, clip(r_s) A_s) * (segment's token-weight sum) over valid segments; zero_out != 0 (sentinel batch,
+ *       a single column): loss 0 and coef 0.
  *   prl_gspo_expand        per-segment float32 [n_segments] -> per-token float32 [1, cols]: token_grad[u] = coef[segment_ids[u]]
  *       and token_indicator[u] = indicator[segment_ids[u] - segment_ids[0]] (the j-th sequence starting or continuing in the
  *       slice takes the value of global segment j, rl/__init__.py:347-350), indices clamped to [0, n_segments).
@@ -294,6 +299,8 @@ int prl_gspo_segment_sums(const prl_loss_config* cfg, int64_t cols, int32_t n_se
                           const int64_t* labels, const float* new_logprobs, const float* old_logprobs,
                           const float* advantages, const float* group_tokens, const float* overflow,
                           double* sums, prl_stream_t stream);
+int prl_gspo_segment_terms(const prl_loss_config* cfg, int32_t n_segments, const double* sums, float grad_scale,
+                           int32_t zero_out, float* coef, float* indicator, float* loss, prl_stream_t stream);
 int prl_gspo_expand(int64_t cols, int32_t n_segments, const int64_t* segment_ids, const float* coef,
                     const float* indicator, float* token_grad, float* token_indicator, prl_stream_t stream);
 

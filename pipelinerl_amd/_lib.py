@@ -13,7 +13,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl.so"
 
-PRL_ABI_VERSION = 12
+PRL_ABI_VERSION = 13
 PRL_OK = 0
 PRL_EINVAL = -22
 PRL_ENOMEM = -12
@@ -150,6 +150,7 @@ PROTOTYPES: dict[str, tuple] = {
     "prl_scale_unless": (c_int32, [_P, c_int64, c_int32, _P, c_float, _P]),
     "prl_segment_sums": (c_int32, [c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prl_gspo_segment_sums": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "prl_gspo_segment_terms": (c_int32, [_P, c_int32, _P, c_float, c_int32, _P, _P, _P, _P]),
     "prl_gspo_expand": (c_int32, [c_int64, c_int32, _P, _P, _P, _P, _P, _P]),
     "prl_value_head_workspace_bytes": (c_int32, [c_int64, c_int64, POINTER(c_size_t)]),
     "prl_value_head_fwd_bwd": (c_int32, [POINTER(PrlLossConfig), c_int64, c_int64, _P, _P, c_int32] + [_P] * 8 + [_P, c_size_t, _P]),

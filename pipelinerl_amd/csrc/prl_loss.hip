@@ -751,6 +751,47 @@ __global__ __launch_bounds__(kBlock) void gspo_order_check_kernel(int64_t cols, 
   }
 }
 
+// Between the two per-token ends: the O(#segments) arithmetic of the sequence-level term (rl/__init__.py:316-343) in one small
+// launch - clipped sequence ratio, its loss contribution, the coefficient d loss / d new_logprobs shares over a segment's tokens
+// and the clip indicator - instead of ~20 eager launches on [S]-sized tensors.  One workgroup; the loss is reduced in a fixed order.
+__global__ __launch_bounds__(kBlock) void gspo_segment_terms_kernel(prl_loss_config cfg, int32_t n_segments, const double* __restrict__ sums,
+                                                                    float grad_scale, int32_t zero_out, float* __restrict__ coef,
+                                                                    float* __restrict__ indicator, float* __restrict__ loss_out) {
+  __shared__ double red[kBlock / prl::kWave];
+  double part = 0.0;
+  for (int32_t s = threadIdx.x; s < n_segments; s += kBlock) {
+    const float cnt = (float)sums[2 * (int64_t)n_segments + s];
+    const float den = cnt < 1e-6f ? 1e-6f : cnt;
+    const float ratio = expf((float)sums[s] / den);                       // exp(mean log(new / old)) over the segment (:321-323)
+    const float adv = (float)sums[(int64_t)n_segments + s] / den;         // mean advantage (:324)
+    const float w = (float)sums[3 * (int64_t)n_segments + s];             // sum of the segment's token weights
+    const bool valid = cnt > 0.0f && w > 0.0f;
+    const float clipped = ratio < cfg.clip_lo ? cfg.clip_lo : (ratio > cfg.clip_hi ? cfg.clip_hi : ratio);
+    const float s1 = ratio * adv, s2 = clipped * adv;
+    const bool inside = ratio >= cfg.clip_lo && ratio <= cfg.clip_hi;
+    // d min(s1, s2) / d ratio, torch.min's tie rule (half to each side), clamp passing the gradient on [lo, hi] inclusive
+    const float in = inside ? 1.0f : 0.0f;
+    const float dmin = s1 < s2 ? adv : (s2 < s1 ? adv * in : 0.5f * adv + 0.5f * adv * in);
+    const float v = valid ? 1.0f : 0.0f;
+    float c = -(w * v) * dmin * ratio / den * grad_scale;
+    float m = s1 < s2 ? s1 : s2;
+    if (!(s1 == s1) || !(s2 == s2)) m = s1 + s2;  // NaN propagates like torch.minimum
+    if (zero_out) c = 0.0f;
+    coef[s] = c;
+    indicator[s] = (clipped != ratio && valid) ? 1.0f : 0.0f;
+    part += (double)(m * v * w);
+  }
+  part = prl::wave_sum(part);
+  const int lane = threadIdx.x & (prl::kWave - 1), wid = threadIdx.x / prl::kWave;
+  if (lane == 0) red[wid] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < kBlock / prl::kWave; ++w) t += red[w];
+    *loss_out = zero_out ? 0.0f : (float)(-t);
+  }
+}
+
 // The way back: every token takes its segment's gradient coefficient, and the clip indicator of the j-th sequence starting or
 // continuing in this (slice of a) batch (rl/__init__.py:347-350: zip(local segments, per-segment values)).
 __global__ __launch_bounds__(kBlock) void gspo_expand_kernel(int64_t cols, int32_t n_segments, const int64_t* __restrict__ seg,
@@ -788,6 +829,17 @@ extern "C" int prl_gspo_segment_sums(const prl_loss_config* cfg, int64_t cols, i
   PRL_LAUNCH_CHECK("gspo_segment_sums_kernel");
   hipLaunchKernelGGL(gspo_order_check_kernel, dim3(1), dim3(kBlock), 0, s, cols, n_segments, segment_ids, labels, sums);
   PRL_LAUNCH_CHECK("gspo_order_check_kernel");
+  return PRL_OK;
+}
+
+extern "C" int prl_gspo_segment_terms(const prl_loss_config* cfg, int32_t n_segments, const double* sums, float grad_scale,
+                                      int32_t zero_out, float* coef, float* indicator, float* loss, prl_stream_t stream) {
+  PRL_CHECK_ARG(cfg != nullptr, "null config");
+  PRL_CHECK_ARG(n_segments >= 0, "negative shape");
+  PRL_CHECK_ARG(loss && (n_segments == 0 || (sums && coef && indicator)), "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gspo_segment_terms_kernel, dim3(1), dim3(kBlock), 0, s, *cfg, n_segments, sums, grad_scale, zero_out, coef, indicator, loss);
+  PRL_LAUNCH_CHECK("gspo_segment_terms_kernel");
   return PRL_OK;
 }
 

@@ -243,8 +243,9 @@ def gspo_segment_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, new_log
     """Sequence-level (GSPO) policy term, reference rl/__init__.py:310-352 + rl/utils.py:106-208:
     per-segment masked means of log(new/old) and of the advantages (segment-sum kernel), clipped
     sequence ratio, loss = -sum_s min(r_s A_s, clip(r_s) A_s) * (sum of the segment's token weights).
-    Returns (loss scalar, per-token d loss/d new_logprobs coefficient, per-token clip indicator);
-    the O(#segments) arithmetic runs as a handful of device tensor ops.
+    Returns (loss scalar, per-token d loss/d new_logprobs coefficient, per-token clip indicator).  Three launches: the four
+    per-segment sums (`prl_gspo_segment_sums`), the O(#segments) arithmetic (`prl_gspo_segment_terms`), the way back to the
+    tokens (`prl_gspo_expand`).
 
     With `seq_parallel_group` the batch is one `make_slices` slice of a packed sequence: the four
     per-segment sums are added over the group in ONE all-reduce (the reference issues one per
@@ -279,27 +280,14 @@ def gspo_segment_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, new_log
     if sp:
         sums = _group_all_reduce(sums, seq_parallel_group, dist.ReduceOp.SUM)
         grad_scale = float(dist.get_world_size(seq_parallel_group))
-    lrn_sum, adv_sum, cnt, w_sum = sums[0], sums[1], sums[2], sums[3]
-    cnt32 = cnt.to(f32)
-    den = cnt32.clamp(min=1e-6)
-    ratio = torch.exp(lrn_sum.to(f32) / den)
-    adv = adv_sum.to(f32) / den
-    w_sum = w_sum.to(f32)
-    valid = (cnt32 > 0) & (w_sum > 0)
-    s1 = ratio * adv
-    clipped = ratio.clamp(cfg.clip_lo, cfg.clip_hi)
-    indicator = (clipped != ratio) & valid
-    s2 = clipped * adv
+    # the O(#segments) arithmetic - clipped sequence ratio, loss, per-segment gradient coefficient, clip indicator - in one small launch
+    coef = torch.empty(max(n_seg, 0), dtype=f32, device=dev)
+    indicator = torch.empty_like(coef)
+    loss = torch.empty((), dtype=f32, device=dev)
     T = new_logprobs.shape[-1]
-    if batch.sentinel or T <= 1:
-        loss = torch.zeros((), dtype=f32, device=new_logprobs.device)
-    else:
-        loss = -(torch.minimum(s1, s2) * valid.to(f32) * w_sum).sum()
-    inside = ((ratio >= cfg.clip_lo) & (ratio <= cfg.clip_hi)).to(f32)
-    dmin = torch.where(s1 < s2, adv, torch.where(s2 < s1, adv * inside, 0.5 * adv + 0.5 * adv * inside))
-    coef = -(w_sum * valid.to(f32)) * dmin * ratio / den * grad_scale
-    if batch.sentinel:
-        coef = torch.zeros_like(coef)
+    with torch.cuda.device(dev):
+        _lib.check(lib.prl_gspo_segment_terms(ctypes.byref(cfg), n_seg, _lib.ptr(sums.contiguous()), float(grad_scale), 1 if (batch.sentinel or T <= 1) else 0,
+                                              _lib.ptr(coef), _lib.ptr(indicator), _lib.ptr(loss), _lib.current_stream_ptr(dev)))
     # back to the tokens in one launch: the segment's coefficient, and the clip indicator of the j-th sequence STARTING OR CONTINUING in
     # this slice (the reference zips local segments with per-segment values, rl/__init__.py:347-350; identical to indexing by segment
     # id when the slice starts at segment 0)
@@ -307,8 +295,8 @@ def gspo_segment_terms(cfg: PrlLossConfig, batch: PipelineBatchEncoding, new_log
     ext_c = torch.empty_like(ext_g)
     if n_seg > 0 and ext_g.numel():
         with torch.cuda.device(dev):
-            _lib.check(lib.prl_gspo_expand(ext_g.shape[-1], n_seg, _lib.ptr(cont(seg_ids)), _lib.ptr(coef.to(f32).contiguous()),
-                                           _lib.ptr(indicator.to(f32).contiguous()), _lib.ptr(ext_g), _lib.ptr(ext_c), _lib.current_stream_ptr(dev)))
+            _lib.check(lib.prl_gspo_expand(ext_g.shape[-1], n_seg, _lib.ptr(cont(seg_ids)), _lib.ptr(coef), _lib.ptr(indicator),
+                                           _lib.ptr(ext_g), _lib.ptr(ext_c), _lib.current_stream_ptr(dev)))
     else:
         ext_g.zero_()
         ext_c.zero_()
