@@ -67,6 +67,14 @@ def test_fused_and_pack_entry_points_reject_bad_arguments(libprl):
     assert lib.prl_seq_scan(3, None, P, P, None, None, 2, P, P, None) == _lib.PRL_EINVAL
     assert lib.prl_group_advantages(2, 1, 1, P, P, P, P, P, None, P, 1, P, P, P, P, None) == _lib.PRL_EINVAL
     assert lib.prl_segment_sums(-1, 1, P, P, P, P, P, P, P, None) == _lib.PRL_EINVAL
+    # the three GSPO entry points: null config, negative shapes, null pointers - refused before any launch
+    assert lib.prl_gspo_segment_sums(None, 8, 1, P, P, P, P, P, P, P, P, None) == _lib.PRL_EINVAL
+    assert lib.prl_gspo_segment_sums(ctypes.byref(_cfg()), -1, 1, P, P, P, P, P, P, P, P, None) == _lib.PRL_EINVAL
+    assert lib.prl_gspo_segment_sums(ctypes.byref(_cfg()), 8, 1, P, P, P, None, P, P, P, P, None) == _lib.PRL_EINVAL
+    assert lib.prl_gspo_segment_terms(None, 1, P, 1.0, 0, P, P, P, None) == _lib.PRL_EINVAL
+    assert lib.prl_gspo_segment_terms(ctypes.byref(_cfg()), 1, P, 1.0, 0, P, P, None, None) == _lib.PRL_EINVAL
+    assert lib.prl_gspo_expand(8, 0, P, P, P, P, P, None) == _lib.PRL_EINVAL
+    assert lib.prl_gspo_expand(8, 1, P, None, P, P, P, None) == _lib.PRL_EINVAL
 
 
 def test_ring_and_wsync_reject_bad_arguments(libprl):
