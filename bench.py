@@ -280,10 +280,9 @@ def cpu_baseline(seq_length: int, vocab: int) -> dict:
         "cores": cores,
         "kind": "port",
         "measured_in_this_run": True,
-        "sample": f"oracle (port of the reference, pinned to it by golden vectors): preprocess+collate of {n_seq} x {seq_length}-token "
-                  f"sequences, single process ({t_pre * 1e3:.1f} ms/seq) + logits->loss->dlogits on {t_logits} tokens x V={vocab} with vectorised "
-                  f"fp32 torch CPU kernels (closed-form gradient) on {cores} threads, median of 3 ({t_loss_tok * 1e6:.0f} us/token), "
-                  f"extrapolated to {seq_length}-token samples",
+        "sample": f"oracle (golden-pinned port of the reference): preprocess+collate of {n_seq} x {seq_length}-token sequences, one process "
+                  f"({t_pre * 1e3:.1f} ms/seq) + logits->loss->dlogits on {t_logits} tokens x V={vocab}, vectorised fp32 torch CPU kernels "
+                  f"(closed-form gradient), {cores} threads, median of 3 ({t_loss_tok * 1e6:.0f} us/token); extrapolated to {seq_length}-token samples",
         "legs": legs,
         "legs_note": "BASELINE.md §2 legs: the port measured on THIS box (us_per_token) next to the reference's own function measured in the build "
                      "container (reference_us_per_token, 8 cores of a different host)",
