@@ -96,9 +96,17 @@ __global__ __launch_bounds__(kBlock) void seq_scan_kernel(
 
 // ---------------------------------------------------------------------------------------
 // K5b: leave-one-out advantages per (group_id, step_index) key; mean rollout tokens per
-// group.  fp64 like the reference's pandas path; members are visited in dataset order so
-// the result is deterministic.  O(#sequences) work: one lane per key / per group.
+// group.  fp64 like the reference's pandas path.  One WAVE per key / per group: the members'
+// values are loaded by the 64 lanes at once (one lane per member: two dependent loads deep instead
+// of 3 x n), then every lane adds them up in DATASET ORDER out of its neighbours' registers
+// (`__shfl`), so the sums are the ones a single lane walking the members would form - the results
+// do not depend on the launch geometry.  Keys larger than a wave are walked in chunks of 64.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double ordered_wave_sum(double acc, double v, int count) {
+  for (int j = 0; j < count; ++j) acc += __shfl(v, j, kWave);
+  return acc;
+}
+
 __global__ __launch_bounds__(kBlock) void group_adv_kernel(
     int32_t n_keys, int32_t n_groups, const int32_t* __restrict__ key_off,
     const int32_t* __restrict__ key_members, const int32_t* __restrict__ group_off,
@@ -106,23 +114,29 @@ __global__ __launch_bounds__(kBlock) void group_adv_kernel(
     const double* __restrict__ reward, const int64_t* __restrict__ seq_off, int divide_by_std,
     double* __restrict__ adv64, double* __restrict__ gt64, float* __restrict__ adv32,
     float* __restrict__ gt32) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
-  if (t < n_keys) {
-    const int b = key_off[t], e = key_off[t + 1];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = (blockIdx.x * kBlock + threadIdx.x) / kWave;  // one wave per unit: keys first, then groups
+  if (w < n_keys) {
+    const int b = key_off[w], e = key_off[w + 1];
     const int n = e - b;
     double sum = 0.0;
-    for (int i = b; i < e; ++i) sum += reward[key_members[i]];
+    for (int c = b; c < e; c += kWave) {
+      const int i = c + lane;
+      const double v = i < e ? reward[key_members[i]] : 0.0;
+      sum = ordered_wave_sum(sum, v, min(kWave, e - c));
+    }
     double sd = 0.0;  // nan_to_num(std): NaN for singleton keys -> 0
     if (n > 1) {
       const double mean = sum / (double)n;
       double ss = 0.0;
-      for (int i = b; i < e; ++i) {
-        const double d = reward[key_members[i]] - mean;
-        ss += d * d;
+      for (int c = b; c < e; c += kWave) {
+        const int i = c + lane;
+        const double d = i < e ? reward[key_members[i]] - mean : 0.0;
+        ss = ordered_wave_sum(ss, d * d, min(kWave, e - c));
       }
       sd = sqrt(ss / (double)(n - 1));  // pandas std, ddof = 1
     }
-    for (int i = b; i < e; ++i) {
+    for (int i = b + lane; i < e; i += kWave) {
       const int s = key_members[i];
       const double r = reward[s];
       const double loo = (n > 1) ? (sum - r) / (double)(n - 1) : r;
@@ -130,16 +144,17 @@ __global__ __launch_bounds__(kBlock) void group_adv_kernel(
       adv64[s] = a;
       adv32[s] = (float)a;
     }
-  }
-  if (t < n_groups) {
+  } else if (w - n_keys < n_groups) {
+    const int t = w - n_keys;
     const int b = group_off[t], e = group_off[t + 1];
-    int64_t tok = 0;
-    for (int i = b; i < e; ++i) {
+    int64_t tok = 0;  // integers: any order gives the same sum
+    for (int i = b + lane; i < e; i += kWave) {
       const int s = group_members[i];
       tok += seq_off[s + 1] - seq_off[s];
     }
+    for (int off = kWave / 2; off > 0; off >>= 1) tok += __shfl_xor(tok, off, kWave);
     const double g = (double)tok / (double)group_n_rollouts[t];
-    for (int i = b; i < e; ++i) {
+    for (int i = b + lane; i < e; i += kWave) {
       const int s = group_members[i];
       gt64[s] = g;
       gt32[s] = (float)g;
@@ -563,8 +578,9 @@ extern "C" int prl_group_advantages(int32_t n_seqs, int32_t n_keys, int32_t n_gr
   PRL_CHECK_ARG(key_off && key_members && group_off && group_members && group_n_rollouts && reward &&
                     seq_off && advantage64 && group_tokens64 && advantage32 && group_tokens32,
                 "null pointer");
-  const int n = n_keys > n_groups ? n_keys : n_groups;
-  hipLaunchKernelGGL(group_adv_kernel, dim3(blocks_for(n)), dim3(kBlock), 0,
+  const int64_t waves = (int64_t)n_keys + n_groups;  // one wave per key and per group
+  const int64_t per_block = kBlock / kWave;
+  hipLaunchKernelGGL(group_adv_kernel, dim3((unsigned)((waves + per_block - 1) / per_block)), dim3(kBlock), 0,
                      static_cast<hipStream_t>(stream), n_keys, n_groups, key_off, key_members,
                      group_off, group_members, group_n_rollouts, reward, seq_off, divide_by_std,
                      advantage64, group_tokens64, advantage32, group_tokens32);
