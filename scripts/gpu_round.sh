@@ -27,7 +27,7 @@ d = json.loads(text)
 print("line bytes", len(text), {k: d[k] for k in ("value", "ms_per_step", "value_skip_unlabelled", "wall_s")}, "roofline", round(d["roofline"]["frac"], 4), d["roofline"]["avg_us"])
 print(" cpu_baseline", d["cpu_baseline"], "\n weight_sync", d["weight_sync"], "\n hbm_frac", d["hbm_frac"], "skipped", d.get("skipped"))
 PY
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-weight-sync --no-live-pmc --skip-unlabelled-steps 0 --detail-out $OUT/bench_rocprof_detail.json > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-weight-sync --no-live-pmc --skip-unlabelled-steps 0 --detail-out $OUT/bench_rocprof_detail.json > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
 # the summary for profiles/: names shortened, ALL numeric columns kept (a width cut lost the dominant kernel's numbers in round 3)
 cd $GRAFT_REPO_ROOT; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do python scripts/kernel_stats_summary.py $f $OUT/bench_kernel_stats.csv; head -8 $OUT/bench_kernel_stats.csv; done
 find $OUT/prof -name "*kernel_trace.csv" -delete
