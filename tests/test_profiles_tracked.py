@@ -122,3 +122,19 @@ def test_the_round_6_driver_line_is_small_recomputes_and_agrees_with_rocprofv3()
     full = json.loads((ROOT / "profiles" / "r06f_bench_default_detail.json").read_text())
     assert full["value"] == d["value"] and set(d["hbm_frac"]) == {k for k, v in full["kernels"].items() if "hbm_frac" in v}
     assert full["cpu_baseline"]["legs"]["logprob_fwd_bwd_closed_form"]["us_per_token"] > 0
+
+
+def test_hip_events_and_rocprofv3_agree_inside_one_process():
+    """profiles/r06w_bench_under_rocprof.json is the line `bench.py --steps 20 --warmup 5` printed WHILE rocprofv3 traced it, r06w_bench_kernel_stats.csv
+    the tracer's summary of that same process: the dominant kernel's average by HIP events (timed steps) and by the tracer (all 25 steps) agree to
+    1 %, and the launch counts are the run's."""
+    import json
+
+    d = json.loads((ROOT / "profiles" / "r06w_bench_under_rocprof.json").read_text())
+    r = d["roofline"]
+    rows = [l for l in (ROOT / "profiles" / "r06w_bench_kernel_stats.csv").read_text().splitlines() if l.startswith('"fused_logits_loss_keep_kernel')]
+    assert len(rows) == 1
+    calls, _, avg_ns = rows[0].split('",')[1].split(",")[:3]
+    assert int(calls) == 4096 * (d["steps"] + d["warmup"]) and r["launches"] == 4096 * d["steps"]
+    assert abs(float(avg_ns) * 1e-3 - r["avg_us"]) / r["avg_us"] < 0.01
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9, rel=1e-6)
