@@ -47,3 +47,25 @@ print(" samples/s", round(s["samples_per_s"], 3), "s/step", round(s["s_per_step"
       "wsync under load ms", s["weight_sync_under_load_ms"], "peak GB", s["learner_peak_memory_GB"], "engines equal trainer", s["engine_weights_equal_trainer_at_last_version"])
 PY
 fi
+if [ "${3:-}" == "topologies" ]; then
+  # BASELINE configs[3] (4 learners + 4 engines) and configs[4] (4 learners + 2 x TP2 engines, KL on) as TOPOLOGIES on one GPU, two-layer model:
+  # ten / eight processes, real kernels, gloo gradients; IPC hand-off to four engines / per-TP-rank gloo groups with sharded updates
+  for cfg in "cfg3_4x4_ipc --learners 4 --engines 4 --weights ipc" "cfg4_4x2xTP2_gloo_kl --learners 4 --engines 2 --engine-tp 2 --weights gloo --kl-coef 0.001"; do
+    set -- $cfg
+    name=pipeline_tiny_$1; shift
+    ( time timeout 900 python scripts/pipeline_cfg1.py --model tiny --global-batch 32 --seq-length 128 --attempts 4 --steps 3 "$@" --stacks-after 600 --out $OUT/$name.json ) > $OUT/$name.log 2> $OUT/$name.err
+    echo "$name exit $?"
+    python - "$OUT/$name.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read())
+except Exception as e:
+    print(" no result", e); sys.exit(0)
+if "error" in d:
+    print(" ERROR", json.dumps(d["error"])[:3000]); sys.exit(0)
+s = d["summary"]
+print(" steps", s["optimizer_steps"], "topology", {k: s["topology"][k] for k in ("learners", "engines", "engine_tp", "grad_backend", "weight_transport", "micro_batches_per_learner", "updates_per_engine")},
+      "wsync ms", round(s["weight_sync_under_load_ms"]["median"], 1), "engines equal trainer", s["engine_weights_equal_trainer_at_last_version"])
+PY
+  done
+fi

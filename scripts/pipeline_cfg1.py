@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--wire", default="full", choices=["full", "compact"], help="training_data records: the expanded batch, or the ragged columns (K6 on the learner's GPU)")
     ap.add_argument("--learners", type=int, default=1, help="data-parallel learner ranks (lead trainers)")
     ap.add_argument("--engines", type=int, default=1, help="inference engines (weight-update group = engines + 1)")
+    ap.add_argument("--engine-tp", type=int, default=1, help="tensor-parallel degree of an engine (> 1: every TP rank receives only its slices; --weights rccl | gloo)")
     ap.add_argument("--weights", default="ipc", choices=["ipc", "rccl", "gloo"], help="trainer -> engines transport")
     ap.add_argument("--own-gpus", action="store_true", help="one GPU per engine and per learner rank (engines first); default: every stage on GPU 0")
     ap.add_argument("--kl-coef", type=float, default=0.0, help="> 0: KL-to-reference on, the preprocessor holds the frozen reference policy (configs[4]: 0.001)")
@@ -71,7 +72,7 @@ def _spec_from_flags(a, exp, PipelineSpec):
     return PipelineSpec(exp_path=exp, model=a.model, global_batch=a.global_batch or 512, seq_length=a.seq_length, pack_budget=a.pack_budget, attempts=a.attempts, steps=a.steps,
                         max_lag=a.max_lag, weight_update_interval=a.weight_update_interval, dense=a.dense, engine_load=a.engine_load,
                         gradient_checkpointing=a.gradient_checkpointing, learner=a.learner, wire=a.wire, stage_timeout_s=a.timeout, stacks_after_s=a.stacks_after,
-                        n_learners=a.learners, n_engines=a.engines, weight_transport=a.weights, share_device=not a.own_gpus, kl_coef=a.kl_coef)
+                        n_learners=a.learners, n_engines=a.engines, engine_tp=a.engine_tp, weight_transport=a.weights, share_device=not a.own_gpus, kl_coef=a.kl_coef)
 
 
 if __name__ == "__main__":
